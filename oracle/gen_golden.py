@@ -1,0 +1,173 @@
+"""Generates tests/golden/*.npz by RUNNING the two reference modules that import in the build container.
+
+Run once, here (the GPU box has no /root/reference):   python oracle/gen_golden.py
+
+  * maskrefiner/modeling/mask_refiner/post_processing.py  (torch only; loaded by file path)
+  * explicit_error_estimation/util.py                     (cv2 / segmentation_models_pytorch are imported at
+    module top but unused by the two functions called; empty stand-in modules are registered for the import)
+
+Only inputs and the reference's outputs are stored.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from quber_amd import synth  # noqa: E402
+
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def load(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    post = load("ref_post", "maskrefiner/modeling/mask_refiner/post_processing.py")
+    for n in ("cv2", "segmentation_models_pytorch"):
+        sys.modules.setdefault(n, types.ModuleType(n))
+    util = load("ref_eee_util", "explicit_error_estimation/util.py")
+    gen = util.PerturbedInputOffsetGenerator(sigma=10)
+
+    def save(name, **kw):
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **kw)
+        print("wrote", name, {k: getattr(v, "shape", None) for k, v in kw.items()})
+
+    # ---------------------------------------------------------------- encode (a1) + fg-union (a2)
+    def enc_case(name, masks):
+        masks = np.ascontiguousarray(masks.astype(np.uint8))
+        out = gen([m for m in masks]).numpy()
+        fg = util.masks_to_fg_mask(masks)
+        save("encode_" + name, masks=np.packbits(masks != 0, axis=-1), shape=np.array(masks.shape),
+             value=np.array([int(masks.max())]), out=out, fg=fg)
+
+    h, w = 96, 128
+    rng = np.random.default_rng(1)
+    _, m8 = synth.make_masks(rng, 8, h, w)
+    enc_case("n8_96x128", m8 * 255)
+    # border-touching, an empty mask, overlapping pair, half-integer centroid, single pixel
+    m = np.zeros((7, h, w), np.uint8)
+    m[0, 0:10, 0:14] = 1            # top-left corner (window clipped)
+    m[1, 80:96, 100:128] = 1        # bottom-right corner
+    # m[2] stays empty (skipped)
+    m[3, 30:60, 40:90] = 1
+    m[4, 45:70, 60:110] = 1         # overlaps m[3]; later wins in the offset planes
+    m[5, 10:12, 50:52] = 1          # centroid at (10.5, 50.5): banker's rounding
+    m[6, 70, 5] = 1                 # single pixel
+    enc_case("edge_96x128", m)
+    enc_case("n1_96x128", m[3:4] * 255)
+    sc = synth.make_scene(7, 480, 640, 20)
+    enc_case("n20_480x640", sc["masks"])
+    # fg-union wrap-around: 256 overlapping masks of value 255 sum to 0 mod 256
+    mw = np.zeros((256, 8, 16), np.uint8)
+    mw[:, 2:5, 3:9] = 255
+    mw[:100, 6, 10] = 255
+    save("fgunion_wrap", masks=mw, fg=util.masks_to_fg_mask(mw))
+
+    # ---------------------------------------------------------------- find_instance_center (a8)
+    def ctr_case(name, c):
+        c = torch.as_tensor(c, dtype=torch.float32).reshape(1, *c.shape[-2:])
+        out = post.find_instance_center(c.clone(), threshold=0.3, nms_kernel=7, top_k=200)
+        save("centers_" + name, center=c.numpy(), out=out.numpy())
+
+    enc = gen([x for x in (m8 * 255).astype(np.uint8)]).numpy()
+    ctr_case("scene_96x128", enc[0])
+    ctr_case("plateau", np.where(np.add.outer(np.arange(h), np.arange(w)) % 37 < 2, 0.5, 0.1))
+    ctr_case("const", np.full((h, w), 0.5))
+    ctr_case("below", np.full((h, w), 0.29))
+    c = np.full((h, w), 0.1, np.float32)
+    c[10, 10] = 0.3                                         # exactly the threshold: not a centre
+    c[20, 20] = np.nextafter(np.float32(0.3), np.float32(1))
+    c[40, 40] = 0.9
+    c[40, 44] = 0.9                                         # tie inside one NMS window: both survive
+    c[0, 0] = 0.7
+    c[h - 1, w - 1] = 0.8
+    ctr_case("threshold_ties", c)
+    rng = np.random.default_rng(3)
+    ctr_case("random_many", rng.random((h, w)).astype(np.float32))          # > 200 candidates
+    cc = np.full((120, 160), 0.1, np.float32)
+    vals = 0.31 + 0.002 * np.arange(15 * 20)
+    cc[4::8, 4::8] = vals.reshape(15, 20)                                     # 300 isolated peaks, distinct
+    ctr_case("peaks300_distinct", cc)
+    cc2 = cc.copy()
+    cc2[4::8, 4::8] = np.round(vals.reshape(15, 20), 2)                       # many equal values at the cut
+    ctr_case("peaks300_ties", cc2)
+    cc3 = np.full((120, 160), 0.1, np.float32)
+    cc3[4::8, 4::8].flat[:200] = 0.5 + 0.001 * np.arange(200)                 # exactly 200 candidates
+    ctr_case("peaks200_exact", cc3)
+    sc_enc = gen([x for x in sc["masks"]]).numpy()
+    ctr_case("scene_480x640", sc_enc[0])
+
+    # ---------------------------------------------------------------- group_pixels (a9)
+    def grp_case(name, centers, offsets):
+        centers = torch.as_tensor(centers, dtype=torch.int64)
+        offsets = torch.as_tensor(offsets, dtype=torch.float32)
+        out = post.group_pixels(centers, offsets)
+        save("group_" + name, centers=centers.numpy(), offsets=offsets.numpy(), out=out.numpy().astype(np.int32))
+
+    rng = np.random.default_rng(5)
+    grp_case("k1", [[40, 60]], rng.normal(0, 3, (2, h, w)))
+    grp_case("ties_int", [[10, 10], [10, 30], [30, 10], [30, 30]], np.zeros((2, h, w)))   # exact ties -> first index
+    ck = np.stack([rng.integers(0, h, 20), rng.integers(0, w, 20)], 1)
+    grp_case("k20", ck, rng.normal(0, 5, (2, h, w)))
+    ck = np.stack([rng.integers(0, h, 199), rng.integers(0, w, 199)], 1)
+    grp_case("k199", ck, rng.normal(0, 20, (2, h, w)))
+    _, ctr_s, off_s = synth.fake_head_outputs(sc_enc, sc["masks"], np.random.default_rng(11), noise=0.5)
+    cs = post.find_instance_center(torch.as_tensor(ctr_s).clone(), 0.3, 7, 200)
+    grp_case("scene_480x640", cs.numpy(), off_s)
+
+    # ---------------------------------------------------------------- full panoptic (a8-a10)
+    def pan_case(name, fg_logit, center, offsets):
+        fg_logit = torch.as_tensor(fg_logit, dtype=torch.float32).reshape(1, *np.shape(fg_logit)[-2:])
+        center = torch.as_tensor(center, dtype=torch.float32).reshape(1, *np.shape(center)[-2:])
+        offsets = torch.as_tensor(offsets, dtype=torch.float32)
+        fg = fg_logit.sigmoid().round()
+        pan, ctr = post.get_panoptic_segmentation(
+            fg, center.clone(), offsets, thing_ids=[0], label_divisor=1000, stuff_area=2048,
+            void_label=-1, threshold=0.3, nms_kernel=7, top_k=200)
+        save("panoptic_" + name, fg_logit=fg_logit.numpy(), center=center.numpy(), offsets=offsets.numpy(),
+             fg=fg.numpy(), pan=pan.numpy(), centers=ctr.numpy())
+
+    lg, ce, of = synth.fake_head_outputs(enc, m8 * 255, np.random.default_rng(12), noise=0.3)
+    pan_case("scene_96x128", lg, ce, of)
+    lg, ce, of = synth.fake_head_outputs(sc_enc, sc["masks"], np.random.default_rng(13), noise=0.5)
+    pan_case("scene_480x640", lg, ce, of)
+    # 511 vs 512 px instances
+    fgl = np.full((h, w), -4.0, np.float32)
+    ce = np.full((h, w), 0.1, np.float32)
+    of = np.zeros((2, h, w), np.float32)
+    fgl[10:26, 10:42] = 4.0            # 16x32 = 512 px  -> kept
+    fgl[25, 41] = 4.0
+    ce[18, 26] = 0.9
+    fgl[50:66, 60:92] = 4.0            # 512 px, one removed -> 511 -> dropped
+    fgl[50, 60] = -4.0
+    ce[58, 76] = 0.8
+    pan_case("area_511_512", fgl, ce, of)
+    # K = 0 with a large fg blob -> label 1000; and with a small blob -> all void
+    fgl = np.full((h, w), -4.0, np.float32)
+    fgl[20:70, 30:100] = 4.0
+    pan_case("k0_blob", fgl, np.full((h, w), 0.1, np.float32), of)
+    fgl = np.full((h, w), -4.0, np.float32)
+    fgl[20:40, 30:60] = 4.0
+    pan_case("k0_small", fgl, np.full((h, w), 0.1, np.float32), of)
+    # sigmoid().round() around 0: probes from SURVEY 8c
+    fgl = np.zeros((h, w), np.float32)
+    vals = np.array([-1.2e-7, -6e-8, 0.0, 6e-8, 1.2e-7, 2.4e-7, 1e-3, -1e-3], np.float32)
+    fgl[:] = np.resize(vals, (h, w))
+    ce = np.full((h, w), 0.1, np.float32)
+    ce[48, 64] = 0.9
+    pan_case("sigmoid_round", fgl, ce, of)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,82 @@
+"""CPU: the oracle restatements against the fixtures produced from the imported reference modules."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, load_encode_case
+from oracle import encode_np, errmaps_np, postproc_ref
+
+
+@pytest.mark.parametrize("path", golden("encode"), ids=os.path.basename)
+def test_encode_matches_reference(path):
+    masks, out, fg = load_encode_case(path)
+    got = encode_np.encode_initial_masks(masks)
+    assert got.dtype == np.float32
+    np.testing.assert_array_equal(got.view(np.uint32), out.view(np.uint32))
+    np.testing.assert_array_equal(errmaps_np.masks_to_fg_mask(masks), fg)
+
+
+def test_fg_union_wraps_like_reference():
+    z = np.load(golden("fgunion")[0])
+    np.testing.assert_array_equal(errmaps_np.masks_to_fg_mask(z["masks"]), z["fg"])
+    assert z["fg"][3, 4] == 0 and z["fg"][6, 10] == 1     # 256 x 255 wraps to 0; 100 x 255 does not
+
+
+@pytest.mark.parametrize("path", golden("centers"), ids=os.path.basename)
+def test_centers(path):
+    z = np.load(path)
+    got = postproc_ref.find_centers(torch.from_numpy(z["center"]))
+    np.testing.assert_array_equal(got.numpy(), z["out"])
+
+
+@pytest.mark.parametrize("path", golden("group"), ids=os.path.basename)
+def test_group(path):
+    z = np.load(path)
+    got = postproc_ref.group_pixels(torch.from_numpy(z["centers"]), torch.from_numpy(z["offsets"]), chunk=4099)
+    np.testing.assert_array_equal(got.numpy().astype(np.int32), z["out"])
+
+
+@pytest.mark.parametrize("path", golden("panoptic"), ids=os.path.basename)
+def test_panoptic(path):
+    z = np.load(path)
+    lg = torch.from_numpy(z["fg_logit"])
+    fg = lg.sigmoid().round()
+    np.testing.assert_array_equal(fg.numpy(), z["fg"])
+    pan, ctr = postproc_ref.panoptic(fg, torch.from_numpy(z["center"]), torch.from_numpy(z["offsets"]))
+    assert pan.dtype == torch.float32
+    np.testing.assert_array_equal(pan.numpy(), z["pan"])
+    np.testing.assert_array_equal(ctr.numpy(), z["centers"][0])
+
+
+def test_boundary_hand_derived():
+    # rectangle well inside: band of width d on the inside; touching the border counts as boundary
+    h, w = 60, 80
+    m = np.zeros((h, w), np.uint8)
+    m[10:40, 20:70] = 255
+    b = errmaps_np.mask_to_boundary(m, dilation_ratio=0.05)      # d = round(0.05*100) = 5
+    exp = m.copy()
+    exp[15:35, 25:65] = 0
+    np.testing.assert_array_equal(b, exp)
+    m2 = np.zeros((h, w), np.uint8)
+    m2[0:20, 0:30] = 1
+    b2 = errmaps_np.mask_to_boundary(m2, dilation_ratio=0.03)    # d = 3
+    exp2 = m2.copy()
+    exp2[3:17, 3:27] = 0
+    np.testing.assert_array_equal(b2, exp2)
+    # thin mask vanishes entirely under erosion -> whole mask is boundary
+    m3 = np.zeros((h, w), np.uint8)
+    m3[30:34, 5:60] = 1
+    np.testing.assert_array_equal(errmaps_np.mask_to_boundary(m3, 0.03), m3)
+    assert errmaps_np.boundary_width(480, 640, 0.01) == 8
+    assert errmaps_np.boundary_width(720, 1280, 0.01) == 15
+
+
+def test_quadruple_is_one_hot():
+    rng = np.random.default_rng(0)
+    from quber_amd import synth
+    gt, init = synth.make_masks(rng, 6, 96, 128)
+    e = errmaps_np.explicit_error_maps(init.astype(np.uint8), gt.astype(np.uint8))
+    assert e.shape == (2, 4, 96, 128)
+    np.testing.assert_array_equal(e.sum(1), np.ones((2, 96, 128), np.uint8))
