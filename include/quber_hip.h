@@ -1,0 +1,128 @@
+/* libquber_hip.so - C ABI of the MI355X (gfx950) QuBER mask-refinement hot path.
+ *
+ * The reference (gist-ailab/QuBER) has no native interface on this path: everything below the Python
+ * predictor is stock torch ops.  The entry points therefore replace *Python call sites*; each one cites the
+ * reference code it stands in for.  All `const T* dev_*` / `T* dev_*` arguments are DEVICE pointers
+ * (e.g. torch.Tensor.data_ptr() of a ROCm tensor); every hot call is asynchronous on `stream`
+ * (a hipStream_t passed as void*), allocates nothing, and never synchronises.  Return value: 0 on
+ * success, negative on error with the text available from quber_last_error() (thread-local).
+ * One context per GPU / stream; a context is not re-entrant.
+ */
+#ifndef QUBER_HIP_H
+#define QUBER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct quber_ctx quber_ctx;
+
+/* Architecture + post-processing constants; defaults mirror
+ * configs/uoais-sim/instance-segmentation/seed77/mask-refiner-rgbd-concat-l2-gn-hf-b-fco-l3-b8.yaml on top of
+ * Base-Mask-Refiner.yaml and maskrefiner/config.py:6-102 (see quber_default_config). */
+typedef struct quber_config {
+    int32_t height, width;           /* frame size; multiples of 16 */
+    int32_t max_batch;               /* frames per call the workspace is sized for */
+    int32_t max_instances;           /* initial masks per frame (<= 254) */
+    int32_t resnet_depth;            /* MODEL.RESNETS.DEPTH: 50 | 101 | 152 */
+    int32_t res5_dilation;           /* MODEL.RESNETS.RES5_DILATION (2) */
+    int32_t backbone_fusion_layers;  /* MODEL.BACKBONE.NUM_FUSION_LAYERS (2) */
+    int32_t head_fusion_layers;      /* MODEL.INS_EMBED_HEAD.NUM_FUSION_LAYERS (3) */
+    int32_t error_classes;           /* ERROR_TYPE e3 -> 4 */
+    int32_t gaussian_sigma;          /* predictor.py:246 (10) */
+    int32_t nms_kernel;              /* PANOPTIC_DEEPLAB.NMS_KERNEL (7) */
+    int32_t top_k;                   /* PANOPTIC_DEEPLAB.TOP_K_INSTANCE (200) */
+    int32_t stuff_area;              /* PANOPTIC_DEEPLAB.STUFF_AREA (2048) */
+    int32_t min_instance_area;       /* post_processing.py:145 (512) */
+    int32_t label_divisor;           /* register_uoais_sim_panoptic.py:177-186 (1000) */
+    int32_t with_network;            /* 0: only the encode / error-map / post-processing kernels are usable */
+    float center_threshold;          /* PANOPTIC_DEEPLAB.CENTER_THRESHOLD (0.3) */
+    float boundary_ratio;            /* explicit_error_estimation/util.py:92 dilation_ratio (0.01) */
+    float pixel_mean[6];             /* MODEL.PIXEL_MEAN */
+    float pixel_std[6];              /* MODEL.PIXEL_STD */
+} quber_config;
+
+/* number of logit planes produced by quber_forward: [fg, centre, off_y, off_x, err_0 .. err_{classes-1}] */
+#define QUBER_LOGIT_BASE 4
+
+void quber_default_config(quber_config* cfg);
+const char* quber_last_error(void);
+const char* quber_version(void);
+
+/* Build a context on the current HIP device.  Replaces MaskRefinerPredictor.__init__'s build_model(cfg)
+ * (maskrefiner/predictor.py:209-229) minus its dataset / output-dir side effects. */
+int quber_create(const quber_config* cfg, quber_ctx** out);
+void quber_destroy(quber_ctx* ctx);
+
+/* Weights: one call per state_dict entry, `name` being the detectron2-compatible key, `host`
+ * a HOST pointer to `numel` contiguous fp32 values in torch's layout (OIHW for convs).  Replaces
+ * DetectionCheckpointer.load (predictor.py:228-229).  quber_finalize_weights folds the frozen / eval
+ * batch-norms into per-channel affines, re-lays the filters out for the implicit-GEMM kernel, uploads them and
+ * fails (listing the first missing key) if the architecture needs a tensor that was not supplied. */
+int quber_set_weight(quber_ctx* ctx, const char* name, const float* host, int64_t numel);
+int quber_finalize_weights(quber_ctx* ctx);
+/* number of tensors the configured architecture expects, and the i-th name / element count */
+int quber_num_weights(quber_ctx* ctx);
+int quber_weight_spec(quber_ctx* ctx, int index, const char** name, int64_t* numel);
+
+/* a1 - initial masks -> (centre heat-map, off_y, off_x).  Replaces the numpy loop of
+ * MaskRefinerPredictor.predict (maskrefiner/predictor.py:304-357).
+ *   dev_masks u8 [B][N][H][W] (non-zero = inside)  ->  dev_out f32 [B][3][H][W] */
+int quber_encode_initial_masks(quber_ctx* ctx, const uint8_t* dev_masks, int32_t batch, int32_t n_masks,
+                               float* dev_out, void* stream);
+
+/* a2 - explicit quadruple error maps.  Replaces masks_to_fg_mask / masks_to_boundary
+ * (explicit_error_estimation/util.py:62-99) and the TP/TN/FP/FN logic of tools/ours/panoptic2eee.py:110-123.
+ *   dev_init u8 [B][N][H][W], dev_gt u8 [B][Ng][H][W]  ->  dev_out u8 [B][2 (region,boundary)][4 (TP,TN,FP,FN)][H][W] */
+int quber_explicit_error_maps(quber_ctx* ctx, const uint8_t* dev_init, int32_t n_init, const uint8_t* dev_gt,
+                              int32_t n_gt, int32_t batch, uint8_t* dev_out, void* stream);
+
+/* a3-a7 - the network.  Replaces MaskRefiner.forward up to the head outputs
+ * (maskrefiner/modeling/mask_refiner/model.py:137-156, 244-250, 689-708).
+ *   dev_bgr u8 [B][H][W][3], dev_depth u8 [B][H][W][3], dev_offsets f32 [B][3][H][W]
+ *   -> dev_logits f32 [B][4+classes][H][W]  (fg logit, centre, off_y px, off_x px, boundary-error logits) */
+int quber_forward(quber_ctx* ctx, const uint8_t* dev_bgr, const uint8_t* dev_depth, const float* dev_offsets,
+                  int32_t batch, float* dev_logits, void* stream);
+
+/* a8-a11 - centre NMS/top-k, pixel grouping, 512-px merge, scores and boxes.  Replaces get_panoptic_segmentation
+ * (maskrefiner/modeling/mask_refiner/post_processing.py:165-221) and the instance loop of model.py:313-356.
+ *   dev_logits f32 [B][n_planes][H][W] (planes 0..3 used)
+ *   -> dev_panoptic f32 [B][H][W]  labels {-1, 1000, 1001, ...}
+ *      dev_count   i32 [B]         instances per frame
+ *      dev_labels  f32 [B][top_k]  their labels, ascending, -1 padded
+ *      dev_scores  f32 [B][top_k], dev_boxes f32 [B][top_k][4] (x0,y0,x1,y1)
+ *      dev_centers i32 [B][top_k][2] (y,x) and dev_ncenters i32 [B]  (the surviving centre points) */
+int quber_postprocess(quber_ctx* ctx, const float* dev_logits, int32_t n_planes, int32_t batch,
+                      float* dev_panoptic, int32_t* dev_count, float* dev_labels, float* dev_scores,
+                      float* dev_boxes, int32_t* dev_centers, int32_t* dev_ncenters, void* stream);
+
+/* pred_masks of model.py:334 for the first `max_inst` labels of every frame:
+ *   -> dev_masks u8 [B][max_inst][H][W] in {0,1} (all zero for slots beyond the frame's count) */
+int quber_extract_masks(quber_ctx* ctx, const float* dev_panoptic, const float* dev_labels, int32_t batch,
+                        int32_t max_inst, uint8_t* dev_masks, void* stream);
+
+/* ---- introspection / kernel-level entry points used by the parity tests and the benchmark ---- */
+/* device pointer + NHWC geometry of a named intermediate of the last quber_forward ("res2", "res3", "res5", "y", ...) */
+int quber_debug_tensor(quber_ctx* ctx, const char* name, float** dev_ptr, int32_t* dims4, int32_t* channel_stride);
+/* algorithmic FLOPs of one forward at batch 1 (2 * MACs of every convolution) */
+double quber_forward_flops(quber_ctx* ctx);
+/* stand-alone convolution: y = act((conv(x, w) * scale + shift) + residual), NHWC, weights OIHW on the device */
+int quber_op_conv2d(const float* dev_x, int32_t batch, int32_t h, int32_t w, int32_t cin, const float* dev_w_oihw,
+                    int32_t cout, int32_t ksize, int32_t stride, int32_t pad, int32_t dil, const float* dev_scale,
+                    const float* dev_shift, const float* dev_residual, int32_t relu, float* dev_packed_scratch,
+                    float* dev_y, void* stream);
+int quber_op_groupnorm(const float* dev_x, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t groups,
+                       const float* dev_gamma, const float* dev_beta, float eps, int32_t relu,
+                       double* dev_stats_scratch, float* dev_y, void* stream);
+int quber_op_bilinear(const float* dev_x, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t oh, int32_t ow,
+                      float* dev_y, void* stream);
+int quber_op_maxpool3x3s2(const float* dev_x, int32_t batch, int32_t h, int32_t w, int32_t c, float* dev_y,
+                          void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,75 @@
+"""ctypes binding of libquber_hip.so (include/quber_hip.h).  No fallback: if the library is missing or
+cannot be loaded the import of anything that needs it raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libquber_hip.so")
+
+
+class QuberConfig(C.Structure):
+    _fields_ = [
+        ("height", C.c_int32), ("width", C.c_int32), ("max_batch", C.c_int32), ("max_instances", C.c_int32),
+        ("resnet_depth", C.c_int32), ("res5_dilation", C.c_int32), ("backbone_fusion_layers", C.c_int32),
+        ("head_fusion_layers", C.c_int32), ("error_classes", C.c_int32), ("gaussian_sigma", C.c_int32),
+        ("nms_kernel", C.c_int32), ("top_k", C.c_int32), ("stuff_area", C.c_int32),
+        ("min_instance_area", C.c_int32), ("label_divisor", C.c_int32), ("with_network", C.c_int32),
+        ("center_threshold", C.c_float), ("boundary_ratio", C.c_float),
+        ("pixel_mean", C.c_float * 6), ("pixel_std", C.c_float * 6),
+    ]
+
+
+class QuberError(RuntimeError):
+    pass
+
+
+_P = C.c_void_p
+_I = C.c_int32
+# name -> (restype, argtypes); every symbol include/quber_hip.h declares
+SIGNATURES = {
+    "quber_default_config": (None, [C.POINTER(QuberConfig)]),
+    "quber_last_error": (C.c_char_p, []),
+    "quber_version": (C.c_char_p, []),
+    "quber_create": (C.c_int, [C.POINTER(QuberConfig), C.POINTER(_P)]),
+    "quber_destroy": (None, [_P]),
+    "quber_set_weight": (C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
+    "quber_finalize_weights": (C.c_int, [_P]),
+    "quber_num_weights": (C.c_int, [_P]),
+    "quber_weight_spec": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64)]),
+    "quber_encode_initial_masks": (C.c_int, [_P, _P, _I, _I, _P, _P]),
+    "quber_explicit_error_maps": (C.c_int, [_P, _P, _I, _P, _I, _I, _P, _P]),
+    "quber_forward": (C.c_int, [_P, _P, _P, _P, _I, _P, _P]),
+    "quber_postprocess": (C.c_int, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "quber_extract_masks": (C.c_int, [_P, _P, _P, _I, _I, _P, _P]),
+    "quber_debug_tensor": (C.c_int, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(_I * 4), C.POINTER(_I)]),
+    "quber_forward_flops": (C.c_double, [_P]),
+    "quber_op_conv2d": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P]),
+    "quber_op_groupnorm": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _P, C.c_float, _I, _P, _P, _P]),
+    "quber_op_bilinear": (C.c_int, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "quber_op_maxpool3x3s2": (C.c_int, [_P, _I, _I, _I, _I, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library (once).  Raises if it is missing: there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise QuberError(
+            f"{LIB_PATH} not found: build it with `make -C quber_amd/csrc` (or __graft_entry__.build()); "
+            "quber_amd has no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise QuberError(load().quber_last_error().decode())

@@ -1,0 +1,131 @@
+"""Parameter inventory of the refiner (detectron2-compatible ``state_dict`` keys) and a
+seeded initialiser.  No trained weights ship with the reference (predictor.py:226 hard-codes a path
+on the authors' machine), so benchmarks and parity tests run on these synthetic weights; a real
+checkpoint's ``state_dict`` (``model`` entry of a detectron2 .pth) loads through the same keys.
+"""
+from collections import OrderedDict
+
+import numpy as np
+
+BLOCKS = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}
+
+
+def param_specs(depth=50, backbone_fusion_layers=2, head_fusion_layers=3, error_classes=4):
+    """OrderedDict name -> (shape, kind); kind in conv|bn_w|bn_b|bn_m|bn_v|gn_w|gn_b|bias|pred_w|pred_b."""
+    s = OrderedDict()
+
+    def conv(n, co, ci, k, bias=False):
+        s[n + ".weight"] = ((co, ci, k, k), "conv")
+        if bias:
+            s[n + ".bias"] = ((co,), "bias")
+
+    def bn(n, c):
+        for t, kind in (("weight", "bn_w"), ("bias", "bn_b"), ("running_mean", "bn_m"), ("running_var", "bn_v")):
+            s[f"{n}.{t}"] = ((c,), kind)
+
+    def gn(n, c):
+        s[n + ".weight"] = ((c,), "gn_w")
+        s[n + ".bias"] = ((c,), "gn_b")
+
+    for stream, pre in (("backbone.rgb_backbone.", ""), ("backbone.depth_backbone.", "depth_")):
+        for i, (co, ci) in enumerate(((32, 6), (32, 32), (64, 32))):
+            conv(f"{stream}stem.conv{i + 1}", co, ci, 3)
+            bn(f"{stream}stem.conv{i + 1}.norm", co)
+        cin, cout, mid = 64, 256, 64
+        for st, nb in enumerate(BLOCKS[depth]):
+            for b in range(nb):
+                p = f"{stream}{pre}res{st + 2}.{b}."
+                if cin != cout:
+                    conv(p + "shortcut", cout, cin, 1)
+                    bn(p + "shortcut.norm", cout)
+                conv(p + "conv1", mid, cin, 1)
+                bn(p + "conv1.norm", mid)
+                conv(p + "conv2", mid, mid, 3)
+                bn(p + "conv2.norm", mid)
+                conv(p + "conv3", cout, mid, 1)
+                bn(p + "conv3.norm", cout)
+                cin = cout
+            cout, mid = cout * 2, mid * 2
+    for k, c in (("res2", 256), ("res3", 512), ("res5", 2048)):
+        p = f"backbone.fusion_{k}."
+        conv(p + "conv", c, 2 * c, 1, bias=True)
+        gn(p + "gn", c)
+        if k != "res5":
+            for i in range(backbone_fusion_layers):
+                conv(p + f"conv{i}", c, c, 3, bias=True)
+                gn(p + f"gn{i}", c)
+    h = "ins_embed_head."
+    a = h + "decoder.res5.project_conv."
+    conv(a + "convs.0", 256, 2048, 1)
+    gn(a + "convs.0.norm", 256)
+    for i in (1, 2, 3):
+        conv(a + f"convs.{i}", 256, 2048, 3)
+        gn(a + f"convs.{i}.norm", 256)
+    conv(a + "convs.4.1", 256, 2048, 1, bias=True)
+    conv(a + "project", 256, 1280, 1)
+    gn(a + "project.norm", 256)
+    for k, cin_f, pc, up in (("res3", 512, 64, 256), ("res2", 256, 32, 128)):
+        p = h + f"decoder.{k}."
+        conv(p + "project_conv", pc, cin_f, 1)
+        gn(p + "project_conv.norm", pc)
+        conv(p + "fuse_conv.0", 128, pc + up, 3)
+        gn(p + "fuse_conv.0.norm", 128)
+        conv(p + "fuse_conv.1", 128, 128, 3)
+        gn(p + "fuse_conv.1.norm", 128)
+    for name, co in (("foreground", 1), ("center", 1), ("offset", 2), ("eee_boundary", error_classes)):
+        p = h + f"{name}_pred_head.head."
+        conv(p + "0", 128, 128, 3)
+        gn(p + "0.norm", 128)
+        conv(p + "1", 32, 128, 3)
+        gn(p + "1.norm", 32)
+        s[h + f"{name}_predictor.predictor.weight"] = ((co, 32, 1, 1), "pred_w")
+        s[h + f"{name}_predictor.predictor.bias"] = ((co,), "pred_b")
+    f = h + "fusion_layers_1.fusion_layers."
+    conv(f + "0", 128, 128 + 32 + error_classes, 1, bias=True)
+    bn(f + "0.norm", 128)
+    for i in range(head_fusion_layers):
+        conv(f + f"{i + 1}", 128, 128, 3, bias=True)
+        bn(f + f"{i + 1}.norm", 128)
+    return s
+
+
+def init_state_dict(seed=0, **kw):
+    """Seeded float32 numpy state_dict.  Convs: He-normal (fan_out) for the encoder as c2_msra_fill
+    (resnet.py:64-66), Xavier-uniform for the heads as c2_xavier_fill (model.py:405-406), predictors
+    N(0, 0.001) (model.py:418-419).  Norm statistics are random but benign so that folding is exercised;
+    the last BN of every bottleneck is damped to keep the residual trunk O(1) without training."""
+    rng = np.random.default_rng(seed)
+    out = OrderedDict()
+    for name, (shape, kind) in param_specs(**kw).items():
+        if kind == "conv":
+            co, ci, k, _ = shape
+            if name.startswith("backbone.rgb_backbone") or name.startswith("backbone.depth_backbone"):
+                v = rng.normal(0, np.sqrt(2.0 / (co * k * k)), shape)
+            else:
+                lim = np.sqrt(3.0) * np.sqrt(2.0 / ((ci + co) * k * k))
+                v = rng.uniform(-lim, lim, shape)
+        elif kind == "bn_w":
+            v = rng.uniform(0.5, 1.5, shape)
+            if ".conv3.norm" in name:
+                v = v * 0.3
+        elif kind in ("bn_b", "bn_m"):
+            v = rng.normal(0, 0.1, shape)
+        elif kind == "bn_v":
+            v = rng.uniform(0.5, 1.5, shape)
+        elif kind == "gn_w":
+            v = rng.uniform(0.8, 1.2, shape)
+        elif kind in ("gn_b", "bias"):
+            v = rng.normal(0, 0.05, shape)
+        elif kind == "pred_w":
+            v = rng.normal(0, 0.001, shape)
+        elif kind == "pred_b":
+            v = np.zeros(shape)
+        else:
+            raise AssertionError(kind)
+        out[name] = np.ascontiguousarray(v, dtype=np.float32)
+    return out
+
+
+def num_parameters(specs=None):
+    specs = specs or param_specs()
+    return int(sum(np.prod(sh) for sh, _ in specs.values()))

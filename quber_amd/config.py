@@ -1,0 +1,154 @@
+"""Minimal yaml + ``_BASE_`` config reader for the keys the refiner inference path consumes.
+
+detectron2 / yacs are not available, so this mirrors just enough of
+``get_cfg(); add_panoptic_deeplab_config(cfg); add_mask_refiner_config(cfg); cfg.merge_from_file(f)``
+(maskrefiner/predictor.py:211-214) for the ~25 keys read on the hot path.  Defaults are those of
+maskrefiner/config.py:6-102 and of detectron2 v0.6; yaml keys outside this
+set (SOLVER, DATALOADER, ...) are kept verbatim and ignored.
+"""
+import copy
+import os
+
+import yaml
+
+
+class CfgNode(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    @staticmethod
+    def wrap(d):
+        if isinstance(d, dict):
+            return CfgNode({k: CfgNode.wrap(v) for k, v in d.items()})
+        return d
+
+    def merge(self, other):
+        for k, v in other.items():
+            if isinstance(v, dict) and isinstance(self.get(k), dict):
+                self[k].merge(v)
+            else:
+                self[k] = CfgNode.wrap(copy.deepcopy(v))
+
+    def clone(self):
+        return CfgNode.wrap(copy.deepcopy(dict(self)))
+
+
+_DEFAULTS = {
+    "VERSION": 2,
+    "SEED": -1,
+    "MODEL": {
+        "META_ARCHITECTURE": "MaskRefiner",
+        "DEVICE": "cuda",
+        "WEIGHTS": "",
+        "PIXEL_MEAN": [103.53, 116.28, 123.675],
+        "PIXEL_STD": [1.0, 1.0, 1.0],
+        "BACKBONE": {"NAME": "build_resnet_deeplab_rgbd_fusion_backbone", "FREEZE_AT": 2,
+                     "FUSION_STRATEGY": "concat", "NUM_FUSION_LAYERS": 3, "WEIGHTS": "", "FREEZE_LAYERS": False},
+        "RESNETS": {"DEPTH": 50, "OUT_FEATURES": ["res4"], "NUM_GROUPS": 1, "NORM": "FrozenBN",
+                    "WIDTH_PER_GROUP": 64, "STRIDE_IN_1X1": True, "RES5_DILATION": 1, "RES2_OUT_CHANNELS": 256,
+                    "STEM_OUT_CHANNELS": 64, "STEM_TYPE": "deeplab", "RES4_DILATION": 1,
+                    "RES5_MULTI_GRID": [1, 2, 4], "DEFORM_ON_PER_STAGE": [False] * 4},
+        "SEM_SEG_HEAD": {"USE_DEPTHWISE_SEPARABLE_CONV": False},
+        "INS_EMBED_HEAD": {
+            "NAME": "PanopticDeepLabInsEmbedHead", "IN_FEATURES": ["res2", "res3", "res5"],
+            "PROJECT_FEATURES": ["res2", "res3"], "PROJECT_CHANNELS": [32, 64], "ASPP_CHANNELS": 256,
+            "ASPP_DILATIONS": [6, 12, 18], "ASPP_DROPOUT": 0.1, "HEAD_CHANNELS": 32, "CONVS_DIM": 128,
+            "COMMON_STRIDE": 4, "NORM": "SyncBN", "EEE_MASK_ON": False, "EEE_POST_PROCESS_ON": False,
+            "EEE_BOUNDARY_ON": True, "HIERARCHICAL_FUSION_ON": False,
+            "HIERARCHY": [["eee_mask", "eee_boundary"], ["foreground", "center", "offset"]],
+            "NUM_FUSION_LAYERS": 3, "FUSION_STRATEGY": "concat", "FUSION_TARGET": ["feat", "pred"],
+            "ERROR_TYPE": "e3"},
+        "PANOPTIC_DEEPLAB": {"STUFF_AREA": 2048, "CENTER_THRESHOLD": 0.1, "NMS_KERNEL": 7, "TOP_K_INSTANCE": 200,
+                             "PREDICT_INSTANCES": True, "USE_DEPTHWISE_SEPARABLE_CONV": False,
+                             "SIZE_DIVISIBILITY": -1, "BENCHMARK_NETWORK_SPEED": False},
+    },
+    "INPUT": {"FORMAT": "BGR", "MIN_SIZE_TEST": 800, "MAX_SIZE_TEST": 1333, "OFFSET_INPUT_ON": False,
+              "DEPTH_ON": False, "RGB_ON": True, "GAUSSIAN_SIGMA": 10, "CROP": {"ENABLED": False}},
+    "DATASETS": {"TRAIN": (), "TEST": ()},
+}
+
+
+def get_cfg():
+    return CfgNode.wrap(copy.deepcopy(_DEFAULTS))
+
+
+def _load_with_base(path):
+    with open(path) as f:
+        node = yaml.safe_load(f) or {}
+    base = node.pop("_BASE_", None)
+    if base is None:
+        return node
+    if not os.path.isabs(base):
+        base = os.path.join(os.path.dirname(path), base)
+    merged = CfgNode.wrap(_load_with_base(base))
+    merged.merge(node)
+    return merged
+
+
+def merge_from_file(cfg, path):
+    cfg.merge(_load_with_base(path))
+    return cfg
+
+
+def canonical_cfg():
+    """The 'QuBER' architecture of SURVEY.md section 8 (seed77/...-hf-b-fco-l3-b8.yaml over Base-Mask-Refiner.yaml)."""
+    cfg = get_cfg()
+    cfg.merge({
+        "MODEL": {
+            "BACKBONE": {"FUSION_STRATEGY": "concat", "NUM_FUSION_LAYERS": 2, "FREEZE_AT": 0},
+            "RESNETS": {"OUT_FEATURES": ["res2", "res3", "res5"], "RES5_DILATION": 2},
+            "PIXEL_MEAN": [103.53, 116.28, 123.675, 127.5, 127.5, 127.5],
+            "PIXEL_STD": [1, 1, 1, 1, 1, 1],
+            "INS_EMBED_HEAD": {"NAME": "MaskRefinerInsEmbedHead", "NORM": "GN", "HIERARCHICAL_FUSION_ON": True,
+                               "EEE_MASK_ON": False, "EEE_BOUNDARY_ON": True,
+                               "HIERARCHY": [["eee_boundary"], ["foreground", "center", "offset"]],
+                               "NUM_FUSION_LAYERS": 3, "FUSION_TARGET": ["feat", "pred"], "ERROR_TYPE": "e3"},
+            "PANOPTIC_DEEPLAB": {"CENTER_THRESHOLD": 0.3, "NMS_KERNEL": 7, "TOP_K_INSTANCE": 200, "STUFF_AREA": 2048,
+                                 "USE_DEPTHWISE_SEPARABLE_CONV": True},
+        },
+        "INPUT": {"MIN_SIZE_TEST": 480, "MAX_SIZE_TEST": 640, "OFFSET_INPUT_ON": True, "DEPTH_ON": True,
+                  "RGB_ON": True},
+        "DATASETS": {"TRAIN": ("uoais_sim_train_panoptic",), "TEST": ("uoais_sim_val_panoptic",)},
+    })
+    return cfg
+
+
+class UnsupportedConfig(ValueError):
+    pass
+
+
+ERROR_CLASSES = {"e3": 4, "e33": 3, "e2": 2, "e32": 2}
+
+
+def validate(cfg):
+    """Raise UnsupportedConfig for variants outside the built hot path (SURVEY.md 8f rank 4 lists them as 'next')."""
+    m, h = cfg.MODEL, cfg.MODEL.INS_EMBED_HEAD
+
+    def need(cond, what):
+        if not cond:
+            raise UnsupportedConfig(f"quber_amd: {what} is not built yet (see DESIGN.md, out of scope / next)")
+
+    need(m.META_ARCHITECTURE == "MaskRefiner", f"META_ARCHITECTURE {m.META_ARCHITECTURE}")
+    need(m.BACKBONE.NAME == "build_resnet_deeplab_rgbd_fusion_backbone", f"backbone {m.BACKBONE.NAME}")
+    need(m.BACKBONE.FUSION_STRATEGY == "concat", "backbone FUSION_STRATEGY other than 'concat'")
+    need(cfg.INPUT.DEPTH_ON and cfg.INPUT.RGB_ON and cfg.INPUT.OFFSET_INPUT_ON, "single-stream / no-offset input")
+    need(list(m.RESNETS.OUT_FEATURES) == ["res2", "res3", "res5"], "RESNETS.OUT_FEATURES other than res2/res3/res5")
+    need(m.RESNETS.STEM_TYPE == "deeplab" and m.RESNETS.NORM == "FrozenBN", "non-deeplab stem / non-frozen BN")
+    need(m.RESNETS.DEPTH in (50, 101, 152), f"ResNet depth {m.RESNETS.DEPTH}")
+    need(h.NAME == "MaskRefinerInsEmbedHead" and h.NORM == "GN", "head other than MaskRefinerInsEmbedHead/GN")
+    need(h.HIERARCHICAL_FUSION_ON and not h.EEE_MASK_ON and h.EEE_BOUNDARY_ON,
+         "head hierarchy other than boundary -> {foreground, center, offset}")
+    need([list(x) for x in h.HIERARCHY] == [["eee_boundary"], ["foreground", "center", "offset"]], "custom HIERARCHY")
+    need(sorted(h.FUSION_TARGET) == ["feat", "pred"], "FUSION_TARGET other than [feat, pred]")
+    need(not m.SEM_SEG_HEAD.USE_DEPTHWISE_SEPARABLE_CONV, "depthwise-separable head convs")
+    need(h.ERROR_TYPE in ERROR_CLASSES, f"ERROR_TYPE {h.ERROR_TYPE}")
+    need(list(h.PROJECT_CHANNELS) == [32, 64] and h.ASPP_CHANNELS == 256 and h.HEAD_CHANNELS == 32
+         and h.CONVS_DIM == 128 and h.COMMON_STRIDE == 4 and list(h.ASPP_DILATIONS) == [6, 12, 18],
+         "non-default decoder widths")
+    return cfg

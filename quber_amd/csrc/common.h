@@ -1,0 +1,84 @@
+// Internal declarations shared by the HIP translation units of libquber_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+namespace quber {
+
+// A strided NHWC view: element (b,y,x,c) lives at p[((b*H + y)*W + x)*cs + c]; `p` already points at
+// the view's first channel, so writers can target a channel slice of a wider (concatenated) buffer.
+// `gs` is the element distance between the G independent operand sets of one grouped launch
+// (blockIdx.z), e.g. the rgb / depth encoder streams.
+struct View {
+    float* p = nullptr;
+    int B = 0, H = 0, W = 0, C = 0;
+    int cs = 0;
+    long gs = 0;
+};
+
+struct ConvP {
+    const float* in;
+    const float* w;      // [G][Cout][Kpad], k = (ky*kw + kx)*Cin + c
+    const float* scale;  // [G][Cout] or null
+    const float* shift;  // [G][Cout] or null
+    const float* res;    // residual view or null
+    float* out;
+    int B, H, W, Cin, in_cs;
+    int OH, OW, Cout, out_cs;
+    int res_cs;
+    int K, Kpad;
+    int kh, kw, stride, pad, dil;
+    int relu;
+    int M;               // B*OH*OW
+    int mtiles, ntiles;
+    long in_gs, out_gs, res_gs, w_gs;
+    int ss_gs;
+};
+
+void set_error(const std::string& msg);
+int fail(const std::string& msg);
+
+// launchers (all asynchronous on `st`, no allocation, no synchronisation)
+int launch_conv(const ConvP& p, int G, hipStream_t st);
+int launch_preprocess(const uint8_t* rgb, const uint8_t* depth, const float* offs, float* x, int B, int Bcap,
+                      int H, int W, const float* mean6, const float* std6, int has_rgb, int has_depth,
+                      hipStream_t st);
+int launch_maxpool3x3s2(const View& in, const View& out, int B, int G, hipStream_t st);
+int launch_gn_stats(const View& in, int B, int G, int groups, double* stats, hipStream_t st);
+int launch_gn_apply(const View& in, const View& out, int B, int G, int groups, const double* stats,
+                    const float* gamma, const float* beta, int param_gs, float eps, int relu, hipStream_t st);
+int launch_bilinear(const View& in, const View& out, int B, hipStream_t st);
+int launch_avgpool(const View& in, const View& out, int B, hipStream_t st);
+int launch_predictor(const View& in, const float* w, const float* bias, int cout, float* q, int q_ch0,
+                     int q_nch, float* softmax_dst, int softmax_cs, int B, hipStream_t st);
+int launch_upsample_logits(const float* q, float* out, int B, int nch, int h, int w, int scale,
+                           unsigned mul_mask, hipStream_t st);
+
+int launch_encode(const uint8_t* masks, int B, int N, int H, int W, const float* gauss, int sigma,
+                  void* ws, float* out, hipStream_t st);
+size_t encode_ws_bytes(int B, int N, int H, int W);
+
+int launch_errmaps(const uint8_t* init, int N, const uint8_t* gt, int Ng, int B, int H, int W, int d,
+                   uint8_t* ws, uint8_t* out, hipStream_t st);
+size_t errmaps_ws_bytes(int B, int H, int W);
+
+struct PostCfg {
+    float threshold;
+    int nms_kernel, top_k, stuff_area, min_area, label_divisor, cap;
+};
+int launch_postprocess(const float* logits, int nch, int B, int H, int W, const PostCfg& c, void* ws,
+                       float* pan, int* count, float* labels, float* scores, float* boxes, int* centers,
+                       int* ncenters, hipStream_t st);
+size_t postprocess_ws_bytes(int B, int H, int W, int cap);
+int launch_extract_masks(const float* pan, const float* labels, int B, int H, int W, int cap, int max_inst,
+                         uint8_t* out, hipStream_t st);
+
+}  // namespace quber
+
+#define QB_CHECK(expr)                                                                         \
+    do {                                                                                       \
+        hipError_t e__ = (expr);                                                               \
+        if (e__ != hipSuccess)                                                                 \
+            return quber::fail(std::string(#expr) + ": " + hipGetErrorString(e__));            \
+    } while (0)

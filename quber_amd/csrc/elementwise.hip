@@ -1,0 +1,369 @@
+// HBM-bound glue kernels of the refiner network (NHWC fp32, 16-byte accesses, grid-stride).
+//  * preprocess      - maskrefiner/modeling/mask_refiner/model.py:137-153 + backbone/resnet.py:493-498
+//  * maxpool 3x3/2   - backbone/resnet.py:75
+//  * GroupNorm(32)   - nn.GroupNorm in resnet.py:473,482 and [d2] get_norm("GN") in model.py:386-403
+//  * bilinear resize - F.interpolate(align_corners=False) in [d2] DeepLabV3PlusHead.layers / ASPP
+//  * global avg pool - [d2] ASPP image-pooling branch
+//  * predictor       - SinglePredictor 1x1 conv (+ channel softmax, model.py:413-422, 752-759)
+//  * logits x4       - model.py:689-708
+#include "common.h"
+
+namespace quber {
+
+static inline int cap_grid(long work, int per_block) {
+    long g = (work + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > 256 * 8) g = 256 * 8;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// u8 HWC rgb + u8 HWC depth + f32 planar offsets -> two 8-channel NHWC stream inputs
+// x[0] = [(bgr - mean)/std, heat, off_y, off_x, 0, 0],  x[1] = [(depth - mean)/std, heat, off_y, off_x, 0, 0]
+__global__ void preprocess_kernel(const uint8_t* __restrict__ rgb, const uint8_t* __restrict__ depth,
+                                  const float* __restrict__ offs, float* __restrict__ x, int B, long gstride,
+                                  int HW, float m0, float m1, float m2, float m3, float m4, float m5, float s0,
+                                  float s1, float s2, float s3, float s4, float s5) {
+    const long total = (long)B * HW;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / HW;
+        const long pix = i - b * HW;
+        const float* o = offs + b * 3 * HW + pix;
+        const float heat = o[0], oy = o[HW], ox = o[2 * (long)HW];
+        const uint8_t* r = rgb + i * 3;
+        const uint8_t* d = depth + i * 3;
+        float4 a, c;
+        a.x = ((float)r[0] - m0) / s0;
+        a.y = ((float)r[1] - m1) / s1;
+        a.z = ((float)r[2] - m2) / s2;
+        a.w = heat;
+        c.x = oy; c.y = ox; c.z = 0.f; c.w = 0.f;
+        float4* dst = reinterpret_cast<float4*>(x + i * 8);
+        dst[0] = a;
+        dst[1] = c;
+        a.x = ((float)d[0] - m3) / s3;
+        a.y = ((float)d[1] - m4) / s4;
+        a.z = ((float)d[2] - m5) / s5;
+        dst = reinterpret_cast<float4*>(x + gstride + i * 8);
+        dst[0] = a;
+        dst[1] = c;
+    }
+}
+
+int launch_preprocess(const uint8_t* rgb, const uint8_t* depth, const float* offs, float* x, int B, int Bcap,
+                      int H, int W, const float* mean6, const float* std6, int, int, hipStream_t st) {
+    const long total = (long)B * H * W;
+    hipLaunchKernelGGL(preprocess_kernel, dim3(cap_grid(total, 256)), dim3(256), 0, st, rgb, depth, offs, x, B,
+                       (long)Bcap * H * W * 8, H * W, mean6[0], mean6[1], mean6[2], mean6[3], mean6[4], mean6[5],
+                       std6[0], std6[1], std6[2], std6[3], std6[4], std6[5]);
+    QB_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void maxpool_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C4,
+                               int in_cs, int OH, int OW, int out_cs, long in_gs, long out_gs) {
+    in += blockIdx.y * in_gs;
+    out += blockIdx.y * out_gs;
+    const long total = (long)B * OH * OW * C4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = i % C4;
+        long pix = i / C4;
+        const int ox = pix % OW;
+        pix /= OW;
+        const int oy = pix % OH;
+        const int b = pix / OH;
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = oy * 2 - 1 + dy;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ix = ox * 2 - 1 + dx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const float4 v = *reinterpret_cast<const float4*>(in + ((long)(b * H + iy) * W + ix) * in_cs + c4 * 4);
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        *reinterpret_cast<float4*>(out + ((long)(b * OH + oy) * OW + ox) * out_cs + c4 * 4) = m;
+    }
+}
+
+int launch_maxpool3x3s2(const View& in, const View& out, int B, int G, hipStream_t st) {
+    const long total = (long)B * out.H * out.W * (in.C / 4);
+    hipLaunchKernelGGL(maxpool_kernel, dim3(cap_grid(total, 256), G), dim3(256), 0, st, in.p, out.p, B, in.H, in.W,
+                       in.C / 4, in.cs, out.H, out.W, out.cs, in.gs, out.gs);
+    QB_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm statistics: sum and sum of squares per (group-of-launch g, sample b, norm group), in fp64.
+// grid = (chunks, B, G); every block streams a contiguous run of pixels with float4 loads.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ in, int HW, int C, int cs, long gs,
+                                                       long bstride, int groups, int ppb, double* __restrict__ stats,
+                                                       int B) {
+    __shared__ double acc[64 * 2];
+    const int t = threadIdx.x;
+    if (t < 128) acc[t] = 0.0;
+    __syncthreads();
+    const int b = blockIdx.y, g = blockIdx.z;
+    const float* base = in + g * gs + b * bstride;
+    const int C4 = C >> 2;
+    const int cpg = C / groups;
+    const int p0 = blockIdx.x * ppb;
+    const int p1 = min(HW, p0 + ppb);
+    // column passes keep the norm group of a thread fixed inside a pass
+    const int colsper = min(C4, 256);
+    const int rows = 256 / colsper;
+    const int col = t % colsper, row = t / colsper;
+    for (int cp = 0; cp < C4; cp += colsper) {
+        const int c4 = cp + col;
+        if (row >= rows || c4 >= C4) continue;   // idle lanes when 256 is not a multiple of the row width
+        double s = 0.0, ss = 0.0;
+        for (int pix = p0 + row; pix < p1; pix += rows) {
+            const float4 v = *reinterpret_cast<const float4*>(base + (long)pix * cs + c4 * 4);
+            if (cpg >= 4) {
+                s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+                ss += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+            } else {
+                // cpg in {1,2}: a float4 spans several norm groups
+                const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int grp = (c4 * 4 + j) / cpg;
+                    atomicAdd(&acc[grp * 2], (double)e[j]);
+                    atomicAdd(&acc[grp * 2 + 1], (double)e[j] * e[j]);
+                }
+            }
+        }
+        if (cpg >= 4) {
+            const int grp = (c4 * 4) / cpg;
+            atomicAdd(&acc[grp * 2], s);
+            atomicAdd(&acc[grp * 2 + 1], ss);
+        }
+    }
+    __syncthreads();
+    if (t < groups * 2) atomicAdd(&stats[((long)(g * B + b) * groups) * 2 + t], acc[t]);
+}
+
+int launch_gn_stats(const View& in, int B, int G, int groups, double* stats, hipStream_t st) {
+    if (groups > 64 || in.C % groups || in.C % 4) return fail("groupnorm: unsupported channel/group count");
+    const int HW = in.H * in.W;
+    QB_CHECK(hipMemsetAsync(stats, 0, sizeof(double) * 2 * groups * B * G, st));
+    int ppb = 65536 / in.C;
+    if (ppb < 8) ppb = 8;
+    const int chunks = (HW + ppb - 1) / ppb;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks, B, G), dim3(256), 0, st, in.p, HW, in.C, in.cs, in.gs,
+                       (long)HW * in.cs, groups, ppb, stats, B);
+    QB_CHECK(hipGetLastError());
+    return 0;
+}
+
+// y = relu(x*scale + bias), scale = rstd*gamma, bias = beta - mean*scale  (torch's GroupNorm CPU form)
+__global__ void gn_apply_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int HW, int C, int in_cs,
+                                int out_cs, long in_gs, long out_gs, int groups, const double* __restrict__ stats,
+                                const float* __restrict__ gamma, const float* __restrict__ beta, int param_gs,
+                                float eps, int relu) {
+    const int g = blockIdx.y;
+    in += g * in_gs;
+    out += g * out_gs;
+    gamma += g * param_gs;
+    beta += g * param_gs;
+    const int C4 = C >> 2, cpg = C / groups;
+    const double n = (double)HW * cpg;
+    const long total = (long)B * HW * C4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = i % C4;
+        const long pix = i / C4;
+        const int b = pix / HW;
+        const float4 v = *reinterpret_cast<const float4*>(in + pix * in_cs + c4 * 4);
+        const float e[4] = {v.x, v.y, v.z, v.w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c4 * 4 + j;
+            const double* s = stats + ((long)(g * B + b) * groups + c / cpg) * 2;
+            const double mean = s[0] / n;
+            double var = s[1] / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+            const float sc = rstd * gamma[c];
+            const float bi = beta[c] - (float)mean * sc;
+            float y = fmaf(e[j], sc, bi);
+            if (relu) y = fmaxf(y, 0.f);
+            o[j] = y;
+        }
+        *reinterpret_cast<float4*>(out + pix * out_cs + c4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+int launch_gn_apply(const View& in, const View& out, int B, int G, int groups, const double* stats,
+                    const float* gamma, const float* beta, int param_gs, float eps, int relu, hipStream_t st) {
+    const int HW = in.H * in.W;
+    const long total = (long)B * HW * (in.C / 4);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(cap_grid(total, 256), G), dim3(256), 0, st, in.p, out.p, B, HW, in.C,
+                       in.cs, out.cs, in.gs, out.gs, groups, stats, gamma, beta, param_gs, eps, relu);
+    QB_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// torch's area_pixel_compute_source_index (align_corners=False): src = max(scale*(dst+0.5)-0.5, 0)
+__device__ inline void bilin_src(int o, float scale, int in_size, int& i0, int& i1, float& l1) {
+    float s = scale * ((float)o + 0.5f) - 0.5f;
+    if (s < 0.f) s = 0.f;
+    i0 = (int)s;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+}
+
+__global__ void bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C4,
+                                int in_cs, int OH, int OW, int out_cs, float sy, float sx) {
+    const long total = (long)B * OH * OW * C4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = i % C4;
+        long pix = i / C4;
+        const int ox = pix % OW;
+        pix /= OW;
+        const int oy = pix % OH;
+        const int b = pix / OH;
+        int y0, y1, x0, x1;
+        float ly, lx;
+        bilin_src(oy, sy, H, y0, y1, ly);
+        bilin_src(ox, sx, W, x0, x1, lx);
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const float* base = in + (long)b * H * W * in_cs + c4 * 4;
+        const float4 v00 = *reinterpret_cast<const float4*>(base + ((long)y0 * W + x0) * in_cs);
+        const float4 v01 = *reinterpret_cast<const float4*>(base + ((long)y0 * W + x1) * in_cs);
+        const float4 v10 = *reinterpret_cast<const float4*>(base + ((long)y1 * W + x0) * in_cs);
+        const float4 v11 = *reinterpret_cast<const float4*>(base + ((long)y1 * W + x1) * in_cs);
+        float4 r;
+        r.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+        r.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+        r.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+        r.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+        *reinterpret_cast<float4*>(out + ((long)(b * OH + oy) * OW + ox) * out_cs + c4 * 4) = r;
+    }
+}
+
+int launch_bilinear(const View& in, const View& out, int B, hipStream_t st) {
+    const long total = (long)B * out.H * out.W * (in.C / 4);
+    hipLaunchKernelGGL(bilinear_kernel, dim3(cap_grid(total, 256)), dim3(256), 0, st, in.p, out.p, B, in.H, in.W,
+                       in.C / 4, in.cs, out.H, out.W, out.cs, (float)in.H / (float)out.H, (float)in.W / (float)out.W);
+    QB_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// global average pool: grid (C/64, B); 256 threads = 64 channels x 4 pixel lanes
+__global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ in, float* __restrict__ out, int HW,
+                                                      int C, int in_cs, int out_cs) {
+    __shared__ double part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int lane = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    double s = 0.0;
+    if (c < C)
+        for (int p = lane; p < HW; p += 4) s += (double)in[((long)b * HW + p) * in_cs + c];
+    part[lane][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (lane == 0 && c < C) {
+        s = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        out[(long)b * out_cs + c] = (float)(s / (double)HW);
+    }
+}
+
+int launch_avgpool(const View& in, const View& out, int B, hipStream_t st) {
+    hipLaunchKernelGGL(avgpool_kernel, dim3((in.C + 63) / 64, B), dim3(256), 0, st, in.p, out.p, in.H * in.W, in.C,
+                       in.cs, out.cs);
+    QB_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 1x1 predictor on the 32-channel head features -> planar quarter-resolution logits q[B][q_nch][h*w],
+// optionally also softmax over its `cout` classes into an NHWC channel slice (the 'pred' fusion target).
+template <int CIN>
+__global__ void predictor_kernel(const float* __restrict__ in, int in_cs, const float* __restrict__ w,
+                                 const float* __restrict__ bias, int cout, float* __restrict__ q, int q_ch0,
+                                 int q_nch, float* __restrict__ sm, int sm_cs, int B, int HW) {
+    __shared__ float ws[4 * CIN + 4];
+    for (int i = threadIdx.x; i < cout * CIN; i += blockDim.x) ws[i] = w[i];
+    if (threadIdx.x < cout) ws[4 * CIN + threadIdx.x] = bias[threadIdx.x];
+    __syncthreads();
+    const long total = (long)B * HW;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        float x[CIN];
+        const float4* src = reinterpret_cast<const float4*>(in + i * in_cs);
+#pragma unroll
+        for (int j = 0; j < CIN / 4; ++j) {
+            const float4 v = src[j];
+            x[4 * j] = v.x; x[4 * j + 1] = v.y; x[4 * j + 2] = v.z; x[4 * j + 3] = v.w;
+        }
+        const long b = i / HW, pix = i - b * HW;
+        float o[4];
+        for (int k = 0; k < cout; ++k) {
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < CIN; ++j) a = fmaf(x[j], ws[k * CIN + j], a);
+            a += ws[4 * CIN + k];
+            o[k] = a;
+            q[((long)b * q_nch + q_ch0 + k) * HW + pix] = a;
+        }
+        if (sm) {
+            float mx = o[0];
+            for (int k = 1; k < cout; ++k) mx = fmaxf(mx, o[k]);
+            float e[4], s = 0.f;
+            for (int k = 0; k < cout; ++k) { e[k] = expf(o[k] - mx); s += e[k]; }
+            for (int k = 0; k < cout; ++k) sm[i * sm_cs + k] = e[k] / s;
+        }
+    }
+}
+
+int launch_predictor(const View& in, const float* w, const float* bias, int cout, float* q, int q_ch0, int q_nch,
+                     float* softmax_dst, int softmax_cs, int B, hipStream_t st) {
+    if (in.C != 32 || cout > 4) return fail("predictor: expects 32 input channels and <= 4 outputs");
+    const long total = (long)B * in.H * in.W;
+    hipLaunchKernelGGL(predictor_kernel<32>, dim3(cap_grid(total, 256)), dim3(256), 0, st, in.p, in.cs, w, bias, cout,
+                       q, q_ch0, q_nch, softmax_dst, softmax_cs, B, in.H * in.W);
+    QB_CHECK(hipGetLastError());
+    return 0;
+}
+
+// planar bilinear x`scale` of the predictor logits; channels whose bit is set in mul_mask are multiplied by
+// `scale` afterwards (the offset maps, model.py:695-700)
+__global__ void upsample_logits_kernel(const float* __restrict__ q, float* __restrict__ out, int planes, int h, int w,
+                                       int nch, int scale, unsigned mul_mask) {
+    const int OH = h * scale, OW = w * scale;
+    const float inv = 1.f / (float)scale;
+    const long total = (long)planes * OH * OW;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ox = i % OW;
+        long r = i / OW;
+        const int oy = r % OH;
+        const long pl = r / OH;
+        int y0, y1, x0, x1;
+        float ly, lx;
+        bilin_src(oy, inv, h, y0, y1, ly);
+        bilin_src(ox, inv, w, x0, x1, lx);
+        const float* s = q + pl * h * w;
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        float v = hy * (hx * s[y0 * w + x0] + lx * s[y0 * w + x1]) + ly * (hx * s[y1 * w + x0] + lx * s[y1 * w + x1]);
+        if ((mul_mask >> (pl % nch)) & 1u) v *= (float)scale;
+        out[i] = v;
+    }
+}
+
+int launch_upsample_logits(const float* q, float* out, int B, int nch, int h, int w, int scale, unsigned mul_mask,
+                           hipStream_t st) {
+    const long total = (long)B * nch * h * w * scale * scale;
+    hipLaunchKernelGGL(upsample_logits_kernel, dim3(cap_grid(total, 256)), dim3(256), 0, st, q, out, B * nch, h, w,
+                       nch, scale, mul_mask);
+    QB_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace quber

@@ -1,0 +1,655 @@
+// Context, weight ingestion, the network launch plan and the C ABI of libquber_hip.so.
+//
+// The plan is the MI355X-side equivalent of detectron2's build_model(cfg) for the QuBER refiner:
+// it walks the same module tree as
+//   maskrefiner/modeling/backbone/resnet.py:358-519   (two ResNet-DeepLab streams + concat fusion)
+//   [d2] DeepLabV3PlusHead / ASPP                      (decoder)
+//   maskrefiner/modeling/mask_refiner/model.py:711-764 (hierarchical boundary-error -> fg/centre/offset heads)
+// but emits a flat list of kernel launches over NHWC buffers.  Design points:
+//   * the rgb and depth streams run as ONE grouped launch per layer (blockIdx.z selects the stream),
+//     as do the three second-level prediction heads;
+//   * every torch.cat of the reference is free: producers write straight into a channel slice of
+//     the concatenated buffer (stream outputs, ASPP branches, decoder skip joins, the 164-channel
+//     y | feat_b | softmax(pred_b) fusion input);
+//   * FrozenBN / eval-BN / bias are folded into the convolution epilogue's per-channel affine;
+//   * the head-fusion stack the reference evaluates three times (model.py:760-762) is evaluated once.
+#include <math.h>
+#include <string.h>
+
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/quber_hip.h"
+#include "common.h"
+
+namespace quber {
+
+static thread_local std::string g_err;
+void set_error(const std::string& m) { g_err = m; }
+int fail(const std::string& m) {
+    g_err = m;
+    return -1;
+}
+
+}  // namespace quber
+
+using namespace quber;
+
+struct quber_ctx {
+    quber_config cfg;
+    std::map<std::string, std::vector<float>> hostw;
+    std::vector<std::pair<std::string, int64_t>> specs;
+    std::vector<void*> allocs;
+    std::vector<std::function<int(int, hipStream_t)>> ops;
+    std::map<std::string, View> taps;
+    float* gauss = nullptr;
+    void* enc_ws = nullptr;
+    uint8_t* err_ws = nullptr;
+    void* post_ws = nullptr;
+    double* gn_stats = nullptr;
+    float* X = nullptr;   // [2][Bmax][H][W][8]
+    float* q = nullptr;   // [Bmax][planes][H/4][W/4]
+    const uint8_t* cur_bgr = nullptr;
+    const uint8_t* cur_depth = nullptr;
+    const float* cur_off = nullptr;
+    float* cur_out = nullptr;
+    double flops = 0.0;
+    bool finalized = false;
+    int device = 0;
+};
+
+namespace {
+
+constexpr int BLOCKS50[4] = {3, 4, 6, 3}, BLOCKS101[4] = {3, 4, 23, 3}, BLOCKS152[4] = {3, 8, 36, 3};
+
+enum Affine { AF_NONE, AF_FROZEN_BN, AF_BIAS, AF_BIAS_BN };
+
+struct Builder {
+    quber_ctx* c;
+    bool dry;
+    std::string err;
+    int Bmax, H, W;
+
+    Builder(quber_ctx* ctx, bool d) : c(ctx), dry(d), Bmax(ctx->cfg.max_batch), H(ctx->cfg.height), W(ctx->cfg.width) {}
+
+    // ---- host weights ----
+    const float* hw(const std::string& name, int64_t numel) {
+        if (dry) {
+            c->specs.emplace_back(name, numel);
+            return nullptr;
+        }
+        auto it = c->hostw.find(name);
+        if (it == c->hostw.end()) {
+            if (err.empty()) err = "missing weight '" + name + "'";
+            return nullptr;
+        }
+        if ((int64_t)it->second.size() != numel) {
+            if (err.empty())
+                err = "weight '" + name + "' has " + std::to_string(it->second.size()) + " elements, expected " +
+                      std::to_string(numel);
+            return nullptr;
+        }
+        return it->second.data();
+    }
+
+    // ---- device memory ----
+    void* dalloc_bytes(size_t bytes) {
+        if (dry) return nullptr;
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) {
+            if (err.empty()) err = "hipMalloc of " + std::to_string(bytes) + " bytes failed";
+            return nullptr;
+        }
+        hipMemset(p, 0, bytes ? bytes : 16);
+        c->allocs.push_back(p);
+        return p;
+    }
+    float* upload(const std::vector<float>& v) {
+        float* d = (float*)dalloc_bytes(v.size() * sizeof(float));
+        if (d) hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice);
+        return d;
+    }
+    View make(int C, int h, int w, int G = 1) {
+        View v;
+        v.B = Bmax; v.H = h; v.W = w; v.C = C; v.cs = C;
+        v.gs = (long)Bmax * h * w * C;
+        v.p = (float*)dalloc_bytes(sizeof(float) * (size_t)v.gs * G);
+        return v;
+    }
+    static View slice(View v, int coff, int C, long gs = -1) {
+        if (v.p) v.p += coff;
+        v.C = C;
+        if (gs >= 0) v.gs = gs;
+        return v;
+    }
+
+    // ---- ops ----
+    // `names`: one conv key prefix per group (e.g. "backbone.rgb_backbone.stem.conv1")
+    void conv(const std::vector<std::string>& names, const View& in, int cin_real, const View& out, int k, int stride,
+              int pad, int dil, Affine af, const View* res, bool relu) {
+        const int G = (int)names.size();
+        const int Cin = in.C, Cout = out.C;
+        const int K = k * k * Cin, Kpad = (K + 31) / 32 * 32;
+        std::vector<float> packed, scale, shift;
+        if (!dry) {
+            packed.assign((size_t)G * Cout * Kpad, 0.f);
+            scale.assign((size_t)G * Cout, 1.f);
+            shift.assign((size_t)G * Cout, 0.f);
+        }
+        for (int g = 0; g < G; ++g) {
+            const std::string& n = names[g];
+            const float* w = hw(n + ".weight", (int64_t)Cout * cin_real * k * k);
+            const float *bias = nullptr, *bw = nullptr, *bb = nullptr, *bm = nullptr, *bv = nullptr;
+            if (af == AF_BIAS || af == AF_BIAS_BN) bias = hw(n + ".bias", Cout);
+            if (af == AF_FROZEN_BN || af == AF_BIAS_BN) {
+                bw = hw(n + ".norm.weight", Cout);
+                bb = hw(n + ".norm.bias", Cout);
+                bm = hw(n + ".norm.running_mean", Cout);
+                bv = hw(n + ".norm.running_var", Cout);
+            }
+            if (dry || !w) continue;
+            for (int o = 0; o < Cout; ++o) {
+                float* dst = &packed[((size_t)g * Cout + o) * Kpad];
+                for (int ci = 0; ci < cin_real; ++ci)
+                    for (int t = 0; t < k * k; ++t) dst[t * Cin + ci] = w[((size_t)o * cin_real + ci) * k * k + t];
+                float sc = 1.f, sh = 0.f;
+                if (af == AF_FROZEN_BN || af == AF_BIAS_BN) {
+                    if (!bw || !bb || !bm || !bv) continue;
+                    sc = bw[o] * (1.0f / sqrtf(bv[o] + 1e-5f));
+                    sh = bb[o] - bm[o] * sc;
+                    if (af == AF_BIAS_BN && bias) sh = fmaf(bias[o], sc, sh);
+                } else if (af == AF_BIAS && bias) {
+                    sh = bias[o];
+                }
+                scale[(size_t)g * Cout + o] = sc;
+                shift[(size_t)g * Cout + o] = sh;
+            }
+        }
+        const int OH = (in.H + 2 * pad - dil * (k - 1) - 1) / stride + 1;
+        const int OW = (in.W + 2 * pad - dil * (k - 1) - 1) / stride + 1;
+        if (!dry) c->flops += 2.0 * OH * OW * (double)cin_real * k * k * Cout * G;
+        if (dry) return;
+        if (OH != out.H || OW != out.W) {
+            if (err.empty()) err = "internal: conv output geometry mismatch at " + names[0];
+            return;
+        }
+        ConvP p{};
+        p.in = in.p; p.w = upload(packed);
+        p.scale = af == AF_NONE ? nullptr : upload(scale);
+        p.shift = af == AF_NONE ? nullptr : upload(shift);
+        p.res = res ? res->p : nullptr;
+        p.out = out.p;
+        p.H = in.H; p.W = in.W; p.Cin = Cin; p.in_cs = in.cs;
+        p.OH = OH; p.OW = OW; p.Cout = Cout; p.out_cs = out.cs;
+        p.res_cs = res ? res->cs : 0;
+        p.K = K; p.Kpad = Kpad;
+        p.kh = k; p.kw = k; p.stride = stride; p.pad = pad; p.dil = dil;
+        p.relu = relu;
+        p.in_gs = in.gs; p.out_gs = out.gs; p.res_gs = res ? res->gs : 0;
+        p.w_gs = (long)Cout * Kpad; p.ss_gs = Cout;
+        c->ops.push_back([p, G](int B, hipStream_t st) mutable {
+            p.B = B;
+            p.M = B * p.OH * p.OW;
+            return launch_conv(p, G, st);
+        });
+    }
+
+    // GroupNorm(32) + ReLU from `in` into `out` (possibly a concat slice); names = norm key prefixes per group
+    void gn_relu(const std::vector<std::string>& names, const View& in, const View& out) {
+        const int G = (int)names.size(), C = in.C;
+        std::vector<float> gamma, beta;
+        for (int g = 0; g < G; ++g) {
+            const float* w = hw(names[g] + ".weight", C);
+            const float* b = hw(names[g] + ".bias", C);
+            if (dry || !w || !b) continue;
+            gamma.insert(gamma.end(), w, w + C);
+            beta.insert(beta.end(), b, b + C);
+        }
+        if (dry) return;
+        const float* dg = upload(gamma);
+        const float* db = upload(beta);
+        double* stats = c->gn_stats;
+        c->ops.push_back([=](int B, hipStream_t st) {
+            int rc = launch_gn_stats(in, B, G, 32, stats, st);
+            if (rc) return rc;
+            return launch_gn_apply(in, out, B, G, 32, stats, dg, db, C, 1e-5f, 1, st);
+        });
+    }
+
+    void op(std::function<int(int, hipStream_t)> f) {
+        if (!dry) c->ops.push_back(std::move(f));
+    }
+
+    // conv (no bias) -> GN -> ReLU, the [d2] Conv2d(norm=GN, activation=relu) pattern
+    void conv_gn(const std::string& n, const View& in, const View& tmp, const View& out, int k, int dil) {
+        conv({n}, in, in.C, tmp, k, 1, k == 3 ? dil : 0, dil, AF_NONE, nullptr, false);
+        gn_relu({n + ".norm"}, tmp, out);
+    }
+
+    void build() {
+        const quber_config& cf = c->cfg;
+        const int* nb = cf.resnet_depth == 50 ? BLOCKS50 : cf.resnet_depth == 101 ? BLOCKS101 : BLOCKS152;
+        const int h2 = H / 2, w2 = W / 2, h4 = H / 4, w4 = W / 4, h8 = H / 8, w8 = W / 8, h16 = H / 16, w16 = W / 16;
+        const std::string R = "backbone.rgb_backbone.", D = "backbone.depth_backbone.";
+        auto two = [&](const std::string& tail, bool stage_prefix) -> std::vector<std::string> {
+            return {R + tail, D + (stage_prefix ? "depth_" : "") + tail};
+        };
+        if (!dry) c->gn_stats = (double*)dalloc_bytes(sizeof(double) * 2 * 64 * Bmax * 4);
+
+        // ---------------- input + stems (both streams as G = 2) ----------------
+        View X = make(8, H, W, 2);
+        if (!dry) c->X = X.p;
+        View s1 = make(32, h2, w2, 2), s2 = make(32, h2, w2, 2), s3 = make(64, h2, w2, 2);
+        conv(two("stem.conv1", false), X, 6, s1, 3, 2, 1, 1, AF_FROZEN_BN, nullptr, true);
+        conv(two("stem.conv2", false), s1, 32, s2, 3, 1, 1, 1, AF_FROZEN_BN, nullptr, true);
+        conv(two("stem.conv3", false), s2, 32, s3, 3, 1, 1, 1, AF_FROZEN_BN, nullptr, true);
+        View x = make(64, h4, w4, 2);
+        op([=](int B, hipStream_t st) { return launch_maxpool3x3s2(s3, x, B, 2, st); });
+
+        // ---------------- res2..res5 ----------------
+        View cat[4];  // concatenated [rgb | depth] stage outputs
+        int cin = 64, cout = 256, mid = 64, ch = h4, cw = w4;
+        for (int s = 0; s < 4; ++s) {
+            const int stage = s + 2;
+            const int sdil = stage == 5 ? cf.res5_dilation : 1;
+            const int first = (s == 0 || sdil > 1) ? 1 : 2;
+            const int oh = ch / first, ow = cw / first;
+            View t1 = make(mid, oh, ow, 2), t2 = make(mid, oh, ow, 2), sc = make(cout, oh, ow, 2);
+            View oa = make(cout, oh, ow, 2), ob = make(cout, oh, ow, 2);
+            const bool tapped = stage != 4;
+            if (tapped) {
+                View cb = make(2 * cout, oh, ow, 1);
+                cat[s] = cb;
+            }
+            static const int mg[3] = {1, 2, 4};
+            for (int i = 0; i < nb[s]; ++i) {
+                const int stride = i == 0 ? first : 1;
+                const int dil = stage == 5 ? sdil * mg[i % 3] : 1;
+                const std::string tail = "res" + std::to_string(stage) + "." + std::to_string(i) + ".";
+                const bool last = i == nb[s] - 1;
+                View out = (last && tapped) ? slice(cat[s], 0, cout, cout) : ((i & 1) ? ob : oa);
+                conv(two(tail + "conv1", true), x, cin, t1, 1, stride, 0, 1, AF_FROZEN_BN, nullptr, true);
+                conv(two(tail + "conv2", true), t1, mid, t2, 3, 1, dil, dil, AF_FROZEN_BN, nullptr, true);
+                View resv = x;
+                if (cin != cout) {
+                    conv(two(tail + "shortcut", true), x, cin, sc, 1, stride, 0, 1, AF_FROZEN_BN, nullptr, false);
+                    resv = sc;
+                }
+                conv(two(tail + "conv3", true), t2, mid, out, 1, 1, 0, 1, AF_FROZEN_BN, &resv, true);
+                x = out;
+                cin = cout;
+            }
+            ch = oh; cw = ow;
+            cout *= 2; mid *= 2;
+        }
+
+        // ---------------- backbone fusion (resnet.py:472-485) ----------------
+        View F[4];
+        const int fch[4] = {256, 512, 1024, 2048};
+        for (int s : {0, 1, 3}) {
+            const std::string n = "backbone.fusion_res" + std::to_string(s + 2) + ".";
+            const int C = fch[s], fh = cat[s].H, fw = cat[s].W;
+            View t = make(C, fh, fw), a = make(C, fh, fw);
+            conv({n + "conv"}, cat[s], 2 * C, t, 1, 1, 0, 1, AF_BIAS, nullptr, false);
+            gn_relu({n + "gn"}, t, a);
+            if (s != 3) {
+                View b2 = make(C, fh, fw);
+                View cur = a, nxt = b2;
+                for (int i = 0; i < cf.backbone_fusion_layers; ++i) {
+                    conv({n + "conv" + std::to_string(i)}, cur, C, t, 3, 1, 1, 1, AF_BIAS, nullptr, false);
+                    gn_relu({n + "gn" + std::to_string(i)}, t, nxt);
+                    std::swap(cur, nxt);
+                }
+                a = cur;
+            }
+            F[s] = a;
+            if (!dry) c->taps["res" + std::to_string(s + 2)] = a;
+        }
+        (void)h8; (void)w8;
+
+        // ---------------- decoder ([d2] DeepLabV3PlusHead.layers) ----------------
+        const std::string Hd = "ins_embed_head.";
+        const std::string A = Hd + "decoder.res5.project_conv.";
+        View catA = make(1280, h16, w16), tA = make(256, h16, w16);
+        conv_gn(A + "convs.0", F[3], tA, slice(catA, 0, 256), 1, 1);
+        const int adil[3] = {6, 12, 18};
+        for (int i = 0; i < 3; ++i) conv_gn(A + "convs." + std::to_string(i + 1), F[3], tA, slice(catA, 256 * (i + 1), 256), 3, adil[i]);
+        {
+            View pooled = make(2048, 1, 1), pc = make(256, 1, 1);
+            View f5 = F[3];
+            op([=](int B, hipStream_t st) { return launch_avgpool(f5, pooled, B, st); });
+            conv({A + "convs.4.1"}, pooled, 2048, pc, 1, 1, 0, 1, AF_BIAS, nullptr, true);
+            View dst = slice(catA, 1024, 256);
+            op([=](int B, hipStream_t st) { return launch_bilinear(pc, dst, B, st); });
+        }
+        View y5 = make(256, h16, w16);
+        conv_gn(A + "project", catA, tA, y5, 1, 1);
+
+        View cat3 = make(64 + 256, F[1].H, F[1].W), t64 = make(64, F[1].H, F[1].W), t128a = make(128, F[1].H, F[1].W);
+        conv_gn(Hd + "decoder.res3.project_conv", F[1], t64, slice(cat3, 0, 64), 1, 1);
+        {
+            View dst = slice(cat3, 64, 256);
+            op([=](int B, hipStream_t st) { return launch_bilinear(y5, dst, B, st); });
+        }
+        View u3 = make(128, F[1].H, F[1].W), y3 = make(128, F[1].H, F[1].W);
+        conv_gn(Hd + "decoder.res3.fuse_conv.0", cat3, t128a, u3, 3, 1);
+        conv_gn(Hd + "decoder.res3.fuse_conv.1", u3, t128a, y3, 3, 1);
+
+        const int ncls = cf.error_classes;
+        const int ypc = 128 + 32 + ncls;
+        View cat2 = make(32 + 128, h4, w4), t32 = make(32, h4, w4), t128 = make(128, h4, w4);
+        View YP = make(ypc, h4, w4);
+        conv_gn(Hd + "decoder.res2.project_conv", F[0], t32, slice(cat2, 0, 32), 1, 1);
+        {
+            View dst = slice(cat2, 32, 128);
+            op([=](int B, hipStream_t st) { return launch_bilinear(y3, dst, B, st); });
+        }
+        View u2 = make(128, h4, w4);
+        conv_gn(Hd + "decoder.res2.fuse_conv.0", cat2, t128, u2, 3, 1);
+        View y = slice(YP, 0, 128);
+        conv_gn(Hd + "decoder.res2.fuse_conv.1", u2, t128, y, 3, 1);
+        if (!dry) c->taps["y"] = y;
+
+        // ---------------- level 0: boundary-error head (model.py:743-747) ----------------
+        const int planes = QUBER_LOGIT_BASE + ncls;
+        if (!dry) c->q = (float*)dalloc_bytes(sizeof(float) * (size_t)Bmax * planes * h4 * w4);
+        float* q = c->q;
+        View hb = make(128, h4, w4), featb = slice(YP, 128, 32);
+        conv_gn(Hd + "eee_boundary_pred_head.head.0", y, t128, hb, 3, 1);
+        conv_gn(Hd + "eee_boundary_pred_head.head.1", hb, t32, featb, 3, 1);
+        {
+            const float* pw = hw(Hd + "eee_boundary_predictor.predictor.weight", (int64_t)ncls * 32);
+            const float* pb = hw(Hd + "eee_boundary_predictor.predictor.bias", ncls);
+            if (!dry && pw && pb) {
+                const float* dw = upload(std::vector<float>(pw, pw + ncls * 32));
+                const float* db = upload(std::vector<float>(pb, pb + ncls));
+                float* sm = YP.p + 160;
+                op([=](int B, hipStream_t st) {
+                    return launch_predictor(featb, dw, db, ncls, q, QUBER_LOGIT_BASE, planes, sm, ypc, B, st);
+                });
+            }
+            if (!dry) c->taps["feat_b"] = featb;
+        }
+
+        // ---------------- head fusion (model.py:424-458), evaluated once ----------------
+        const std::string FL = Hd + "fusion_layers_1.fusion_layers.";
+        View za = make(128, h4, w4), zb = make(128, h4, w4);
+        conv({FL + "0"}, YP, ypc, za, 1, 1, 0, 1, AF_BIAS_BN, nullptr, true);
+        View cur = za, nxt = zb;
+        for (int i = 0; i < cf.head_fusion_layers; ++i) {
+            conv({FL + std::to_string(i + 1)}, cur, 128, nxt, 3, 1, 1, 1, AF_BIAS_BN, nullptr, true);
+            std::swap(cur, nxt);
+        }
+        View z = cur;
+        if (!dry) c->taps["z"] = z;
+
+        // ---------------- level 1: foreground / centre / offset heads as one grouped launch ----------------
+        const std::vector<std::string> keys = {"foreground", "center", "offset"};
+        std::vector<std::string> h0, h1, n0, n1;
+        for (auto& k : keys) {
+            h0.push_back(Hd + k + "_pred_head.head.0");
+            h1.push_back(Hd + k + "_pred_head.head.1");
+            n0.push_back(h0.back() + ".norm");
+            n1.push_back(h1.back() + ".norm");
+        }
+        View g128 = make(128, h4, w4, 3), g128n = make(128, h4, w4, 3), g32 = make(32, h4, w4, 3), g32n = make(32, h4, w4, 3);
+        View zin = z;
+        zin.gs = 0;  // all three heads read the same fused features
+        conv(h0, zin, 128, g128, 3, 1, 1, 1, AF_NONE, nullptr, false);
+        gn_relu(n0, g128, g128n);
+        conv(h1, g128n, 128, g32, 3, 1, 1, 1, AF_NONE, nullptr, false);
+        gn_relu(n1, g32, g32n);
+        const int pch0[3] = {0, 1, 2}, pn[3] = {1, 1, 2};
+        for (int k = 0; k < 3; ++k) {
+            const float* pw = hw(Hd + keys[k] + "_predictor.predictor.weight", (int64_t)pn[k] * 32);
+            const float* pb = hw(Hd + keys[k] + "_predictor.predictor.bias", pn[k]);
+            if (dry || !pw || !pb) continue;
+            const float* dw = upload(std::vector<float>(pw, pw + pn[k] * 32));
+            const float* db = upload(std::vector<float>(pb, pb + pn[k]));
+            View in = g32n;
+            if (in.p) in.p += (long)k * g32n.gs;
+            const int ch0 = pch0[k], nn = pn[k];
+            op([=](int B, hipStream_t st) { return launch_predictor(in, dw, db, nn, q, ch0, planes, nullptr, 0, B, st); });
+        }
+        // x4 bilinear of every plane, offsets scaled by the stride (model.py:689-708)
+        quber_ctx* ctx = c;
+        const int cs = 4;
+        op([=](int B, hipStream_t st) {
+            return launch_upsample_logits(q, ctx->cur_out, B, planes, h4, w4, cs, 0xCu, st);
+        });
+    }
+};
+
+int check_cfg(const quber_config& c) {
+    if (c.height <= 0 || c.width <= 0 || c.height % 16 || c.width % 16) return fail("height/width must be positive multiples of 16");
+    if (c.max_batch < 1) return fail("max_batch must be >= 1");
+    if (c.max_instances < 1 || c.max_instances > 254) return fail("max_instances must be in 1..254");
+    if (c.resnet_depth != 50 && c.resnet_depth != 101 && c.resnet_depth != 152) return fail("resnet_depth must be 50, 101 or 152");
+    if (c.res5_dilation != 1 && c.res5_dilation != 2 && c.res5_dilation != 4) return fail("res5_dilation must be 1, 2 or 4");
+    if (c.res5_dilation == 1) return fail("res5_dilation 1 (output stride 32) is not supported by this build");
+    if (c.error_classes < 2 || c.error_classes > 4) return fail("error_classes must be 2..4");
+    if (c.top_k < 1 || c.top_k > 254) return fail("top_k must be in 1..254");
+    if (c.gaussian_sigma < 1 || c.gaussian_sigma > 40) return fail("gaussian_sigma out of range");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* quber_last_error(void) { return quber::g_err.c_str(); }
+const char* quber_version(void) { return "quber-hip 0.1 (gfx950, fp32 MFMA)"; }
+
+void quber_default_config(quber_config* c) {
+    memset(c, 0, sizeof(*c));
+    c->height = 480; c->width = 640; c->max_batch = 1; c->max_instances = 64;
+    c->resnet_depth = 50; c->res5_dilation = 2; c->backbone_fusion_layers = 2; c->head_fusion_layers = 3;
+    c->error_classes = 4; c->gaussian_sigma = 10; c->nms_kernel = 7; c->top_k = 200; c->stuff_area = 2048;
+    c->min_instance_area = 512; c->label_divisor = 1000; c->with_network = 1;
+    c->center_threshold = 0.3f; c->boundary_ratio = 0.01f;
+    const float mean[6] = {103.53f, 116.28f, 123.675f, 127.5f, 127.5f, 127.5f};
+    for (int i = 0; i < 6; ++i) { c->pixel_mean[i] = mean[i]; c->pixel_std[i] = 1.f; }
+}
+
+int quber_create(const quber_config* cfg, quber_ctx** out) {
+    if (!cfg || !out) return fail("null argument");
+    if (check_cfg(*cfg)) return -1;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device available");
+    quber_ctx* c = new quber_ctx();
+    c->cfg = *cfg;
+    hipGetDevice(&c->device);
+    const int B = cfg->max_batch, H = cfg->height, W = cfg->width;
+    // Gaussian template (predictor.py:246-251): float64 exp rounded to f32
+    const int sg = cfg->gaussian_sigma, side = 6 * sg + 3, c0 = 3 * sg + 1;
+    std::vector<float> g((size_t)side * side);
+    for (int y = 0; y < side; ++y)
+        for (int x = 0; x < side; ++x)
+            g[(size_t)y * side + x] = (float)exp(-((double)((x - c0) * (x - c0)) + (double)((y - c0) * (y - c0))) / (2.0 * sg * sg));
+    Builder b(c, false);
+    c->gauss = b.upload(g);
+    c->enc_ws = b.dalloc_bytes(encode_ws_bytes(B, cfg->max_instances, H, W));
+    c->err_ws = (uint8_t*)b.dalloc_bytes(errmaps_ws_bytes(B, H, W));
+    c->post_ws = b.dalloc_bytes(postprocess_ws_bytes(B, H, W, cfg->top_k));
+    if (!b.err.empty()) {
+        std::string e = b.err;
+        quber_destroy(c);
+        return fail(e);
+    }
+    if (cfg->with_network) {
+        Builder dry(c, true);
+        dry.build();
+    }
+    *out = c;
+    return 0;
+}
+
+void quber_destroy(quber_ctx* c) {
+    if (!c) return;
+    for (void* p : c->allocs) hipFree(p);
+    delete c;
+}
+
+int quber_num_weights(quber_ctx* c) { return c ? (int)c->specs.size() : 0; }
+int quber_weight_spec(quber_ctx* c, int i, const char** name, int64_t* numel) {
+    if (!c || i < 0 || i >= (int)c->specs.size()) return fail("weight index out of range");
+    *name = c->specs[i].first.c_str();
+    *numel = c->specs[i].second;
+    return 0;
+}
+
+int quber_set_weight(quber_ctx* c, const char* name, const float* host, int64_t numel) {
+    if (!c || !name || !host || numel <= 0) return fail("bad argument to quber_set_weight");
+    if (c->finalized) return fail("weights already finalized");
+    c->hostw[name].assign(host, host + numel);
+    return 0;
+}
+
+int quber_finalize_weights(quber_ctx* c) {
+    if (!c) return fail("null context");
+    if (!c->cfg.with_network) return fail("context was created with with_network = 0");
+    if (c->finalized) return fail("weights already finalized");
+    Builder b(c, false);
+    c->flops = 0.0;
+    b.build();
+    if (!b.err.empty()) {
+        c->ops.clear();
+        return fail(b.err);
+    }
+    QB_CHECK(hipDeviceSynchronize());
+    c->hostw.clear();
+    c->finalized = true;
+    return 0;
+}
+
+double quber_forward_flops(quber_ctx* c) { return c ? c->flops : 0.0; }
+
+static int check_batch(quber_ctx* c, int batch) {
+    if (!c) return fail("null context");
+    if (batch < 1 || batch > c->cfg.max_batch) return fail("batch outside 1..max_batch");
+    return 0;
+}
+
+int quber_encode_initial_masks(quber_ctx* c, const uint8_t* masks, int32_t batch, int32_t n, float* out, void* stream) {
+    if (check_batch(c, batch)) return -1;
+    if (n > c->cfg.max_instances) return fail("more initial masks than max_instances");
+    if (!masks && n > 0) return fail("null masks");
+    return launch_encode(masks, batch, n, c->cfg.height, c->cfg.width, c->gauss, c->cfg.gaussian_sigma, c->enc_ws, out,
+                         (hipStream_t)stream);
+}
+
+int quber_explicit_error_maps(quber_ctx* c, const uint8_t* init, int32_t n_init, const uint8_t* gt, int32_t n_gt,
+                              int32_t batch, uint8_t* out, void* stream) {
+    if (check_batch(c, batch)) return -1;
+    const int H = c->cfg.height, W = c->cfg.width;
+    // util.py:80-83: dilation = max(1, int(round(ratio * diag)))   (Python round = half to even)
+    int d = (int)rint((double)c->cfg.boundary_ratio * sqrt((double)H * H + (double)W * W));
+    if (d < 1) d = 1;
+    return launch_errmaps(init, n_init, gt, n_gt, batch, H, W, d, c->err_ws, out, (hipStream_t)stream);
+}
+
+int quber_forward(quber_ctx* c, const uint8_t* bgr, const uint8_t* depth, const float* offs, int32_t batch,
+                  float* logits, void* stream) {
+    if (check_batch(c, batch)) return -1;
+    if (!c->finalized) return fail("quber_forward before quber_finalize_weights");
+    if (!bgr || !depth || !offs || !logits) return fail("null tensor");
+    hipStream_t st = (hipStream_t)stream;
+    c->cur_out = logits;
+    int rc = launch_preprocess(bgr, depth, offs, c->X, batch, c->cfg.max_batch, c->cfg.height, c->cfg.width,
+                               c->cfg.pixel_mean, c->cfg.pixel_std, 1, 1, st);
+    if (rc) return rc;
+    for (auto& op : c->ops) {
+        rc = op(batch, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int quber_postprocess(quber_ctx* c, const float* logits, int32_t n_planes, int32_t batch, float* pan, int32_t* count,
+                      float* labels, float* scores, float* boxes, int32_t* centers, int32_t* ncenters, void* stream) {
+    if (check_batch(c, batch)) return -1;
+    PostCfg pc;
+    pc.threshold = c->cfg.center_threshold; pc.nms_kernel = c->cfg.nms_kernel; pc.top_k = c->cfg.top_k;
+    pc.stuff_area = c->cfg.stuff_area; pc.min_area = c->cfg.min_instance_area; pc.label_divisor = c->cfg.label_divisor;
+    pc.cap = c->cfg.top_k;
+    return launch_postprocess(logits, n_planes, batch, c->cfg.height, c->cfg.width, pc, c->post_ws, pan, count, labels,
+                              scores, boxes, centers, ncenters, (hipStream_t)stream);
+}
+
+int quber_extract_masks(quber_ctx* c, const float* pan, const float* labels, int32_t batch, int32_t max_inst,
+                        uint8_t* masks, void* stream) {
+    if (check_batch(c, batch)) return -1;
+    return launch_extract_masks(pan, labels, batch, c->cfg.height, c->cfg.width, c->cfg.top_k, max_inst, masks,
+                                (hipStream_t)stream);
+}
+
+int quber_debug_tensor(quber_ctx* c, const char* name, float** ptr, int32_t* dims4, int32_t* cs) {
+    if (!c || !name) return fail("null argument");
+    auto it = c->taps.find(name);
+    if (it == c->taps.end()) return fail(std::string("no intermediate named '") + name + "'");
+    *ptr = it->second.p;
+    dims4[0] = it->second.B; dims4[1] = it->second.H; dims4[2] = it->second.W; dims4[3] = it->second.C;
+    *cs = it->second.cs;
+    return 0;
+}
+
+// ---------------- stand-alone ops (tests / micro-benchmarks) ----------------
+__global__ void pack_oihw_kernel(const float* __restrict__ w, int O, int I, int k, int Kpad, float* __restrict__ out) {
+    const long total = (long)O * Kpad;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int o = i / Kpad, kk = i % Kpad;
+        float v = 0.f;
+        if (kk < k * k * I) {
+            const int tap = kk / I, ci = kk % I;
+            v = w[((long)o * I + ci) * k * k + tap];
+        }
+        out[i] = v;
+    }
+}
+
+int quber_op_conv2d(const float* x, int32_t B, int32_t h, int32_t w, int32_t cin, const float* w_oihw, int32_t cout,
+                    int32_t k, int32_t stride, int32_t pad, int32_t dil, const float* scale, const float* shift,
+                    const float* residual, int32_t relu, float* packed, float* y, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int K = k * k * cin, Kpad = (K + 31) / 32 * 32;
+    hipLaunchKernelGGL(pack_oihw_kernel, dim3(256), dim3(256), 0, st, w_oihw, cout, cin, k, Kpad, packed);
+    ConvP p{};
+    p.in = x; p.w = packed; p.scale = scale; p.shift = shift; p.res = residual; p.out = y;
+    p.B = B; p.H = h; p.W = w; p.Cin = cin; p.in_cs = cin;
+    p.OH = (h + 2 * pad - dil * (k - 1) - 1) / stride + 1;
+    p.OW = (w + 2 * pad - dil * (k - 1) - 1) / stride + 1;
+    p.Cout = cout; p.out_cs = cout; p.res_cs = cout; p.K = K; p.Kpad = Kpad;
+    p.kh = k; p.kw = k; p.stride = stride; p.pad = pad; p.dil = dil; p.relu = relu;
+    p.M = B * p.OH * p.OW;
+    p.w_gs = 0; p.ss_gs = 0;
+    return launch_conv(p, 1, st);
+}
+
+static View mkview(const float* p, int B, int h, int w, int c) {
+    View v;
+    v.p = const_cast<float*>(p); v.B = B; v.H = h; v.W = w; v.C = c; v.cs = c; v.gs = 0;
+    return v;
+}
+
+int quber_op_groupnorm(const float* x, int32_t B, int32_t h, int32_t w, int32_t c, int32_t groups, const float* gamma,
+                       const float* beta, float eps, int32_t relu, double* stats, float* y, void* stream) {
+    View in = mkview(x, B, h, w, c), out = mkview(y, B, h, w, c);
+    int rc = launch_gn_stats(in, B, 1, groups, stats, (hipStream_t)stream);
+    if (rc) return rc;
+    return launch_gn_apply(in, out, B, 1, groups, stats, gamma, beta, 0, eps, relu, (hipStream_t)stream);
+}
+
+int quber_op_bilinear(const float* x, int32_t B, int32_t h, int32_t w, int32_t c, int32_t oh, int32_t ow, float* y,
+                      void* stream) {
+    if (c % 4) return fail("bilinear: channels must be a multiple of 4");
+    return launch_bilinear(mkview(x, B, h, w, c), mkview(y, B, oh, ow, c), B, (hipStream_t)stream);
+}
+
+int quber_op_maxpool3x3s2(const float* x, int32_t B, int32_t h, int32_t w, int32_t c, float* y, void* stream) {
+    if (c % 4) return fail("maxpool: channels must be a multiple of 4");
+    return launch_maxpool3x3s2(mkview(x, B, h, w, c), mkview(y, B, (h + 1) / 2, (w + 1) / 2, c), B, 1, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,335 @@
+// Post-processing: head logits -> panoptic label map + per-instance score / box / mask, without
+// host synchronisation (fixed capacity `cap` = TOP_K_INSTANCE = 200 slots per frame).
+// Replaces
+//   maskrefiner/modeling/mask_refiner/post_processing.py:9-41    find_instance_center
+//   maskrefiner/modeling/mask_refiner/post_processing.py:44-76   group_pixels
+//   maskrefiner/modeling/mask_refiner/post_processing.py:110-162 merge_semantic_and_instance
+//   maskrefiner/modeling/mask_refiner/model.py:291-356           sigmoid().round(), instance extraction
+// Bit-exactness notes (all probed against torch CPU):
+//   * sigmoid(x).round() == 1  <=>  x > 1.5 * 2^-24 in correctly rounded fp32 arithmetic,
+//   * torch.norm over the (dy,dx) pair evaluates sqrt(fma(dx, dx, dy*dy)); argmin keeps the first minimum,
+//   * top-k keeps values STRICTLY greater than max(k-th largest, 0): at most k-1 centres, raster order,
+//   * instances smaller than 512 px are dropped before the running relabel 1001, 1002, ...
+#include "common.h"
+
+namespace quber {
+
+constexpr int NT = 32;  // NMS tile
+
+// ---- P1: threshold + (2r+1)^2 max-pool NMS -> candidate map (value or -1) ----
+__global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ logits, int nch, int H, int W, float thr,
+                                                  int r, float* __restrict__ cand) {
+    extern __shared__ float sv[];  // (NT+2r)^2
+    const int b = blockIdx.z;
+    const int P = NT + 2 * r;
+    const float* c = logits + ((long)b * nch + 1) * H * W;
+    const int ty0 = blockIdx.y * NT, tx0 = blockIdx.x * NT;
+    for (int i = threadIdx.x; i < P * P; i += 256) {
+        const int ly = i / P, lx = i - ly * P;
+        const int gy = ty0 + ly - r, gx = tx0 + lx - r;
+        float v = -INFINITY;
+        if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+            v = c[(long)gy * W + gx];
+            v = v > thr ? v : -1.f;
+        }
+        sv[i] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NT * NT; i += 256) {
+        const int ly = i / NT, lx = i - ly * NT;
+        const int gy = ty0 + ly, gx = tx0 + lx;
+        if (gy >= H || gx >= W) continue;
+        const float v = sv[(ly + r) * P + lx + r];
+        float m = -INFINITY;
+        for (int dy = 0; dy <= 2 * r; ++dy)
+            for (int dx = 0; dx <= 2 * r; ++dx) m = fmaxf(m, sv[(ly + dy) * P + lx + dx]);
+        cand[(long)b * H * W + (long)gy * W + gx] = (v == m) ? v : -1.f;
+    }
+}
+
+// ---- P2: exact k-th largest (radix select on the float bits) + raster-order compaction; one block per frame ----
+__global__ __launch_bounds__(1024) void select_kernel(const float* __restrict__ cand, int HW, int W, int top_k, int cap,
+                                                      int* __restrict__ centers, int* __restrict__ ncenters) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix, s_mask, s_remaining, s_npos;
+    __shared__ unsigned scan[1024];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float* c = cand + (long)b * HW;
+    // count strictly positive candidates
+    unsigned local = 0;
+    for (int i = t; i < HW; i += 1024) local += c[i] > 0.f;
+    if (t == 0) s_npos = 0;
+    __syncthreads();
+    atomicAdd(&s_npos, local);
+    __syncthreads();
+    float cut = 0.f;  // max(k-th largest, 0); with fewer than k positives the k-th value is -1 -> 0
+    if ((int)s_npos >= top_k) {
+        if (t == 0) { s_prefix = 0; s_mask = 0; s_remaining = (unsigned)top_k; }
+        __syncthreads();
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            if (t < 256) hist[t] = 0;
+            __syncthreads();
+            const unsigned prefix = s_prefix, mask = s_mask;
+            for (int i = t; i < HW; i += 1024) {
+                const float v = c[i];
+                if (v > 0.f) {
+                    const unsigned u = __float_as_uint(v);
+                    if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+                }
+            }
+            __syncthreads();
+            if (t == 0) {
+                unsigned rem = s_remaining;
+                int d = 255;
+                for (; d > 0; --d) {
+                    if (hist[d] >= rem) break;
+                    rem -= hist[d];
+                }
+                s_prefix = prefix | ((unsigned)d << shift);
+                s_mask = mask | (255u << shift);
+                s_remaining = rem;
+            }
+            __syncthreads();
+        }
+        cut = __uint_as_float(s_prefix);
+    }
+    // ordered compaction: thread t owns the contiguous pixel run [t*seg, (t+1)*seg)
+    const int seg = (HW + 1023) / 1024;
+    const int p0 = t * seg, p1 = min(HW, p0 + seg);
+    unsigned n = 0;
+    for (int i = p0; i < p1; ++i) n += c[i] > cut;
+    scan[t] = n;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const unsigned v = t >= o ? scan[t - o] : 0;
+        __syncthreads();
+        scan[t] += v;
+        __syncthreads();
+    }
+    unsigned pos = scan[t] - n;
+    for (int i = p0; i < p1; ++i)
+        if (c[i] > cut) {
+            if ((int)pos < cap) {
+                centers[((long)b * cap + pos) * 2] = i / W;
+                centers[((long)b * cap + pos) * 2 + 1] = i % W;
+            }
+            ++pos;
+        }
+    if (t == 1023) ncenters[b] = min((int)scan[1023], cap);
+}
+
+// ---- P3: nearest-centre grouping + instance areas ----
+// idmap: 0 = background, 1..K = instance id on foreground, 255 = foreground with no centre at all
+__global__ __launch_bounds__(256) void group_kernel(const float* __restrict__ logits, int nch, int H, int W, int cap,
+                                                    const int* __restrict__ centers, const int* __restrict__ ncenters,
+                                                    uint8_t* __restrict__ idmap, unsigned* __restrict__ area) {
+    __shared__ float cy[256], cx[256];
+    __shared__ unsigned harea[256];
+    const int b = blockIdx.y;
+    const int K = ncenters[b];
+    harea[threadIdx.x] = 0;
+    if (threadIdx.x < K) {
+        cy[threadIdx.x] = (float)centers[((long)b * cap + threadIdx.x) * 2];
+        cx[threadIdx.x] = (float)centers[((long)b * cap + threadIdx.x) * 2 + 1];
+    }
+    __syncthreads();
+    const long HW = (long)H * W;
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < HW) {
+        const float* base = logits + (long)b * nch * HW;
+        const bool fg = base[p] > 0x1.8p-24f;  // sigmoid(x).round() == 1
+        unsigned id = 0;
+        if (fg) {
+            if (K == 0) {
+                id = 255;
+            } else {
+                const int y = (int)(p / W), x = (int)(p - (long)y * W);
+                const float ly = __fadd_rn((float)y, base[2 * HW + p]);
+                const float lx = __fadd_rn((float)x, base[3 * HW + p]);
+                float best = INFINITY;
+                for (int k = 0; k < K; ++k) {
+                    const float dy = __fsub_rn(cy[k], ly), dx = __fsub_rn(cx[k], lx);
+                    const float d = __fsqrt_rn(__fmaf_rn(dx, dx, __fmul_rn(dy, dy)));
+                    if (d < best) { best = d; id = k + 1; }
+                }
+                if (id == 0) id = 1;  // all-NaN distances: argmin returns index 0
+            }
+            atomicAdd(&harea[id], 1u);
+        }
+        idmap[(long)b * HW + p] = (uint8_t)id;
+    }
+    __syncthreads();
+    if (harea[threadIdx.x]) atomicAdd(&area[(long)b * 256 + threadIdx.x], harea[threadIdx.x]);
+}
+
+struct InstStat {
+    double prob;
+    unsigned long long sy, sx;
+    unsigned cnt;
+    int xmin, ymin, xmax, ymax;
+    int pad;
+};
+
+// ---- P4: 512-px filter + running relabel; one block per frame ----
+__global__ void relabel_kernel(const unsigned* __restrict__ area, const int* __restrict__ ncenters, int min_area,
+                               int stuff_area, int label_divisor, int cap, float* __restrict__ lut,
+                               int* __restrict__ count, float* __restrict__ labels, InstStat* __restrict__ stats) {
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) lut[(long)b * 256 + i] = -1.f;
+    for (int i = threadIdx.x; i < cap; i += blockDim.x) {
+        labels[(long)b * cap + i] = -1.f;
+        InstStat s;
+        s.prob = 0.0; s.sy = 0; s.sx = 0; s.cnt = 0;
+        s.xmin = 1 << 30; s.ymin = 1 << 30; s.xmax = -1; s.ymax = -1; s.pad = 0;
+        stats[(long)b * cap + i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int K = ncenters[b];
+        int n = 0;
+        if (K == 0) {
+            // class 1 is 'stuff' for thing_ids = [0]: a centre-less foreground blob becomes label 1*divisor
+            if ((int)area[(long)b * 256 + 255] >= stuff_area) {
+                lut[(long)b * 256 + 255] = (float)label_divisor;
+                labels[(long)b * cap] = (float)label_divisor;
+                n = 1;
+            }
+        } else {
+            for (int k = 1; k <= K; ++k) {
+                if ((int)area[(long)b * 256 + k] < min_area) continue;
+                ++n;
+                lut[(long)b * 256 + k] = (float)(label_divisor + n);
+                labels[(long)b * cap + n - 1] = (float)(label_divisor + n);
+            }
+        }
+        count[b] = n;
+    }
+}
+
+// ---- P5: write the panoptic map and accumulate per-instance statistics ----
+__global__ __launch_bounds__(256) void paint_stats_kernel(const float* __restrict__ logits, int nch, int H, int W,
+                                                          int cap, int label_divisor, const uint8_t* __restrict__ idmap,
+                                                          const float* __restrict__ lut, float* __restrict__ pan,
+                                                          InstStat* __restrict__ stats) {
+    __shared__ float slut[256];
+    const int b = blockIdx.y;
+    slut[threadIdx.x] = lut[(long)b * 256 + threadIdx.x];
+    __syncthreads();
+    const long HW = (long)H * W;
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    const float lab = slut[idmap[(long)b * HW + p]];
+    pan[(long)b * HW + p] = lab;
+    if (lab >= 0.f) {
+        int slot = (int)lab - label_divisor;     // 1000 -> 0 (K = 0 blob), 1001.. -> 0..
+        if (slot > 0) slot -= 1;
+        const int y = (int)(p / W), x = (int)(p - (long)y * W);
+        const float lg = logits[(long)b * nch * HW + p];
+        const float pr = 1.f / (1.f + expf(-lg));
+        InstStat* s = stats + (long)b * cap + slot;
+        atomicAdd(&s->prob, (double)pr);
+        atomicAdd(&s->sy, (unsigned long long)y);
+        atomicAdd(&s->sx, (unsigned long long)x);
+        atomicAdd(&s->cnt, 1u);
+        atomicMin(&s->xmin, x);
+        atomicMin(&s->ymin, y);
+        atomicMax(&s->xmax, x);
+        atomicMax(&s->ymax, y);
+    }
+}
+
+// ---- P6: scores and boxes ----
+__global__ void finalize_kernel(const float* __restrict__ logits, int nch, int H, int W, int cap,
+                                const int* __restrict__ count, const InstStat* __restrict__ stats,
+                                float* __restrict__ scores, float* __restrict__ boxes) {
+    const int b = blockIdx.x;
+    const long HW = (long)H * W;
+    for (int i = threadIdx.x; i < cap; i += blockDim.x) {
+        float sc = 0.f, bx[4] = {0.f, 0.f, 0.f, 0.f};
+        if (i < count[b]) {
+            const InstStat s = stats[(long)b * cap + i];
+            if (s.cnt) {
+                const float sem = (float)(s.prob / (double)s.cnt);
+                const float my = (float)((double)s.sy / (double)s.cnt);
+                const float mx = (float)((double)s.sx / (double)s.cnt);
+                const float cs = logits[((long)b * nch + 1) * HW + (long)((int)my) * W + (int)mx];
+                sc = sem * cs;
+                bx[0] = (float)s.xmin; bx[1] = (float)s.ymin; bx[2] = (float)(s.xmax + 1); bx[3] = (float)(s.ymax + 1);
+            }
+        }
+        scores[(long)b * cap + i] = sc;
+        for (int k = 0; k < 4; ++k) boxes[((long)b * cap + i) * 4 + k] = bx[k];
+    }
+}
+
+// ---- P7: per-instance binary masks ----
+__global__ void extract_masks_kernel(const float* __restrict__ pan, const float* __restrict__ labels, int HW, int cap,
+                                     int max_inst, uint8_t* __restrict__ out) {
+    const int b = blockIdx.z, i = blockIdx.y;
+    const float lab = labels[(long)b * cap + i];
+    const long p = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (p >= HW) return;
+    const float4* src = reinterpret_cast<const float4*>(pan + (long)b * HW + p);
+    unsigned w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float4 v = src[k];
+        w[k] = (lab >= 0.f && v.x == lab ? 1u : 0u) | (lab >= 0.f && v.y == lab ? 1u << 8 : 0u) |
+               (lab >= 0.f && v.z == lab ? 1u << 16 : 0u) | (lab >= 0.f && v.w == lab ? 1u << 24 : 0u);
+    }
+    *reinterpret_cast<uint4*>(out + ((long)b * max_inst + i) * HW + p) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// workspace layout (bytes): cand f32 B*HW | idmap u8 B*HW | area u32 B*256 | lut f32 B*256 | stats B*cap
+static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+size_t postprocess_ws_bytes(int B, int H, int W, int cap) {
+    const size_t HW = (size_t)H * W;
+    return al(B * HW * 4) + al(B * HW) + al((size_t)B * 256 * 4) * 2 + al((size_t)B * cap * sizeof(InstStat));
+}
+
+int launch_postprocess(const float* logits, int nch, int B, int H, int W, const PostCfg& c, void* ws, float* pan,
+                       int* count, float* labels, float* scores, float* boxes, int* centers, int* ncenters,
+                       hipStream_t st) {
+    if (c.cap > 254 || c.top_k > c.cap) return fail("postprocess: top_k must be <= capacity <= 254");
+    if (nch < 4) return fail("postprocess: logits need >= 4 channels (fg, centre, off_y, off_x)");
+    if ((c.nms_kernel & 1) == 0 || c.nms_kernel > 15) return fail("postprocess: NMS kernel must be odd and <= 15");
+    if ((long)H * W < c.top_k) return fail("postprocess: frame smaller than top_k");
+    const size_t HW = (size_t)H * W;
+    char* w = reinterpret_cast<char*>(ws);
+    float* cand = reinterpret_cast<float*>(w); w += al(B * HW * 4);
+    uint8_t* idmap = reinterpret_cast<uint8_t*>(w); w += al(B * HW);
+    unsigned* area = reinterpret_cast<unsigned*>(w); w += al((size_t)B * 256 * 4);
+    float* lut = reinterpret_cast<float*>(w); w += al((size_t)B * 256 * 4);
+    InstStat* stats = reinterpret_cast<InstStat*>(w);
+
+    const int r = (c.nms_kernel - 1) / 2;
+    const int P = NT + 2 * r;
+    hipLaunchKernelGGL(nms_kernel, dim3((W + NT - 1) / NT, (H + NT - 1) / NT, B), dim3(256), sizeof(float) * P * P, st,
+                       logits, nch, H, W, c.threshold, r, cand);
+    hipLaunchKernelGGL(select_kernel, dim3(B), dim3(1024), 0, st, cand, (int)HW, W, c.top_k, c.cap, centers, ncenters);
+    QB_CHECK(hipMemsetAsync(area, 0, (size_t)B * 256 * 4, st));
+    const int pblocks = (int)((HW + 255) / 256);
+    hipLaunchKernelGGL(group_kernel, dim3(pblocks, B), dim3(256), 0, st, logits, nch, H, W, c.cap, centers, ncenters,
+                       idmap, area);
+    hipLaunchKernelGGL(relabel_kernel, dim3(B), dim3(256), 0, st, area, ncenters, c.min_area, c.stuff_area,
+                       c.label_divisor, c.cap, lut, count, labels, stats);
+    hipLaunchKernelGGL(paint_stats_kernel, dim3(pblocks, B), dim3(256), 0, st, logits, nch, H, W, c.cap,
+                       c.label_divisor, idmap, lut, pan, stats);
+    hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(256), 0, st, logits, nch, H, W, c.cap, count, stats, scores,
+                       boxes);
+    QB_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_extract_masks(const float* pan, const float* labels, int B, int H, int W, int cap, int max_inst,
+                         uint8_t* out, hipStream_t st) {
+    const long HW = (long)H * W;
+    if (HW % 16) return fail("extract_masks: H*W must be a multiple of 16");
+    if (max_inst < 1 || max_inst > cap) return fail("extract_masks: max_inst out of range");
+    hipLaunchKernelGGL(extract_masks_kernel, dim3((int)((HW / 16 + 255) / 256), max_inst, B), dim3(256), 0, st, pan,
+                       labels, (int)HW, cap, max_inst, out);
+    QB_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace quber

@@ -1,0 +1,178 @@
+"""Thin host-side driver of libquber_hip.so: owns one ``quber_ctx`` and hands torch (ROCm) tensors'
+device pointers and the current HIP stream to the C ABI.  torch is plumbing only (device memory,
+streams); every computation on the hot path happens in the HIP library.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import ERROR_CLASSES
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def make_config(height=480, width=640, max_batch=1, max_instances=64, cfg=None, with_network=True):
+    """quber_config from an (optional) validated yaml CfgNode."""
+    lib = _lib.load()
+    qc = _lib.QuberConfig()
+    lib.quber_default_config(C.byref(qc))
+    qc.height, qc.width, qc.max_batch, qc.max_instances = height, width, max_batch, max_instances
+    qc.with_network = 1 if with_network else 0
+    if cfg is not None:
+        m = cfg.MODEL
+        qc.resnet_depth = m.RESNETS.DEPTH
+        qc.res5_dilation = m.RESNETS.RES5_DILATION
+        qc.backbone_fusion_layers = m.BACKBONE.NUM_FUSION_LAYERS
+        qc.head_fusion_layers = m.INS_EMBED_HEAD.NUM_FUSION_LAYERS
+        qc.error_classes = ERROR_CLASSES[m.INS_EMBED_HEAD.ERROR_TYPE]
+        qc.gaussian_sigma = cfg.INPUT.get("GAUSSIAN_SIGMA", 10)
+        qc.nms_kernel = m.PANOPTIC_DEEPLAB.NMS_KERNEL
+        qc.top_k = m.PANOPTIC_DEEPLAB.TOP_K_INSTANCE
+        qc.stuff_area = m.PANOPTIC_DEEPLAB.STUFF_AREA
+        qc.center_threshold = m.PANOPTIC_DEEPLAB.CENTER_THRESHOLD
+        for i in range(6):
+            qc.pixel_mean[i] = float(m.PIXEL_MEAN[i])
+            qc.pixel_std[i] = float(m.PIXEL_STD[i])
+    return qc
+
+
+class Engine:
+    """One context on the current device.  All methods are asynchronous on torch's current stream."""
+
+    def __init__(self, qcfg, device=None):
+        if not torch.cuda.is_available():
+            raise _lib.QuberError("quber_amd needs a ROCm GPU (torch.cuda.is_available() is False); no CPU fallback")
+        self.lib = _lib.load()
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.qcfg = qcfg
+        self.H, self.W = qcfg.height, qcfg.width
+        self.planes = 4 + qcfg.error_classes
+        self.cap = qcfg.top_k
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.quber_create(C.byref(qcfg), C.byref(h)))
+        self.h = h
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            torch.cuda.synchronize(self.device)
+            self.lib.quber_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights ----
+    def weight_specs(self):
+        out = []
+        name, numel = C.c_char_p(), C.c_int64()
+        for i in range(self.lib.quber_num_weights(self.h)):
+            _lib.check(self.lib.quber_weight_spec(self.h, i, C.byref(name), C.byref(numel)))
+            out.append((name.value.decode(), numel.value))
+        return out
+
+    def load_state_dict(self, sd):
+        """sd: name -> numpy / torch array in torch layout (detectron2-compatible keys)."""
+        for name, numel in self.weight_specs():
+            if name not in sd:
+                raise KeyError(f"state_dict lacks '{name}'")
+            v = sd[name]
+            if isinstance(v, torch.Tensor):
+                v = v.detach().cpu().numpy()
+            v = np.ascontiguousarray(v, dtype=np.float32)
+            if v.size != numel:
+                raise ValueError(f"'{name}' has {v.size} elements, expected {numel}")
+            _lib.check(self.lib.quber_set_weight(self.h, name.encode(), C.c_void_p(v.ctypes.data), v.size))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.quber_finalize_weights(self.h))
+
+    def forward_flops(self):
+        return self.lib.quber_forward_flops(self.h)
+
+    # ---- hot path ----
+    def encode(self, masks, out=None):
+        """masks u8 [B,N,H,W] (device) -> f32 [B,3,H,W]."""
+        B, N = masks.shape[:2]
+        assert masks.dtype == torch.uint8 and masks.is_contiguous() and masks.shape[2:] == (self.H, self.W)
+        if out is None:
+            out = torch.empty((B, 3, self.H, self.W), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.quber_encode_initial_masks(self.h, _ptr(masks), B, N, _ptr(out), _stream()))
+        return out
+
+    def error_maps(self, init_masks, gt_masks, out=None):
+        B, N = init_masks.shape[:2]
+        Ng = gt_masks.shape[1]
+        assert init_masks.dtype == torch.uint8 and gt_masks.dtype == torch.uint8
+        assert init_masks.is_contiguous() and gt_masks.is_contiguous()
+        if out is None:
+            out = torch.empty((B, 2, 4, self.H, self.W), dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.quber_explicit_error_maps(self.h, _ptr(init_masks), N, _ptr(gt_masks), Ng, B, _ptr(out),
+                                                      _stream()))
+        return out
+
+    def forward(self, bgr, depth, offsets, out=None):
+        """bgr, depth u8 [B,H,W,3]; offsets f32 [B,3,H,W] -> logits f32 [B,planes,H,W]."""
+        B = bgr.shape[0]
+        assert bgr.dtype == torch.uint8 and depth.dtype == torch.uint8 and offsets.dtype == torch.float32
+        assert bgr.shape == (B, self.H, self.W, 3) and depth.shape == bgr.shape and offsets.shape == (B, 3, self.H, self.W)
+        assert bgr.is_contiguous() and depth.is_contiguous() and offsets.is_contiguous()
+        if out is None:
+            out = torch.empty((B, self.planes, self.H, self.W), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.quber_forward(self.h, _ptr(bgr), _ptr(depth), _ptr(offsets), B, _ptr(out), _stream()))
+        return out
+
+    def alloc_post(self, B):
+        d, cap = self.device, self.cap
+        return {
+            "panoptic": torch.empty((B, self.H, self.W), dtype=torch.float32, device=d),
+            "count": torch.empty((B,), dtype=torch.int32, device=d),
+            "labels": torch.empty((B, cap), dtype=torch.float32, device=d),
+            "scores": torch.empty((B, cap), dtype=torch.float32, device=d),
+            "boxes": torch.empty((B, cap, 4), dtype=torch.float32, device=d),
+            "centers": torch.zeros((B, cap, 2), dtype=torch.int32, device=d),
+            "ncenters": torch.empty((B,), dtype=torch.int32, device=d),
+        }
+
+    def postprocess(self, logits, out=None):
+        B, planes = logits.shape[:2]
+        assert logits.dtype == torch.float32 and logits.is_contiguous() and logits.shape[2:] == (self.H, self.W)
+        o = out if out is not None else self.alloc_post(B)
+        _lib.check(self.lib.quber_postprocess(
+            self.h, _ptr(logits), planes, B, _ptr(o["panoptic"]), _ptr(o["count"]), _ptr(o["labels"]),
+            _ptr(o["scores"]), _ptr(o["boxes"]), _ptr(o["centers"]), _ptr(o["ncenters"]), _stream()))
+        return o
+
+    def extract_masks(self, post, max_inst, out=None):
+        B = post["panoptic"].shape[0]
+        if out is None:
+            out = torch.empty((B, max_inst, self.H, self.W), dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.quber_extract_masks(self.h, _ptr(post["panoptic"]), _ptr(post["labels"]), B, max_inst,
+                                                _ptr(out), _stream()))
+        return out
+
+    def debug_tensor(self, name, batch):
+        """NHWC copy [batch,H,W,C] of a named intermediate of the last forward."""
+        p, dims, cs = C.c_void_p(), (C.c_int32 * 4)(), C.c_int32()
+        _lib.check(self.lib.quber_debug_tensor(self.h, name.encode(), C.byref(p), C.byref(dims), C.byref(cs)))
+        Bm, H, W, Cc = list(dims)
+        n = (batch * H * W - 1) * cs.value + Cc        # the view may be a channel slice of a wider buffer
+        buf = torch.empty(n, dtype=torch.float32, device=self.device)
+        torch.cuda.synchronize(self.device)
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        rc = hip.hipMemcpy(C.c_void_p(buf.data_ptr()), p, n * 4, 3)
+        if rc != 0:
+            raise _lib.QuberError(f"hipMemcpy failed ({rc})")
+        return torch.as_strided(buf, (batch, H, W, Cc), (H * W * cs.value, W * cs.value, cs.value, 1))

@@ -1,0 +1,68 @@
+"""Drop-in for the reference's ``eval/refiner_model.py:MaskRefiner`` adapter (reference lines 214-297):
+``MaskRefiner(config_file, weights_file, dataset).predict(rgb_path, depth_path, initial_masks, fg_mask)
+-> (refined_masks bool [K,H,W] | [], output dict, seconds, fg_mask)``.
+
+Built: file loading, resize to 640x480, ``normalize_depth`` (eval/preprocess_utils.py:12-28), nearest depth
+resize, the HIP predictor, the OCID zero-depth masking (refiner_model.py:279-288).
+Not built yet (DESIGN.md "next"): ``cv2.inpaint`` TELEA depth in-painting (zero-depth
+pixels are left at 0 here; frames without zero depth are unaffected because the reference only rewrites
+zero pixels, preprocess_utils.py:63) and the LMFFNet foreground post-filter (``fg_mask`` is returned as None
+and no mask is dropped).  cv2 / imageio are absent, so images are read with PIL and resized with PIL's
+bilinear filter, which is not bit-identical to cv2.resize.
+"""
+import time
+
+import numpy as np
+from PIL import Image
+
+from ..maskrefiner.predictor import MaskRefinerPredictor
+
+W = 640
+H = 480
+
+
+def normalize_depth(depth, min_val=250.0, max_val=1500.0):
+    depth = np.array(depth, dtype=np.float64 if depth.dtype == np.float64 else np.float32)
+    depth = np.clip(depth, min_val, max_val)
+    depth = (depth - min_val) / (max_val - min_val) * 255
+    if depth.ndim == 2:
+        depth = depth[..., None]
+    return np.uint8(np.repeat(depth, 3, -1))
+
+
+def _resize_nearest(img, w, h):
+    ys = (np.arange(h) * (img.shape[0] / h)).astype(np.int64).clip(0, img.shape[0] - 1)
+    xs = (np.arange(w) * (img.shape[1] / w)).astype(np.int64).clip(0, img.shape[1] - 1)
+    return img[ys][:, xs]
+
+
+class MaskRefiner:
+    def __init__(self, config_file=None, weights_file=None, dataset="OSD", device="cuda:0"):
+        self.refiner_predictor = MaskRefinerPredictor(config_file, weights_file=weights_file, device=device)
+        self.dataset = dataset
+
+    def predict(self, rgb_path, depth_path, initial_masks, fg_mask=None):
+        rgb = np.asarray(Image.open(rgb_path).convert("RGB"))[:, :, ::-1]        # BGR like cv2.imread
+        depth = np.load(depth_path) if "npy" in depth_path else np.asarray(Image.open(depth_path))
+        if rgb.shape[:2] != (H, W):
+            rgb = np.asarray(Image.fromarray(np.ascontiguousarray(rgb)).resize((W, H), Image.BILINEAR))
+        zero_depth = np.where(depth == 0)
+        depth = normalize_depth(depth, 0.25, 1.5) if "npy" in depth_path else normalize_depth(depth)
+        if depth.shape[:2] != (H, W):
+            depth = _resize_nearest(depth, W, H)
+        initial_masks = np.asarray(initial_masks)
+        if initial_masks.dtype == np.bool_:
+            initial_masks = np.uint8(initial_masks) * 255
+
+        start = time.time()
+        output = self.refiner_predictor.predict(np.ascontiguousarray(rgb), depth, initial_masks)[0]
+        if "instances" not in output:
+            refined = []
+        else:
+            refined = output["instances"].to("cpu").pred_masks.numpy()
+        elapsed = time.time() - start
+        if self.dataset == "OCID" and len(refined):
+            refined = refined.copy()
+            for m in refined:
+                m[zero_depth] = False
+        return refined, output, elapsed, None

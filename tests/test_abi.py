@@ -1,0 +1,87 @@
+"""CPU: the C-ABI library loads and exports every symbol include/quber_hip.h declares; host-side config logic."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from quber_amd import _lib, arch, config
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "quber_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(quber_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    syms = header_symbols()
+    assert len(syms) >= 18
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/quber_hip.h but not exported"
+    assert set(syms) == set(_lib.SIGNATURES), set(syms) ^ set(_lib.SIGNATURES)
+
+
+def test_config_struct_matches_header_defaults():
+    lib = _lib.load()
+    qc = _lib.QuberConfig()
+    lib.quber_default_config(ctypes.byref(qc))
+    assert (qc.height, qc.width, qc.resnet_depth, qc.top_k, qc.nms_kernel) == (480, 640, 50, 200, 7)
+    assert abs(qc.center_threshold - 0.3) < 1e-7 and abs(qc.pixel_mean[5] - 127.5) < 1e-7 and qc.pixel_std[0] == 1.0
+    assert b"gfx950" in lib.quber_version()
+
+
+def test_create_without_gpu_fails_loudly(has_gpu):
+    if has_gpu:
+        pytest.skip("GPU present")
+    lib = _lib.load()
+    qc = _lib.QuberConfig()
+    lib.quber_default_config(ctypes.byref(qc))
+    h = ctypes.c_void_p()
+    assert lib.quber_create(ctypes.byref(qc), ctypes.byref(h)) != 0
+    assert b"HIP device" in lib.quber_last_error()
+    from quber_amd import engine
+    with pytest.raises(_lib.QuberError):
+        engine.Engine(qc)
+
+
+def test_yaml_base_merge_and_validation(tmp_path):
+    base = tmp_path / "Base.yaml"
+    base.write_text("MODEL:\n  META_ARCHITECTURE: MaskRefiner\n  RESNETS:\n    OUT_FEATURES: [res2, res3, res5]\n    RES5_DILATION: 2\n"
+                    "  PIXEL_MEAN: [103.53, 116.28, 123.675, 127.5, 127.5, 127.5]\n  PIXEL_STD: [1, 1, 1, 1, 1, 1]\n"
+                    "  BACKBONE:\n    FUSION_STRATEGY: add\n    NUM_FUSION_LAYERS: 3\n"
+                    "  INS_EMBED_HEAD:\n    NAME: MaskRefinerInsEmbedHead\n    NORM: GN\n    EEE_MASK_ON: True\n    ERROR_TYPE: e2\n"
+                    "  PANOPTIC_DEEPLAB:\n    CENTER_THRESHOLD: 0.3\nINPUT:\n  OFFSET_INPUT_ON: True\n  DEPTH_ON: True\nSOLVER:\n  BASE_LR: 0.1\n")
+    d = tmp_path / "seed77"
+    d.mkdir()
+    child = d / "quber.yaml"
+    child.write_text("_BASE_: ../Base.yaml\nMODEL:\n  BACKBONE:\n    FUSION_STRATEGY: concat\n    NUM_FUSION_LAYERS: 2\n"
+                     "  INS_EMBED_HEAD:\n    HIERARCHICAL_FUSION_ON: True\n    EEE_MASK_ON: False\n"
+                     "    HIERARCHY: [[eee_boundary], [foreground, center, offset]]\n    ERROR_TYPE: e3\n")
+    cfg = config.merge_from_file(config.get_cfg(), str(child))
+    assert cfg.MODEL.BACKBONE.FUSION_STRATEGY == "concat" and cfg.MODEL.BACKBONE.NUM_FUSION_LAYERS == 2
+    assert cfg.MODEL.PANOPTIC_DEEPLAB.CENTER_THRESHOLD == 0.3 and cfg.MODEL.PANOPTIC_DEEPLAB.NMS_KERNEL == 7
+    assert cfg.SOLVER.BASE_LR == 0.1
+    config.validate(cfg)
+    bad = config.merge_from_file(config.get_cfg(), str(base))
+    with pytest.raises(config.UnsupportedConfig):
+        config.validate(bad)
+    config.validate(config.canonical_cfg())
+
+
+def test_param_specs_match_oracle_module_tree():
+    from oracle.network_torch import ArchCfg, MaskRefinerNet
+    for depth in (50, 101):
+        specs = arch.param_specs(depth=depth)
+        sd = MaskRefinerNet(ArchCfg(depth=depth)).state_dict()
+        keys = [k for k in sd if not k.endswith("num_batches_tracked")]
+        assert set(keys) == set(specs)
+        for k in keys:
+            assert tuple(sd[k].shape) == tuple(specs[k][0]), k
+    assert 79.0e6 < arch.num_parameters() < 80.5e6          # ~79.5 M
+    sd = arch.init_state_dict(seed=3)
+    sd2 = arch.init_state_dict(seed=3)
+    assert all(np.array_equal(sd[k], sd2[k]) for k in sd)

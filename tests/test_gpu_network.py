@@ -1,0 +1,89 @@
+"""GPU: the HIP network (a3-a7) against the pure-torch oracle restatement, fp32, tolerance 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.network_torch import ArchCfg, MaskRefinerNet
+from oracle import encode_np, postproc_ref
+from quber_amd import arch, engine, synth
+from quber_amd.maskrefiner.predictor import MaskRefinerPredictor
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4   # BASELINE.json north_star: float outputs within 1e-4 of the reference CPU path
+
+
+def oracle_net(sd, depth=50):
+    net = MaskRefinerNet(ArchCfg(depth=depth)).eval()
+    missing, unexpected = net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing)
+    return net
+
+
+def inputs(seed, b, h, w, n):
+    batch = synth.make_batch(seed, b, h, w, n)
+    offs = np.stack([encode_np.encode_initial_masks(m) for m in batch["masks"]])
+    return batch, offs
+
+
+def rel_err(got, ref):
+    return float((got - ref).abs().max() / max(1.0, float(ref.abs().max())))
+
+
+@pytest.mark.parametrize("h,w,b,depth", [(64, 96, 2, 50), (128, 160, 1, 50), (64, 64, 1, 101)])
+def test_network_vs_oracle_small(h, w, b, depth):
+    sd = arch.init_state_dict(seed=1, depth=depth)
+    net = oracle_net(sd, depth)
+    batch, offs = inputs(3, b, h, w, 4)
+    qc = engine.make_config(h, w, max_batch=b + 1)
+    qc.resnet_depth = depth
+    eng = engine.Engine(qc, "cuda:0")
+    eng.load_state_dict(sd)
+    bgr, dep = torch.from_numpy(batch["rgb"]).cuda(), torch.from_numpy(batch["depth"]).cuda()
+    logits = eng.forward(bgr, dep, torch.from_numpy(offs).cuda()).cpu()
+    image = torch.cat([torch.from_numpy(batch["rgb"]), torch.from_numpy(batch["depth"])], -1).permute(0, 3, 1, 2)
+    taps = {}
+    with torch.no_grad():
+        ref = net(image, torch.from_numpy(offs), taps)
+    for name in ("res2", "res3", "res5", "y", "feat_b", "z"):
+        got = eng.debug_tensor(name, b).cpu().permute(0, 3, 1, 2)
+        assert rel_err(got, taps[name]) < TOL, name
+    exp = torch.cat([ref["foreground"], ref["center"], ref["offset"], ref["eee_boundary"]], 1)
+    assert logits.shape == exp.shape
+    assert float((logits - exp).abs().max()) < TOL
+    assert abs(eng.forward_flops() / 2e9 - 187.8 * (h * w) / (480 * 640)) < 0.02 * 187.8 * (h * w) / (480 * 640) or depth != 50
+    eng.close()
+
+
+def test_network_vs_oracle_full_frame_and_predictor():
+    h, w, n = 480, 640, 8
+    pred = MaskRefinerPredictor(None, seed=2)
+    sd = pred.model.state_dict
+    net = oracle_net(sd)
+    sc = synth.make_scene(5, h, w, n)
+    out = pred.predict(sc["rgb"], sc["depth"], sc["masks"])
+    assert isinstance(out, list) and len(out) == 1
+    r = out[0]
+    assert r["sem_seg"].shape == (1, h, w) and r["eee_boundary"].shape == (4, h, w)
+    assert r["panoptic_seg"][0].shape == (h, w) and r["panoptic_seg"][1] is None
+    offs = encode_np.encode_initial_masks(sc["masks"])[None]
+    image = torch.from_numpy(np.concatenate([sc["rgb"], sc["depth"]], -1)).permute(2, 0, 1)[None]
+    with torch.no_grad():
+        ref = net(image, torch.from_numpy(offs))
+    assert float((r["sem_seg"].cpu() - ref["foreground"][0]).abs().max()) < TOL
+    assert float((r["eee_boundary"].cpu() - ref["eee_boundary"][0]).abs().max()) < TOL
+    # the detectron2-style entry point gives the same result as predict()
+    r2 = pred.model([{"image": image[0], "height": h, "width": w, "initial_pred_offset": torch.from_numpy(offs[0])}])[0]
+    assert torch.equal(r2["sem_seg"], r["sem_seg"]) and torch.equal(r2["panoptic_seg"][0], r["panoptic_seg"][0])
+    # post-processing of the HIP logits through the oracle gives the HIP label map bit for bit
+    eng = pred.model.engine_for(h, w, 1)
+    lg = eng.forward(torch.from_numpy(sc["rgb"][None]).cuda(), torch.from_numpy(sc["depth"][None]).cuda(),
+                     torch.from_numpy(offs).cuda()).cpu()
+    o = postproc_ref.postprocess(lg[0, 0:1], lg[0, 1:2], lg[0, 2:4])
+    np.testing.assert_array_equal(r["panoptic_seg"][0].cpu().numpy(), o["panoptic"].numpy())
+    if len(o["labels"]):
+        inst = r["instances"].to("cpu")
+        np.testing.assert_array_equal(inst.pred_masks.numpy(), o["masks"].numpy())
+        assert inst.pred_masks.dtype == torch.bool and list(inst.pred_classes) == list(o["classes"])
+    else:
+        assert "instances" not in r

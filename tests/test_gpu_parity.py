@@ -1,0 +1,257 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle and the golden fixtures."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, load_encode_case
+from oracle import encode_np, errmaps_np, postproc_ref
+from quber_amd import _lib, engine, synth
+
+pytestmark = pytest.mark.gpu
+
+_ENGINES = {}
+
+
+def eng_for(h, w, batch=4, n=256, net=False):
+    key = (h, w)
+    e = _ENGINES.get(key)
+    if e is None or e.qcfg.max_batch < batch:
+        qc = engine.make_config(h, w, max_batch=max(batch, 4), max_instances=254, with_network=net)
+        e = engine.Engine(qc, "cuda:0")
+        _ENGINES[key] = e
+    return e
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# --------------------------------------------------------------------------------------------- a1 encode
+@pytest.mark.parametrize("path", golden("encode"), ids=os.path.basename)
+def test_encode_golden(path):
+    masks, out, _ = load_encode_case(path)
+    e = eng_for(*masks.shape[1:])
+    got = e.encode(dev(masks[None])).cpu().numpy()[0]
+    np.testing.assert_array_equal(got.view(np.uint32), out.view(np.uint32))
+
+
+def test_gaussian_template_bits():
+    e = eng_for(96, 128)
+    m = np.zeros((1, 1, 96, 128), np.uint8)
+    m[0, 0, 48, 64] = 1
+    heat = e.encode(dev(m)).cpu().numpy()[0, 0]
+    g = encode_np.gaussian_template(10).astype(np.float32)
+    np.testing.assert_array_equal(heat[48 - 31:48 + 32, 64 - 31:64 + 32].view(np.uint32), g.view(np.uint32))
+
+
+@pytest.mark.parametrize("h,w,n,b", [(480, 640, 20, 3), (720, 1280, 30, 2), (96, 128, 1, 1), (480, 640, 200, 1)])
+def test_encode_vs_oracle(h, w, n, b):
+    rng = np.random.default_rng(h + n)
+    masks = np.stack([synth.make_masks(rng, n, h, w)[1] for _ in range(b)]).astype(np.uint8) * 255
+    masks[0, n // 2] = 0                                   # an empty mask is skipped
+    e = eng_for(h, w, b)
+    got = e.encode(dev(masks)).cpu().numpy()
+    for i in range(b):
+        exp = encode_np.encode_initial_masks(masks[i])
+        np.testing.assert_array_equal(got[i].view(np.uint32), exp.view(np.uint32))
+
+
+def test_encode_zero_masks_and_errors():
+    e = eng_for(96, 128)
+    out = e.encode(torch.zeros((2, 0, 96, 128), dtype=torch.uint8, device="cuda"))
+    assert float(out.abs().max()) == 0.0
+    with pytest.raises(_lib.QuberError):
+        e.encode(torch.zeros((99, 1, 96, 128), dtype=torch.uint8, device="cuda"))   # batch > max_batch
+
+
+# --------------------------------------------------------------------------------------------- a2 error maps
+@pytest.mark.parametrize("h,w,n", [(96, 128, 6), (480, 640, 20), (720, 1280, 12)])
+def test_error_maps_vs_oracle(h, w, n):
+    rng = np.random.default_rng(n)
+    gt, init = synth.make_masks(rng, n, h, w)
+    gt, init = gt.astype(np.uint8) * 255, init.astype(np.uint8) * 255
+    init[0, :20, :30] = 255                                 # touches the border
+    e = eng_for(h, w)
+    got = e.error_maps(dev(init[None]), dev(gt[None])).cpu().numpy()[0]
+    exp = errmaps_np.explicit_error_maps(init, gt)
+    np.testing.assert_array_equal(got, exp)
+    assert (got.sum(1) == 1).all()
+
+
+def test_error_maps_uint8_wrap_semantics():
+    z = np.load(golden("fgunion")[0])
+    masks = np.zeros((256, 96, 128), np.uint8)
+    masks[:, :8, :16] = z["masks"]
+    e = eng_for(96, 128)
+    # n_init = 254 is the ABI limit for the encoder only; error maps take any N
+    got = e.error_maps(dev(masks[None]), dev(masks[None, :1])).cpu().numpy()[0]
+    exp = errmaps_np.explicit_error_maps(masks, masks[:1])
+    np.testing.assert_array_equal(got, exp)
+
+
+# --------------------------------------------------------------------------------------------- a8-a11 post-processing
+def run_post(fg_logit, center, offsets):
+    h, w = center.shape[-2:]
+    e = eng_for(h, w)
+    lg = np.concatenate([fg_logit.reshape(1, h, w), center.reshape(1, h, w), offsets.reshape(2, h, w)]).astype(np.float32)
+    post = e.postprocess(dev(lg[None]))
+    return e, {k: v.cpu().numpy()[0] for k, v in post.items()}, post
+
+
+@pytest.mark.parametrize("path", golden("centers"), ids=os.path.basename)
+def test_centers_golden(path):
+    z = np.load(path)
+    c = z["center"]
+    h, w = c.shape[-2:]
+    _, o, _ = run_post(np.full((h, w), -4.0, np.float32), c, np.zeros((2, h, w), np.float32))
+    k = int(o["ncenters"])
+    np.testing.assert_array_equal(o["centers"][:k], z["out"])
+
+
+@pytest.mark.parametrize("path", [p for p in golden("group") if "k20" not in p and "k199" not in p], ids=os.path.basename)
+def test_group_golden(path):
+    # fixtures whose centre list is in raster order can be reproduced through a centre map with peaks there
+    z = np.load(path)
+    h, w = z["offsets"].shape[1:]
+    c = np.full((h, w), 0.1, np.float32)
+    for i, (y, x) in enumerate(z["centers"]):
+        c[y, x] = 0.9
+    _, o, _ = run_post(np.full((h, w), 4.0, np.float32), c, z["offsets"])
+    k = int(o["ncenters"])
+    np.testing.assert_array_equal(o["centers"][:k], z["centers"])
+    # with every pixel foreground the panoptic ids are the group ids, relabelled over areas >= 512
+    ids = z["out"][0]
+    areas = np.bincount(ids.ravel(), minlength=k + 1)
+    lut = np.full(k + 1, -1.0, np.float32)
+    n = 0
+    for i in range(1, k + 1):
+        if areas[i] >= 512:
+            n += 1
+            lut[i] = 1000 + n
+    np.testing.assert_array_equal(o["panoptic"], lut[ids])
+
+
+@pytest.mark.parametrize("path", golden("panoptic"), ids=os.path.basename)
+def test_panoptic_golden(path):
+    z = np.load(path)
+    _, o, _ = run_post(z["fg_logit"], z["center"], z["offsets"])
+    np.testing.assert_array_equal(o["panoptic"], z["pan"][0])
+    k = int(o["ncenters"])
+    np.testing.assert_array_equal(o["centers"][:k], z["centers"][0])
+
+
+@pytest.mark.parametrize("h,w,n,seed", [(480, 640, 20, 1), (480, 640, 8, 2), (720, 1280, 30, 3), (96, 128, 3, 4)])
+def test_postprocess_vs_oracle(h, w, n, seed):
+    rng = np.random.default_rng(seed)
+    sc = synth.make_scene(seed, h, w, n)
+    enc = encode_np.encode_initial_masks(sc["masks"])
+    lg, ce, of = synth.fake_head_outputs(enc, sc["masks"], rng, noise=0.4)
+    e, o, post = run_post(lg, ce, of)
+    ref = postproc_ref.postprocess(torch.from_numpy(lg), torch.from_numpy(ce), torch.from_numpy(of))
+    np.testing.assert_array_equal(o["panoptic"], ref["panoptic"].numpy())
+    k = int(o["count"])
+    assert k == len(ref["labels"]) and k > 0
+    np.testing.assert_array_equal(o["labels"][:k], ref["labels"].numpy())
+    assert (o["labels"][k:] == -1).all()
+    np.testing.assert_array_equal(o["boxes"][:k], ref["boxes"].numpy())
+    np.testing.assert_allclose(o["scores"][:k], ref["scores"].numpy(), rtol=2e-5, atol=1e-6)
+    masks = e.extract_masks(post, k).cpu().numpy()[0]
+    np.testing.assert_array_equal(masks.astype(bool), ref["masks"].numpy())
+
+
+def test_postprocess_batch_is_per_frame():
+    h, w = 96, 128
+    frames = []
+    for seed in range(3):
+        sc = synth.make_scene(seed + 10, h, w, 3)
+        enc = encode_np.encode_initial_masks(sc["masks"])
+        lg, ce, of = synth.fake_head_outputs(enc, sc["masks"], np.random.default_rng(seed), 0.3)
+        frames.append(np.concatenate([lg, ce, of]))
+    e = eng_for(h, w)
+    post = e.postprocess(dev(np.stack(frames)))
+    pan = post["panoptic"].cpu().numpy()
+    for i, f in enumerate(frames):
+        ref = postproc_ref.postprocess(torch.from_numpy(f[0:1]), torch.from_numpy(f[1:2]), torch.from_numpy(f[2:4]))
+        np.testing.assert_array_equal(pan[i], ref["panoptic"].numpy())
+
+
+# --------------------------------------------------------------------------------------------- kernel-level ops
+def _conv_case(B, H, W, Cin, Cout, k, stride, dil, affine, residual, relu, seed=0):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    wt = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+    pad = dil * (k // 2)
+    sc = torch.rand(Cout, generator=g) + 0.5 if affine else None
+    sh = torch.randn(Cout, generator=g) if affine else None
+    ref = torch.nn.functional.conv2d(x.double(), wt.double(), None, stride, pad, dil)
+    if affine:
+        ref = ref * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+    res = torch.randn(ref.shape, generator=g) if residual else None
+    if residual:
+        ref = ref + res.double()
+    if relu:
+        ref = ref.relu()
+    OH, OW = ref.shape[-2:]
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wd = wt.contiguous().cuda()
+    y = torch.empty((B, OH, OW, Cout), device="cuda")
+    packed = torch.empty(Cout * ((k * k * Cin + 31) // 32 * 32), device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    scd, shd = (sc.cuda(), sh.cuda()) if affine else (None, None)
+    resd = res.permute(0, 2, 3, 1).contiguous().cuda() if residual else None
+    _lib.check(lib.quber_op_conv2d(p(xd), B, H, W, Cin, p(wd), Cout, k, stride, pad, dil, p(scd), p(shd), p(resd),
+                                   int(relu), p(packed), p(y), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    got = y.cpu().permute(0, 3, 1, 2).double()
+    err = (got - ref).abs().max().item()
+    scale = max(1.0, ref.abs().max().item())
+    return err / scale
+
+
+@pytest.mark.parametrize("case", [
+    # B, H, W, Cin, Cout, k, stride, dil, affine, residual, relu
+    (2, 24, 32, 8, 32, 3, 2, 1, True, False, True),        # stem conv1 (K = 72, tail), 256x32 tile
+    (2, 24, 32, 32, 64, 3, 1, 1, True, False, True),       # 256x64 tile
+    (2, 16, 20, 64, 256, 1, 1, 1, True, True, True),       # bottleneck conv3 + residual
+    (1, 30, 40, 256, 128, 1, 2, 1, True, False, True),     # strided 1x1
+    (1, 15, 20, 128, 128, 3, 1, 4, True, False, True),     # dilated 3x3
+    (1, 15, 20, 64, 96, 3, 1, 18, False, False, False),    # ASPP-style dilation larger than the map
+    (3, 33, 47, 164, 128, 1, 1, 1, True, False, True),     # K = 164 (tail of 4), ragged M
+    (2, 64, 80, 128, 130, 3, 1, 1, False, False, False),   # 128x128 tiles, ragged N
+    (1, 1, 1, 2048, 256, 1, 1, 1, True, False, True),      # ASPP pooling branch (M = 1)
+])
+def test_conv_igemm_vs_torch(case):
+    assert _conv_case(*case) < 2e-6
+
+
+def test_groupnorm_bilinear_maxpool_vs_torch():
+    lib = _lib.load()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    g = torch.Generator().manual_seed(1)
+    for (B, H, W, Cc) in [(2, 30, 40, 256), (1, 12, 16, 2048), (3, 17, 23, 32), (2, 8, 8, 64), (2, 9, 11, 128)]:
+        x = torch.randn(B, Cc, H, W, generator=g) * 3 + 1
+        gam, bet = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g)
+        ref = torch.nn.functional.group_norm(x, 32, gam, bet, 1e-5).relu()
+        xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+        y = torch.empty_like(xd)
+        stats = torch.empty(2 * 32 * B, dtype=torch.float64, device="cuda")
+        _lib.check(lib.quber_op_groupnorm(p(xd), B, H, W, Cc, 32, p(gam.cuda()), p(bet.cuda()), 1e-5, 1, p(stats), p(y), st))
+        np.testing.assert_allclose(y.cpu().permute(0, 3, 1, 2).numpy(), ref.numpy(), rtol=1e-5, atol=2e-6)
+    for (B, H, W, Cc, OH, OW) in [(2, 30, 40, 64, 60, 80), (1, 1, 1, 256, 30, 40), (2, 15, 20, 8, 60, 80), (1, 7, 9, 4, 10, 31)]:
+        x = torch.randn(B, Cc, H, W, generator=g)
+        ref = torch.nn.functional.interpolate(x, size=(OH, OW), mode="bilinear", align_corners=False)
+        xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+        y = torch.empty((B, OH, OW, Cc), device="cuda")
+        _lib.check(lib.quber_op_bilinear(p(xd), B, H, W, Cc, OH, OW, p(y), st))
+        np.testing.assert_allclose(y.cpu().permute(0, 3, 1, 2).numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
+    for (B, H, W, Cc) in [(2, 48, 64, 64), (1, 10, 14, 8)]:
+        x = torch.randn(B, Cc, H, W, generator=g)
+        ref = torch.nn.functional.max_pool2d(x, 3, 2, 1)
+        xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+        y = torch.empty((B, H // 2, W // 2, Cc), device="cuda")
+        _lib.check(lib.quber_op_maxpool3x3s2(p(xd), B, H, W, Cc, p(y), st))
+        np.testing.assert_array_equal(y.cpu().permute(0, 3, 1, 2).numpy(), ref.numpy())
