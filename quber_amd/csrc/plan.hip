@@ -423,7 +423,8 @@ struct Builder {
 };
 
 int check_cfg(const quber_config& c) {
-    if (c.height <= 0 || c.width <= 0 || c.height % 16 || c.width % 16) return fail("height/width must be positive multiples of 16");
+    if (c.height <= 0 || c.width <= 0 || c.width % 16) return fail("width must be a positive multiple of 16");
+    if (c.with_network && c.height % 16) return fail("height must be a multiple of 16 when the network is enabled");
     if (c.max_batch < 1) return fail("max_batch must be >= 1");
     if (c.max_instances < 1 || c.max_instances > 254) return fail("max_instances must be in 1..254");
     if (c.resnet_depth != 50 && c.resnet_depth != 101 && c.resnet_depth != 152) return fail("resnet_depth must be 50, 101 or 152");

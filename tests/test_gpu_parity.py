@@ -239,7 +239,8 @@ def test_groupnorm_bilinear_maxpool_vs_torch():
         xd = x.permute(0, 2, 3, 1).contiguous().cuda()
         y = torch.empty_like(xd)
         stats = torch.empty(2 * 32 * B, dtype=torch.float64, device="cuda")
-        _lib.check(lib.quber_op_groupnorm(p(xd), B, H, W, Cc, 32, p(gam.cuda()), p(bet.cuda()), 1e-5, 1, p(stats), p(y), st))
+        gd, bd = gam.cuda(), bet.cuda()          # keep the device copies alive across the asynchronous call
+        _lib.check(lib.quber_op_groupnorm(p(xd), B, H, W, Cc, 32, p(gd), p(bd), 1e-5, 1, p(stats), p(y), st))
         np.testing.assert_allclose(y.cpu().permute(0, 3, 1, 2).numpy(), ref.numpy(), rtol=1e-5, atol=2e-6)
     for (B, H, W, Cc, OH, OW) in [(2, 30, 40, 64, 60, 80), (1, 1, 1, 256, 30, 40), (2, 15, 20, 8, 60, 80), (1, 7, 9, 4, 10, 31)]:
         x = torch.randn(B, Cc, H, W, generator=g)
