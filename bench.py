@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Headline benchmark: refined masks / second on synthetic 640x480 RGB-D, N = 20 initial instances per frame,
+batch 16 per GPU (BASELINE.json configs[1]); weak scaling over --gpus (one process per GPU, frames sharded,
+RCCL broadcast of the weights at start-up and gather of the refined label maps per step).
+
+A step = one pass of the hot path over one resident batch:
+    encode initial masks -> network (fp32 MFMA) -> grouping / merge / scores -> per-instance masks.
+Prints ONE JSON line on rank 0 (see the contract in the task statement): value = whole-job masks/s,
+`roofline` for the dominant kernel (the implicit-GEMM convolution, MFMA-bound) measured live with HIP
+events on the launch stream, `cpu_baseline` = the oracle (pure-torch CPU restatement of the reference
+path) timed on this box's host cores over a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from quber_amd import arch, engine, synth  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--instances", type=int, default=20)
+    ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-gather", action="store_true", help="skip the per-step RCCL gather of label maps")
+    return ap.parse_args()
+
+
+def cpu_baseline(sd, h, w, n, frames):
+    """The oracle end to end (encode -> network -> grouping -> instances), batch 1 like the reference."""
+    from oracle import encode_np, postproc_ref
+    from oracle.network_torch import MaskRefinerNet
+    net = MaskRefinerNet().eval()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    cores = torch.get_num_threads()
+    times = []
+    with torch.no_grad():   # the reference builds an autograd graph (predictor.py:358); no_grad favours the baseline
+        for i in range(frames + 1):
+            sc = synth.make_scene(100 + i, h, w, n)
+            t0 = time.perf_counter()
+            offs = encode_np.encode_initial_masks(sc["masks"])
+            image = torch.from_numpy(np.concatenate([sc["rgb"], sc["depth"]], -1)).permute(2, 0, 1)[None]
+            out = net(image, torch.from_numpy(offs[None]))
+            postproc_ref.postprocess(out["foreground"][0], out["center"][0], out["offset"][0])
+            times.append(time.perf_counter() - t0)
+    times = times[1:]                                       # the reference drops the first sample (eval_utils.py:342)
+    med = float(np.median(times))
+    return {"value": n / med, "unit": "refined masks/s", "cores": cores, "kind": "port",
+            "sample": f"{frames} frames {w}x{h} N={n} batch 1, median {med * 1e3:.0f} ms/frame, torch {torch.__version__} CPU, no_grad"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+    B, H, W, N = a.batch, a.height, a.width, a.instances
+
+    # ---- weights: rank 0 owns the checkpoint, the others receive it over RCCL ----
+    specs = arch.param_specs()
+    if rank == 0:
+        sd = arch.init_state_dict(seed=0)
+        flat = torch.from_numpy(np.concatenate([sd[k].ravel() for k in specs])).to(dev)
+    else:
+        flat = torch.empty(arch.num_parameters(specs), dtype=torch.float32, device=dev)
+    if dist is not None:
+        dist.broadcast(flat, src=0)
+        host = flat.cpu().numpy()
+        sd, o = {}, 0
+        for k, (shape, _) in specs.items():
+            n = int(np.prod(shape))
+            sd[k] = host[o:o + n].reshape(shape)
+            o += n
+    del flat
+
+    eng = engine.Engine(engine.make_config(H, W, max_batch=B, max_instances=max(N, 1)), dev)
+    eng.load_state_dict(sd)
+
+    # ---- synthetic inputs, resident in HBM before the timed region; each rank has its own frames ----
+    batch = synth.make_batch(7 + rank, B, H, W, N)
+    masks = torch.from_numpy(batch["masks"]).to(dev)
+    bgr = torch.from_numpy(batch["rgb"]).to(dev)
+    depth = torch.from_numpy(batch["depth"]).to(dev)
+    offsets = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
+    logits = torch.empty((B, eng.planes, H, W), dtype=torch.float32, device=dev)
+    post = eng.alloc_post(B)
+    max_inst = min(eng.cap, max(N, 1) + 12)
+    out_masks = torch.empty((B, max_inst, H, W), dtype=torch.uint8, device=dev)
+    gathered = None
+    if dist is not None and not a.no_gather and rank == 0:
+        gathered = [torch.empty_like(post["panoptic"]) for _ in range(world)]
+
+    def step():
+        eng.encode(masks, offsets)
+        eng.forward(bgr, depth, offsets, logits)
+        eng.postprocess(logits, post)
+        eng.extract_masks(post, max_inst, out_masks)
+        if dist is not None and not a.no_gather:
+            dist.gather(post["panoptic"], gathered, dst=0)
+
+    for _ in range(a.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel family: HIP events around every conv launch, on the launch stream ----
+        conv_ms, conv_n, norm_ms, other_ms = [], 0, [], []
+        for _ in range(3):
+            _, prof = eng.forward_profiled(bgr, depth, offsets, logits)
+            conv_ms.append(prof["conv"][0])
+            conv_n = prof["conv"][1]
+            norm_ms.append(prof["norm"][0])
+            other_ms.append(prof["other"][0])
+        cms = float(np.median(conv_ms))
+        flops = eng.forward_flops() * B                       # algorithmic: 2*MAC of every conv, fusion stack once
+        achieved = flops / (cms * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "conv_hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        count = post["count"].cpu().numpy()
+        ms_per_step = elapsed / a.steps * 1e3
+        line = {
+            "metric": "refined masks/sec on 640x480 RGB-D (N=20 inst)",
+            "value": world * B * N * a.steps / elapsed,
+            "unit": "refined masks/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"batch={B} {W}x{H} RGB-D, {N} initial instances/frame, ResNet-50 RGB-D refiner "
+                                   f"(boundary-error -> fg/centre/offset), encode+network+grouping+mask extraction",
+                       "frames_per_step_per_gpu": B, "parallelism": f"dp{world}",
+                       "weights": "seeded synthetic (no checkpoint ships with the reference)",
+                       "instances_out_per_frame_mean": float(count.mean())},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "kernel": "conv_igemm_f32 (all instantiations)", "launches_per_step": conv_n,
+                         "avg_launch_ms": cms / max(conv_n, 1), "flops_per_launch": flops / max(conv_n, 1),
+                         "forward_ms": {"conv": cms, "groupnorm": float(np.median(norm_ms)),
+                                        "other": float(np.median(other_ms))}},
+        }
+        if world == 1 and a.cpu_frames > 0:
+            line["cpu_baseline"] = cpu_baseline(sd, H, W, N, a.cpu_frames)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

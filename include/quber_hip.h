@@ -87,6 +87,13 @@ int quber_explicit_error_maps(quber_ctx* ctx, const uint8_t* dev_init, int32_t n
 int quber_forward(quber_ctx* ctx, const uint8_t* dev_bgr, const uint8_t* dev_depth, const float* dev_offsets,
                   int32_t batch, float* dev_logits, void* stream);
 
+/* quber_forward with a HIP-event pair around every launch group of the plan, on `stream` (synchronises it).
+ *   kind_ms[3] / kind_launches[3]: summed device time and launch-group count of
+ *   [0] implicit-GEMM convolutions, [1] GroupNorm (stats + apply), [2] everything else.  Benchmark use only. */
+int quber_forward_profiled(quber_ctx* ctx, const uint8_t* dev_bgr, const uint8_t* dev_depth,
+                           const float* dev_offsets, int32_t batch, float* dev_logits, void* stream,
+                           double* kind_ms, int32_t* kind_launches);
+
 /* a8-a11 - centre NMS/top-k, pixel grouping, 512-px merge, scores and boxes.  Replaces get_panoptic_segmentation
  * (maskrefiner/modeling/mask_refiner/post_processing.py:165-221) and the instance loop of model.py:313-356.
  *   dev_logits f32 [B][n_planes][H][W] (planes 0..3 used)
@@ -109,6 +116,10 @@ int quber_extract_masks(quber_ctx* ctx, const float* dev_panoptic, const float* 
 int quber_debug_tensor(quber_ctx* ctx, const char* name, float** dev_ptr, int32_t* dims4, int32_t* channel_stride);
 /* algorithmic FLOPs of one forward at batch 1 (2 * MACs of every convolution) */
 double quber_forward_flops(quber_ctx* ctx);
+/* the launch plan of quber_forward, in execution order (after the input pre-processing kernel):
+ * kind 0 = convolution, 1 = GroupNorm, 2 = other; flops = algorithmic FLOPs at batch 1 */
+int quber_num_ops(quber_ctx* ctx);
+int quber_op_info(quber_ctx* ctx, int index, const char** name, int32_t* kind, double* flops, int32_t* launches);
 /* stand-alone convolution: y = act((conv(x, w) * scale + shift) + residual), NHWC, weights OIHW on the device */
 int quber_op_conv2d(const float* dev_x, int32_t batch, int32_t h, int32_t w, int32_t cin, const float* dev_w_oihw,
                     int32_t cout, int32_t ksize, int32_t stride, int32_t pad, int32_t dil, const float* dev_scale,

@@ -39,10 +39,13 @@ SIGNATURES = {
     "quber_encode_initial_masks": (C.c_int, [_P, _P, _I, _I, _P, _P]),
     "quber_explicit_error_maps": (C.c_int, [_P, _P, _I, _P, _I, _I, _P, _P]),
     "quber_forward": (C.c_int, [_P, _P, _P, _P, _I, _P, _P]),
+    "quber_forward_profiled": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, C.POINTER(C.c_double * 3), C.POINTER(_I * 3)]),
     "quber_postprocess": (C.c_int, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "quber_extract_masks": (C.c_int, [_P, _P, _P, _I, _I, _P, _P]),
     "quber_debug_tensor": (C.c_int, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(_I * 4), C.POINTER(_I)]),
     "quber_forward_flops": (C.c_double, [_P]),
+    "quber_num_ops": (C.c_int, [_P]),
+    "quber_op_info": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(_I), C.POINTER(C.c_double), C.POINTER(_I)]),
     "quber_op_conv2d": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P]),
     "quber_op_groupnorm": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _P, C.c_float, _I, _P, _P, _P]),
     "quber_op_bilinear": (C.c_int, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),

@@ -37,12 +37,21 @@ int fail(const std::string& m) {
 
 using namespace quber;
 
+enum OpKind { OP_CONV = 0, OP_NORM = 1, OP_OTHER = 2, OP_KINDS = 3 };
+struct Op {
+    std::function<int(int, hipStream_t)> run;
+    int kind;
+    std::string name;   // first weight key (convs / norms) or a short tag
+    double flops;       // algorithmic FLOPs at batch 1 (convolutions only)
+    int launches;       // kernel launches per run (memsets not counted)
+};
+
 struct quber_ctx {
     quber_config cfg;
     std::map<std::string, std::vector<float>> hostw;
     std::vector<std::pair<std::string, int64_t>> specs;
     std::vector<void*> allocs;
-    std::vector<std::function<int(int, hipStream_t)>> ops;
+    std::vector<Op> ops;
     std::map<std::string, View> taps;
     float* gauss = nullptr;
     void* enc_ws = nullptr;
@@ -56,6 +65,7 @@ struct quber_ctx {
     const float* cur_off = nullptr;
     float* cur_out = nullptr;
     double flops = 0.0;
+    std::vector<hipEvent_t> prof_events;
     bool finalized = false;
     int device = 0;
 };
@@ -189,11 +199,11 @@ struct Builder {
         p.relu = relu;
         p.in_gs = in.gs; p.out_gs = out.gs; p.res_gs = res ? res->gs : 0;
         p.w_gs = (long)Cout * Kpad; p.ss_gs = Cout;
-        c->ops.push_back([p, G](int B, hipStream_t st) mutable {
+        c->ops.push_back({[p, G](int B, hipStream_t st) mutable {
             p.B = B;
             p.M = B * p.OH * p.OW;
             return launch_conv(p, G, st);
-        });
+        }, OP_CONV, names[0], 2.0 * OH * OW * (double)cin_real * k * k * Cout * G, 1});
     }
 
     // GroupNorm(32) + ReLU from `in` into `out` (possibly a concat slice); names = norm key prefixes per group
@@ -211,15 +221,15 @@ struct Builder {
         const float* dg = upload(gamma);
         const float* db = upload(beta);
         double* stats = c->gn_stats;
-        c->ops.push_back([=](int B, hipStream_t st) {
+        c->ops.push_back({[=](int B, hipStream_t st) {
             int rc = launch_gn_stats(in, B, G, 32, stats, st);
             if (rc) return rc;
             return launch_gn_apply(in, out, B, G, 32, stats, dg, db, C, 1e-5f, 1, st);
-        });
+        }, OP_NORM, names[0], 0.0, 2});
     }
 
     void op(std::function<int(int, hipStream_t)> f) {
-        if (!dry) c->ops.push_back(std::move(f));
+        if (!dry) c->ops.push_back({std::move(f), OP_OTHER, "elementwise", 0.0, 1});
     }
 
     // conv (no bias) -> GN -> ReLU, the [d2] Conv2d(norm=GN, activation=relu) pattern
@@ -489,6 +499,7 @@ int quber_create(const quber_config* cfg, quber_ctx** out) {
 
 void quber_destroy(quber_ctx* c) {
     if (!c) return;
+    for (hipEvent_t e : c->prof_events) hipEventDestroy(e);
     for (void* p : c->allocs) hipFree(p);
     delete c;
 }
@@ -527,6 +538,16 @@ int quber_finalize_weights(quber_ctx* c) {
 
 double quber_forward_flops(quber_ctx* c) { return c ? c->flops : 0.0; }
 
+int quber_num_ops(quber_ctx* c) { return c ? (int)c->ops.size() : 0; }
+int quber_op_info(quber_ctx* c, int i, const char** name, int32_t* kind, double* flops, int32_t* launches) {
+    if (!c || i < 0 || i >= (int)c->ops.size()) return fail("op index out of range");
+    *name = c->ops[i].name.c_str();
+    *kind = c->ops[i].kind;
+    *flops = c->ops[i].flops;
+    *launches = c->ops[i].launches;
+    return 0;
+}
+
 static int check_batch(quber_ctx* c, int batch) {
     if (!c) return fail("null context");
     if (batch < 1 || batch > c->cfg.max_batch) return fail("batch outside 1..max_batch");
@@ -562,8 +583,41 @@ int quber_forward(quber_ctx* c, const uint8_t* bgr, const uint8_t* depth, const 
                                c->cfg.pixel_mean, c->cfg.pixel_std, 1, 1, st);
     if (rc) return rc;
     for (auto& op : c->ops) {
-        rc = op(batch, st);
+        rc = op.run(batch, st);
         if (rc) return rc;
+    }
+    return 0;
+}
+
+int quber_forward_profiled(quber_ctx* c, const uint8_t* bgr, const uint8_t* depth, const float* offs, int32_t batch,
+                           float* logits, void* stream, double* kind_ms, int32_t* kind_launches) {
+    if (check_batch(c, batch)) return -1;
+    if (!c->finalized) return fail("quber_forward_profiled before quber_finalize_weights");
+    if (!bgr || !depth || !offs || !logits || !kind_ms || !kind_launches) return fail("null argument");
+    hipStream_t st = (hipStream_t)stream;
+    c->cur_out = logits;
+    const size_t n = c->ops.size();
+    if (c->prof_events.size() < 2 * n) {
+        const size_t old = c->prof_events.size();
+        c->prof_events.resize(2 * n);
+        for (size_t i = old; i < 2 * n; ++i) QB_CHECK(hipEventCreate(&c->prof_events[i]));
+    }
+    int rc = launch_preprocess(bgr, depth, offs, c->X, batch, c->cfg.max_batch, c->cfg.height, c->cfg.width,
+                               c->cfg.pixel_mean, c->cfg.pixel_std, 1, 1, st);
+    if (rc) return rc;
+    for (size_t i = 0; i < n; ++i) {
+        QB_CHECK(hipEventRecord(c->prof_events[2 * i], st));
+        rc = c->ops[i].run(batch, st);
+        if (rc) return rc;
+        QB_CHECK(hipEventRecord(c->prof_events[2 * i + 1], st));
+    }
+    QB_CHECK(hipStreamSynchronize(st));
+    for (int k = 0; k < OP_KINDS; ++k) { kind_ms[k] = 0.0; kind_launches[k] = 0; }
+    for (size_t i = 0; i < n; ++i) {
+        float ms = 0.f;
+        QB_CHECK(hipEventElapsedTime(&ms, c->prof_events[2 * i], c->prof_events[2 * i + 1]));
+        kind_ms[c->ops[i].kind] += ms;
+        kind_launches[c->ops[i].kind] += 1;
     }
     return 0;
 }

@@ -207,34 +207,81 @@ __global__ void relabel_kernel(const unsigned* __restrict__ area, const int* __r
 }
 
 // ---- P5: write the panoptic map and accumulate per-instance statistics ----
+// Each block owns PS_PIX consecutive pixels.  Statistics are first combined per wave (shuffles, when the 64
+// lanes agree on the instance - the common case inside an object), then per block in LDS, and only then
+// flushed with one global atomic per (block, instance, field): a frame costs a few thousand global atomics
+// instead of eight per foreground pixel.
+constexpr int PS_PIX = 4096;
+
 __global__ __launch_bounds__(256) void paint_stats_kernel(const float* __restrict__ logits, int nch, int H, int W,
                                                           int cap, int label_divisor, const uint8_t* __restrict__ idmap,
                                                           const float* __restrict__ lut, float* __restrict__ pan,
                                                           InstStat* __restrict__ stats) {
     __shared__ float slut[256];
-    const int b = blockIdx.y;
-    slut[threadIdx.x] = lut[(long)b * 256 + threadIdx.x];
+    __shared__ double s_prob[256];
+    __shared__ unsigned s_cnt[256], s_sy[256], s_sx[256];
+    __shared__ int s_x0[256], s_y0[256], s_x1[256], s_y1[256];
+    const int b = blockIdx.y, t = threadIdx.x;
+    slut[t] = lut[(long)b * 256 + t];
+    s_prob[t] = 0.0; s_cnt[t] = 0; s_sy[t] = 0; s_sx[t] = 0;
+    s_x0[t] = 1 << 30; s_y0[t] = 1 << 30; s_x1[t] = -1; s_y1[t] = -1;
     __syncthreads();
     const long HW = (long)H * W;
-    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= HW) return;
-    const float lab = slut[idmap[(long)b * HW + p]];
-    pan[(long)b * HW + p] = lab;
-    if (lab >= 0.f) {
-        int slot = (int)lab - label_divisor;     // 1000 -> 0 (K = 0 blob), 1001.. -> 0..
-        if (slot > 0) slot -= 1;
-        const int y = (int)(p / W), x = (int)(p - (long)y * W);
-        const float lg = logits[(long)b * nch * HW + p];
-        const float pr = 1.f / (1.f + expf(-lg));
-        InstStat* s = stats + (long)b * cap + slot;
-        atomicAdd(&s->prob, (double)pr);
-        atomicAdd(&s->sy, (unsigned long long)y);
-        atomicAdd(&s->sx, (unsigned long long)x);
-        atomicAdd(&s->cnt, 1u);
-        atomicMin(&s->xmin, x);
-        atomicMin(&s->ymin, y);
-        atomicMax(&s->xmax, x);
-        atomicMax(&s->ymax, y);
+    const long base = (long)blockIdx.x * PS_PIX;
+    for (int it = 0; it < PS_PIX / 256; ++it) {
+        const long p = base + it * 256 + t;
+        int slot = -1, y = 0, x = 0;
+        double pr = 0.0;
+        if (p < HW) {
+            const float lab = slut[idmap[(long)b * HW + p]];
+            pan[(long)b * HW + p] = lab;
+            if (lab >= 0.f) {
+                slot = (int)lab - label_divisor;     // 1000 -> 0 (centre-less blob), 1001.. -> 0..
+                if (slot > 0) slot -= 1;
+                y = (int)(p / W);
+                x = (int)(p - (long)y * W);
+                const float lg = logits[(long)b * nch * HW + p];
+                pr = (double)(1.f / (1.f + expf(-lg)));
+            }
+        }
+        const int first = __shfl(slot, 0);
+        if (__all(slot == first)) {
+            if (first < 0) continue;                 // whole wave is background
+            unsigned cnt = 1, sy = (unsigned)y, sx = (unsigned)x;
+            int x0 = x, y0 = y, x1 = x, y1 = y;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                cnt += __shfl_down(cnt, o);
+                sy += __shfl_down(sy, o);
+                sx += __shfl_down(sx, o);
+                pr += __shfl_down(pr, o);
+                x0 = min(x0, __shfl_down(x0, o)); y0 = min(y0, __shfl_down(y0, o));
+                x1 = max(x1, __shfl_down(x1, o)); y1 = max(y1, __shfl_down(y1, o));
+            }
+            if ((t & 63) == 0) {
+                atomicAdd(&s_prob[first], pr); atomicAdd(&s_cnt[first], cnt);
+                atomicAdd(&s_sy[first], sy); atomicAdd(&s_sx[first], sx);
+                atomicMin(&s_x0[first], x0); atomicMin(&s_y0[first], y0);
+                atomicMax(&s_x1[first], x1); atomicMax(&s_y1[first], y1);
+            }
+        } else if (slot >= 0) {
+            atomicAdd(&s_prob[slot], pr); atomicAdd(&s_cnt[slot], 1u);
+            atomicAdd(&s_sy[slot], (unsigned)y); atomicAdd(&s_sx[slot], (unsigned)x);
+            atomicMin(&s_x0[slot], x); atomicMin(&s_y0[slot], y);
+            atomicMax(&s_x1[slot], x); atomicMax(&s_y1[slot], y);
+        }
+    }
+    __syncthreads();
+    if (t < cap && s_cnt[t]) {
+        InstStat* s = stats + (long)b * cap + t;
+        atomicAdd(&s->prob, s_prob[t]);
+        atomicAdd(&s->sy, (unsigned long long)s_sy[t]);
+        atomicAdd(&s->sx, (unsigned long long)s_sx[t]);
+        atomicAdd(&s->cnt, s_cnt[t]);
+        atomicMin(&s->xmin, s_x0[t]);
+        atomicMin(&s->ymin, s_y0[t]);
+        atomicMax(&s->xmax, s_x1[t]);
+        atomicMax(&s->ymax, s_y1[t]);
     }
 }
 
@@ -313,7 +360,7 @@ int launch_postprocess(const float* logits, int nch, int B, int H, int W, const 
                        idmap, area);
     hipLaunchKernelGGL(relabel_kernel, dim3(B), dim3(256), 0, st, area, ncenters, c.min_area, c.stuff_area,
                        c.label_divisor, c.cap, lut, count, labels, stats);
-    hipLaunchKernelGGL(paint_stats_kernel, dim3(pblocks, B), dim3(256), 0, st, logits, nch, H, W, c.cap,
+    hipLaunchKernelGGL(paint_stats_kernel, dim3((int)((HW + PS_PIX - 1) / PS_PIX), B), dim3(256), 0, st, logits, nch, H, W, c.cap,
                        c.label_divisor, idmap, lut, pan, stats);
     hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(256), 0, st, logits, nch, H, W, c.cap, count, stats, scores,
                        boxes);

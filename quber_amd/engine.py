@@ -98,6 +98,15 @@ class Engine:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.quber_finalize_weights(self.h))
 
+    def plan(self):
+        """[(name, kind, flops at batch 1, launches)] of quber_forward in execution order."""
+        out = []
+        name, kind, fl, ln = C.c_char_p(), C.c_int32(), C.c_double(), C.c_int32()
+        for i in range(self.lib.quber_num_ops(self.h)):
+            _lib.check(self.lib.quber_op_info(self.h, i, C.byref(name), C.byref(kind), C.byref(fl), C.byref(ln)))
+            out.append((name.value.decode(), ("conv", "norm", "other")[kind.value], fl.value, ln.value))
+        return out
+
     def forward_flops(self):
         return self.lib.quber_forward_flops(self.h)
 
@@ -132,6 +141,16 @@ class Engine:
             out = torch.empty((B, self.planes, self.H, self.W), dtype=torch.float32, device=self.device)
         _lib.check(self.lib.quber_forward(self.h, _ptr(bgr), _ptr(depth), _ptr(offsets), B, _ptr(out), _stream()))
         return out
+
+    def forward_profiled(self, bgr, depth, offsets, out=None):
+        """forward with HIP events around every launch group -> (logits, {kind: (ms, launches)})."""
+        B = bgr.shape[0]
+        if out is None:
+            out = torch.empty((B, self.planes, self.H, self.W), dtype=torch.float32, device=self.device)
+        ms, cnt = (C.c_double * 3)(), (C.c_int32 * 3)()
+        _lib.check(self.lib.quber_forward_profiled(self.h, _ptr(bgr), _ptr(depth), _ptr(offsets), B, _ptr(out),
+                                                   _stream(), C.byref(ms), C.byref(cnt)))
+        return out, {k: (ms[i], cnt[i]) for i, k in enumerate(("conv", "norm", "other"))}
 
     def alloc_post(self, B):
         d, cap = self.device, self.cap
