@@ -22,7 +22,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from quber_amd import arch, engine, synth  # noqa: E402
+from quber_amd import arch, dist as qdist, engine, synth  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 
@@ -79,22 +79,11 @@ def main():
     torch.cuda.set_device(dev)
     B, H, W, N = a.batch, a.height, a.width, a.instances
 
-    # ---- weights: rank 0 owns the checkpoint, the others receive it over RCCL ----
+    # ---- weights: rank 0 owns the checkpoint, the others receive it in one RCCL broadcast ----
     specs = arch.param_specs()
-    if rank == 0:
-        sd = arch.init_state_dict(seed=0)
-        flat = torch.from_numpy(np.concatenate([sd[k].ravel() for k in specs])).to(dev)
-    else:
-        flat = torch.empty(arch.num_parameters(specs), dtype=torch.float32, device=dev)
+    sd = arch.init_state_dict(seed=0) if rank == 0 else None
     if dist is not None:
-        dist.broadcast(flat, src=0)
-        host = flat.cpu().numpy()
-        sd, o = {}, 0
-        for k, (shape, _) in specs.items():
-            n = int(np.prod(shape))
-            sd[k] = host[o:o + n].reshape(shape)
-            o += n
-    del flat
+        sd = qdist.broadcast_state_dict(sd, specs, src=0, device=dev)
 
     eng = engine.Engine(engine.make_config(H, W, max_batch=B, max_instances=max(N, 1)), dev)
     eng.load_state_dict(sd)
@@ -109,9 +98,7 @@ def main():
     post = eng.alloc_post(B)
     max_inst = min(eng.cap, max(N, 1) + 12)
     out_masks = torch.empty((B, max_inst, H, W), dtype=torch.uint8, device=dev)
-    gathered = None
-    if dist is not None and not a.no_gather and rank == 0:
-        gathered = [torch.empty_like(post["panoptic"]) for _ in range(world)]
+    counts = [B] * world
 
     def step():
         eng.encode(masks, offsets)
@@ -119,7 +106,7 @@ def main():
         eng.postprocess(logits, post)
         eng.extract_masks(post, max_inst, out_masks)
         if dist is not None and not a.no_gather:
-            dist.gather(post["panoptic"], gathered, dst=0)
+            qdist.gather_label_maps(post["panoptic"], counts, dst=0)
 
     for _ in range(a.warmup):
         step()

@@ -116,6 +116,8 @@ int quber_extract_masks(quber_ctx* ctx, const float* dev_panoptic, const float* 
 int quber_debug_tensor(quber_ctx* ctx, const char* name, float** dev_ptr, int32_t* dims4, int32_t* channel_stride);
 /* algorithmic FLOPs of one forward at batch 1 (2 * MACs of every convolution) */
 double quber_forward_flops(quber_ctx* ctx);
+/* kernel-selection knobs for tuning experiments (key 0 = convolution main-loop variant); not part of the product path */
+void quber_set_tuning(int32_t key, int32_t value);
 /* the launch plan of quber_forward, in execution order (after the input pre-processing kernel):
  * kind 0 = convolution, 1 = GroupNorm, 2 = other; flops = algorithmic FLOPs at batch 1 */
 int quber_num_ops(quber_ctx* ctx);

@@ -32,6 +32,8 @@ struct ConvP {
     int relu;
     int M;               // B*OH*OW
     int mtiles, ntiles;
+    int order;           // tile-order experiment knob
+    int vec_out;         // 16-byte epilogue accesses are legal for this launch
     long in_gs, out_gs, res_gs, w_gs;
     int ss_gs;
 };
@@ -41,6 +43,7 @@ int fail(const std::string& msg);
 
 // launchers (all asynchronous on `st`, no allocation, no synchronisation)
 int launch_conv(const ConvP& p, int G, hipStream_t st);
+void set_conv_order(int v);   // tile-order experiment knob
 int launch_preprocess(const uint8_t* rgb, const uint8_t* depth, const float* offs, float* x, int B, int Bcap,
                       int H, int W, const float* mean6, const float* std6, int has_rgb, int has_depth,
                       hipStream_t st);

@@ -22,19 +22,29 @@
 namespace quber {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+// native vector type for register staging: HIP's float4 is a struct whose copies can lower to memcpy and
+// keep the staging arrays in scratch
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int BK = 32;
 constexpr int PITCH = 36;
 
+// Main-loop variants that were measured and rejected (profiles/r01c_conv_variants.md): double-buffered LDS with one
+// barrier per K-slice, a per-block s_setprio stagger, and 256x128 / 128x256 tiles on 8 waves were all 1-10 % slower
+// than this single-buffer, register-prefetch loop at 3 blocks per CU.
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
+__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
+    constexpr int NTH = WM * WN * 64;
+    constexpr int RPP = NTH / 8;      // tile rows covered by one pass of the loader
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
-    constexpr int AL = BM / 32;  // float4 loads per thread per K-slice (A)
-    constexpr int BL = BN / 32;  // (B)
-    static_assert(WM * WN == 4, "4 waves");
-    __shared__ __attribute__((aligned(16))) float As[BM * PITCH];
-    __shared__ __attribute__((aligned(16))) float Bs[BN * PITCH];
+    constexpr int AL = BM / RPP;      // float4 loads per thread per K-slice (A)
+    constexpr int BL = BN / RPP;      // (B)
+    constexpr int NBUF = 1;
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "loader geometry");
+    __shared__ __attribute__((aligned(16))) float smem[NBUF * (BM + BN) * PITCH];
+    float* const As = smem;
+    float* const Bs = smem + NBUF * BM * PITCH;
 
     const int t = threadIdx.x;
     const int g = blockIdx.z;
@@ -46,21 +56,35 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
         const int bid = blockIdx.x, nblk = gridDim.x;
         const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        if (p.order == 1) tile = bid;
     }
-    const int nt = tile % p.ntiles;
-    const int mt = tile / p.ntiles;
+    int nt = tile % p.ntiles;
+    int mt = tile / p.ntiles;
+    if (p.order == 2) {
+        // groups of 8 m-tiles x all n-tiles, m fastest inside the group
+        const int gsz = 8 * p.ntiles;
+        const int grp = tile / gsz, within = tile - grp * gsz;
+        const int rows = min(8, p.mtiles - grp * 8);
+        mt = grp * 8 + within % rows;
+        nt = within / rows;
+    }
     const int m0 = mt * BM, n0 = nt * BN;
 
     const float* __restrict__ in = p.in + (long)g * p.in_gs;
     const float* __restrict__ wt = p.w + (long)g * p.w_gs;
 
-    // ---- loader state (loop invariant) ----
+    // ---- loader state ----
+    // Each thread owns one 16-byte column (4 consecutive k) of AL A-rows and BL B-rows.  Its position inside the
+    // filter window (ky, kx, channel c) advances by BK per K-slice and is tracked incrementally (no divisions in
+    // the loop).  Loads are unconditional: an out-of-image tap reads a valid dummy address and is zeroed when
+    // the slice is written to LDS, so the compiler can issue all loads of a slice back to back.
     const int kq = (t & 7) * 4;
     const int lrow = t >> 3;
-    int iy0[AL], ix0[AL], pbase[AL];
+    int iy0[AL], ix0[AL];
+    const float* rowp[AL];
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
-        const int m = m0 + lrow + 32 * i;
+        const int m = m0 + lrow + RPP * i;
         if (m < p.M) {
             const int ohw = p.OH * p.OW;
             const int b = m / ohw;
@@ -69,60 +93,59 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
             const int ox = rem - oy * p.OW;
             iy0[i] = oy * p.stride - p.pad;
             ix0[i] = ox * p.stride - p.pad;
-            pbase[i] = b * p.H * p.W;
+            rowp[i] = in + ((long)b * p.H * p.W + (long)iy0[i] * p.W + ix0[i]) * p.in_cs;
         } else {
             iy0[i] = -(1 << 28);
             ix0[i] = 0;
-            pbase[i] = 0;
+            rowp[i] = in;
         }
     }
     const float* wrow[BL];
-    bool wok[BL];
 #pragma unroll
     for (int i = 0; i < BL; ++i) {
-        const int n = n0 + lrow + 32 * i;
-        wok[i] = n < p.Cout;
-        wrow[i] = wt + (long)(wok[i] ? n : 0) * p.Kpad + kq;
+        const int n = n0 + lrow + RPP * i;
+        wrow[i] = wt + (long)(n < p.Cout ? n : 0) * p.Kpad + kq;   // columns >= Cout are never stored
+    }
+    int kc, kx, ky;
+    {
+        const int tap = kq / p.Cin;
+        kc = kq - tap * p.Cin;
+        ky = tap / p.kw;
+        kx = tap - ky * p.kw;
     }
 
-    float4 ra[AL], rb[BL];
-    auto gload = [&](int kt) {
-        const int k = kt * BK + kq;
-        int dy = 0, dx = 0, c = 0;
-        const bool kok = k < p.K;
-        if (kok) {
-            const int tap = k / p.Cin;
-            c = k - tap * p.Cin;
-            const int ky = tap / p.kw;
-            dy = ky * p.dil;
-            dx = (tap - ky * p.kw) * p.dil;
-        }
+    f32x4 ra[AL], rb[BL];
+    bool aok[AL];
+    auto gload = [&](int kt) __attribute__((always_inline)) {
+        const bool kok = ky < p.kh;
+        const int dy = ky * p.dil, dx = kx * p.dil;
+        const long off = ((long)dy * p.W + dx) * p.in_cs + kc;
 #pragma unroll
         for (int i = 0; i < AL; ++i) {
-            const int iy = iy0[i] + dy, ix = ix0[i] + dx;
-            const bool ok = kok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            if (ok) {
-                const long off = ((long)(pbase[i] + iy * p.W + ix)) * p.in_cs + c;
-                ra[i] = *reinterpret_cast<const float4*>(in + off);
-            } else {
-                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = kok && (unsigned)(iy0[i] + dy) < (unsigned)p.H && (unsigned)(ix0[i] + dx) < (unsigned)p.W;
+            aok[i] = ok;
+            ra[i] = *reinterpret_cast<const f32x4*>(ok ? rowp[i] + off : in);
+        }
+#pragma unroll
+        for (int i = 0; i < BL; ++i) rb[i] = *reinterpret_cast<const f32x4*>(wrow[i] + kt * BK);
+        // advance to the next K-slice
+        kc += BK;
+#pragma unroll
+        for (int it = 0; it < BK / 8; ++it) {      // Cin >= 8: at most BK/8 filter taps per K-slice
+            if (kc >= p.Cin) {
+                kc -= p.Cin;
+                if (++kx == p.kw) { kx = 0; ++ky; }
             }
         }
-#pragma unroll
-        for (int i = 0; i < BL; ++i) {
-            if (wok[i])
-                rb[i] = *reinterpret_cast<const float4*>(wrow[i] + kt * BK);
-            else
-                rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
     };
-    auto lstore = [&]() {
+    auto lstore = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < AL; ++i)
-            *reinterpret_cast<float4*>(&As[(lrow + 32 * i) * PITCH + kq]) = ra[i];
+            *reinterpret_cast<f32x4*>(&As[buf * BM * PITCH + (lrow + RPP * i) * PITCH + kq]) =
+                aok[i] ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < BL; ++i)
-            *reinterpret_cast<float4*>(&Bs[(lrow + 32 * i) * PITCH + kq]) = rb[i];
+            *reinterpret_cast<f32x4*>(&Bs[buf * BN * PITCH + (lrow + RPP * i) * PITCH + kq]) = rb[i];
     };
 
     const int wave = t >> 6, lane = t & 63;
@@ -138,71 +161,114 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvP p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nk = p.Kpad / BK;
+    auto mma = [&](int buf, int ks) __attribute__((always_inline)) {
+        const float* ap = &As[buf * BM * PITCH + (wm * TM * 32 + r) * PITCH + 4 * h];
+        const float* bp = &Bs[buf * BN * PITCH + (wn * 32 + r) * PITCH + 4 * h];
+        f32x4 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(ap + i * 32 * PITCH + ks * 8);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(bp + j * WN * 32 * PITCH + ks * 8);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+            }
+    };
     gload(0);
-    lstore();
+    lstore(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) gload(kt + 1);
-        const float* ap = &As[(wm * TM * 32 + r) * PITCH + 4 * h];
-        const float* bp = &Bs[(wn * TN * 32 + r) * PITCH + 4 * h];
 #pragma unroll
-        for (int ks = 0; ks < BK / 8; ++ks) {
-            float4 a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4*>(ap + i * 32 * PITCH + ks * 8);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4*>(bp + j * 32 * PITCH + ks * 8);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-                }
-        }
+        for (int ks = 0; ks < BK / 8; ++ks) mma(0, ks);
         __syncthreads();
         if (kt + 1 < nk) {
-            lstore();
+            lstore(0);
             __syncthreads();
         }
     }
 
     // ---- epilogue: y = acc*scale + shift (+ residual) (ReLU) ----
+    // The accumulators are transposed through LDS one 32-column tile per wave at a time, so that global
+    // stores (and residual loads) are 16 bytes per lane over WN*32 consecutive channels of a pixel.
     float* __restrict__ out = p.out + (long)g * p.out_gs;
     const float* __restrict__ res = p.res ? p.res + (long)g * p.res_gs : nullptr;
+    const float* __restrict__ scale = p.scale ? p.scale + g * p.ss_gs : nullptr;
+    const float* __restrict__ shift = p.shift ? p.shift + g * p.ss_gs : nullptr;
+    constexpr int SW = WN * 32;        // staged columns per pass
+    constexpr int SP = SW + 4;         // staging pitch (floats)
+    static_assert(BM * SP <= NBUF * (BM + BN) * PITCH, "staging tile must fit in the K-slice buffers");
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + (wn * TN + j) * 32 + r;
-        const bool nok = n < p.Cout;
-        float sc = 1.f, sh = 0.f;
-        if (nok) {
-            if (p.scale) sc = p.scale[g * p.ss_gs + n];
-            if (p.shift) sh = p.shift[g * p.ss_gs + n];
-        }
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (nok && m < p.M) {
-                    float v = fmaf(acc[i][j][e], sc, sh);
+                const int row = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                smem[row * SP + wn * 32 + r] = acc[i][j][e];
+            }
+        __syncthreads();
+        const int nb = n0 + j * SW;    // first channel of this pass
+        if (p.vec_out) {
+            constexpr int CPR = SW / 4;  // float4 chunks per row
+#pragma unroll
+            for (int c = t; c < BM * CPR; c += NTH) {
+                const int row = c / CPR, q = (c - row * CPR) * 4;
+                const int m = m0 + row, n = nb + q;
+                if (m < p.M && n < p.Cout) {
+                    float4 v = *reinterpret_cast<const float4*>(&smem[row * SP + q]);
+                    if (scale) {
+                        const float4 sc = *reinterpret_cast<const float4*>(scale + n);
+                        const float4 sh = *reinterpret_cast<const float4*>(shift + n);
+                        v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
+                        v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+                    }
+                    if (res) {
+                        const float4 rv = *reinterpret_cast<const float4*>(res + (long)m * p.res_cs + n);
+                        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                    }
+                    if (p.relu) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    *reinterpret_cast<float4*>(out + (long)m * p.out_cs + n) = v;
+                }
+            }
+        } else {
+            for (int c = t; c < BM * SW; c += NTH) {
+                const int row = c / SW, q = c - row * SW;
+                const int m = m0 + row, n = nb + q;
+                if (m < p.M && n < p.Cout) {
+                    float v = smem[row * SP + q];
+                    if (scale) v = fmaf(v, scale[n], shift[n]);
                     if (res) v += res[(long)m * p.res_cs + n];
                     if (p.relu) v = fmaxf(v, 0.f);
                     out[(long)m * p.out_cs + n] = v;
                 }
             }
         }
+        if (j + 1 < TN) __syncthreads();
     }
 }
+
+static int g_order = 0;
+void set_conv_order(int v) { g_order = v; }
 
 template <int BM, int BN, int WM, int WN>
 static int run(ConvP p, int G, hipStream_t st) {
     p.mtiles = (p.M + BM - 1) / BM;
     p.ntiles = (p.Cout + BN - 1) / BN;
+    p.order = g_order;
+    p.vec_out = (p.Cout % 4 == 0) && (p.out_cs % 4 == 0) && (((uintptr_t)p.out & 15) == 0) && (p.out_gs % 4 == 0) &&
+                (!p.res || ((p.res_cs % 4 == 0) && (((uintptr_t)p.res & 15) == 0) && (p.res_gs % 4 == 0))) &&
+                (!p.scale || ((((uintptr_t)p.scale & 15) == 0) && (p.ss_gs % 4 == 0)));
     dim3 grid(p.mtiles * p.ntiles, 1, G);
-    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN>), grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN>), grid, dim3(WM * WN * 64), 0, st, p);
     QB_CHECK(hipGetLastError());
     return 0;
 }
@@ -213,6 +279,7 @@ int launch_conv(const ConvP& p, int G, hipStream_t st) {
     if (((uintptr_t)p.in & 15) || ((uintptr_t)p.w & 15) || (p.in_gs & 3) || (p.w_gs & 3))
         return fail("conv: operands must be 16-byte aligned");
     if (p.M <= 0 || p.Cout <= 0) return fail("conv: empty problem");
+    if ((p.scale == nullptr) != (p.shift == nullptr)) return fail("conv: scale and shift go together");
     if (p.Cout <= 32) return run<256, 32, 4, 1>(p, G, st);
     if (p.Cout <= 64) return run<256, 64, 4, 1>(p, G, st);
     const long tiles128 = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * G;

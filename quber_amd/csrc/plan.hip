@@ -537,6 +537,9 @@ int quber_finalize_weights(quber_ctx* c) {
 }
 
 double quber_forward_flops(quber_ctx* c) { return c ? c->flops : 0.0; }
+void quber_set_tuning(int32_t key, int32_t value) {
+    if (key == 1) set_conv_order(value);
+}
 
 int quber_num_ops(quber_ctx* c) { return c ? (int)c->ops.size() : 0; }
 int quber_op_info(quber_ctx* c, int i, const char** name, int32_t* kind, double* flops, int32_t* launches) {

@@ -1,0 +1,50 @@
+"""Data-parallel sharding of frames over the GPUs of one node (one process per GPU, torch.distributed).
+
+Frames are independent, so the data path has no exchange step: rank r refines its own shard.
+The only collectives are (1) a broadcast of the flat weight vector from the rank that owns the checkpoint and
+(2) a gather of the refined label maps (and per-frame counts) to rank 0.  Backend "nccl" is RCCL over xGMI on
+ROCm; the same code runs on "gloo" for the CPU tests.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous, balanced [start, stop) of `n_items` for `rank` (first n%world ranks get one extra)."""
+    q, r = divmod(n_items, world)
+    start = rank * q + min(rank, r)
+    return start, start + q + (1 if rank < r else 0)
+
+
+def broadcast_state_dict(sd, specs, src=0, device="cpu"):
+    """sd: name -> numpy array on `src` (ignored elsewhere); specs: ordered name -> (shape, kind).  Returns the
+    full state_dict on every rank after ONE broadcast of the concatenated fp32 vector."""
+    total = int(sum(int(np.prod(s)) for s, _ in specs.values()))
+    if dist.get_rank() == src:
+        flat = torch.from_numpy(np.concatenate([np.asarray(sd[k], np.float32).ravel() for k in specs])).to(device)
+    else:
+        flat = torch.empty(total, dtype=torch.float32, device=device)
+    dist.broadcast(flat, src=src)
+    host = flat.cpu().numpy()
+    out, o = {}, 0
+    for k, (shape, _) in specs.items():
+        n = int(np.prod(shape))
+        out[k] = host[o:o + n].reshape(shape)
+        o += n
+    return out
+
+
+def gather_label_maps(local, counts, dst=0):
+    """local: [b_r, H, W] label maps of this rank (b_r may differ by one between ranks); counts: frames per rank.
+    Returns the concatenated [sum(b_r), H, W] tensor on `dst`, None elsewhere."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    bmax = max(counts)
+    pad = local
+    if local.shape[0] < bmax:
+        pad = torch.cat([local, local.new_full((bmax - local.shape[0],) + tuple(local.shape[1:]), -1)])
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad.contiguous(), bufs, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)])
