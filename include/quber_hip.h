@@ -43,9 +43,18 @@ typedef struct quber_config {
     float boundary_ratio;            /* explicit_error_estimation/util.py:92 dilation_ratio (0.01) */
     float pixel_mean[6];             /* MODEL.PIXEL_MEAN */
     float pixel_std[6];              /* MODEL.PIXEL_STD */
+    /* prediction-head wiring (maskrefiner/modeling/mask_refiner/model.py:545-608, 738-762).
+     * head ids: 0 foreground, 1 center, 2 offset, 3 eee_mask, 4 eee_boundary */
+    int32_t eee_mask_on;             /* INS_EMBED_HEAD.EEE_MASK_ON */
+    int32_t eee_boundary_on;         /* INS_EMBED_HEAD.EEE_BOUNDARY_ON */
+    int32_t hierarchical;            /* INS_EMBED_HEAD.HIERARCHICAL_FUSION_ON */
+    int32_t fusion_feat;             /* "feat" in INS_EMBED_HEAD.FUSION_TARGET */
+    int32_t fusion_pred;             /* "pred" in INS_EMBED_HEAD.FUSION_TARGET */
+    int32_t n_levels;                /* len(INS_EMBED_HEAD.HIERARCHY) */
+    int32_t level_heads[5][5];       /* head ids per level, -1 padded */
 } quber_config;
 
-/* number of logit planes produced by quber_forward: [fg, centre, off_y, off_x, err_0 .. err_{classes-1}] */
+/* logit planes produced by quber_forward: [fg, centre, off_y, off_x, eee_boundary x classes (if on), eee_mask x classes (if on)] */
 #define QUBER_LOGIT_BASE 4
 
 void quber_default_config(quber_config* cfg);

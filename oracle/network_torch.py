@@ -42,7 +42,12 @@ class ArchCfg:
     convs_dim: int = 128
     common_stride: int = 4
     head_fusion_layers: int = 3              # MODEL.INS_EMBED_HEAD.NUM_FUSION_LAYERS
-    error_classes: int = 4                   # ERROR_TYPE e3
+    error_classes: int = 4                   # ERROR_TYPE e3 -> 4, e33 -> 3, e2 / e32 -> 2
+    eee_mask_on: bool = False
+    eee_boundary_on: bool = True
+    hierarchical: bool = True
+    hierarchy: List[List[str]] = field(default_factory=lambda: [["eee_boundary"], ["foreground", "center", "offset"]])
+    fusion_target: List[str] = field(default_factory=lambda: ["feat", "pred"])
     pixel_mean: List[float] = field(default_factory=lambda: [103.53, 116.28, 123.675, 127.5, 127.5, 127.5])
     pixel_std: List[float] = field(default_factory=lambda: [1.0] * 6)
 
@@ -254,10 +259,23 @@ class InsEmbedHead(nn.Module):
         dec["res5"] = nn.ModuleDict({"project_conv": ASPP(2048, cfg.aspp_channels, cfg.aspp_dilations)})
         self.decoder = dec
         d, h = cfg.convs_dim, cfg.head_channels
-        for name, c in (("foreground", 1), ("center", 1), ("offset", 2), ("eee_boundary", cfg.error_classes)):
+        self.out_ch = {"foreground": 1, "center": 1, "offset": 2}
+        if cfg.eee_mask_on:
+            self.out_ch["eee_mask"] = cfg.error_classes
+        if cfg.eee_boundary_on:
+            self.out_ch["eee_boundary"] = cfg.error_classes
+        for name, c in self.out_ch.items():
             self.add_module(f"{name}_pred_head", PredHead(d, h))
             self.add_module(f"{name}_predictor", Predictor(h, c))
-        self.fusion_layers_1 = HeadFusion(d + h + cfg.error_classes, d, cfg.head_fusion_layers)
+        # model.py:576-608: one FusionLayers per hierarchy level >= 1
+        if cfg.hierarchical:
+            for i in range(1, len(cfg.hierarchy)):
+                cin = d
+                if "feat" in cfg.fusion_target:
+                    cin += h * len(cfg.hierarchy[i - 1])
+                if "pred" in cfg.fusion_target:
+                    cin += sum(self.out_ch[k] for k in cfg.hierarchy[i - 1])
+                self.add_module(f"fusion_layers_{i}", HeadFusion(cin, d, cfg.head_fusion_layers))
 
     def decode(self, feats):
         y = self.decoder["res5"]["project_conv"](feats["res5"])
@@ -268,18 +286,32 @@ class InsEmbedHead(nn.Module):
         return y
 
     def forward(self, feats, taps=None):
+        cfg = self.cfg
         y = self.decode(feats)
-        fb = self.eee_boundary_pred_head(y)
-        lb = self.eee_boundary_predictor(fb)
-        yp = torch.cat([y, fb, lb.softmax(1)], 1)
-        # the reference evaluates this stack once per key (model.py:760-762); results are identical
-        z = self.fusion_layers_1(yp)
-        out = {"eee_boundary": lb}
-        for k in ("foreground", "center", "offset"):
-            out[k] = getattr(self, f"{k}_predictor")(getattr(self, f"{k}_pred_head")(z))
+        feat, out = {}, {}
+        levels = cfg.hierarchy if cfg.hierarchical else [list(self.out_ch)]
+        for i, keys in enumerate(levels):
+            x = y
+            if i > 0:                                             # model.py:749-762
+                yp = y
+                if "feat" in cfg.fusion_target:
+                    for pk in levels[i - 1]:
+                        yp = torch.cat([yp, feat[pk]], 1)
+                if "pred" in cfg.fusion_target:
+                    for pk in levels[i - 1]:
+                        o = out[pk]
+                        yp = torch.cat([yp, o.softmax(1) if "eee" in pk else o.sigmoid()], 1)
+                # the reference evaluates this stack once per key (model.py:760-762); results are identical
+                x = getattr(self, f"fusion_layers_{i}")(yp)
+                if taps is not None:
+                    taps[f"z{i}"] = x
+            for k in keys:
+                feat[k] = getattr(self, f"{k}_pred_head")(x)
+                out[k] = getattr(self, f"{k}_predictor")(feat[k])
         if taps is not None:
-            taps.update({"y": y, "feat_b": fb, "z": z})
-        s = self.cfg.common_stride
+            taps.update({"y": y})
+            taps.update({f"feat_{k}": v for k, v in feat.items()})
+        s = cfg.common_stride
         up = {k: F.interpolate(v, scale_factor=s, mode="bilinear", align_corners=False) for k, v in out.items()}
         up["offset"] = up["offset"] * s
         return up

@@ -16,6 +16,9 @@ class QuberConfig(C.Structure):
         ("min_instance_area", C.c_int32), ("label_divisor", C.c_int32), ("with_network", C.c_int32),
         ("center_threshold", C.c_float), ("boundary_ratio", C.c_float),
         ("pixel_mean", C.c_float * 6), ("pixel_std", C.c_float * 6),
+        ("eee_mask_on", C.c_int32), ("eee_boundary_on", C.c_int32), ("hierarchical", C.c_int32),
+        ("fusion_feat", C.c_int32), ("fusion_pred", C.c_int32), ("n_levels", C.c_int32),
+        ("level_heads", (C.c_int32 * 5) * 5),
     ]
 
 

@@ -10,7 +10,21 @@ import numpy as np
 BLOCKS = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}
 
 
-def param_specs(depth=50, backbone_fusion_layers=2, head_fusion_layers=3, error_classes=4):
+HEADS = ("foreground", "center", "offset", "eee_mask", "eee_boundary")      # head ids of the C ABI
+DEFAULT_HIERARCHY = (("eee_boundary",), ("foreground", "center", "offset"))
+
+
+def head_channels(error_classes=4, eee_mask_on=False, eee_boundary_on=True):
+    ch = {"foreground": 1, "center": 1, "offset": 2}
+    if eee_mask_on:
+        ch["eee_mask"] = error_classes
+    if eee_boundary_on:
+        ch["eee_boundary"] = error_classes
+    return ch
+
+
+def param_specs(depth=50, backbone_fusion_layers=2, head_fusion_layers=3, error_classes=4, eee_mask_on=False,
+                eee_boundary_on=True, hierarchical=True, hierarchy=DEFAULT_HIERARCHY, fusion_target=("feat", "pred")):
     """OrderedDict name -> (shape, kind); kind in conv|bn_w|bn_b|bn_m|bn_v|gn_w|gn_b|bias|pred_w|pred_b."""
     s = OrderedDict()
 
@@ -72,7 +86,8 @@ def param_specs(depth=50, backbone_fusion_layers=2, head_fusion_layers=3, error_
         gn(p + "fuse_conv.0.norm", 128)
         conv(p + "fuse_conv.1", 128, 128, 3)
         gn(p + "fuse_conv.1.norm", 128)
-    for name, co in (("foreground", 1), ("center", 1), ("offset", 2), ("eee_boundary", error_classes)):
+    out_ch = head_channels(error_classes, eee_mask_on, eee_boundary_on)
+    for name, co in out_ch.items():
         p = h + f"{name}_pred_head.head."
         conv(p + "0", 128, 128, 3)
         gn(p + "0.norm", 128)
@@ -80,12 +95,19 @@ def param_specs(depth=50, backbone_fusion_layers=2, head_fusion_layers=3, error_
         gn(p + "1.norm", 32)
         s[h + f"{name}_predictor.predictor.weight"] = ((co, 32, 1, 1), "pred_w")
         s[h + f"{name}_predictor.predictor.bias"] = ((co,), "pred_b")
-    f = h + "fusion_layers_1.fusion_layers."
-    conv(f + "0", 128, 128 + 32 + error_classes, 1, bias=True)
-    bn(f + "0.norm", 128)
-    for i in range(head_fusion_layers):
-        conv(f + f"{i + 1}", 128, 128, 3, bias=True)
-        bn(f + f"{i + 1}.norm", 128)
+    if hierarchical:                                     # model.py:576-608
+        for i in range(1, len(hierarchy)):
+            cin = 128
+            if "feat" in fusion_target:
+                cin += 32 * len(hierarchy[i - 1])
+            if "pred" in fusion_target:
+                cin += sum(out_ch[k] for k in hierarchy[i - 1])
+            f = h + f"fusion_layers_{i}.fusion_layers."
+            conv(f + "0", 128, cin, 1, bias=True)
+            bn(f + "0.norm", 128)
+            for j in range(head_fusion_layers):
+                conv(f + f"{j + 1}", 128, 128, 3, bias=True)
+                bn(f + f"{j + 1}.norm", 128)
     return s
 
 

@@ -96,6 +96,16 @@ def merge_from_file(cfg, path):
     return cfg
 
 
+def arch_kwargs(cfg):
+    """The architecture switches of a validated cfg, as keyword arguments of quber_amd.arch.param_specs."""
+    m, h = cfg.MODEL, cfg.MODEL.INS_EMBED_HEAD
+    return dict(depth=m.RESNETS.DEPTH, backbone_fusion_layers=m.BACKBONE.NUM_FUSION_LAYERS,
+                head_fusion_layers=h.NUM_FUSION_LAYERS, error_classes=ERROR_CLASSES[h.ERROR_TYPE],
+                eee_mask_on=bool(h.EEE_MASK_ON), eee_boundary_on=bool(h.EEE_BOUNDARY_ON),
+                hierarchical=bool(h.HIERARCHICAL_FUSION_ON), hierarchy=tuple(tuple(l) for l in h.HIERARCHY),
+                fusion_target=tuple(h.FUSION_TARGET))
+
+
 def canonical_cfg():
     """The 'QuBER' architecture of SURVEY.md section 8 (seed77/...-hf-b-fco-l3-b8.yaml over Base-Mask-Refiner.yaml)."""
     cfg = get_cfg()
@@ -142,10 +152,14 @@ def validate(cfg):
     need(m.RESNETS.STEM_TYPE == "deeplab" and m.RESNETS.NORM == "FrozenBN", "non-deeplab stem / non-frozen BN")
     need(m.RESNETS.DEPTH in (50, 101, 152), f"ResNet depth {m.RESNETS.DEPTH}")
     need(h.NAME == "MaskRefinerInsEmbedHead" and h.NORM == "GN", "head other than MaskRefinerInsEmbedHead/GN")
-    need(h.HIERARCHICAL_FUSION_ON and not h.EEE_MASK_ON and h.EEE_BOUNDARY_ON,
-         "head hierarchy other than boundary -> {foreground, center, offset}")
-    need([list(x) for x in h.HIERARCHY] == [["eee_boundary"], ["foreground", "center", "offset"]], "custom HIERARCHY")
-    need(sorted(h.FUSION_TARGET) == ["feat", "pred"], "FUSION_TARGET other than [feat, pred]")
+    heads = {"foreground", "center", "offset"} | ({"eee_mask"} if h.EEE_MASK_ON else set()) | \
+        ({"eee_boundary"} if h.EEE_BOUNDARY_ON else set())
+    if h.HIERARCHICAL_FUSION_ON:
+        flat = [k for lvl in h.HIERARCHY for k in lvl]
+        need(1 <= len(h.HIERARCHY) <= 5 and sorted(flat) == sorted(heads),
+             "a HIERARCHY that does not list every enabled head exactly once")
+        need(set(h.FUSION_TARGET) <= {"feat", "pred"} and len(h.FUSION_TARGET) > 0 or len(h.HIERARCHY) == 1,
+             "FUSION_TARGET outside {feat, pred}")
     need(not m.SEM_SEG_HEAD.USE_DEPTHWISE_SEPARABLE_CONV, "depthwise-separable head convs")
     need(h.ERROR_TYPE in ERROR_CLASSES, f"ERROR_TYPE {h.ERROR_TYPE}")
     need(list(h.PROJECT_CHANNELS) == [32, 64] and h.ASPP_CHANNELS == 256 and h.HEAD_CHANNELS == 32

@@ -19,7 +19,7 @@ struct View {
 
 struct ConvP {
     const float* in;
-    const float* w;      // [G][Cout][Kpad], k = (ky*kw + kx)*Cin + c
+    const float* w;      // [G][Cout][Kpad]; k order per `kmode`
     const float* scale;  // [G][Cout] or null
     const float* shift;  // [G][Cout] or null
     const float* res;    // residual view or null
@@ -34,6 +34,7 @@ struct ConvP {
     int mtiles, ntiles;
     int order;           // tile-order experiment knob
     int vec_out;         // 16-byte epilogue accesses are legal for this launch
+    int kmode;           // 0: k = (tap, c)   1: k = (c/32, tap, c%32)  (weights packed accordingly)
     long in_gs, out_gs, res_gs, w_gs;
     int ss_gs;
 };
@@ -54,7 +55,9 @@ int launch_gn_apply(const View& in, const View& out, int B, int G, int groups, c
 int launch_bilinear(const View& in, const View& out, int B, hipStream_t st);
 int launch_avgpool(const View& in, const View& out, int B, hipStream_t st);
 int launch_predictor(const View& in, const float* w, const float* bias, int cout, float* q, int q_ch0,
-                     int q_nch, float* softmax_dst, int softmax_cs, int B, hipStream_t st);
+                     int q_nch, float* act_dst, int act_cs, int act /*0 none, 1 softmax, 2 sigmoid*/, int B,
+                     hipStream_t st);
+int launch_copy_channels(const View& in, const View& out, int B, hipStream_t st);
 int launch_upsample_logits(const float* q, float* out, int B, int nch, int h, int w, int scale,
                            unsigned mul_mask, hipStream_t st);
 

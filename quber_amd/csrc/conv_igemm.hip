@@ -30,7 +30,7 @@ constexpr int BK = 32;
 constexpr int PITCH = 36;
 
 // Main-loop variants that were measured and rejected (profiles/r01c_conv_variants.md): double-buffered LDS with one
-// barrier per K-slice, a per-block s_setprio stagger, and 256x128 / 128x256 tiles on 8 waves were all 1-10 % slower
+// barrier per K-slice, a a per-block s_setprio stagger, and 256x128 / 128x256 tiles (8 waves, or 4 waves of 128x64) were all 1-25 % slower
 // than this single-buffer, register-prefetch loop at 3 blocks per CU.
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
@@ -42,7 +42,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
     constexpr int BL = BN / RPP;      // (B)
     constexpr int NBUF = 1;
     static_assert(BM % RPP == 0 && BN % RPP == 0, "loader geometry");
-    __shared__ __attribute__((aligned(16))) float smem[NBUF * (BM + BN) * PITCH];
+    constexpr int SW = WN * 32;        // columns staged per epilogue pass
+    constexpr int SP = SW + 4;         // staging pitch (floats)
+    constexpr int KSLICE_FLOATS = NBUF * (BM + BN) * PITCH;
+    constexpr int SMEM_FLOATS = KSLICE_FLOATS > BM * SP ? KSLICE_FLOATS : BM * SP;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     float* const As = smem;
     float* const Bs = smem + NBUF * BM * PITCH;
 
@@ -107,7 +111,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
         wrow[i] = wt + (long)(n < p.Cout ? n : 0) * p.Kpad + kq;   // columns >= Cout are never stored
     }
     int kc, kx, ky;
-    {
+    if (p.kmode) {
+        kc = kq; kx = 0; ky = 0;
+    } else {
         const int tap = kq / p.Cin;
         kc = kq - tap * p.Cin;
         ky = tap / p.kw;
@@ -117,7 +123,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
     f32x4 ra[AL], rb[BL];
     bool aok[AL];
     auto gload = [&](int kt) __attribute__((always_inline)) {
-        const bool kok = ky < p.kh;
+        const bool kok = p.kmode || ky < p.kh;
         const int dy = ky * p.dil, dx = kx * p.dil;
         const long off = ((long)dy * p.W + dx) * p.in_cs + kc;
 #pragma unroll
@@ -129,12 +135,21 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
 #pragma unroll
         for (int i = 0; i < BL; ++i) rb[i] = *reinterpret_cast<const f32x4*>(wrow[i] + kt * BK);
         // advance to the next K-slice
-        kc += BK;
+        if (p.kmode) {
+            // slice-major K order (k = (c/32, tap, c%32)): the taps of one 32-channel slice are consecutive K-slices,
+            // so the 9 shifted reads of a 3x3 window hit the same cache lines back to back instead of 8+ slices apart
+            if (++kx == p.kw) {
+                kx = 0;
+                if (++ky == p.kh) { ky = 0; kc += BK; }
+            }
+        } else {
+            kc += BK;
 #pragma unroll
-        for (int it = 0; it < BK / 8; ++it) {      // Cin >= 8: at most BK/8 filter taps per K-slice
-            if (kc >= p.Cin) {
-                kc -= p.Cin;
-                if (++kx == p.kw) { kx = 0; ++ky; }
+            for (int it = 0; it < BK / 8; ++it) {      // Cin >= 8: at most BK/8 filter taps per K-slice
+                if (kc >= p.Cin) {
+                    kc -= p.Cin;
+                    if (++kx == p.kw) { kx = 0; ++ky; }
+                }
             }
         }
     };
@@ -200,9 +215,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
     const float* __restrict__ res = p.res ? p.res + (long)g * p.res_gs : nullptr;
     const float* __restrict__ scale = p.scale ? p.scale + g * p.ss_gs : nullptr;
     const float* __restrict__ shift = p.shift ? p.shift + g * p.ss_gs : nullptr;
-    constexpr int SW = WN * 32;        // staged columns per pass
-    constexpr int SP = SW + 4;         // staging pitch (floats)
-    static_assert(BM * SP <= NBUF * (BM + BN) * PITCH, "staging tile must fit in the K-slice buffers");
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -279,6 +291,7 @@ int launch_conv(const ConvP& p, int G, hipStream_t st) {
     if (((uintptr_t)p.in & 15) || ((uintptr_t)p.w & 15) || (p.in_gs & 3) || (p.w_gs & 3))
         return fail("conv: operands must be 16-byte aligned");
     if (p.M <= 0 || p.Cout <= 0) return fail("conv: empty problem");
+    if (p.kmode && (p.Cin % BK || p.K != p.Kpad)) return fail("conv: slice-major weights need Cin % 32 == 0");
     if ((p.scale == nullptr) != (p.shift == nullptr)) return fail("conv: scale and shift go together");
     if (p.Cout <= 32) return run<256, 32, 4, 1>(p, G, st);
     if (p.Cout <= 64) return run<256, 64, 4, 1>(p, G, st);

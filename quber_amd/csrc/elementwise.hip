@@ -289,7 +289,7 @@ int launch_avgpool(const View& in, const View& out, int B, hipStream_t st) {
 template <int CIN>
 __global__ void predictor_kernel(const float* __restrict__ in, int in_cs, const float* __restrict__ w,
                                  const float* __restrict__ bias, int cout, float* __restrict__ q, int q_ch0,
-                                 int q_nch, float* __restrict__ sm, int sm_cs, int B, int HW) {
+                                 int q_nch, float* __restrict__ sm, int sm_cs, int act, int B, int HW) {
     __shared__ float ws[4 * CIN + 4];
     for (int i = threadIdx.x; i < cout * CIN; i += blockDim.x) ws[i] = w[i];
     if (threadIdx.x < cout) ws[4 * CIN + threadIdx.x] = bias[threadIdx.x];
@@ -313,7 +313,9 @@ __global__ void predictor_kernel(const float* __restrict__ in, int in_cs, const 
             o[k] = a;
             q[((long)b * q_nch + q_ch0 + k) * HW + pix] = a;
         }
-        if (sm) {
+        if (sm && act == 2) {
+            for (int k = 0; k < cout; ++k) sm[i * sm_cs + k] = 1.f / (1.f + expf(-o[k]));
+        } else if (sm) {
             float mx = o[0];
             for (int k = 1; k < cout; ++k) mx = fmaxf(mx, o[k]);
             float e[4], s = 0.f;
@@ -324,11 +326,29 @@ __global__ void predictor_kernel(const float* __restrict__ in, int in_cs, const 
 }
 
 int launch_predictor(const View& in, const float* w, const float* bias, int cout, float* q, int q_ch0, int q_nch,
-                     float* softmax_dst, int softmax_cs, int B, hipStream_t st) {
+                     float* softmax_dst, int softmax_cs, int act, int B, hipStream_t st) {
     if (in.C != 32 || cout > 4) return fail("predictor: expects 32 input channels and <= 4 outputs");
     const long total = (long)B * in.H * in.W;
     hipLaunchKernelGGL(predictor_kernel<32>, dim3(cap_grid(total, 256)), dim3(256), 0, st, in.p, in.cs, w, bias, cout,
-                       q, q_ch0, q_nch, softmax_dst, softmax_cs, B, in.H * in.W);
+                       q, q_ch0, q_nch, softmax_dst, softmax_cs, act, B, in.H * in.W);
+    QB_CHECK(hipGetLastError());
+    return 0;
+}
+
+__global__ void copy_channels_kernel(const float* __restrict__ in, float* __restrict__ out, long pixels, int C4,
+                                     int in_cs, int out_cs) {
+    const long total = pixels * C4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / C4;
+        const int c4 = (int)(i - pix * C4);
+        *reinterpret_cast<float4*>(out + pix * out_cs + c4 * 4) = *reinterpret_cast<const float4*>(in + pix * in_cs + c4 * 4);
+    }
+}
+
+int launch_copy_channels(const View& in, const View& out, int B, hipStream_t st) {
+    const long pixels = (long)B * in.H * in.W;
+    hipLaunchKernelGGL(copy_channels_kernel, dim3(cap_grid(pixels * (in.C / 4), 256)), dim3(256), 0, st, in.p, out.p,
+                       pixels, in.C / 4, in.cs, out.cs);
     QB_CHECK(hipGetLastError());
     return 0;
 }

@@ -142,6 +142,7 @@ struct Builder {
         const int G = (int)names.size();
         const int Cin = in.C, Cout = out.C;
         const int K = k * k * Cin, Kpad = (K + 31) / 32 * 32;
+        const int kmode = (k > 1 && Cin % 32 == 0) ? 1 : 0;   // slice-major K order for the 3x3 layers
         std::vector<float> packed, scale, shift;
         if (!dry) {
             packed.assign((size_t)G * Cout * Kpad, 0.f);
@@ -163,7 +164,10 @@ struct Builder {
             for (int o = 0; o < Cout; ++o) {
                 float* dst = &packed[((size_t)g * Cout + o) * Kpad];
                 for (int ci = 0; ci < cin_real; ++ci)
-                    for (int t = 0; t < k * k; ++t) dst[t * Cin + ci] = w[((size_t)o * cin_real + ci) * k * k + t];
+                    for (int t = 0; t < k * k; ++t) {
+                        const size_t kk = kmode ? ((size_t)(ci / 32) * k * k + t) * 32 + ci % 32 : (size_t)t * Cin + ci;
+                        dst[kk] = w[((size_t)o * cin_real + ci) * k * k + t];
+                    }
                 float sc = 1.f, sh = 0.f;
                 if (af == AF_FROZEN_BN || af == AF_BIAS_BN) {
                     if (!bw || !bb || !bm || !bv) continue;
@@ -197,6 +201,7 @@ struct Builder {
         p.K = K; p.Kpad = Kpad;
         p.kh = k; p.kw = k; p.stride = stride; p.pad = pad; p.dil = dil;
         p.relu = relu;
+        p.kmode = kmode;
         p.in_gs = in.gs; p.out_gs = out.gs; p.res_gs = res ? res->gs : 0;
         p.w_gs = (long)Cout * Kpad; p.ss_gs = Cout;
         c->ops.push_back({[p, G](int B, hipStream_t st) mutable {
@@ -347,10 +352,39 @@ struct Builder {
         conv_gn(Hd + "decoder.res3.fuse_conv.0", cat3, t128a, u3, 3, 1);
         conv_gn(Hd + "decoder.res3.fuse_conv.1", u3, t128a, y3, 3, 1);
 
+        // ---------------- prediction heads: generic hierarchy (model.py:738-762) ----------------
+        // head ids: 0 foreground, 1 center, 2 offset, 3 eee_mask, 4 eee_boundary
+        static const char* HN[5] = {"foreground", "center", "offset", "eee_mask", "eee_boundary"};
         const int ncls = cf.error_classes;
-        const int ypc = 128 + 32 + ncls;
+        const int hch[5] = {1, 1, 2, ncls, ncls};
+        const int hplane[5] = {0, 1, 2, QUBER_LOGIT_BASE + (cf.eee_boundary_on ? ncls : 0), QUBER_LOGIT_BASE};
+        const bool enabled[5] = {true, true, true, cf.eee_mask_on != 0, cf.eee_boundary_on != 0};
+        std::vector<std::vector<int>> levels;
+        if (cf.hierarchical) {
+            for (int i = 0; i < cf.n_levels; ++i) {
+                std::vector<int> l;
+                for (int j = 0; j < 5 && cf.level_heads[i][j] >= 0; ++j) l.push_back(cf.level_heads[i][j]);
+                levels.push_back(l);
+            }
+        } else {
+            std::vector<int> l;
+            for (int k : {3, 4, 0, 1, 2})
+                if (enabled[k]) l.push_back(k);
+            levels.push_back(l);
+        }
+        const int nlev = (int)levels.size();
+        // concatenated fusion inputs y | feats(prev level) | activations(prev level), one per level >= 1
+        std::vector<View> YP(nlev);
+        std::vector<int> ypw(nlev, 0);
+        for (int i = 1; i < nlev; ++i) {
+            int wd = 128;
+            if (cf.fusion_feat) wd += 32 * (int)levels[i - 1].size();
+            if (cf.fusion_pred)
+                for (int k : levels[i - 1]) wd += hch[k];
+            ypw[i] = wd;
+            YP[i] = make((wd + 3) / 4 * 4, h4, w4);
+        }
         View cat2 = make(32 + 128, h4, w4), t32 = make(32, h4, w4), t128 = make(128, h4, w4);
-        View YP = make(ypc, h4, w4);
         conv_gn(Hd + "decoder.res2.project_conv", F[0], t32, slice(cat2, 0, 32), 1, 1);
         {
             View dst = slice(cat2, 32, 128);
@@ -358,76 +392,77 @@ struct Builder {
         }
         View u2 = make(128, h4, w4);
         conv_gn(Hd + "decoder.res2.fuse_conv.0", cat2, t128, u2, 3, 1);
-        View y = slice(YP, 0, 128);
+        View y = nlev > 1 ? slice(YP[1], 0, 128) : make(128, h4, w4);
         conv_gn(Hd + "decoder.res2.fuse_conv.1", u2, t128, y, 3, 1);
+        for (int i = 2; i < nlev; ++i) {
+            View dst = slice(YP[i], 0, 128);
+            op([=](int B, hipStream_t st) { return launch_copy_channels(y, dst, B, st); });
+        }
         if (!dry) c->taps["y"] = y;
 
-        // ---------------- level 0: boundary-error head (model.py:743-747) ----------------
-        const int planes = QUBER_LOGIT_BASE + ncls;
+        const int planes = QUBER_LOGIT_BASE + ncls * ((cf.eee_mask_on ? 1 : 0) + (cf.eee_boundary_on ? 1 : 0));
         if (!dry) c->q = (float*)dalloc_bytes(sizeof(float) * (size_t)Bmax * planes * h4 * w4);
         float* q = c->q;
-        View hb = make(128, h4, w4), featb = slice(YP, 128, 32);
-        conv_gn(Hd + "eee_boundary_pred_head.head.0", y, t128, hb, 3, 1);
-        conv_gn(Hd + "eee_boundary_pred_head.head.1", hb, t32, featb, 3, 1);
-        {
-            const float* pw = hw(Hd + "eee_boundary_predictor.predictor.weight", (int64_t)ncls * 32);
-            const float* pb = hw(Hd + "eee_boundary_predictor.predictor.bias", ncls);
-            if (!dry && pw && pb) {
-                const float* dw = upload(std::vector<float>(pw, pw + ncls * 32));
-                const float* db = upload(std::vector<float>(pb, pb + ncls));
-                float* sm = YP.p + 160;
+        for (int i = 0; i < nlev; ++i) {
+            const int G = (int)levels[i].size();
+            View x = y;
+            if (i > 0) {
+                // FusionLayers_i (model.py:424-458), evaluated once (the reference re-runs it per key, model.py:760-762)
+                const std::string FL = Hd + "fusion_layers_" + std::to_string(i) + ".fusion_layers.";
+                View za = make(128, h4, w4), zb = make(128, h4, w4);
+                conv({FL + "0"}, YP[i], ypw[i], za, 1, 1, 0, 1, AF_BIAS_BN, nullptr, true);
+                View cur = za, nxt = zb;
+                for (int j = 0; j < cf.head_fusion_layers; ++j) {
+                    conv({FL + std::to_string(j + 1)}, cur, 128, nxt, 3, 1, 1, 1, AF_BIAS_BN, nullptr, true);
+                    std::swap(cur, nxt);
+                }
+                x = cur;
+                if (!dry) c->taps["z" + std::to_string(i)] = x;
+            }
+            std::vector<std::string> h0, h1, n0, n1;
+            for (int k : levels[i]) {
+                h0.push_back(Hd + HN[k] + "_pred_head.head.0");
+                h1.push_back(Hd + HN[k] + "_pred_head.head.1");
+                n0.push_back(h0.back() + ".norm");
+                n1.push_back(h1.back() + ".norm");
+            }
+            View g128 = make(128, h4, w4, G), g128n = make(128, h4, w4, G), g32 = make(32, h4, w4, G);
+            const bool next = i + 1 < nlev;
+            View feat = (next && cf.fusion_feat) ? slice(YP[i + 1], 128, 32, 32) : make(32, h4, w4, G);
+            View xin = x;
+            xin.gs = 0;   // every head of the level reads the same features
+            conv(h0, xin, 128, g128, 3, 1, 1, 1, AF_NONE, nullptr, false);
+            gn_relu(n0, g128, g128n);
+            conv(h1, g128n, 128, g32, 3, 1, 1, 1, AF_NONE, nullptr, false);
+            gn_relu(n1, g32, feat);
+            int act_off = 128 + (cf.fusion_feat ? 32 * G : 0);
+            for (int j = 0; j < G; ++j) {
+                const int k = levels[i][j];
+                const float* pw = hw(Hd + HN[k] + "_predictor.predictor.weight", (int64_t)hch[k] * 32);
+                const float* pb = hw(Hd + HN[k] + "_predictor.predictor.bias", hch[k]);
+                View in = feat;
+                if (in.p) in.p += (long)j * feat.gs;
+                if (!dry) c->taps[std::string("feat_") + HN[k]] = in;
+                float* act_dst = nullptr;
+                int act_cs = 0;
+                if (next && cf.fusion_pred) {
+                    act_dst = YP[i + 1].p ? YP[i + 1].p + act_off : nullptr;
+                    act_cs = YP[i + 1].cs;
+                    act_off += hch[k];
+                }
+                if (dry || !pw || !pb) continue;
+                const float* dw = upload(std::vector<float>(pw, pw + hch[k] * 32));
+                const float* db = upload(std::vector<float>(pb, pb + hch[k]));
+                const int ch0 = hplane[k], nn = hch[k], act = act_dst ? (k >= 3 ? 1 : 2) : 0;
                 op([=](int B, hipStream_t st) {
-                    return launch_predictor(featb, dw, db, ncls, q, QUBER_LOGIT_BASE, planes, sm, ypc, B, st);
+                    return launch_predictor(in, dw, db, nn, q, ch0, planes, act_dst, act_cs, act, B, st);
                 });
             }
-            if (!dry) c->taps["feat_b"] = featb;
-        }
-
-        // ---------------- head fusion (model.py:424-458), evaluated once ----------------
-        const std::string FL = Hd + "fusion_layers_1.fusion_layers.";
-        View za = make(128, h4, w4), zb = make(128, h4, w4);
-        conv({FL + "0"}, YP, ypc, za, 1, 1, 0, 1, AF_BIAS_BN, nullptr, true);
-        View cur = za, nxt = zb;
-        for (int i = 0; i < cf.head_fusion_layers; ++i) {
-            conv({FL + std::to_string(i + 1)}, cur, 128, nxt, 3, 1, 1, 1, AF_BIAS_BN, nullptr, true);
-            std::swap(cur, nxt);
-        }
-        View z = cur;
-        if (!dry) c->taps["z"] = z;
-
-        // ---------------- level 1: foreground / centre / offset heads as one grouped launch ----------------
-        const std::vector<std::string> keys = {"foreground", "center", "offset"};
-        std::vector<std::string> h0, h1, n0, n1;
-        for (auto& k : keys) {
-            h0.push_back(Hd + k + "_pred_head.head.0");
-            h1.push_back(Hd + k + "_pred_head.head.1");
-            n0.push_back(h0.back() + ".norm");
-            n1.push_back(h1.back() + ".norm");
-        }
-        View g128 = make(128, h4, w4, 3), g128n = make(128, h4, w4, 3), g32 = make(32, h4, w4, 3), g32n = make(32, h4, w4, 3);
-        View zin = z;
-        zin.gs = 0;  // all three heads read the same fused features
-        conv(h0, zin, 128, g128, 3, 1, 1, 1, AF_NONE, nullptr, false);
-        gn_relu(n0, g128, g128n);
-        conv(h1, g128n, 128, g32, 3, 1, 1, 1, AF_NONE, nullptr, false);
-        gn_relu(n1, g32, g32n);
-        const int pch0[3] = {0, 1, 2}, pn[3] = {1, 1, 2};
-        for (int k = 0; k < 3; ++k) {
-            const float* pw = hw(Hd + keys[k] + "_predictor.predictor.weight", (int64_t)pn[k] * 32);
-            const float* pb = hw(Hd + keys[k] + "_predictor.predictor.bias", pn[k]);
-            if (dry || !pw || !pb) continue;
-            const float* dw = upload(std::vector<float>(pw, pw + pn[k] * 32));
-            const float* db = upload(std::vector<float>(pb, pb + pn[k]));
-            View in = g32n;
-            if (in.p) in.p += (long)k * g32n.gs;
-            const int ch0 = pch0[k], nn = pn[k];
-            op([=](int B, hipStream_t st) { return launch_predictor(in, dw, db, nn, q, ch0, planes, nullptr, 0, B, st); });
         }
         // x4 bilinear of every plane, offsets scaled by the stride (model.py:689-708)
         quber_ctx* ctx = c;
-        const int cs = 4;
         op([=](int B, hipStream_t st) {
-            return launch_upsample_logits(q, ctx->cur_out, B, planes, h4, w4, cs, 0xCu, st);
+            return launch_upsample_logits(q, ctx->cur_out, B, planes, h4, w4, 4, 0xCu, st);
         });
     }
 };
@@ -441,6 +476,21 @@ int check_cfg(const quber_config& c) {
     if (c.res5_dilation != 1 && c.res5_dilation != 2 && c.res5_dilation != 4) return fail("res5_dilation must be 1, 2 or 4");
     if (c.res5_dilation == 1) return fail("res5_dilation 1 (output stride 32) is not supported by this build");
     if (c.error_classes < 2 || c.error_classes > 4) return fail("error_classes must be 2..4");
+    if (c.with_network && c.hierarchical) {
+        if (c.n_levels < 1 || c.n_levels > 5) return fail("n_levels must be 1..5");
+        int seen[5] = {0, 0, 0, 0, 0};
+        for (int i = 0; i < c.n_levels; ++i) {
+            if (c.level_heads[i][0] < 0) return fail("empty hierarchy level");
+            for (int j = 0; j < 5 && c.level_heads[i][j] >= 0; ++j) {
+                const int k = c.level_heads[i][j];
+                if (k > 4) return fail("hierarchy head id out of range");
+                seen[k]++;
+            }
+        }
+        const int want[5] = {1, 1, 1, c.eee_mask_on ? 1 : 0, c.eee_boundary_on ? 1 : 0};
+        for (int k = 0; k < 5; ++k)
+            if (seen[k] != want[k]) return fail("the hierarchy must list every enabled head exactly once");
+    }
     if (c.top_k < 1 || c.top_k > 254) return fail("top_k must be in 1..254");
     if (c.gaussian_sigma < 1 || c.gaussian_sigma > 40) return fail("gaussian_sigma out of range");
     return 0;
@@ -459,6 +509,12 @@ void quber_default_config(quber_config* c) {
     c->resnet_depth = 50; c->res5_dilation = 2; c->backbone_fusion_layers = 2; c->head_fusion_layers = 3;
     c->error_classes = 4; c->gaussian_sigma = 10; c->nms_kernel = 7; c->top_k = 200; c->stuff_area = 2048;
     c->min_instance_area = 512; c->label_divisor = 1000; c->with_network = 1;
+    c->eee_mask_on = 0; c->eee_boundary_on = 1; c->hierarchical = 1; c->fusion_feat = 1; c->fusion_pred = 1;
+    c->n_levels = 2;
+    for (int i = 0; i < 5; ++i)
+        for (int j = 0; j < 5; ++j) c->level_heads[i][j] = -1;
+    c->level_heads[0][0] = 4;                                   // [[eee_boundary], [foreground, center, offset]]
+    c->level_heads[1][0] = 0; c->level_heads[1][1] = 1; c->level_heads[1][2] = 2;
     c->center_threshold = 0.3f; c->boundary_ratio = 0.01f;
     const float mean[6] = {103.53f, 116.28f, 123.675f, 127.5f, 127.5f, 127.5f};
     for (int i = 0; i < 6; ++i) { c->pixel_mean[i] = mean[i]; c->pixel_std[i] = 1.f; }
@@ -654,13 +710,22 @@ int quber_debug_tensor(quber_ctx* c, const char* name, float** ptr, int32_t* dim
 }
 
 // ---------------- stand-alone ops (tests / micro-benchmarks) ----------------
-__global__ void pack_oihw_kernel(const float* __restrict__ w, int O, int I, int k, int Kpad, float* __restrict__ out) {
+__global__ void pack_oihw_kernel(const float* __restrict__ w, int O, int I, int k, int Kpad, int kmode,
+                                 float* __restrict__ out) {
     const long total = (long)O * Kpad;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int o = i / Kpad, kk = i % Kpad;
         float v = 0.f;
         if (kk < k * k * I) {
-            const int tap = kk / I, ci = kk % I;
+            int tap, ci;
+            if (kmode) {
+                const int cb = kk / (k * k * 32), rem = kk % (k * k * 32);
+                tap = rem / 32;
+                ci = cb * 32 + rem % 32;
+            } else {
+                tap = kk / I;
+                ci = kk % I;
+            }
             v = w[((long)o * I + ci) * k * k + tap];
         }
         out[i] = v;
@@ -672,7 +737,8 @@ int quber_op_conv2d(const float* x, int32_t B, int32_t h, int32_t w, int32_t cin
                     const float* residual, int32_t relu, float* packed, float* y, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int K = k * k * cin, Kpad = (K + 31) / 32 * 32;
-    hipLaunchKernelGGL(pack_oihw_kernel, dim3(256), dim3(256), 0, st, w_oihw, cout, cin, k, Kpad, packed);
+    const int kmode = (k > 1 && cin % 32 == 0) ? 1 : 0;
+    hipLaunchKernelGGL(pack_oihw_kernel, dim3(256), dim3(256), 0, st, w_oihw, cout, cin, k, Kpad, kmode, packed);
     ConvP p{};
     p.in = x; p.w = packed; p.scale = scale; p.shift = shift; p.res = residual; p.out = y;
     p.B = B; p.H = h; p.W = w; p.Cin = cin; p.in_cs = cin;
@@ -680,6 +746,7 @@ int quber_op_conv2d(const float* x, int32_t B, int32_t h, int32_t w, int32_t cin
     p.OW = (w + 2 * pad - dil * (k - 1) - 1) / stride + 1;
     p.Cout = cout; p.out_cs = cout; p.res_cs = cout; p.K = K; p.Kpad = Kpad;
     p.kh = k; p.kw = k; p.stride = stride; p.pad = pad; p.dil = dil; p.relu = relu;
+    p.kmode = kmode;
     p.M = B * p.OH * p.OW;
     p.w_gs = 0; p.ss_gs = 0;
     return launch_conv(p, 1, st);

@@ -8,7 +8,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from .config import ERROR_CLASSES
+from . import arch
+from .config import arch_kwargs
 
 
 def _ptr(t):
@@ -17,6 +18,24 @@ def _ptr(t):
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def set_arch(qc, depth=50, backbone_fusion_layers=2, head_fusion_layers=3, error_classes=4, eee_mask_on=False,
+             eee_boundary_on=True, hierarchical=True, hierarchy=arch.DEFAULT_HIERARCHY, fusion_target=("feat", "pred")):
+    """Write the architecture switches (keyword arguments of arch.param_specs) into a quber_config."""
+    qc.resnet_depth, qc.backbone_fusion_layers, qc.head_fusion_layers = depth, backbone_fusion_layers, head_fusion_layers
+    qc.error_classes, qc.eee_mask_on, qc.eee_boundary_on = error_classes, int(eee_mask_on), int(eee_boundary_on)
+    qc.hierarchical = int(hierarchical)
+    qc.fusion_feat, qc.fusion_pred = int("feat" in fusion_target), int("pred" in fusion_target)
+    levels = list(hierarchy) if hierarchical else []
+    qc.n_levels = len(levels)
+    for i in range(5):
+        for j in range(5):
+            qc.level_heads[i][j] = -1
+    for i, lvl in enumerate(levels):
+        for j, k in enumerate(lvl):
+            qc.level_heads[i][j] = arch.HEADS.index(k)
+    return qc
 
 
 def make_config(height=480, width=640, max_batch=1, max_instances=64, cfg=None, with_network=True):
@@ -28,11 +47,8 @@ def make_config(height=480, width=640, max_batch=1, max_instances=64, cfg=None, 
     qc.with_network = 1 if with_network else 0
     if cfg is not None:
         m = cfg.MODEL
-        qc.resnet_depth = m.RESNETS.DEPTH
+        set_arch(qc, **arch_kwargs(cfg))
         qc.res5_dilation = m.RESNETS.RES5_DILATION
-        qc.backbone_fusion_layers = m.BACKBONE.NUM_FUSION_LAYERS
-        qc.head_fusion_layers = m.INS_EMBED_HEAD.NUM_FUSION_LAYERS
-        qc.error_classes = ERROR_CLASSES[m.INS_EMBED_HEAD.ERROR_TYPE]
         qc.gaussian_sigma = cfg.INPUT.get("GAUSSIAN_SIGMA", 10)
         qc.nms_kernel = m.PANOPTIC_DEEPLAB.NMS_KERNEL
         qc.top_k = m.PANOPTIC_DEEPLAB.TOP_K_INSTANCE
@@ -54,7 +70,7 @@ class Engine:
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.qcfg = qcfg
         self.H, self.W = qcfg.height, qcfg.width
-        self.planes = 4 + qcfg.error_classes
+        self.planes = 4 + qcfg.error_classes * (int(bool(qcfg.eee_mask_on)) + int(bool(qcfg.eee_boundary_on)))
         self.cap = qcfg.top_k
         h = C.c_void_p()
         with torch.cuda.device(self.device):

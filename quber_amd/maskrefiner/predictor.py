@@ -74,10 +74,16 @@ class RefinerModel:
         kmax = int(count.max()) if B else 0
         masks = eng.extract_masks(post, kmax) if kmax > 0 else None
         out = []
-        ncls = logits.shape[1] - 4
+        qc = eng.qcfg
+        ncls, o = qc.error_classes, 4
         for b in range(B):
             r = {"sem_seg": logits[b, 0:1], "panoptic_seg": (post["panoptic"][b], None)}
-            r["eee_boundary"] = logits[b, 4:4 + ncls]
+            o = 4
+            if qc.eee_boundary_on:                       # model.py:310-313
+                r["eee_boundary"] = logits[b, o:o + ncls]
+                o += ncls
+            if qc.eee_mask_on:
+                r["eee_mask"] = logits[b, o:o + ncls]
             k = int(count[b])
             if k > 0:
                 labels = post["labels"][b, :k]
@@ -115,10 +121,7 @@ class MaskRefinerPredictor:
         self.input_format = self.cfg.INPUT.FORMAT
         assert self.input_format in ["RGB", "BGR"], self.input_format
         self.sigma = 10
-        m = self.cfg.MODEL
-        kw = dict(depth=m.RESNETS.DEPTH, backbone_fusion_layers=m.BACKBONE.NUM_FUSION_LAYERS,
-                  head_fusion_layers=m.INS_EMBED_HEAD.NUM_FUSION_LAYERS,
-                  error_classes=qconfig.ERROR_CLASSES[m.INS_EMBED_HEAD.ERROR_TYPE])
+        kw = qconfig.arch_kwargs(self.cfg)
         path = weights_file
         if path is not None and not os.path.exists(path) and config_file is not None:
             # the reference derives the path from the config location (predictor.py:222-225)

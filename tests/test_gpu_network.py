@@ -13,8 +13,17 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4   # BASELINE.json north_star: float outputs within 1e-4 of the reference CPU path
 
 
-def oracle_net(sd, depth=50):
-    net = MaskRefinerNet(ArchCfg(depth=depth)).eval()
+def oracle_cfg(**kw):
+    kw = dict(kw)
+    if "hierarchy" in kw:
+        kw["hierarchy"] = [list(l) for l in kw["hierarchy"]]
+    if "fusion_target" in kw:
+        kw["fusion_target"] = list(kw["fusion_target"])
+    return ArchCfg(**kw)
+
+
+def oracle_net(sd, depth=50, **kw):
+    net = MaskRefinerNet(oracle_cfg(depth=depth, **kw)).eval()
     missing, unexpected = net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
     assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing)
     return net
@@ -45,7 +54,7 @@ def test_network_vs_oracle_small(h, w, b, depth):
     taps = {}
     with torch.no_grad():
         ref = net(image, torch.from_numpy(offs), taps)
-    for name in ("res2", "res3", "res5", "y", "feat_b", "z"):
+    for name in ("res2", "res3", "res5", "y", "feat_eee_boundary", "z1", "feat_center"):
         got = eng.debug_tensor(name, b).cpu().permute(0, 3, 1, 2)
         assert rel_err(got, taps[name]) < TOL, name
     exp = torch.cat([ref["foreground"], ref["center"], ref["offset"], ref["eee_boundary"]], 1)
@@ -53,6 +62,63 @@ def test_network_vs_oracle_small(h, w, b, depth):
     assert float((logits - exp).abs().max()) < TOL
     assert abs(eng.forward_flops() / 2e9 - 187.8 * (h * w) / (480 * 640)) < 0.02 * 187.8 * (h * w) / (480 * 640) or depth != 50
     eng.close()
+
+
+VARIANTS = {
+    # run_eval.py's default config: ...-hf-m-b-f-c-o-l3-e2-b8.yaml (5 levels, 2 error classes, mask + boundary)
+    "m-b-f-c-o-e2": dict(eee_mask_on=True, error_classes=2, fusion_target=("pred", "feat"),
+                         hierarchy=(("eee_mask",), ("eee_boundary",), ("foreground",), ("center",), ("offset",))),
+    "m-b-fco-feat": dict(eee_mask_on=True, fusion_target=("feat",),
+                         hierarchy=(("eee_mask",), ("eee_boundary",), ("foreground", "center", "offset"))),
+    "bfco-single-level": dict(hierarchy=(("eee_boundary", "foreground", "center", "offset"),)),
+    "noeee-flat": dict(hierarchical=False, eee_boundary_on=False, error_classes=2),
+    "mb-fco-e33-pred": dict(eee_mask_on=True, error_classes=3, fusion_target=("pred",),
+                            hierarchy=(("eee_mask", "eee_boundary"), ("foreground", "center", "offset"))),
+    "l0-backbone-fusion": dict(backbone_fusion_layers=0),
+}
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_head_hierarchy_variants(name):
+    kw = VARIANTS[name]
+    h, w, b = 64, 96, 2
+    sd = arch.init_state_dict(seed=4, **kw)
+    net = oracle_net(sd, **kw)
+    batch, offs = inputs(5, b, h, w, 3)
+    qc = engine.set_arch(engine.make_config(h, w, max_batch=b), **kw)
+    eng = engine.Engine(qc, "cuda:0")
+    assert sorted(n for n, _ in eng.weight_specs()) == sorted(sd)
+    eng.load_state_dict(sd)
+    logits = eng.forward(torch.from_numpy(batch["rgb"]).cuda(), torch.from_numpy(batch["depth"]).cuda(),
+                         torch.from_numpy(offs).cuda()).cpu()
+    image = torch.cat([torch.from_numpy(batch["rgb"]), torch.from_numpy(batch["depth"])], -1).permute(0, 3, 1, 2)
+    with torch.no_grad():
+        ref = net(image, torch.from_numpy(offs))
+    parts = [ref["foreground"], ref["center"], ref["offset"]]
+    parts += [ref["eee_boundary"]] if "eee_boundary" in ref else []
+    parts += [ref["eee_mask"]] if "eee_mask" in ref else []
+    exp = torch.cat(parts, 1)
+    assert logits.shape == exp.shape
+    assert float((logits - exp).abs().max()) < TOL
+    eng.close()
+
+
+def test_reference_default_yaml_loads(tmp_path):
+    # the yaml text below restates the keys of the reference's run_eval.py default config over its base file
+    (tmp_path / "Base.yaml").write_text(
+        "MODEL:\n  META_ARCHITECTURE: MaskRefiner\n  BACKBONE:\n    NAME: build_resnet_deeplab_rgbd_fusion_backbone\n"
+        "    FUSION_STRATEGY: add\n    NUM_FUSION_LAYERS: 3\n  RESNETS:\n    OUT_FEATURES: [res2, res3, res5]\n    RES5_DILATION: 2\n"
+        "  PIXEL_MEAN: [103.53, 116.28, 123.675, 127.5, 127.5, 127.5]\n  PIXEL_STD: [1, 1, 1, 1, 1, 1]\n"
+        "  INS_EMBED_HEAD:\n    NAME: MaskRefinerInsEmbedHead\n    NORM: GN\n    EEE_MASK_ON: True\n    EEE_BOUNDARY_ON: True\n    ERROR_TYPE: e2\n"
+        "  PANOPTIC_DEEPLAB:\n    CENTER_THRESHOLD: 0.3\n    STUFF_AREA: 2048\nINPUT:\n  OFFSET_INPUT_ON: True\n  DEPTH_ON: True\n")
+    (tmp_path / "default.yaml").write_text(
+        "_BASE_: Base.yaml\nMODEL:\n  BACKBONE:\n    FUSION_STRATEGY: concat\n    NUM_FUSION_LAYERS: 2\n  INS_EMBED_HEAD:\n"
+        "    HIERARCHICAL_FUSION_ON: True\n    HIERARCHY: [[eee_mask], [eee_boundary], [foreground], [center], [offset]]\n"
+        "    NUM_FUSION_LAYERS: 3\n    FUSION_TARGET: [pred, feat]\n    ERROR_TYPE: e2\n")
+    pred = MaskRefinerPredictor(str(tmp_path / "default.yaml"), seed=1)
+    sc = synth.make_scene(2, 64, 96, 2)
+    r = pred.predict(sc["rgb"], sc["depth"], sc["masks"])[0]
+    assert r["eee_mask"].shape == (2, 64, 96) and r["eee_boundary"].shape == (2, 64, 96)
 
 
 def test_network_vs_oracle_full_frame_and_predictor():
