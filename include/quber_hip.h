@@ -52,6 +52,9 @@ typedef struct quber_config {
     int32_t fusion_pred;             /* "pred" in INS_EMBED_HEAD.FUSION_TARGET */
     int32_t n_levels;                /* len(INS_EMBED_HEAD.HIERARCHY) */
     int32_t level_heads[5][5];       /* head ids per level, -1 padded */
+    int32_t fusion_add;              /* MODEL.BACKBONE.FUSION_STRATEGY == "add" (0 = "concat") */
+    int32_t streams;                 /* 2: rgb + depth streams (build_resnet_deeplab_rgbd_fusion_backbone); 1: single stream
+                                        (build_resnet_deeplab_fusion_backbone: rgb-only or depth-only, pixel_mean[0..2]) */
 } quber_config;
 
 /* logit planes produced by quber_forward: [fg, centre, off_y, off_x, eee_boundary x classes (if on), eee_mask x classes (if on)] */
@@ -91,7 +94,8 @@ int quber_explicit_error_maps(quber_ctx* ctx, const uint8_t* dev_init, int32_t n
 
 /* a3-a7 - the network.  Replaces MaskRefiner.forward up to the head outputs
  * (maskrefiner/modeling/mask_refiner/model.py:137-156, 244-250, 689-708).
- *   dev_bgr u8 [B][H][W][3], dev_depth u8 [B][H][W][3], dev_offsets f32 [B][3][H][W]
+ *   dev_bgr u8 [B][H][W][3], dev_depth u8 [B][H][W][3] (NULL when streams == 1: dev_bgr then carries the single
+ *   image, rgb or depth), dev_offsets f32 [B][3][H][W]
  *   -> dev_logits f32 [B][4+classes][H][W]  (fg logit, centre, off_y px, off_x px, boundary-error logits) */
 int quber_forward(quber_ctx* ctx, const uint8_t* dev_bgr, const uint8_t* dev_depth, const float* dev_offsets,
                   int32_t batch, float* dev_logits, void* stream);

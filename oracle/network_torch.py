@@ -48,6 +48,8 @@ class ArchCfg:
     hierarchical: bool = True
     hierarchy: List[List[str]] = field(default_factory=lambda: [["eee_boundary"], ["foreground", "center", "offset"]])
     fusion_target: List[str] = field(default_factory=lambda: ["feat", "pred"])
+    fusion_add: bool = False                 # MODEL.BACKBONE.FUSION_STRATEGY "add"
+    streams: int = 2                         # 2: RGBDFusionBackbone; 1: plain ResNet (rgb-only / depth-only configs)
     pixel_mean: List[float] = field(default_factory=lambda: [103.53, 116.28, 123.675, 127.5, 127.5, 127.5])
     pixel_std: List[float] = field(default_factory=lambda: [1.0] * 6)
 
@@ -169,11 +171,13 @@ class Backbone(nn.Module):
         self.rgb_backbone = Stream(cfg, "")
         self.depth_backbone = Stream(cfg, "depth_")
         ch = {"res2": 256, "res3": 512, "res5": 2048}
+        self.add = cfg.fusion_add
         for k, c in ch.items():
             seq = nn.Sequential()
-            seq.add_module("conv", nn.Conv2d(2 * c, c, 1))
-            seq.add_module("gn", nn.GroupNorm(32, c))
-            seq.add_module("relu", nn.ReLU())
+            if not cfg.fusion_add:                      # resnet.py:472-475: only the concat strategy has the 1x1 reduction
+                seq.add_module("conv", nn.Conv2d(2 * c, c, 1))
+                seq.add_module("gn", nn.GroupNorm(32, c))
+                seq.add_module("relu", nn.ReLU())
             if k != "res5":
                 for i in range(cfg.backbone_fusion_layers):
                     seq.add_module(f"conv{i}", nn.Conv2d(c, c, 3, padding=1))
@@ -185,7 +189,8 @@ class Backbone(nn.Module):
         rgb = torch.cat([x[:, :3], x[:, 6:]], 1)
         dep = torch.cat([x[:, 3:6], x[:, 6:]], 1)
         fr, fd = self.rgb_backbone(rgb), self.depth_backbone(dep)
-        return {k: getattr(self, f"fusion_{k}")(torch.cat([fr[k], fd[k]], 1)) for k in ("res2", "res3", "res5")}
+        return {k: getattr(self, f"fusion_{k}")(fr[k] + fd[k] if self.add else torch.cat([fr[k], fd[k]], 1))
+                for k in ("res2", "res3", "res5")}
 
 
 def gn_conv(cin, cout, k, dilation=1):
@@ -323,15 +328,18 @@ class MaskRefinerNet(nn.Module):
     def __init__(self, cfg: ArchCfg = None):
         super().__init__()
         self.cfg = cfg or ArchCfg()
-        self.backbone = Backbone(self.cfg)
+        # build_resnet_deeplab_rgbd_fusion_backbone (resnet.py:510-519) or build_resnet_deeplab_fusion_backbone (:358-449)
+        self.backbone = Backbone(self.cfg) if self.cfg.streams == 2 else Stream(self.cfg, "")
         self.ins_embed_head = InsEmbedHead(self.cfg)
-        self.register_buffer("pixel_mean", torch.tensor(self.cfg.pixel_mean).view(-1, 1, 1), False)
-        self.register_buffer("pixel_std", torch.tensor(self.cfg.pixel_std).view(-1, 1, 1), False)
+        nch = 3 * self.cfg.streams
+        self.register_buffer("pixel_mean", torch.tensor(self.cfg.pixel_mean[:nch]).view(-1, 1, 1), False)
+        self.register_buffer("pixel_std", torch.tensor(self.cfg.pixel_std[:nch]).view(-1, 1, 1), False)
 
     def forward(self, image, offsets, taps=None):
         x = (image.to(self.pixel_mean.dtype) - self.pixel_mean) / self.pixel_std   # model.py:138
         x = torch.cat([x, offsets.to(x.dtype)], 1)                                # model.py:153
         feats = self.backbone(x)
+        feats = {k: feats[k] for k in ("res2", "res3", "res5")}
         if taps is not None:
             taps.update(feats)
         return self.ins_embed_head(feats, taps)

@@ -18,7 +18,7 @@ class QuberConfig(C.Structure):
         ("pixel_mean", C.c_float * 6), ("pixel_std", C.c_float * 6),
         ("eee_mask_on", C.c_int32), ("eee_boundary_on", C.c_int32), ("hierarchical", C.c_int32),
         ("fusion_feat", C.c_int32), ("fusion_pred", C.c_int32), ("n_levels", C.c_int32),
-        ("level_heads", (C.c_int32 * 5) * 5),
+        ("level_heads", (C.c_int32 * 5) * 5), ("fusion_add", C.c_int32), ("streams", C.c_int32),
     ]
 
 

@@ -24,7 +24,8 @@ def head_channels(error_classes=4, eee_mask_on=False, eee_boundary_on=True):
 
 
 def param_specs(depth=50, backbone_fusion_layers=2, head_fusion_layers=3, error_classes=4, eee_mask_on=False,
-                eee_boundary_on=True, hierarchical=True, hierarchy=DEFAULT_HIERARCHY, fusion_target=("feat", "pred")):
+                eee_boundary_on=True, hierarchical=True, hierarchy=DEFAULT_HIERARCHY, fusion_target=("feat", "pred"),
+                streams=2, fusion_add=False):
     """OrderedDict name -> (shape, kind); kind in conv|bn_w|bn_b|bn_m|bn_v|gn_w|gn_b|bias|pred_w|pred_b."""
     s = OrderedDict()
 
@@ -41,7 +42,9 @@ def param_specs(depth=50, backbone_fusion_layers=2, head_fusion_layers=3, error_
         s[n + ".weight"] = ((c,), "gn_w")
         s[n + ".bias"] = ((c,), "gn_b")
 
-    for stream, pre in (("backbone.rgb_backbone.", ""), ("backbone.depth_backbone.", "depth_")):
+    stream_list = (("backbone.rgb_backbone.", ""), ("backbone.depth_backbone.", "depth_")) if streams == 2 \
+        else (("backbone.", ""),)
+    for stream, pre in stream_list:
         for i, (co, ci) in enumerate(((32, 6), (32, 32), (64, 32))):
             conv(f"{stream}stem.conv{i + 1}", co, ci, 3)
             bn(f"{stream}stem.conv{i + 1}.norm", co)
@@ -60,10 +63,11 @@ def param_specs(depth=50, backbone_fusion_layers=2, head_fusion_layers=3, error_
                 bn(p + "conv3.norm", cout)
                 cin = cout
             cout, mid = cout * 2, mid * 2
-    for k, c in (("res2", 256), ("res3", 512), ("res5", 2048)):
+    for k, c in ((("res2", 256), ("res3", 512), ("res5", 2048)) if streams == 2 else ()):
         p = f"backbone.fusion_{k}."
-        conv(p + "conv", c, 2 * c, 1, bias=True)
-        gn(p + "gn", c)
+        if not fusion_add:
+            conv(p + "conv", c, 2 * c, 1, bias=True)
+            gn(p + "gn", c)
         if k != "res5":
             for i in range(backbone_fusion_layers):
                 conv(p + f"conv{i}", c, c, 3, bias=True)
@@ -121,7 +125,7 @@ def init_state_dict(seed=0, **kw):
     for name, (shape, kind) in param_specs(**kw).items():
         if kind == "conv":
             co, ci, k, _ = shape
-            if name.startswith("backbone.rgb_backbone") or name.startswith("backbone.depth_backbone"):
+            if name.startswith("backbone.") and not name.startswith("backbone.fusion_"):
                 v = rng.normal(0, np.sqrt(2.0 / (co * k * k)), shape)
             else:
                 lim = np.sqrt(3.0) * np.sqrt(2.0 / ((ci + co) * k * k))

@@ -103,7 +103,9 @@ def arch_kwargs(cfg):
                 head_fusion_layers=h.NUM_FUSION_LAYERS, error_classes=ERROR_CLASSES[h.ERROR_TYPE],
                 eee_mask_on=bool(h.EEE_MASK_ON), eee_boundary_on=bool(h.EEE_BOUNDARY_ON),
                 hierarchical=bool(h.HIERARCHICAL_FUSION_ON), hierarchy=tuple(tuple(l) for l in h.HIERARCHY),
-                fusion_target=tuple(h.FUSION_TARGET))
+                fusion_target=tuple(h.FUSION_TARGET),
+                streams=2 if m.BACKBONE.NAME == "build_resnet_deeplab_rgbd_fusion_backbone" else 1,
+                fusion_add=m.BACKBONE.FUSION_STRATEGY == "add")
 
 
 def canonical_cfg():
@@ -145,9 +147,16 @@ def validate(cfg):
             raise UnsupportedConfig(f"quber_amd: {what} is not built yet (see DESIGN.md, out of scope / next)")
 
     need(m.META_ARCHITECTURE == "MaskRefiner", f"META_ARCHITECTURE {m.META_ARCHITECTURE}")
-    need(m.BACKBONE.NAME == "build_resnet_deeplab_rgbd_fusion_backbone", f"backbone {m.BACKBONE.NAME}")
-    need(m.BACKBONE.FUSION_STRATEGY == "concat", "backbone FUSION_STRATEGY other than 'concat'")
-    need(cfg.INPUT.DEPTH_ON and cfg.INPUT.RGB_ON and cfg.INPUT.OFFSET_INPUT_ON, "single-stream / no-offset input")
+    need(m.BACKBONE.NAME in ("build_resnet_deeplab_rgbd_fusion_backbone", "build_resnet_deeplab_fusion_backbone"),
+         f"backbone {m.BACKBONE.NAME}")
+    need(cfg.INPUT.OFFSET_INPUT_ON, "a refiner without the initial-mask offset input")
+    if m.BACKBONE.NAME == "build_resnet_deeplab_rgbd_fusion_backbone":
+        need(m.BACKBONE.FUSION_STRATEGY in ("concat", "add"), f"backbone FUSION_STRATEGY {m.BACKBONE.FUSION_STRATEGY}")
+        need(cfg.INPUT.DEPTH_ON and cfg.INPUT.RGB_ON, "the RGB-D fusion backbone without both RGB_ON and DEPTH_ON")
+        need(len(m.PIXEL_MEAN) == 6 and len(m.PIXEL_STD) == 6, "PIXEL_MEAN/STD without 6 entries")
+    else:
+        need(bool(cfg.INPUT.DEPTH_ON) != bool(cfg.INPUT.RGB_ON), "a single-stream backbone with both RGB_ON and DEPTH_ON")
+        need(len(m.PIXEL_MEAN) >= 3 and len(m.PIXEL_STD) >= 3, "PIXEL_MEAN/STD without 3 entries")
     need(list(m.RESNETS.OUT_FEATURES) == ["res2", "res3", "res5"], "RESNETS.OUT_FEATURES other than res2/res3/res5")
     need(m.RESNETS.STEM_TYPE == "deeplab" and m.RESNETS.NORM == "FrozenBN", "non-deeplab stem / non-frozen BN")
     need(m.RESNETS.DEPTH in (50, 101, 152), f"ResNet depth {m.RESNETS.DEPTH}")

@@ -46,8 +46,7 @@ int fail(const std::string& msg);
 int launch_conv(const ConvP& p, int G, hipStream_t st);
 void set_conv_order(int v);   // tile-order experiment knob
 int launch_preprocess(const uint8_t* rgb, const uint8_t* depth, const float* offs, float* x, int B, int Bcap,
-                      int H, int W, const float* mean6, const float* std6, int has_rgb, int has_depth,
-                      hipStream_t st);
+                      int H, int W, const float* mean6, const float* std6, int streams, hipStream_t st);
 int launch_maxpool3x3s2(const View& in, const View& out, int B, int G, hipStream_t st);
 int launch_gn_stats(const View& in, int B, int G, int groups, double* stats, hipStream_t st);
 int launch_gn_apply(const View& in, const View& out, int B, int G, int groups, const double* stats,
@@ -58,6 +57,7 @@ int launch_predictor(const View& in, const float* w, const float* bias, int cout
                      int q_nch, float* act_dst, int act_cs, int act /*0 none, 1 softmax, 2 sigmoid*/, int B,
                      hipStream_t st);
 int launch_copy_channels(const View& in, const View& out, int B, hipStream_t st);
+int launch_add_channels(const View& a, const View& b, const View& out, int B, hipStream_t st);
 int launch_upsample_logits(const float* q, float* out, int B, int nch, int h, int w, int scale,
                            unsigned mul_mask, hipStream_t st);
 

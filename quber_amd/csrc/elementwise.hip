@@ -22,7 +22,7 @@ static inline int cap_grid(long work, int per_block) {
 // x[0] = [(bgr - mean)/std, heat, off_y, off_x, 0, 0],  x[1] = [(depth - mean)/std, heat, off_y, off_x, 0, 0]
 __global__ void preprocess_kernel(const uint8_t* __restrict__ rgb, const uint8_t* __restrict__ depth,
                                   const float* __restrict__ offs, float* __restrict__ x, int B, long gstride,
-                                  int HW, float m0, float m1, float m2, float m3, float m4, float m5, float s0,
+                                  int streams, int HW, float m0, float m1, float m2, float m3, float m4, float m5, float s0,
                                   float s1, float s2, float s3, float s4, float s5) {
     const long total = (long)B * HW;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -31,7 +31,7 @@ __global__ void preprocess_kernel(const uint8_t* __restrict__ rgb, const uint8_t
         const float* o = offs + b * 3 * HW + pix;
         const float heat = o[0], oy = o[HW], ox = o[2 * (long)HW];
         const uint8_t* r = rgb + i * 3;
-        const uint8_t* d = depth + i * 3;
+        const uint8_t* d = streams == 2 ? depth + i * 3 : r;
         float4 a, c;
         a.x = ((float)r[0] - m0) / s0;
         a.y = ((float)r[1] - m1) / s1;
@@ -41,20 +41,22 @@ __global__ void preprocess_kernel(const uint8_t* __restrict__ rgb, const uint8_t
         float4* dst = reinterpret_cast<float4*>(x + i * 8);
         dst[0] = a;
         dst[1] = c;
-        a.x = ((float)d[0] - m3) / s3;
-        a.y = ((float)d[1] - m4) / s4;
-        a.z = ((float)d[2] - m5) / s5;
-        dst = reinterpret_cast<float4*>(x + gstride + i * 8);
-        dst[0] = a;
-        dst[1] = c;
+        if (streams == 2) {
+            a.x = ((float)d[0] - m3) / s3;
+            a.y = ((float)d[1] - m4) / s4;
+            a.z = ((float)d[2] - m5) / s5;
+            dst = reinterpret_cast<float4*>(x + gstride + i * 8);
+            dst[0] = a;
+            dst[1] = c;
+        }
     }
 }
 
 int launch_preprocess(const uint8_t* rgb, const uint8_t* depth, const float* offs, float* x, int B, int Bcap,
-                      int H, int W, const float* mean6, const float* std6, int, int, hipStream_t st) {
+                      int H, int W, const float* mean6, const float* std6, int streams, hipStream_t st) {
     const long total = (long)B * H * W;
     hipLaunchKernelGGL(preprocess_kernel, dim3(cap_grid(total, 256)), dim3(256), 0, st, rgb, depth, offs, x, B,
-                       (long)Bcap * H * W * 8, H * W, mean6[0], mean6[1], mean6[2], mean6[3], mean6[4], mean6[5],
+                       (long)Bcap * H * W * 8, streams, H * W, mean6[0], mean6[1], mean6[2], mean6[3], mean6[4], mean6[5],
                        std6[0], std6[1], std6[2], std6[3], std6[4], std6[5]);
     QB_CHECK(hipGetLastError());
     return 0;
@@ -343,6 +345,26 @@ __global__ void copy_channels_kernel(const float* __restrict__ in, float* __rest
         const int c4 = (int)(i - pix * C4);
         *reinterpret_cast<float4*>(out + pix * out_cs + c4 * 4) = *reinterpret_cast<const float4*>(in + pix * in_cs + c4 * 4);
     }
+}
+
+__global__ void add_channels_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                    long pixels, int C4, int a_cs, int b_cs, int out_cs) {
+    const long total = pixels * C4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / C4;
+        const int c4 = (int)(i - pix * C4);
+        const float4 x = *reinterpret_cast<const float4*>(a + pix * a_cs + c4 * 4);
+        const float4 y = *reinterpret_cast<const float4*>(b + pix * b_cs + c4 * 4);
+        *reinterpret_cast<float4*>(out + pix * out_cs + c4 * 4) = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+    }
+}
+
+int launch_add_channels(const View& a, const View& b, const View& out, int B, hipStream_t st) {
+    const long pixels = (long)B * a.H * a.W;
+    hipLaunchKernelGGL(add_channels_kernel, dim3(cap_grid(pixels * (a.C / 4), 256)), dim3(256), 0, st, a.p, b.p, out.p,
+                       pixels, a.C / 4, a.cs, b.cs, out.cs);
+    QB_CHECK(hipGetLastError());
+    return 0;
 }
 
 int launch_copy_channels(const View& in, const View& out, int B, hipStream_t st) {

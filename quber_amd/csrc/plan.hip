@@ -248,20 +248,22 @@ struct Builder {
         const int* nb = cf.resnet_depth == 50 ? BLOCKS50 : cf.resnet_depth == 101 ? BLOCKS101 : BLOCKS152;
         const int h2 = H / 2, w2 = W / 2, h4 = H / 4, w4 = W / 4, h8 = H / 8, w8 = W / 8, h16 = H / 16, w16 = W / 16;
         const std::string R = "backbone.rgb_backbone.", D = "backbone.depth_backbone.";
+        const int NS = cf.streams;   // 2: rgb + depth streams with concat fusion; 1: a single ResNet (rgb-only / depth-only)
         auto two = [&](const std::string& tail, bool stage_prefix) -> std::vector<std::string> {
+            if (NS == 1) return {"backbone." + tail};
             return {R + tail, D + (stage_prefix ? "depth_" : "") + tail};
         };
         if (!dry) c->gn_stats = (double*)dalloc_bytes(sizeof(double) * 2 * 64 * Bmax * 4);
 
         // ---------------- input + stems (both streams as G = 2) ----------------
-        View X = make(8, H, W, 2);
+        View X = make(8, H, W, NS);
         if (!dry) c->X = X.p;
-        View s1 = make(32, h2, w2, 2), s2 = make(32, h2, w2, 2), s3 = make(64, h2, w2, 2);
+        View s1 = make(32, h2, w2, NS), s2 = make(32, h2, w2, NS), s3 = make(64, h2, w2, NS);
         conv(two("stem.conv1", false), X, 6, s1, 3, 2, 1, 1, AF_FROZEN_BN, nullptr, true);
         conv(two("stem.conv2", false), s1, 32, s2, 3, 1, 1, 1, AF_FROZEN_BN, nullptr, true);
         conv(two("stem.conv3", false), s2, 32, s3, 3, 1, 1, 1, AF_FROZEN_BN, nullptr, true);
-        View x = make(64, h4, w4, 2);
-        op([=](int B, hipStream_t st) { return launch_maxpool3x3s2(s3, x, B, 2, st); });
+        View x = make(64, h4, w4, NS);
+        op([=](int B, hipStream_t st) { return launch_maxpool3x3s2(s3, x, B, NS, st); });
 
         // ---------------- res2..res5 ----------------
         View cat[4];  // concatenated [rgb | depth] stage outputs
@@ -271,11 +273,11 @@ struct Builder {
             const int sdil = stage == 5 ? cf.res5_dilation : 1;
             const int first = (s == 0 || sdil > 1) ? 1 : 2;
             const int oh = ch / first, ow = cw / first;
-            View t1 = make(mid, oh, ow, 2), t2 = make(mid, oh, ow, 2), sc = make(cout, oh, ow, 2);
-            View oa = make(cout, oh, ow, 2), ob = make(cout, oh, ow, 2);
+            View t1 = make(mid, oh, ow, NS), t2 = make(mid, oh, ow, NS), sc = make(cout, oh, ow, NS);
+            View oa = make(cout, oh, ow, NS), ob = make(cout, oh, ow, NS);
             const bool tapped = stage != 4;
             if (tapped) {
-                View cb = make(2 * cout, oh, ow, 1);
+                View cb = make(NS * cout, oh, ow, 1);
                 cat[s] = cb;
             }
             static const int mg[3] = {1, 2, 4};
@@ -304,11 +306,21 @@ struct Builder {
         View F[4];
         const int fch[4] = {256, 512, 1024, 2048};
         for (int s : {0, 1, 3}) {
+            if (NS == 1) {   // build_resnet_deeplab_fusion_backbone: the stage outputs feed the head directly
+                F[s] = cat[s];
+                if (!dry) c->taps["res" + std::to_string(s + 2)] = F[s];
+                continue;
+            }
             const std::string n = "backbone.fusion_res" + std::to_string(s + 2) + ".";
             const int C = fch[s], fh = cat[s].H, fw = cat[s].W;
             View t = make(C, fh, fw), a = make(C, fh, fw);
-            conv({n + "conv"}, cat[s], 2 * C, t, 1, 1, 0, 1, AF_BIAS, nullptr, false);
-            gn_relu({n + "gn"}, t, a);
+            if (cf.fusion_add) {   // FUSION_STRATEGY "add" (resnet.py:502-503): rgb + depth, no 1x1 reduction
+                View ra = slice(cat[s], 0, C), rb = slice(cat[s], C, C);
+                op([=](int B, hipStream_t st) { return launch_add_channels(ra, rb, a, B, st); });
+            } else {
+                conv({n + "conv"}, cat[s], 2 * C, t, 1, 1, 0, 1, AF_BIAS, nullptr, false);
+                gn_relu({n + "gn"}, t, a);
+            }
             if (s != 3) {
                 View b2 = make(C, fh, fw);
                 View cur = a, nxt = b2;
@@ -476,6 +488,7 @@ int check_cfg(const quber_config& c) {
     if (c.res5_dilation != 1 && c.res5_dilation != 2 && c.res5_dilation != 4) return fail("res5_dilation must be 1, 2 or 4");
     if (c.res5_dilation == 1) return fail("res5_dilation 1 (output stride 32) is not supported by this build");
     if (c.error_classes < 2 || c.error_classes > 4) return fail("error_classes must be 2..4");
+    if (c.streams != 1 && c.streams != 2) return fail("streams must be 1 or 2");
     if (c.with_network && c.hierarchical) {
         if (c.n_levels < 1 || c.n_levels > 5) return fail("n_levels must be 1..5");
         int seen[5] = {0, 0, 0, 0, 0};
@@ -511,6 +524,8 @@ void quber_default_config(quber_config* c) {
     c->min_instance_area = 512; c->label_divisor = 1000; c->with_network = 1;
     c->eee_mask_on = 0; c->eee_boundary_on = 1; c->hierarchical = 1; c->fusion_feat = 1; c->fusion_pred = 1;
     c->n_levels = 2;
+    c->streams = 2;
+    c->fusion_add = 0;
     for (int i = 0; i < 5; ++i)
         for (int j = 0; j < 5; ++j) c->level_heads[i][j] = -1;
     c->level_heads[0][0] = 4;                                   // [[eee_boundary], [foreground, center, offset]]
@@ -635,11 +650,11 @@ int quber_forward(quber_ctx* c, const uint8_t* bgr, const uint8_t* depth, const 
                   float* logits, void* stream) {
     if (check_batch(c, batch)) return -1;
     if (!c->finalized) return fail("quber_forward before quber_finalize_weights");
-    if (!bgr || !depth || !offs || !logits) return fail("null tensor");
+    if (!bgr || (!depth && c->cfg.streams == 2) || !offs || !logits) return fail("null tensor");
     hipStream_t st = (hipStream_t)stream;
     c->cur_out = logits;
     int rc = launch_preprocess(bgr, depth, offs, c->X, batch, c->cfg.max_batch, c->cfg.height, c->cfg.width,
-                               c->cfg.pixel_mean, c->cfg.pixel_std, 1, 1, st);
+                               c->cfg.pixel_mean, c->cfg.pixel_std, c->cfg.streams, st);
     if (rc) return rc;
     for (auto& op : c->ops) {
         rc = op.run(batch, st);
@@ -652,7 +667,7 @@ int quber_forward_profiled(quber_ctx* c, const uint8_t* bgr, const uint8_t* dept
                            float* logits, void* stream, double* kind_ms, int32_t* kind_launches) {
     if (check_batch(c, batch)) return -1;
     if (!c->finalized) return fail("quber_forward_profiled before quber_finalize_weights");
-    if (!bgr || !depth || !offs || !logits || !kind_ms || !kind_launches) return fail("null argument");
+    if (!bgr || (!depth && c->cfg.streams == 2) || !offs || !logits || !kind_ms || !kind_launches) return fail("null argument");
     hipStream_t st = (hipStream_t)stream;
     c->cur_out = logits;
     const size_t n = c->ops.size();
@@ -662,7 +677,7 @@ int quber_forward_profiled(quber_ctx* c, const uint8_t* bgr, const uint8_t* dept
         for (size_t i = old; i < 2 * n; ++i) QB_CHECK(hipEventCreate(&c->prof_events[i]));
     }
     int rc = launch_preprocess(bgr, depth, offs, c->X, batch, c->cfg.max_batch, c->cfg.height, c->cfg.width,
-                               c->cfg.pixel_mean, c->cfg.pixel_std, 1, 1, st);
+                               c->cfg.pixel_mean, c->cfg.pixel_std, c->cfg.streams, st);
     if (rc) return rc;
     for (size_t i = 0; i < n; ++i) {
         QB_CHECK(hipEventRecord(c->prof_events[2 * i], st));

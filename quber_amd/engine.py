@@ -21,11 +21,14 @@ def _stream():
 
 
 def set_arch(qc, depth=50, backbone_fusion_layers=2, head_fusion_layers=3, error_classes=4, eee_mask_on=False,
-             eee_boundary_on=True, hierarchical=True, hierarchy=arch.DEFAULT_HIERARCHY, fusion_target=("feat", "pred")):
+             eee_boundary_on=True, hierarchical=True, hierarchy=arch.DEFAULT_HIERARCHY, fusion_target=("feat", "pred"),
+             streams=2, fusion_add=False):
     """Write the architecture switches (keyword arguments of arch.param_specs) into a quber_config."""
     qc.resnet_depth, qc.backbone_fusion_layers, qc.head_fusion_layers = depth, backbone_fusion_layers, head_fusion_layers
     qc.error_classes, qc.eee_mask_on, qc.eee_boundary_on = error_classes, int(eee_mask_on), int(eee_boundary_on)
     qc.hierarchical = int(hierarchical)
+    qc.streams = streams
+    qc.fusion_add = int(fusion_add)
     qc.fusion_feat, qc.fusion_pred = int("feat" in fusion_target), int("pred" in fusion_target)
     levels = list(hierarchy) if hierarchical else []
     qc.n_levels = len(levels)
@@ -54,7 +57,7 @@ def make_config(height=480, width=640, max_batch=1, max_instances=64, cfg=None, 
         qc.top_k = m.PANOPTIC_DEEPLAB.TOP_K_INSTANCE
         qc.stuff_area = m.PANOPTIC_DEEPLAB.STUFF_AREA
         qc.center_threshold = m.PANOPTIC_DEEPLAB.CENTER_THRESHOLD
-        for i in range(6):
+        for i in range(min(6, len(m.PIXEL_MEAN))):
             qc.pixel_mean[i] = float(m.PIXEL_MEAN[i])
             qc.pixel_std[i] = float(m.PIXEL_STD[i])
     return qc
@@ -148,11 +151,16 @@ class Engine:
         return out
 
     def forward(self, bgr, depth, offsets, out=None):
-        """bgr, depth u8 [B,H,W,3]; offsets f32 [B,3,H,W] -> logits f32 [B,planes,H,W]."""
+        """bgr, depth u8 [B,H,W,3] (depth None for a single-stream model: `bgr` is then THE image, rgb or depth);
+        offsets f32 [B,3,H,W] -> logits f32 [B,planes,H,W]."""
         B = bgr.shape[0]
-        assert bgr.dtype == torch.uint8 and depth.dtype == torch.uint8 and offsets.dtype == torch.float32
-        assert bgr.shape == (B, self.H, self.W, 3) and depth.shape == bgr.shape and offsets.shape == (B, 3, self.H, self.W)
-        assert bgr.is_contiguous() and depth.is_contiguous() and offsets.is_contiguous()
+        assert bgr.dtype == torch.uint8 and offsets.dtype == torch.float32
+        assert bgr.shape == (B, self.H, self.W, 3) and offsets.shape == (B, 3, self.H, self.W)
+        assert bgr.is_contiguous() and offsets.is_contiguous()
+        if self.qcfg.streams == 2:
+            assert depth is not None and depth.dtype == torch.uint8 and depth.shape == bgr.shape and depth.is_contiguous()
+        else:
+            depth = None
         if out is None:
             out = torch.empty((B, self.planes, self.H, self.W), dtype=torch.float32, device=self.device)
         _lib.check(self.lib.quber_forward(self.h, _ptr(bgr), _ptr(depth), _ptr(offsets), B, _ptr(out), _stream()))

@@ -100,10 +100,12 @@ class RefinerModel:
         dev = self.device
         imgs = torch.stack([x["image"] for x in batched_inputs]).to(dev)
         offs = torch.stack([x["initial_pred_offset"] for x in batched_inputs]).to(dev, torch.float32).contiguous()
-        if imgs.shape[1] != 6:
-            raise qconfig.UnsupportedConfig("quber_amd: the built path is the RGB-D (6-channel) refiner")
+        nch = 3 * qconfig.arch_kwargs(self.cfg)["streams"]
+        if imgs.shape[1] != nch:
+            raise ValueError(f"expected a {nch}-channel image, got {imgs.shape[1]}")
         hwc = imgs.to(torch.uint8).permute(0, 2, 3, 1)
-        bgr, depth = hwc[..., :3].contiguous(), hwc[..., 3:].contiguous()
+        bgr = hwc[..., :3].contiguous()
+        depth = hwc[..., 3:].contiguous() if nch == 6 else None
         eng, logits, post = self.run(bgr, depth, offs)
         return self.results(eng, logits, post)
 
@@ -143,9 +145,13 @@ class MaskRefinerPredictor:
 
     def predict_batch(self, rgb_imgs, depth_imgs, masks_list):
         """rgb_imgs/depth_imgs: u8 [B,H,W,3] arrays; masks_list: B arrays u8/bool [N_b,H,W].  -> list of B dicts."""
-        if depth_imgs is None:
-            raise qconfig.UnsupportedConfig("quber_amd: the built path is the RGB-D refiner (depth image required)")
         B, H, W = rgb_imgs.shape[:3]
+        if self.depth_on and depth_imgs is None:
+            raise ValueError("this config has INPUT.DEPTH_ON: a depth image is required")
+        if not self.rgb_on:                               # depth-only: the image IS the depth map (predictor.py:296-298)
+            rgb_imgs, depth_imgs = depth_imgs, None
+        elif not self.depth_on:
+            depth_imgs = None
         n = max([len(m) for m in masks_list] + [1])
         mk = np.zeros((B, n, H, W), np.uint8)
         for b, m in enumerate(masks_list):
@@ -155,7 +161,7 @@ class MaskRefinerPredictor:
         eng = self.model.engine_for(H, W, B, n)
         d_masks = torch.from_numpy(mk).to(dev)
         bgr = torch.from_numpy(np.ascontiguousarray(rgb_imgs, dtype=np.uint8)).to(dev)
-        depth = torch.from_numpy(np.ascontiguousarray(depth_imgs, dtype=np.uint8)).to(dev)
+        depth = None if depth_imgs is None else torch.from_numpy(np.ascontiguousarray(depth_imgs, dtype=np.uint8)).to(dev)
         offsets = eng.encode(d_masks)
         logits = eng.forward(bgr, depth, offsets)
         post = eng.postprocess(logits)

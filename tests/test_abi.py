@@ -66,7 +66,21 @@ def test_yaml_base_merge_and_validation(tmp_path):
     assert cfg.MODEL.PANOPTIC_DEEPLAB.CENTER_THRESHOLD == 0.3 and cfg.MODEL.PANOPTIC_DEEPLAB.NMS_KERNEL == 7
     assert cfg.SOLVER.BASE_LR == 0.1
     config.validate(cfg)
-    bad = config.merge_from_file(config.get_cfg(), str(base))
+    # the base file alone (add fusion, flat heads, mask + boundary error heads, e2) is a supported variant too
+    flat = config.validate(config.merge_from_file(config.get_cfg(), str(base)))
+    kw = config.arch_kwargs(flat)
+    assert kw["fusion_add"] and not kw["hierarchical"] and kw["eee_mask_on"] and kw["error_classes"] == 2
+    for key, val in (("META_ARCHITECTURE", "PanopticDeepLab"),):
+        bad = config.merge_from_file(config.get_cfg(), str(child))
+        bad.MODEL[key] = val
+        with pytest.raises(config.UnsupportedConfig):
+            config.validate(bad)
+    bad = config.merge_from_file(config.get_cfg(), str(child))
+    bad.MODEL.INS_EMBED_HEAD.HIERARCHY = [["eee_boundary"], ["foreground", "center"]]      # offset head never evaluated
+    with pytest.raises(config.UnsupportedConfig):
+        config.validate(bad)
+    bad = config.merge_from_file(config.get_cfg(), str(child))
+    bad.MODEL.SEM_SEG_HEAD.USE_DEPTHWISE_SEPARABLE_CONV = True
     with pytest.raises(config.UnsupportedConfig):
         config.validate(bad)
     config.validate(config.canonical_cfg())

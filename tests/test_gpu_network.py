@@ -75,6 +75,8 @@ VARIANTS = {
     "mb-fco-e33-pred": dict(eee_mask_on=True, error_classes=3, fusion_target=("pred",),
                             hierarchy=(("eee_mask", "eee_boundary"), ("foreground", "center", "offset"))),
     "l0-backbone-fusion": dict(backbone_fusion_layers=0),
+    "single-stream": dict(streams=1),
+    "add-fusion-l3": dict(fusion_add=True, backbone_fusion_layers=3),    # Base-Mask-Refiner.yaml's own defaults
 }
 
 
@@ -89,9 +91,10 @@ def test_head_hierarchy_variants(name):
     eng = engine.Engine(qc, "cuda:0")
     assert sorted(n for n, _ in eng.weight_specs()) == sorted(sd)
     eng.load_state_dict(sd)
-    logits = eng.forward(torch.from_numpy(batch["rgb"]).cuda(), torch.from_numpy(batch["depth"]).cuda(),
+    single = kw.get("streams", 2) == 1
+    logits = eng.forward(torch.from_numpy(batch["rgb"]).cuda(), None if single else torch.from_numpy(batch["depth"]).cuda(),
                          torch.from_numpy(offs).cuda()).cpu()
-    image = torch.cat([torch.from_numpy(batch["rgb"]), torch.from_numpy(batch["depth"])], -1).permute(0, 3, 1, 2)
+    image = torch.cat([torch.from_numpy(batch["rgb"])] + ([] if single else [torch.from_numpy(batch["depth"])]), -1).permute(0, 3, 1, 2)
     with torch.no_grad():
         ref = net(image, torch.from_numpy(offs))
     parts = [ref["foreground"], ref["center"], ref["offset"]]
