@@ -38,17 +38,19 @@ def parse():
     ap.add_argument("--instances", type=int, default=20)
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-gather", action="store_true", help="skip the per-step RCCL gather of label maps")
+    ap.add_argument("--graph", action="store_true", help="capture the step's ~330 launches in one hipGraph and replay it")
     return ap.parse_args()
 
 
-def cpu_baseline(sd, h, w, n, frames):
-    """The oracle end to end (encode -> network -> grouping -> instances), batch 1 like the reference."""
+def cpu_baseline(sd, h, w, n, frames, eng=None):
+    """The oracle end to end (encode -> network -> grouping -> instances), batch 1 like the reference.
+    With `eng`, the first timed frame is also pushed through the HIP path and compared (the metric's 'IoU delta vs ref')."""
     from oracle import encode_np, postproc_ref
     from oracle.network_torch import MaskRefinerNet
     net = MaskRefinerNet().eval()
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
     cores = torch.get_num_threads()
-    times = []
+    times, parity = [], None
     with torch.no_grad():   # the reference builds an autograd graph (predictor.py:358); no_grad favours the baseline
         for i in range(frames + 1):
             sc = synth.make_scene(100 + i, h, w, n)
@@ -56,11 +58,23 @@ def cpu_baseline(sd, h, w, n, frames):
             offs = encode_np.encode_initial_masks(sc["masks"])
             image = torch.from_numpy(np.concatenate([sc["rgb"], sc["depth"]], -1)).permute(2, 0, 1)[None]
             out = net(image, torch.from_numpy(offs[None]))
-            postproc_ref.postprocess(out["foreground"][0], out["center"][0], out["offset"][0])
+            ref = postproc_ref.postprocess(out["foreground"][0], out["center"][0], out["offset"][0])
             times.append(time.perf_counter() - t0)
+            if i == 1 and eng is not None:
+                dev = eng.device
+                m = torch.from_numpy(sc["masks"][None]).to(dev)
+                lg = eng.forward(torch.from_numpy(sc["rgb"][None]).to(dev), torch.from_numpy(sc["depth"][None]).to(dev),
+                                 eng.encode(m))
+                pan = eng.postprocess(lg)["panoptic"][0].cpu()
+                exp = torch.cat([out["foreground"], out["center"], out["offset"], out["eee_boundary"]], 1)
+                a, b_ = pan >= 0, ref["panoptic"] >= 0
+                union = int((a | b_).sum())
+                parity = {"max_abs_dlogit": float((lg.cpu() - exp).abs().max()),
+                          "label_map_equal_fraction": float((pan == ref["panoptic"]).float().mean()),
+                          "fg_iou": float((a & b_).sum()) / union if union else 1.0}
     times = times[1:]                                       # the reference drops the first sample (eval_utils.py:342)
     med = float(np.median(times))
-    return {"value": n / med, "unit": "refined masks/s", "cores": cores, "kind": "port",
+    return {"value": n / med, "unit": "refined masks/s", "cores": cores, "kind": "port", "parity_vs_hip": parity,
             "sample": f"{frames} frames {w}x{h} N={n} batch 1, median {med * 1e3:.0f} ms/frame, torch {torch.__version__} CPU, no_grad"}
 
 
@@ -100,11 +114,30 @@ def main():
     out_masks = torch.empty((B, max_inst, H, W), dtype=torch.uint8, device=dev)
     counts = [B] * world
 
-    def step():
+    def gpu_step():
         eng.encode(masks, offsets)
         eng.forward(bgr, depth, offsets, logits)
         eng.postprocess(logits, post)
         eng.extract_masks(post, max_inst, out_masks)
+
+    graph = None
+    if a.graph:
+        # every launch of the step goes to torch's current stream and nothing allocates or synchronises,
+        # so the whole step is capturable (include/quber_hip.h contract)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            gpu_step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            gpu_step()
+
+    def step():
+        if graph is not None:
+            graph.replay()
+        else:
+            gpu_step()
         if dist is not None and not a.no_gather:
             qdist.gather_label_maps(post["panoptic"], counts, dst=0)
 
@@ -154,7 +187,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"batch={B} {W}x{H} RGB-D, {N} initial instances/frame, ResNet-50 RGB-D refiner "
                                    f"(boundary-error -> fg/centre/offset), encode+network+grouping+mask extraction",
-                       "frames_per_step_per_gpu": B, "parallelism": f"dp{world}",
+                       "frames_per_step_per_gpu": B, "parallelism": f"dp{world}", "hipgraph": bool(a.graph),
                        "weights": "seeded synthetic (no checkpoint ships with the reference)",
                        "instances_out_per_frame_mean": float(count.mean())},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -165,7 +198,7 @@ def main():
                                         "other": float(np.median(other_ms))}},
         }
         if world == 1 and a.cpu_frames > 0:
-            line["cpu_baseline"] = cpu_baseline(sd, H, W, N, a.cpu_frames)
+            line["cpu_baseline"] = cpu_baseline(sd, H, W, N, a.cpu_frames, eng)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

@@ -163,36 +163,46 @@ int launch_gn_stats(const View& in, int B, int G, int groups, double* stats, hip
     return 0;
 }
 
+// mean / rstd per (launch group, sample, norm group) from the fp64 sums; written over the sums as two floats
+__global__ void gn_finalize_kernel(double* __restrict__ stats, int count, double n, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const double mean = stats[2 * i] / n;
+    double var = stats[2 * i + 1] / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    float2 mr;
+    mr.x = (float)mean;
+    mr.y = (float)(1.0 / sqrt(var + (double)eps));
+    *reinterpret_cast<float2*>(&stats[2 * i]) = mr;       // first 8 bytes of the 16-byte slot
+}
+
 // y = relu(x*scale + bias), scale = rstd*gamma, bias = beta - mean*scale  (torch's GroupNorm CPU form)
 __global__ void gn_apply_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int HW, int C, int in_cs,
                                 int out_cs, long in_gs, long out_gs, int groups, const double* __restrict__ stats,
                                 const float* __restrict__ gamma, const float* __restrict__ beta, int param_gs,
-                                float eps, int relu) {
+                                int relu) {
     const int g = blockIdx.y;
     in += g * in_gs;
     out += g * out_gs;
     gamma += g * param_gs;
     beta += g * param_gs;
     const int C4 = C >> 2, cpg = C / groups;
-    const double n = (double)HW * cpg;
     const long total = (long)B * HW * C4;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c4 = i % C4;
         const long pix = i / C4;
         const int b = pix / HW;
         const float4 v = *reinterpret_cast<const float4*>(in + pix * in_cs + c4 * 4);
-        const float e[4] = {v.x, v.y, v.z, v.w};
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + c4 * 4);
+        const float4 be = *reinterpret_cast<const float4*>(beta + c4 * 4);
+        const float e[4] = {v.x, v.y, v.z, v.w}, gm[4] = {ga.x, ga.y, ga.z, ga.w}, bt[4] = {be.x, be.y, be.z, be.w};
+        const double* sbase = stats + ((long)(g * B + b) * groups) * 2;
         float o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int c = c4 * 4 + j;
-            const double* s = stats + ((long)(g * B + b) * groups + c / cpg) * 2;
-            const double mean = s[0] / n;
-            double var = s[1] / n - mean * mean;
-            if (var < 0.0) var = 0.0;
-            const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-            const float sc = rstd * gamma[c];
-            const float bi = beta[c] - (float)mean * sc;
+            const float2 mr = *reinterpret_cast<const float2*>(sbase + 2 * ((c4 * 4 + j) / cpg));
+            const float sc = mr.y * gm[j];
+            const float bi = bt[j] - mr.x * sc;
             float y = fmaf(e[j], sc, bi);
             if (relu) y = fmaxf(y, 0.f);
             o[j] = y;
@@ -204,9 +214,12 @@ __global__ void gn_apply_kernel(const float* __restrict__ in, float* __restrict_
 int launch_gn_apply(const View& in, const View& out, int B, int G, int groups, const double* stats,
                     const float* gamma, const float* beta, int param_gs, float eps, int relu, hipStream_t st) {
     const int HW = in.H * in.W;
+    const int count = G * B * groups;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((count + 255) / 256), dim3(256), 0, st, const_cast<double*>(stats), count,
+                       (double)HW * (in.C / groups), eps);
     const long total = (long)B * HW * (in.C / 4);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(cap_grid(total, 256), G), dim3(256), 0, st, in.p, out.p, B, HW, in.C,
-                       in.cs, out.cs, in.gs, out.gs, groups, stats, gamma, beta, param_gs, eps, relu);
+                       in.cs, out.cs, in.gs, out.gs, groups, stats, gamma, beta, param_gs, relu);
     QB_CHECK(hipGetLastError());
     return 0;
 }
