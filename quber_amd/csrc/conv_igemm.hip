@@ -32,8 +32,8 @@ constexpr int PITCH = 36;
 // Main-loop variants that were measured and rejected (profiles/r01c_conv_variants.md): double-buffered LDS with one
 // barrier per K-slice, a a per-block s_setprio stagger, and 256x128 / 128x256 tiles (8 waves, or 4 waves of 128x64) were all 1-25 % slower
 // than this single-buffer, register-prefetch loop at 3 blocks per CU.
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
+template <int BM, int BN, int WM, int WN, bool DIAG = false>
+__global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 3 : 1) void conv_igemm_f32(const ConvP p) {
     constexpr int NTH = WM * WN * 64;
     constexpr int RPP = NTH / 8;      // tile rows covered by one pass of the loader
     constexpr int TM = BM / WM / 32;
@@ -134,24 +134,29 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
         }
 #pragma unroll
         for (int i = 0; i < BL; ++i) rb[i] = *reinterpret_cast<const f32x4*>(wrow[i] + kt * BK);
-        // advance to the next K-slice
-        if (p.kmode) {
-            // slice-major K order (k = (c/32, tap, c%32)): the taps of one 32-channel slice are consecutive K-slices,
-            // so the 9 shifted reads of a 3x3 window hit the same cache lines back to back instead of 8+ slices apart
-            if (++kx == p.kw) {
-                kx = 0;
-                if (++ky == p.kh) { ky = 0; kc += BK; }
-            }
-        } else {
-            kc += BK;
+        // advance to the next K-slice.  Both K orders are evaluated and selected (no branches: the loop body stays
+        // one basic block, and LLVM cannot merge the branch tails into a pointer phi that would push kc/ky to scratch).
+        // slice-major (kmode 1, k = (c/32, tap, c%32)): the taps of one 32-channel slice are consecutive K-slices, so
+        // the 9 shifted reads of a 3x3 window hit the same cache lines back to back instead of 8+ slices apart.
+        const int wx = (kx + 1 == p.kw) ? 1 : 0;
+        const int s_kx = wx ? 0 : kx + 1;
+        const int wy = (ky + wx == p.kh) ? 1 : 0;
+        const int s_ky = wy ? 0 : ky + wx;
+        const int s_kc = kc + (wy ? BK : 0);
+        // tap-major (kmode 0, k = (tap, c)); Cin >= 8, so a K-slice crosses at most BK/8 taps
+        int t_kc = kc + BK, t_kx = kx, t_ky = ky;
 #pragma unroll
-            for (int it = 0; it < BK / 8; ++it) {      // Cin >= 8: at most BK/8 filter taps per K-slice
-                if (kc >= p.Cin) {
-                    kc -= p.Cin;
-                    if (++kx == p.kw) { kx = 0; ++ky; }
-                }
-            }
+        for (int it = 0; it < BK / 8; ++it) {
+            const int ge = t_kc >= p.Cin ? 1 : 0;
+            t_kc -= ge ? p.Cin : 0;
+            const int w = (t_kx + ge == p.kw) ? 1 : 0;
+            t_kx = w ? 0 : t_kx + ge;
+            t_ky += w;
         }
+        const bool sm = p.kmode != 0;
+        kc = sm ? s_kc : t_kc;
+        kx = sm ? s_kx : t_kx;
+        ky = sm ? s_ky : t_ky;
     };
     auto lstore = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -197,15 +202,54 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
     gload(0);
     lstore(0);
     __syncthreads();
+    // The loop body is one basic block (the last iteration re-loads its own slice instead of branching), so the
+    // scheduler may spread the next slice's address arithmetic and global loads between the MFMAs of the current
+    // one: an MFMA occupies the matrix pipe for 64 cycles but the issue port only briefly, and VALU work
+    // interleaved there is free, while the same work in front of the MFMA block leaves the pipe idle.
+    unsigned long long tsum[5] = {0, 0, 0, 0, 0};
+    unsigned long long clk0 = 0, rt0 = 0;
+    if (DIAG) {
+        clk0 = __builtin_amdgcn_s_memtime();
+        rt0 = __builtin_amdgcn_s_memrealtime();
+    }
+    auto stamp = [&]() __attribute__((always_inline)) -> unsigned long long {
+        unsigned long long tt;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt)::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+        return tt;
+    };
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) gload(kt + 1);
+        unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+        if (DIAG) t0 = stamp();
+        gload(kt + 1 < nk ? kt + 1 : kt);
+        if (DIAG) t1 = stamp();
 #pragma unroll
         for (int ks = 0; ks < BK / 8; ++ks) mma(0, ks);
-        __syncthreads();
-        if (kt + 1 < nk) {
-            lstore(0);
-            __syncthreads();
+        if (!DIAG) {
+#pragma unroll
+            for (int i = 0; i < (BK / 8) * TM * TN * 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);   // a few VALU / SALU
+                __builtin_amdgcn_sched_group_barrier(0x120, 1, 0);   // at most one VMEM / LDS read
+            }
         }
+        if (DIAG) t2 = stamp();
+        __syncthreads();
+        if (DIAG) t3 = stamp();
+        lstore(0);
+        if (DIAG) t4 = stamp();
+        __syncthreads();
+        if (DIAG) {
+            t5 = stamp();
+            tsum[0] += t1 - t0; tsum[1] += t2 - t1; tsum[2] += t3 - t2; tsum[3] += t4 - t3; tsum[4] += t5 - t4;
+        }
+    }
+    if (DIAG && p.dbg && (t & 63) == 0) {
+        unsigned long long* d = p.dbg + ((long)blockIdx.x * 4 + wave) * 7;
+        for (int i = 0; i < 5; ++i) d[i] = tsum[i];
+        d[5] = __builtin_amdgcn_s_memtime() - clk0;        // shader cycles spent in the K loop
+        d[6] = __builtin_amdgcn_s_memrealtime() - rt0;     // the same interval in 100 MHz ticks
     }
 
     // ---- epilogue: y = acc*scale + shift (+ residual) (ReLU) ----
@@ -269,6 +313,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
 }
 
 static int g_order = 0;
+static unsigned long long* g_dbg = nullptr;
+void set_conv_dbg(void* p) { g_dbg = (unsigned long long*)p; }
 void set_conv_order(int v) { g_order = v; }
 
 template <int BM, int BN, int WM, int WN>
@@ -297,6 +343,13 @@ int launch_conv(const ConvP& p, int G, hipStream_t st) {
     if (p.Cout <= 64) return run<256, 64, 4, 1>(p, G, st);
     const long tiles128 = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * G;
     if (tiles128 < 512) return run<64, 64, 2, 2>(p, G, st);
+    if (g_dbg) {
+        ConvP q = p;
+        q.dbg = g_dbg;
+        q.mtiles = (q.M + 127) / 128; q.ntiles = (q.Cout + 127) / 128; q.order = g_order; q.vec_out = 0;
+        hipLaunchKernelGGL((conv_igemm_f32<128, 128, 2, 2, true>), dim3(q.mtiles * q.ntiles, 1, G), dim3(256), 0, st, q);
+        return 0;
+    }
     return run<128, 128, 2, 2>(p, G, st);
 }
 
