@@ -290,7 +290,7 @@ class InsEmbedHead(nn.Module):
             y = self.decoder[k]["fuse_conv"](torch.cat([p, y], 1))
         return y
 
-    def forward(self, feats, taps=None):
+    def forward(self, feats, taps=None, size=None):
         cfg = self.cfg
         y = self.decode(feats)
         feat, out = {}, {}
@@ -319,6 +319,8 @@ class InsEmbedHead(nn.Module):
         s = cfg.common_stride
         up = {k: F.interpolate(v, scale_factor=s, mode="bilinear", align_corners=False) for k, v in out.items()}
         up["offset"] = up["offset"] * s
+        if size is not None:   # [d2] sem_seg_postprocess: crop to the image, then resize to (height, width) = identity
+            up = {k: v[:, :, :size[0], :size[1]] for k, v in up.items()}
         return up
 
 
@@ -342,4 +344,4 @@ class MaskRefinerNet(nn.Module):
         feats = {k: feats[k] for k in ("res2", "res3", "res5")}
         if taps is not None:
             taps.update(feats)
-        return self.ins_embed_head(feats, taps)
+        return self.ins_embed_head(feats, taps, size=tuple(image.shape[-2:]))

@@ -60,7 +60,7 @@ int launch_predictor(const View& in, const float* w, const float* bias, int cout
                      hipStream_t st);
 int launch_copy_channels(const View& in, const View& out, int B, hipStream_t st);
 int launch_add_channels(const View& a, const View& b, const View& out, int B, hipStream_t st);
-int launch_upsample_logits(const float* q, float* out, int B, int nch, int h, int w, int scale,
+int launch_upsample_logits(const float* q, float* out, int B, int nch, int h, int w, int scale, int OH, int OW,
                            unsigned mul_mask, hipStream_t st);
 
 int launch_encode(const uint8_t* masks, int B, int N, int H, int W, const float* gauss, int sigma,

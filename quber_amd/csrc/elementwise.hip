@@ -388,11 +388,11 @@ int launch_copy_channels(const View& in, const View& out, int B, hipStream_t st)
     return 0;
 }
 
-// planar bilinear x`scale` of the predictor logits; channels whose bit is set in mul_mask are multiplied by
-// `scale` afterwards (the offset maps, model.py:695-700)
+// planar bilinear x`scale` of the predictor logits, cropped to the frame (sem_seg_postprocess, model.py:266-289:
+// when H or W is not a multiple of 16 the x4 map is larger than the image and only its top-left H x W part is
+// kept); channels whose bit is set in mul_mask are multiplied by `scale` afterwards (offsets, model.py:695-700)
 __global__ void upsample_logits_kernel(const float* __restrict__ q, float* __restrict__ out, int planes, int h, int w,
-                                       int nch, int scale, unsigned mul_mask) {
-    const int OH = h * scale, OW = w * scale;
+                                       int nch, int scale, int OH, int OW, unsigned mul_mask) {
     const float inv = 1.f / (float)scale;
     const long total = (long)planes * OH * OW;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -412,11 +412,12 @@ __global__ void upsample_logits_kernel(const float* __restrict__ q, float* __res
     }
 }
 
-int launch_upsample_logits(const float* q, float* out, int B, int nch, int h, int w, int scale, unsigned mul_mask,
-                           hipStream_t st) {
-    const long total = (long)B * nch * h * w * scale * scale;
+int launch_upsample_logits(const float* q, float* out, int B, int nch, int h, int w, int scale, int OH, int OW,
+                           unsigned mul_mask, hipStream_t st) {
+    if (OH > h * scale || OW > w * scale) return fail("upsample: frame larger than the scaled head map");
+    const long total = (long)B * nch * OH * OW;
     hipLaunchKernelGGL(upsample_logits_kernel, dim3(cap_grid(total, 256)), dim3(256), 0, st, q, out, B * nch, h, w,
-                       nch, scale, mul_mask);
+                       nch, scale, OH, OW, mul_mask);
     QB_CHECK(hipGetLastError());
     return 0;
 }

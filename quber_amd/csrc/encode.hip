@@ -75,6 +75,43 @@ __global__ __launch_bounds__(256) void encode_reduce_kernel(const uint8_t* __res
         if (sm[i]) atomicAdd(&(&stats[(long)b * N].cnt)[i], (unsigned long long)sm[i]);
 }
 
+// Fallback for frame widths that are not a multiple of 16 (rows are then not 16-byte aligned): one pixel per lane.
+__global__ __launch_bounds__(256) void encode_reduce_generic_kernel(const uint8_t* __restrict__ masks, int N, int H, int W,
+                                                                    MaskStat* __restrict__ stats,
+                                                                    uint8_t* __restrict__ last) {
+    extern __shared__ unsigned int sm[];  // [N][3]
+    const int b = blockIdx.y;
+    const long HW = (long)H * W;
+    for (int i = threadIdx.x; i < N * 3; i += blockDim.x) sm[i] = 0;
+    __syncthreads();
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = p < HW;
+    const int y = active ? (int)(p / W) : 0;
+    const int x = active ? (int)(p - (long)y * W) : 0;
+    unsigned lastv = 0;
+    const uint8_t* src = masks + (long)b * N * HW + p;
+    for (int n = 0; n < N; ++n) {
+        const bool on = active && src[(long)n * HW] != 0;
+        if (on) lastv = n + 1;
+        unsigned cnt = on ? 1u : 0u, sy = on ? (unsigned)y : 0u, sx = on ? (unsigned)x : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            cnt += __shfl_down(cnt, o);
+            sy += __shfl_down(sy, o);
+            sx += __shfl_down(sx, o);
+        }
+        if ((threadIdx.x & 63) == 0 && cnt) {
+            atomicAdd(&sm[n * 3], cnt);
+            atomicAdd(&sm[n * 3 + 1], sy);
+            atomicAdd(&sm[n * 3 + 2], sx);
+        }
+    }
+    if (active) last[(long)b * HW + p] = (uint8_t)lastv;
+    __syncthreads();
+    for (int i = threadIdx.x; i < N * 3; i += blockDim.x)
+        if (sm[i]) atomicAdd(&(&stats[(long)b * N].cnt)[i], (unsigned long long)sm[i]);
+}
+
 __global__ __launch_bounds__(256) void encode_paint_kernel(const MaskStat* __restrict__ stats,
                                                            const uint8_t* __restrict__ last,
                                                            const float* __restrict__ gauss, int N, int H, int W,
@@ -125,25 +162,29 @@ __global__ __launch_bounds__(256) void encode_paint_kernel(const MaskStat* __res
 }
 
 size_t encode_ws_bytes(int B, int N, int H, int W) {
-    return (size_t)B * N * sizeof(MaskStat) + (size_t)B * H * W;
+    return (size_t)B * N * sizeof(MaskStat) + (size_t)B * H * W + 16;
 }
 
 int launch_encode(const uint8_t* masks, int B, int N, int H, int W, const float* gauss, int sigma, void* ws,
                   float* out, hipStream_t st) {
     if (N < 0 || N > 254) return fail("encode: at most 254 initial masks per frame");
-    if (W % ENC_PIX) return fail("encode: width must be a multiple of 16");
     const long HW = (long)H * W;
     // workspace: [last-index map B*H*W bytes][MaskStat B*N]  (the map first keeps its 16-byte alignment)
     uint8_t* last = reinterpret_cast<uint8_t*>(ws);
-    MaskStat* stats = reinterpret_cast<MaskStat*>(last + (size_t)B * HW);
+    MaskStat* stats = reinterpret_cast<MaskStat*>(last + (((size_t)B * HW + 15) & ~(size_t)15));
     if (N == 0) {
         QB_CHECK(hipMemsetAsync(out, 0, sizeof(float) * 3 * HW * B, st));
         return 0;
     }
     QB_CHECK(hipMemsetAsync(stats, 0, sizeof(MaskStat) * (size_t)B * N, st));
-    const int blocks = (int)((HW / ENC_PIX + 255) / 256);
-    hipLaunchKernelGGL(encode_reduce_kernel, dim3(blocks, B), dim3(256), sizeof(unsigned) * 3 * N, st, masks, N, H, W,
-                       stats, last);
+    if (W % ENC_PIX == 0 && ((uintptr_t)masks & 15) == 0) {
+        const int blocks = (int)((HW / ENC_PIX + 255) / 256);
+        hipLaunchKernelGGL(encode_reduce_kernel, dim3(blocks, B), dim3(256), sizeof(unsigned) * 3 * N, st, masks, N, H,
+                           W, stats, last);
+    } else {
+        hipLaunchKernelGGL(encode_reduce_generic_kernel, dim3((int)((HW + 255) / 256), B), dim3(256),
+                           sizeof(unsigned) * 3 * N, st, masks, N, H, W, stats, last);
+    }
     QB_CHECK(hipGetLastError());
     const size_t sm2 = (size_t)N * (2 * sizeof(double) + 2 * sizeof(int));
     hipLaunchKernelGGL(encode_paint_kernel, dim3((int)((HW + 255) / 256), B), dim3(256), sm2, st, stats, last, gauss, N,

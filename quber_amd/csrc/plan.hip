@@ -246,7 +246,9 @@ struct Builder {
     void build() {
         const quber_config& cf = c->cfg;
         const int* nb = cf.resnet_depth == 50 ? BLOCKS50 : cf.resnet_depth == 101 ? BLOCKS101 : BLOCKS152;
-        const int h2 = H / 2, w2 = W / 2, h4 = H / 4, w4 = W / 4, h8 = H / 8, w8 = W / 8, h16 = H / 16, w16 = W / 16;
+        // stride-2 stages round up (3x3/s2/p1 conv and pool: out = floor((in - 1) / 2) + 1; strided 1x1: the same)
+        const int h2 = (H + 1) / 2, w2 = (W + 1) / 2, h4 = (h2 + 1) / 2, w4 = (w2 + 1) / 2;
+        const int h8 = (h4 + 1) / 2, w8 = (w4 + 1) / 2, h16 = (h8 + 1) / 2, w16 = (w8 + 1) / 2;
         const std::string R = "backbone.rgb_backbone.", D = "backbone.depth_backbone.";
         const int NS = cf.streams;   // 2: rgb + depth streams with concat fusion; 1: a single ResNet (rgb-only / depth-only)
         auto two = [&](const std::string& tail, bool stage_prefix) -> std::vector<std::string> {
@@ -272,7 +274,7 @@ struct Builder {
             const int stage = s + 2;
             const int sdil = stage == 5 ? cf.res5_dilation : 1;
             const int first = (s == 0 || sdil > 1) ? 1 : 2;
-            const int oh = ch / first, ow = cw / first;
+            const int oh = first == 2 ? (ch + 1) / 2 : ch, ow = first == 2 ? (cw + 1) / 2 : cw;
             View t1 = make(mid, oh, ow, NS), t2 = make(mid, oh, ow, NS), sc = make(cout, oh, ow, NS);
             View oa = make(cout, oh, ow, NS), ob = make(cout, oh, ow, NS);
             const bool tapped = stage != 4;
@@ -474,14 +476,14 @@ struct Builder {
         // x4 bilinear of every plane, offsets scaled by the stride (model.py:689-708)
         quber_ctx* ctx = c;
         op([=](int B, hipStream_t st) {
-            return launch_upsample_logits(q, ctx->cur_out, B, planes, h4, w4, 4, 0xCu, st);
+            return launch_upsample_logits(q, ctx->cur_out, B, planes, h4, w4, 4, ctx->cfg.height, ctx->cfg.width, 0xCu, st);
         });
     }
 };
 
 int check_cfg(const quber_config& c) {
-    if (c.height <= 0 || c.width <= 0 || c.width % 16) return fail("width must be a positive multiple of 16");
-    if (c.with_network && c.height % 16) return fail("height must be a multiple of 16 when the network is enabled");
+    if (c.height <= 0 || c.width <= 0) return fail("height and width must be positive");
+    if (c.with_network && (c.height < 16 || c.width < 16)) return fail("frames smaller than 16 x 16 are not supported");
     if (c.max_batch < 1) return fail("max_batch must be >= 1");
     if (c.max_instances < 1 || c.max_instances > 254) return fail("max_instances must be in 1..254");
     if (c.resnet_depth != 50 && c.resnet_depth != 101 && c.resnet_depth != 152) return fail("resnet_depth must be 50, 101 or 152");

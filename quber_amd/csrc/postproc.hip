@@ -327,6 +327,15 @@ __global__ void extract_masks_kernel(const float* __restrict__ pan, const float*
     *reinterpret_cast<uint4*>(out + ((long)b * max_inst + i) * HW + p) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+__global__ void extract_masks_generic_kernel(const float* __restrict__ pan, const float* __restrict__ labels, int HW,
+                                             int cap, int max_inst, uint8_t* __restrict__ out) {
+    const int b = blockIdx.z, i = blockIdx.y;
+    const float lab = labels[(long)b * cap + i];
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    out[((long)b * max_inst + i) * HW + p] = (lab >= 0.f && pan[(long)b * HW + p] == lab) ? 1 : 0;
+}
+
 // workspace layout (bytes): cand f32 B*HW | idmap u8 B*HW | area u32 B*256 | lut f32 B*256 | stats B*cap
 static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 size_t postprocess_ws_bytes(int B, int H, int W, int cap) {
@@ -371,10 +380,13 @@ int launch_postprocess(const float* logits, int nch, int B, int H, int W, const 
 int launch_extract_masks(const float* pan, const float* labels, int B, int H, int W, int cap, int max_inst,
                          uint8_t* out, hipStream_t st) {
     const long HW = (long)H * W;
-    if (HW % 16) return fail("extract_masks: H*W must be a multiple of 16");
     if (max_inst < 1 || max_inst > cap) return fail("extract_masks: max_inst out of range");
-    hipLaunchKernelGGL(extract_masks_kernel, dim3((int)((HW / 16 + 255) / 256), max_inst, B), dim3(256), 0, st, pan,
-                       labels, (int)HW, cap, max_inst, out);
+    if (HW % 16 == 0 && (((uintptr_t)pan | (uintptr_t)out) & 15) == 0)
+        hipLaunchKernelGGL(extract_masks_kernel, dim3((int)((HW / 16 + 255) / 256), max_inst, B), dim3(256), 0, st, pan,
+                           labels, (int)HW, cap, max_inst, out);
+    else
+        hipLaunchKernelGGL(extract_masks_generic_kernel, dim3((int)((HW + 255) / 256), max_inst, B), dim3(256), 0, st,
+                           pan, labels, (int)HW, cap, max_inst, out);
     QB_CHECK(hipGetLastError());
     return 0;
 }

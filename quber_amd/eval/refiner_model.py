@@ -4,6 +4,8 @@
 
 Built: file loading, resize to 640x480, ``normalize_depth`` (eval/preprocess_utils.py:12-28), nearest depth
 resize, the HIP predictor, the OCID zero-depth masking (refiner_model.py:279-288).
+The ``dataset == 'armbench'`` branch (refiner_model.py:226-244: RGB only, shortest edge 800 / longest 1333, nearest
+resize of the masks) is built too; any frame size is accepted by the HIP path.
 Not built yet (DESIGN.md "next"): ``cv2.inpaint`` TELEA depth in-painting (zero-depth
 pixels are left at 0 here; frames without zero depth are unaffected because the reference only rewrites
 zero pixels, preprocess_utils.py:63) and the LMFFNet foreground post-filter (``fg_mask`` is returned as None
@@ -36,6 +38,16 @@ def _resize_nearest(img, w, h):
     return img[ys][:, xs]
 
 
+def resize_shortest_edge_shape(oldh, oldw, short_edge_length=800, max_size=1333):
+    """[d2] ResizeShortestEdge.get_output_shape, used by the armbench branch (refiner_model.py:228)."""
+    scale = short_edge_length * 1.0 / min(oldh, oldw)
+    newh, neww = (short_edge_length, scale * oldw) if oldh < oldw else (scale * oldh, short_edge_length)
+    if max(newh, neww) > max_size:
+        scale = max_size * 1.0 / max(newh, neww)
+        newh, neww = newh * scale, neww * scale
+    return int(newh + 0.5), int(neww + 0.5)
+
+
 class MaskRefiner:
     def __init__(self, config_file=None, weights_file=None, dataset="OSD", device="cuda:0"):
         self.refiner_predictor = MaskRefinerPredictor(config_file, weights_file=weights_file, device=device)
@@ -43,6 +55,17 @@ class MaskRefiner:
 
     def predict(self, rgb_path, depth_path, initial_masks, fg_mask=None):
         rgb = np.asarray(Image.open(rgb_path).convert("RGB"))[:, :, ::-1]        # BGR like cv2.imread
+        if self.dataset == "armbench":
+            h, w = resize_shortest_edge_shape(rgb.shape[0], rgb.shape[1], 800, 1333)
+            rgb = np.asarray(Image.fromarray(np.ascontiguousarray(rgb)).resize((w, h), Image.BILINEAR))
+            initial_masks = np.asarray(initial_masks)
+            if initial_masks.dtype == np.bool_:
+                initial_masks = np.uint8(initial_masks) * 255
+            initial_masks = np.array([_resize_nearest(m, w, h) for m in initial_masks])
+            start = time.time()
+            output = self.refiner_predictor.predict(np.ascontiguousarray(rgb), None, initial_masks)[0]
+            refined = output["instances"].to("cpu").pred_masks.numpy() if "instances" in output else []
+            return refined, output, time.time() - start, None
         depth = np.load(depth_path) if "npy" in depth_path else np.asarray(Image.open(depth_path))
         if rgb.shape[:2] != (H, W):
             rgb = np.asarray(Image.fromarray(np.ascontiguousarray(rgb)).resize((W, H), Image.BILINEAR))

@@ -39,7 +39,7 @@ def rel_err(got, ref):
     return float((got - ref).abs().max() / max(1.0, float(ref.abs().max())))
 
 
-@pytest.mark.parametrize("h,w,b,depth", [(64, 96, 2, 50), (128, 160, 1, 50), (64, 64, 1, 101)])
+@pytest.mark.parametrize("h,w,b,depth", [(64, 96, 2, 50), (128, 160, 1, 50), (64, 64, 1, 101), (70, 102, 2, 50), (53, 75, 1, 50)])
 def test_network_vs_oracle_small(h, w, b, depth):
     sd = arch.init_state_dict(seed=1, depth=depth)
     net = oracle_net(sd, depth)
@@ -60,7 +60,8 @@ def test_network_vs_oracle_small(h, w, b, depth):
     exp = torch.cat([ref["foreground"], ref["center"], ref["offset"], ref["eee_boundary"]], 1)
     assert logits.shape == exp.shape
     assert float((logits - exp).abs().max()) < TOL
-    assert abs(eng.forward_flops() / 2e9 - 187.8 * (h * w) / (480 * 640)) < 0.02 * 187.8 * (h * w) / (480 * 640) or depth != 50
+    if depth == 50 and h % 16 == 0 and w % 16 == 0:
+        assert abs(eng.forward_flops() / 2e9 - 187.8 * (h * w) / (480 * 640)) < 0.02 * 187.8 * (h * w) / (480 * 640)
     eng.close()
 
 

@@ -47,7 +47,7 @@ def test_gaussian_template_bits():
     np.testing.assert_array_equal(heat[48 - 31:48 + 32, 64 - 31:64 + 32].view(np.uint32), g.view(np.uint32))
 
 
-@pytest.mark.parametrize("h,w,n,b", [(480, 640, 20, 3), (720, 1280, 30, 2), (96, 128, 1, 1), (480, 640, 200, 1)])
+@pytest.mark.parametrize("h,w,n,b", [(480, 640, 20, 3), (720, 1280, 30, 2), (96, 128, 1, 1), (480, 640, 200, 1), (75, 101, 5, 2), (800, 1067, 12, 1)])
 def test_encode_vs_oracle(h, w, n, b):
     rng = np.random.default_rng(h + n)
     masks = np.stack([synth.make_masks(rng, n, h, w)[1] for _ in range(b)]).astype(np.uint8) * 255
@@ -68,7 +68,7 @@ def test_encode_zero_masks_and_errors():
 
 
 # --------------------------------------------------------------------------------------------- a2 error maps
-@pytest.mark.parametrize("h,w,n", [(96, 128, 6), (480, 640, 20), (720, 1280, 12)])
+@pytest.mark.parametrize("h,w,n", [(96, 128, 6), (480, 640, 20), (720, 1280, 12), (75, 101, 4)])
 def test_error_maps_vs_oracle(h, w, n):
     rng = np.random.default_rng(n)
     gt, init = synth.make_masks(rng, n, h, w)
@@ -143,7 +143,7 @@ def test_panoptic_golden(path):
     np.testing.assert_array_equal(o["centers"][:k], z["centers"][0])
 
 
-@pytest.mark.parametrize("h,w,n,seed", [(480, 640, 20, 1), (480, 640, 8, 2), (720, 1280, 30, 3), (96, 128, 3, 4)])
+@pytest.mark.parametrize("h,w,n,seed", [(480, 640, 20, 1), (480, 640, 8, 2), (720, 1280, 30, 3), (96, 128, 3, 4), (150, 203, 4, 5)])
 def test_postprocess_vs_oracle(h, w, n, seed):
     rng = np.random.default_rng(seed)
     sc = synth.make_scene(seed, h, w, n)
