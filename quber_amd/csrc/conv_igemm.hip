@@ -110,12 +110,22 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 3 : 1) voi
         const int n = n0 + lrow + RPP * i;
         wrow[i] = wt + (long)(n < p.Cout ? n : 0) * p.Kpad + kq;   // columns >= Cout are never stored
     }
+    // split-K: blockIdx.y owns the K-slices [k_begin, k_end) and writes a raw partial tile (summed by
+    // splitk_reduce_kernel); used when a layer has too few tiles to fill the chip (small batches)
+    const int nk_all = p.Kpad / BK;
+    const int k_begin = (int)((long)blockIdx.y * nk_all / p.ksplit);
+    const int k_end = (int)((long)(blockIdx.y + 1) * nk_all / p.ksplit);
     int kc, kx, ky;
     if (p.kmode) {
-        kc = kq; kx = 0; ky = 0;
+        const int taps = p.kh * p.kw;
+        const int cb = k_begin / taps, tap = k_begin - cb * taps;
+        kc = cb * BK + kq;
+        ky = tap / p.kw;
+        kx = tap - ky * p.kw;
     } else {
-        const int tap = kq / p.Cin;
-        kc = kq - tap * p.Cin;
+        const int k = k_begin * BK + kq;
+        const int tap = k / p.Cin;
+        kc = k - tap * p.Cin;
         ky = tap / p.kw;
         kx = tap - ky * p.kw;
     }
@@ -123,7 +133,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 3 : 1) voi
     f32x4 ra[AL], rb[BL];
     bool aok[AL];
     auto gload = [&](int kt) __attribute__((always_inline)) {
-        const bool kok = p.kmode || ky < p.kh;
+        const bool kok = p.kmode ? kc < p.Cin : ky < p.kh;   // false for the redundant load after the last slice
         const int dy = ky * p.dil, dx = kx * p.dil;
         const long off = ((long)dy * p.W + dx) * p.in_cs + kc;
 #pragma unroll
@@ -180,7 +190,6 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 3 : 1) voi
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nk = p.Kpad / BK;
     auto mma = [&](int buf, int ks) __attribute__((always_inline)) {
         const float* ap = &As[buf * BM * PITCH + (wm * TM * 32 + r) * PITCH + 4 * h];
         const float* bp = &Bs[buf * BN * PITCH + (wn * 32 + r) * PITCH + 4 * h];
@@ -199,7 +208,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 3 : 1) voi
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
             }
     };
-    gload(0);
+    gload(k_begin);
     lstore(0);
     __syncthreads();
     // The loop body is one basic block (the last iteration re-loads its own slice instead of branching), so the
@@ -219,10 +228,10 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 3 : 1) voi
         __builtin_amdgcn_sched_barrier(0);
         return tt;
     };
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = k_begin; kt < k_end; ++kt) {
         unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
         if (DIAG) t0 = stamp();
-        gload(kt + 1 < nk ? kt + 1 : kt);
+        gload(kt + 1 < k_end ? kt + 1 : kt);
         if (DIAG) t1 = stamp();
 #pragma unroll
         for (int ks = 0; ks < BK / 8; ++ks) mma(0, ks);
@@ -255,10 +264,13 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 3 : 1) voi
     // ---- epilogue: y = acc*scale + shift (+ residual) (ReLU) ----
     // The accumulators are transposed through LDS one 32-column tile per wave at a time, so that global
     // stores (and residual loads) are 16 bytes per lane over WN*32 consecutive channels of a pixel.
-    float* __restrict__ out = p.out + (long)g * p.out_gs;
-    const float* __restrict__ res = p.res ? p.res + (long)g * p.res_gs : nullptr;
-    const float* __restrict__ scale = p.scale ? p.scale + g * p.ss_gs : nullptr;
-    const float* __restrict__ shift = p.shift ? p.shift + g * p.ss_gs : nullptr;
+    const bool partial = p.ksplit > 1;
+    float* __restrict__ out = partial ? p.ws + ((long)blockIdx.y * gridDim.z + g) * (long)p.M * p.Cout : p.out + (long)g * p.out_gs;
+    const int out_cs = partial ? p.Cout : p.out_cs;
+    const float* __restrict__ res = (p.res && !partial) ? p.res + (long)g * p.res_gs : nullptr;
+    const float* __restrict__ scale = (p.scale && !partial) ? p.scale + g * p.ss_gs : nullptr;
+    const float* __restrict__ shift = (p.shift && !partial) ? p.shift + g * p.ss_gs : nullptr;
+    const bool relu = p.relu && !partial;
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -289,10 +301,10 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 3 : 1) voi
                         const float4 rv = *reinterpret_cast<const float4*>(res + (long)m * p.res_cs + n);
                         v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
                     }
-                    if (p.relu) {
+                    if (relu) {
                         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                     }
-                    *reinterpret_cast<float4*>(out + (long)m * p.out_cs + n) = v;
+                    *reinterpret_cast<float4*>(out + (long)m * out_cs + n) = v;
                 }
             }
         } else {
@@ -303,8 +315,8 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 3 : 1) voi
                     float v = smem[row * SP + q];
                     if (scale) v = fmaf(v, scale[n], shift[n]);
                     if (res) v += res[(long)m * p.res_cs + n];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    out[(long)m * p.out_cs + n] = v;
+                    if (relu) v = fmaxf(v, 0.f);
+                    out[(long)m * out_cs + n] = v;
                 }
             }
         }
@@ -312,7 +324,30 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 3 : 1) voi
     }
 }
 
+// sums the split-K partial tiles in a fixed order (deterministic) and applies the fused epilogue
+__global__ void splitk_reduce_kernel(const ConvP p, int S, int G) {
+    const int g = blockIdx.y;
+    const long MN = (long)p.M * p.Cout;
+    const float* __restrict__ scale = p.scale ? p.scale + g * p.ss_gs : nullptr;
+    const float* __restrict__ shift = p.shift ? p.shift + g * p.ss_gs : nullptr;
+    const float* __restrict__ res = p.res ? p.res + (long)g * p.res_gs : nullptr;
+    float* __restrict__ out = p.out + (long)g * p.out_gs;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < MN; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / p.Cout;
+        const int n = (int)(i - m * p.Cout);
+        float v = 0.f;
+        for (int s = 0; s < S; ++s) v += p.ws[((long)s * G + g) * MN + i];
+        if (scale) v = fmaf(v, scale[n], shift[n]);
+        if (res) v += res[m * p.res_cs + n];
+        if (p.relu) v = fmaxf(v, 0.f);
+        out[m * p.out_cs + n] = v;
+    }
+}
+
 static int g_order = 0;
+static float* g_splitk_ws = nullptr;
+static size_t g_splitk_floats = 0;
+void set_conv_splitk_workspace(float* ws, size_t floats) { g_splitk_ws = ws; g_splitk_floats = floats; }
 static unsigned long long* g_dbg = nullptr;
 void set_conv_dbg(void* p) { g_dbg = (unsigned long long*)p; }
 void set_conv_order(int v) { g_order = v; }
@@ -325,8 +360,27 @@ static int run(ConvP p, int G, hipStream_t st) {
     p.vec_out = (p.Cout % 4 == 0) && (p.out_cs % 4 == 0) && (((uintptr_t)p.out & 15) == 0) && (p.out_gs % 4 == 0) &&
                 (!p.res || ((p.res_cs % 4 == 0) && (((uintptr_t)p.res & 15) == 0) && (p.res_gs % 4 == 0))) &&
                 (!p.scale || ((((uintptr_t)p.scale & 15) == 0) && (p.ss_gs % 4 == 0)));
-    dim3 grid(p.mtiles * p.ntiles, 1, G);
+    // split-K when the launch cannot fill the chip (256 CUs x ~3 resident blocks) and K is deep enough
+    const long tiles = (long)p.mtiles * p.ntiles * G;
+    const int nk = p.Kpad / BK;
+    int S = 1;
+    if (g_splitk_ws && tiles < 384 && nk >= 16) {
+        S = (int)((768 + tiles - 1) / tiles);
+        if (S > nk / 8) S = nk / 8;
+        if (S > 16) S = 16;
+        while (S > 1 && (size_t)S * G * p.M * p.Cout > g_splitk_floats) --S;
+        if (S < 2) S = 1;
+    }
+    p.ksplit = S;
+    p.ws = g_splitk_ws;
+    dim3 grid(p.mtiles * p.ntiles, S, G);
     hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN>), grid, dim3(WM * WN * 64), 0, st, p);
+    if (S > 1) {
+        const long MN = (long)p.M * p.Cout;
+        int blocks = (int)((MN + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks, G), dim3(256), 0, st, p, S, G);
+    }
     QB_CHECK(hipGetLastError());
     return 0;
 }
@@ -346,7 +400,7 @@ int launch_conv(const ConvP& p, int G, hipStream_t st) {
     if (g_dbg) {
         ConvP q = p;
         q.dbg = g_dbg;
-        q.mtiles = (q.M + 127) / 128; q.ntiles = (q.Cout + 127) / 128; q.order = g_order; q.vec_out = 0;
+        q.mtiles = (q.M + 127) / 128; q.ntiles = (q.Cout + 127) / 128; q.order = g_order; q.vec_out = 0; q.ksplit = 1;
         hipLaunchKernelGGL((conv_igemm_f32<128, 128, 2, 2, true>), dim3(q.mtiles * q.ntiles, 1, G), dim3(256), 0, st, q);
         return 0;
     }

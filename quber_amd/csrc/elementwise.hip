@@ -154,7 +154,10 @@ int launch_gn_stats(const View& in, int B, int G, int groups, double* stats, hip
     if (groups > 64 || in.C % groups || in.C % 4) return fail("groupnorm: unsupported channel/group count");
     const int HW = in.H * in.W;
     QB_CHECK(hipMemsetAsync(stats, 0, sizeof(double) * 2 * groups * B * G, st));
+    // pixels per block: ~64K floats each at large batch, but never fewer than ~1000 blocks in flight at small batch
     int ppb = 65536 / in.C;
+    const long want = ((long)HW * B * G + 1023) / 1024;
+    if (ppb > want) ppb = (int)want;
     if (ppb < 8) ppb = 8;
     const int chunks = (HW + ppb - 1) / ppb;
     hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks, B, G), dim3(256), 0, st, in.p, HW, in.C, in.cs, in.gs,

@@ -58,6 +58,8 @@ struct quber_ctx {
     uint8_t* err_ws = nullptr;
     void* post_ws = nullptr;
     double* gn_stats = nullptr;
+    float* splitk_ws = nullptr;
+    size_t splitk_floats = 0;
     float* X = nullptr;   // [2][Bmax][H][W][8]
     float* q = nullptr;   // [Bmax][planes][H/4][W/4]
     const uint8_t* cur_bgr = nullptr;
@@ -256,6 +258,10 @@ struct Builder {
             return {R + tail, D + (stage_prefix ? "depth_" : "") + tail};
         };
         if (!dry) c->gn_stats = (double*)dalloc_bytes(sizeof(double) * 2 * 64 * Bmax * 4);
+        if (!dry) {
+            c->splitk_floats = (size_t)16 << 20;   // 64 MiB of partial tiles (only small-batch launches split K)
+            c->splitk_ws = (float*)dalloc_bytes(sizeof(float) * c->splitk_floats);
+        }
 
         // ---------------- input + stems (both streams as G = 2) ----------------
         View X = make(8, H, W, NS);
@@ -656,6 +662,7 @@ int quber_forward(quber_ctx* c, const uint8_t* bgr, const uint8_t* depth, const 
     if (!bgr || (!depth && c->cfg.streams == 2) || !offs || !logits) return fail("null tensor");
     hipStream_t st = (hipStream_t)stream;
     c->cur_out = logits;
+    set_conv_splitk_workspace(c->splitk_ws, c->splitk_floats);
     int rc = launch_preprocess(bgr, depth, offs, c->X, batch, c->cfg.max_batch, c->cfg.height, c->cfg.width,
                                c->cfg.pixel_mean, c->cfg.pixel_std, c->cfg.streams, st);
     if (rc) return rc;
@@ -682,6 +689,7 @@ int quber_forward_profiled(quber_ctx* c, const uint8_t* bgr, const uint8_t* dept
     int rc = launch_preprocess(bgr, depth, offs, c->X, batch, c->cfg.max_batch, c->cfg.height, c->cfg.width,
                                c->cfg.pixel_mean, c->cfg.pixel_std, c->cfg.streams, st);
     if (rc) return rc;
+    set_conv_splitk_workspace(c->splitk_ws, c->splitk_floats);
     for (size_t i = 0; i < n; ++i) {
         QB_CHECK(hipEventRecord(c->prof_events[2 * i], st));
         rc = c->ops[i].run(batch, st);
@@ -767,6 +775,7 @@ int quber_op_conv2d(const float* x, int32_t B, int32_t h, int32_t w, int32_t cin
     p.kmode = kmode;
     p.M = B * p.OH * p.OW;
     p.w_gs = 0; p.ss_gs = 0;
+    set_conv_splitk_workspace(nullptr, 0);   // the stand-alone op has no workspace: never splits K
     return launch_conv(p, 1, st);
 }
 
