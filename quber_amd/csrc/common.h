@@ -37,6 +37,8 @@ struct ConvP {
     unsigned long long* dbg;  // diagnostic build only: per-wave cycle sums
     float* ws;           // split-K partial tiles [ksplit][G][M][Cout]
     int ksplit;          // number of K partitions (grid.y); 1 = direct epilogue
+    int tile_begin;      // first tile of this launch in the (m-major) tile sequence
+    int m_begin;         // first output row covered by the partial slabs
     int kmode;           // 0: k = (tap, c)   1: k = (c/32, tap, c%32)  (weights packed accordingly)
     long in_gs, out_gs, res_gs, w_gs;
     int ss_gs;

@@ -52,6 +52,8 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 3 : 1) voi
 
     const int t = threadIdx.x;
     const int g = blockIdx.z;
+    unsigned long long blk_rt0 = 0;
+    if (DIAG) blk_rt0 = __builtin_amdgcn_s_memrealtime();
 
     // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give every XCD one
     // contiguous run of tiles, n-tile fastest, so neighbouring tiles reuse the same input rows.
@@ -61,6 +63,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 3 : 1) voi
         const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
         if (p.order == 1) tile = bid;
+        tile += p.tile_begin;   // a launch may cover only a run of the tile sequence (full rounds / tail)
     }
     int nt = tile % p.ntiles;
     int mt = tile / p.ntiles;
@@ -255,17 +258,22 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 3 : 1) voi
         }
     }
     if (DIAG && p.dbg && (t & 63) == 0) {
-        unsigned long long* d = p.dbg + ((long)blockIdx.x * 4 + wave) * 7;
+        unsigned long long* d = p.dbg + ((long)blockIdx.x * 4 + wave) * 12;
         for (int i = 0; i < 5; ++i) d[i] = tsum[i];
         d[5] = __builtin_amdgcn_s_memtime() - clk0;        // shader cycles spent in the K loop
         d[6] = __builtin_amdgcn_s_memrealtime() - rt0;     // the same interval in 100 MHz ticks
+        d[7] = blk_rt0;                                    // block start (100 MHz ticks)
+        d[8] = rt0;                                        // K loop start
+        d[10] = ((unsigned long long)__builtin_amdgcn_s_getreg(63492) << 32) | __builtin_amdgcn_s_getreg(63508);  // HW_ID | XCC_ID
     }
 
     // ---- epilogue: y = acc*scale + shift (+ residual) (ReLU) ----
     // The accumulators are transposed through LDS one 32-column tile per wave at a time, so that global
     // stores (and residual loads) are 16 bytes per lane over WN*32 consecutive channels of a pixel.
     const bool partial = p.ksplit > 1;
-    float* __restrict__ out = partial ? p.ws + ((long)blockIdx.y * gridDim.z + g) * (long)p.M * p.Cout : p.out + (long)g * p.out_gs;
+    // partial tiles of the rows [m_begin, M): slab s of group g starts at ((s*G + g) * (M - m_begin)) * Cout
+    float* __restrict__ out = partial ? p.ws + (((long)blockIdx.y * gridDim.z + g) * (long)(p.M - p.m_begin) - p.m_begin) * p.Cout
+                                      : p.out + (long)g * p.out_gs;
     const int out_cs = partial ? p.Cout : p.out_cs;
     const float* __restrict__ res = (p.res && !partial) ? p.res + (long)g * p.res_gs : nullptr;
     const float* __restrict__ scale = (p.scale && !partial) ? p.scale + g * p.ss_gs : nullptr;
@@ -322,19 +330,24 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 3 : 1) voi
         }
         if (j + 1 < TN) __syncthreads();
     }
+    if (DIAG && p.dbg && (t & 63) == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        p.dbg[((long)blockIdx.x * 4 + wave) * 12 + 9] = __builtin_amdgcn_s_memrealtime();   // block end (stores drained)
+    }
 }
 
 // sums the split-K partial tiles in a fixed order (deterministic) and applies the fused epilogue
 __global__ void splitk_reduce_kernel(const ConvP p, int S, int G) {
     const int g = blockIdx.y;
-    const long MN = (long)p.M * p.Cout;
+    const long MN = (long)(p.M - p.m_begin) * p.Cout;
     const float* __restrict__ scale = p.scale ? p.scale + g * p.ss_gs : nullptr;
     const float* __restrict__ shift = p.shift ? p.shift + g * p.ss_gs : nullptr;
     const float* __restrict__ res = p.res ? p.res + (long)g * p.res_gs : nullptr;
     float* __restrict__ out = p.out + (long)g * p.out_gs;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < MN; i += (long)gridDim.x * blockDim.x) {
-        const long m = i / p.Cout;
-        const int n = (int)(i - m * p.Cout);
+        const long mr = i / p.Cout;
+        const int n = (int)(i - mr * p.Cout);
+        const long m = mr + p.m_begin;
         float v = 0.f;
         for (int s = 0; s < S; ++s) v += p.ws[((long)s * G + g) * MN + i];
         if (scale) v = fmaf(v, scale[n], shift[n]);
@@ -360,27 +373,39 @@ static int run(ConvP p, int G, hipStream_t st) {
     p.vec_out = (p.Cout % 4 == 0) && (p.out_cs % 4 == 0) && (((uintptr_t)p.out & 15) == 0) && (p.out_gs % 4 == 0) &&
                 (!p.res || ((p.res_cs % 4 == 0) && (((uintptr_t)p.res & 15) == 0) && (p.res_gs % 4 == 0))) &&
                 (!p.scale || ((((uintptr_t)p.scale & 15) == 0) && (p.ss_gs % 4 == 0)));
-    // split-K when the launch cannot fill the chip (256 CUs x ~3 resident blocks) and K is deep enough
-    const long tiles = (long)p.mtiles * p.ntiles * G;
+    // Work distribution.  `slots` blocks are resident at once (256 CUs x blocks per CU for this tile shape).  With
+    // fewer than half a round of tiles (small batches) K is split so that about one round of blocks exists; the partial
+    // tiles are combined in a fixed order by splitk_reduce_kernel (deterministic).  Splitting only the ragged last
+    // round of larger launches was measured too (profiles/r01g_tail_split.md): +1..3 % on some layers, -2 % on
+    // others, because a lone block on a CU already runs ~1.5x faster than one of three - not kept.
+    constexpr int BPC = (BM == 64) ? 7 : (BM * BN == 256 * 64 ? 2 : 3);   // resident blocks per CU (registers / LDS)
+    const long slots = 256L * BPC;
+    const long T = (long)p.mtiles * p.ntiles;          // tiles per group
+    const long blocks_all = T * G;
     const int nk = p.Kpad / BK;
-    int S = 1;
-    if (g_splitk_ws && tiles < 384 && nk >= 16) {
-        S = (int)((768 + tiles - 1) / tiles);
+    auto split_for = [&](long nblocks, long rows) {
+        if (!g_splitk_ws || nk < 16) return 1;
+        int S = (int)((slots + nblocks - 1) / nblocks);
         if (S > nk / 8) S = nk / 8;
         if (S > 16) S = 16;
-        while (S > 1 && (size_t)S * G * p.M * p.Cout > g_splitk_floats) --S;
-        if (S < 2) S = 1;
-    }
-    p.ksplit = S;
-    p.ws = g_splitk_ws;
-    dim3 grid(p.mtiles * p.ntiles, S, G);
-    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN>), grid, dim3(WM * WN * 64), 0, st, p);
-    if (S > 1) {
-        const long MN = (long)p.M * p.Cout;
-        int blocks = (int)((MN + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks, G), dim3(256), 0, st, p, S, G);
-    }
+        while (S > 1 && (size_t)S * G * rows * p.Cout > g_splitk_floats) --S;
+        return S < 2 ? 1 : S;
+    };
+    auto launch = [&](long tile_begin, long ntile, int S, int m_begin) {
+        ConvP q = p;
+        q.tile_begin = (int)tile_begin;
+        q.ksplit = S;
+        q.m_begin = m_begin;
+        q.ws = g_splitk_ws;
+        hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN>), dim3((unsigned)ntile, S, G), dim3(WM * WN * 64), 0, st, q);
+        if (S > 1) {
+            const long MN = (long)(q.M - m_begin) * q.Cout;
+            int blocks = (int)((MN + 255) / 256);
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks, G), dim3(256), 0, st, q, S, G);
+        }
+    };
+    launch(0, T, blocks_all * 2 < slots ? split_for(blocks_all, p.M) : 1, 0);
     QB_CHECK(hipGetLastError());
     return 0;
 }
@@ -400,7 +425,7 @@ int launch_conv(const ConvP& p, int G, hipStream_t st) {
     if (g_dbg) {
         ConvP q = p;
         q.dbg = g_dbg;
-        q.mtiles = (q.M + 127) / 128; q.ntiles = (q.Cout + 127) / 128; q.order = g_order; q.vec_out = 0; q.ksplit = 1;
+        q.mtiles = (q.M + 127) / 128; q.ntiles = (q.Cout + 127) / 128; q.order = g_order; q.vec_out = (q.Cout % 4 == 0) && (q.out_cs % 4 == 0) && !q.scale && !q.res; q.ksplit = 1; q.tile_begin = 0; q.m_begin = 0;
         hipLaunchKernelGGL((conv_igemm_f32<128, 128, 2, 2, true>), dim3(q.mtiles * q.ntiles, 1, G), dim3(256), 0, st, q);
         return 0;
     }

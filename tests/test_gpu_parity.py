@@ -227,6 +227,23 @@ def test_conv_igemm_vs_torch(case):
     assert _conv_case(*case) < 2e-6
 
 
+@pytest.mark.parametrize("case", [
+    # split-K (needs the op workspace) and launches around the one-round boundary
+    (4, 120, 160, 64, 128, 3, 1, 1, True, True, True),      # 600 tiles of 128x128: below one round, above half
+    (8, 120, 160, 32, 128, 3, 1, 2, True, False, True),     # 1200 tiles: one full round + a 432-tile tail
+    (9, 120, 160, 32, 256, 1, 1, 1, False, False, False),   # 2700 tiles: three full rounds + tail
+    (1, 30, 40, 512, 256, 3, 1, 6, True, False, True),      # 76 tiles of 64x64, K = 4608: split-K
+    (2, 60, 80, 256, 64, 3, 1, 1, True, True, True),        # 256x64 tiles
+])
+def test_conv_split_paths_vs_torch(case):
+    lib = _lib.load()
+    lib.quber_set_tuning(2, 1)
+    try:
+        assert _conv_case(*case) < 2e-6
+    finally:
+        lib.quber_set_tuning(2, 0)
+
+
 def test_groupnorm_bilinear_maxpool_vs_torch():
     lib = _lib.load()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)

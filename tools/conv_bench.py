@@ -45,7 +45,7 @@ def main():
         ref = None
         for rd in range(rounds + 1):
             for v in variants:
-                lib.quber_set_tuning(0, v)
+                lib.quber_set_tuning(2, v)     # variant 1 = with the split-K / tail-split workspace
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(3):
@@ -61,7 +61,7 @@ def main():
                 else:
                     best[v].append(e0.elapsed_time(e1) / 3)
         print(f"| {name} | " + " | ".join("%.1f" % (flops / (np.median(best[v]) * 1e-3) / 1e12) for v in variants) + " |")
-    lib.quber_set_tuning(0, 0)
+    lib.quber_set_tuning(2, 0)
 
 
 if __name__ == "__main__":
