@@ -32,8 +32,11 @@ constexpr int PITCH = 36;
 // Main-loop variants that were measured and rejected (profiles/r01c_conv_variants.md): double-buffered LDS with one
 // barrier per K-slice, a a per-block s_setprio stagger, and 256x128 / 128x256 tiles (8 waves, or 4 waves of 128x64) were all 1-25 % slower
 // than this single-buffer, register-prefetch loop at 3 blocks per CU.
-template <int BM, int BN, int WM, int WN, bool DIAG = false>
-__global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 3 : 1) void conv_igemm_f32(const ConvP p) {
+// SPLIT: blockIdx.y owns a range of K-slices and writes a raw partial tile (split-K for launches that cannot fill the
+// chip).  Kept as a separate instantiation: with the K range a run-time quantity hipcc allocates ~50 more VGPRs for
+// the main loop and the kernel drops from 3 to 2 waves per SIMD.
+template <int BM, int BN, int WM, int WN, bool SPLIT>
+__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
     constexpr int NTH = WM * WN * 64;
     constexpr int RPP = NTH / 8;      // tile rows covered by one pass of the loader
     constexpr int TM = BM / WM / 32;
@@ -52,8 +55,6 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 3 : 1) voi
 
     const int t = threadIdx.x;
     const int g = blockIdx.z;
-    unsigned long long blk_rt0 = 0;
-    if (DIAG) blk_rt0 = __builtin_amdgcn_s_memrealtime();
 
     // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give every XCD one
     // contiguous run of tiles, n-tile fastest, so neighbouring tiles reuse the same input rows.
@@ -63,7 +64,6 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 3 : 1) voi
         const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
         if (p.order == 1) tile = bid;
-        tile += p.tile_begin;   // a launch may cover only a run of the tile sequence (full rounds / tail)
     }
     int nt = tile % p.ntiles;
     int mt = tile / p.ntiles;
@@ -113,18 +113,22 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 3 : 1) voi
         const int n = n0 + lrow + RPP * i;
         wrow[i] = wt + (long)(n < p.Cout ? n : 0) * p.Kpad + kq;   // columns >= Cout are never stored
     }
-    // split-K: blockIdx.y owns the K-slices [k_begin, k_end) and writes a raw partial tile (summed by
-    // splitk_reduce_kernel); used when a layer has too few tiles to fill the chip (small batches)
-    const int nk_all = p.Kpad / BK;
-    const int k_begin = (int)((long)blockIdx.y * nk_all / p.ksplit);
-    const int k_end = (int)((long)(blockIdx.y + 1) * nk_all / p.ksplit);
+    int k_begin = 0, nk = p.Kpad / BK;
+    if constexpr (SPLIT) {
+        const int nk_all = p.Kpad / BK;
+        k_begin = (int)((long)blockIdx.y * nk_all / p.ksplit);
+        nk = (int)((long)(blockIdx.y + 1) * nk_all / p.ksplit);
+    }
     int kc, kx, ky;
     if (p.kmode) {
-        const int taps = p.kh * p.kw;
-        const int cb = k_begin / taps, tap = k_begin - cb * taps;
-        kc = cb * BK + kq;
-        ky = tap / p.kw;
-        kx = tap - ky * p.kw;
+        kc = kq; kx = 0; ky = 0;
+        if constexpr (SPLIT) {
+            const int taps = p.kh * p.kw;
+            const int cb = k_begin / taps, tap = k_begin - cb * taps;
+            kc = cb * BK + kq;
+            ky = tap / p.kw;
+            kx = tap - ky * p.kw;
+        }
     } else {
         const int k = k_begin * BK + kq;
         const int tap = k / p.Cin;
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 3 : 1) voi
     f32x4 ra[AL], rb[BL];
     bool aok[AL];
     auto gload = [&](int kt) __attribute__((always_inline)) {
-        const bool kok = p.kmode ? kc < p.Cin : ky < p.kh;   // false for the redundant load after the last slice
+        const bool kok = p.kmode || ky < p.kh;
         const int dy = ky * p.dil, dx = kx * p.dil;
         const long off = ((long)dy * p.W + dx) * p.in_cs + kc;
 #pragma unroll
@@ -147,29 +151,24 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 3 : 1) voi
         }
 #pragma unroll
         for (int i = 0; i < BL; ++i) rb[i] = *reinterpret_cast<const f32x4*>(wrow[i] + kt * BK);
-        // advance to the next K-slice.  Both K orders are evaluated and selected (no branches: the loop body stays
-        // one basic block, and LLVM cannot merge the branch tails into a pointer phi that would push kc/ky to scratch).
-        // slice-major (kmode 1, k = (c/32, tap, c%32)): the taps of one 32-channel slice are consecutive K-slices, so
-        // the 9 shifted reads of a 3x3 window hit the same cache lines back to back instead of 8+ slices apart.
-        const int wx = (kx + 1 == p.kw) ? 1 : 0;
-        const int s_kx = wx ? 0 : kx + 1;
-        const int wy = (ky + wx == p.kh) ? 1 : 0;
-        const int s_ky = wy ? 0 : ky + wx;
-        const int s_kc = kc + (wy ? BK : 0);
-        // tap-major (kmode 0, k = (tap, c)); Cin >= 8, so a K-slice crosses at most BK/8 taps
-        int t_kc = kc + BK, t_kx = kx, t_ky = ky;
+        // advance to the next K-slice
+        if (p.kmode) {
+            // slice-major K order (k = (c/32, tap, c%32)): the taps of one 32-channel slice are consecutive K-slices,
+            // so the 9 shifted reads of a 3x3 window hit the same cache lines back to back instead of 8+ slices apart
+            if (++kx == p.kw) {
+                kx = 0;
+                if (++ky == p.kh) { ky = 0; kc += BK; }
+            }
+        } else {
+            kc += BK;
 #pragma unroll
-        for (int it = 0; it < BK / 8; ++it) {
-            const int ge = t_kc >= p.Cin ? 1 : 0;
-            t_kc -= ge ? p.Cin : 0;
-            const int w = (t_kx + ge == p.kw) ? 1 : 0;
-            t_kx = w ? 0 : t_kx + ge;
-            t_ky += w;
+            for (int it = 0; it < BK / 8; ++it) {      // Cin >= 8: at most BK/8 filter taps per K-slice
+                if (kc >= p.Cin) {
+                    kc -= p.Cin;
+                    if (++kx == p.kw) { kx = 0; ++ky; }
+                }
+            }
         }
-        const bool sm = p.kmode != 0;
-        kc = sm ? s_kc : t_kc;
-        kx = sm ? s_kx : t_kx;
-        ky = sm ? s_ky : t_ky;
     };
     auto lstore = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -214,71 +213,28 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 3 : 1) voi
     gload(k_begin);
     lstore(0);
     __syncthreads();
-    // The loop body is one basic block (the last iteration re-loads its own slice instead of branching), so the
-    // scheduler may spread the next slice's address arithmetic and global loads between the MFMAs of the current
-    // one: an MFMA occupies the matrix pipe for 64 cycles but the issue port only briefly, and VALU work
-    // interleaved there is free, while the same work in front of the MFMA block leaves the pipe idle.
-    unsigned long long tsum[5] = {0, 0, 0, 0, 0};
-    unsigned long long clk0 = 0, rt0 = 0;
-    if (DIAG) {
-        clk0 = __builtin_amdgcn_s_memtime();
-        rt0 = __builtin_amdgcn_s_memrealtime();
-    }
-    auto stamp = [&]() __attribute__((always_inline)) -> unsigned long long {
-        unsigned long long tt;
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt)::"memory");
-        __builtin_amdgcn_sched_barrier(0);
-        return tt;
-    };
-    for (int kt = k_begin; kt < k_end; ++kt) {
-        unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
-        if (DIAG) t0 = stamp();
-        gload(kt + 1 < k_end ? kt + 1 : kt);
-        if (DIAG) t1 = stamp();
+    for (int kt = k_begin; kt < nk; ++kt) {
+        if (kt + 1 < nk) gload(kt + 1);
 #pragma unroll
         for (int ks = 0; ks < BK / 8; ++ks) mma(0, ks);
-        if (!DIAG) {
-#pragma unroll
-            for (int i = 0; i < (BK / 8) * TM * TN * 4; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
-                __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);   // a few VALU / SALU
-                __builtin_amdgcn_sched_group_barrier(0x120, 1, 0);   // at most one VMEM / LDS read
-            }
-        }
-        if (DIAG) t2 = stamp();
         __syncthreads();
-        if (DIAG) t3 = stamp();
-        lstore(0);
-        if (DIAG) t4 = stamp();
-        __syncthreads();
-        if (DIAG) {
-            t5 = stamp();
-            tsum[0] += t1 - t0; tsum[1] += t2 - t1; tsum[2] += t3 - t2; tsum[3] += t4 - t3; tsum[4] += t5 - t4;
+        if (kt + 1 < nk) {
+            lstore(0);
+            __syncthreads();
         }
-    }
-    if (DIAG && p.dbg && (t & 63) == 0) {
-        unsigned long long* d = p.dbg + ((long)blockIdx.x * 4 + wave) * 12;
-        for (int i = 0; i < 5; ++i) d[i] = tsum[i];
-        d[5] = __builtin_amdgcn_s_memtime() - clk0;        // shader cycles spent in the K loop
-        d[6] = __builtin_amdgcn_s_memrealtime() - rt0;     // the same interval in 100 MHz ticks
-        d[7] = blk_rt0;                                    // block start (100 MHz ticks)
-        d[8] = rt0;                                        // K loop start
-        d[10] = ((unsigned long long)__builtin_amdgcn_s_getreg(63492) << 32) | __builtin_amdgcn_s_getreg(63508);  // HW_ID | XCC_ID
     }
 
     // ---- epilogue: y = acc*scale + shift (+ residual) (ReLU) ----
     // The accumulators are transposed through LDS one 32-column tile per wave at a time, so that global
     // stores (and residual loads) are 16 bytes per lane over WN*32 consecutive channels of a pixel.
-    const bool partial = p.ksplit > 1;
-    // partial tiles of the rows [m_begin, M): slab s of group g starts at ((s*G + g) * (M - m_begin)) * Cout
-    float* __restrict__ out = partial ? p.ws + (((long)blockIdx.y * gridDim.z + g) * (long)(p.M - p.m_begin) - p.m_begin) * p.Cout
-                                      : p.out + (long)g * p.out_gs;
-    const int out_cs = partial ? p.Cout : p.out_cs;
-    const float* __restrict__ res = (p.res && !partial) ? p.res + (long)g * p.res_gs : nullptr;
-    const float* __restrict__ scale = (p.scale && !partial) ? p.scale + g * p.ss_gs : nullptr;
-    const float* __restrict__ shift = (p.shift && !partial) ? p.shift + g * p.ss_gs : nullptr;
-    const bool relu = p.relu && !partial;
+    // SPLIT: raw partial tile into slab (split s, group g) = ws[(s*G + g) * M * Cout ...]; the affine, residual and
+    // ReLU are applied by splitk_reduce_kernel after the slabs have been summed
+    float* __restrict__ out = SPLIT ? p.ws + ((long)blockIdx.y * gridDim.z + g) * (long)p.M * p.Cout : p.out + (long)g * p.out_gs;
+    const int out_cs = SPLIT ? p.Cout : p.out_cs;
+    const float* __restrict__ res = (p.res && !SPLIT) ? p.res + (long)g * p.res_gs : nullptr;
+    const float* __restrict__ scale = (p.scale && !SPLIT) ? p.scale + g * p.ss_gs : nullptr;
+    const float* __restrict__ shift = (p.shift && !SPLIT) ? p.shift + g * p.ss_gs : nullptr;
+    const bool relu = p.relu && !SPLIT;
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -330,24 +286,19 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 3 : 1) voi
         }
         if (j + 1 < TN) __syncthreads();
     }
-    if (DIAG && p.dbg && (t & 63) == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        p.dbg[((long)blockIdx.x * 4 + wave) * 12 + 9] = __builtin_amdgcn_s_memrealtime();   // block end (stores drained)
-    }
 }
 
 // sums the split-K partial tiles in a fixed order (deterministic) and applies the fused epilogue
 __global__ void splitk_reduce_kernel(const ConvP p, int S, int G) {
     const int g = blockIdx.y;
-    const long MN = (long)(p.M - p.m_begin) * p.Cout;
+    const long MN = (long)p.M * p.Cout;
     const float* __restrict__ scale = p.scale ? p.scale + g * p.ss_gs : nullptr;
     const float* __restrict__ shift = p.shift ? p.shift + g * p.ss_gs : nullptr;
     const float* __restrict__ res = p.res ? p.res + (long)g * p.res_gs : nullptr;
     float* __restrict__ out = p.out + (long)g * p.out_gs;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < MN; i += (long)gridDim.x * blockDim.x) {
-        const long mr = i / p.Cout;
-        const int n = (int)(i - mr * p.Cout);
-        const long m = mr + p.m_begin;
+        const long m = i / p.Cout;
+        const int n = (int)(i - m * p.Cout);
         float v = 0.f;
         for (int s = 0; s < S; ++s) v += p.ws[((long)s * G + g) * MN + i];
         if (scale) v = fmaf(v, scale[n], shift[n]);
@@ -361,8 +312,6 @@ static int g_order = 0;
 static float* g_splitk_ws = nullptr;
 static size_t g_splitk_floats = 0;
 void set_conv_splitk_workspace(float* ws, size_t floats) { g_splitk_ws = ws; g_splitk_floats = floats; }
-static unsigned long long* g_dbg = nullptr;
-void set_conv_dbg(void* p) { g_dbg = (unsigned long long*)p; }
 void set_conv_order(int v) { g_order = v; }
 
 template <int BM, int BN, int WM, int WN>
@@ -380,32 +329,28 @@ static int run(ConvP p, int G, hipStream_t st) {
     // others, because a lone block on a CU already runs ~1.5x faster than one of three - not kept.
     constexpr int BPC = (BM == 64) ? 7 : (BM * BN == 256 * 64 ? 2 : 3);   // resident blocks per CU (registers / LDS)
     const long slots = 256L * BPC;
-    const long T = (long)p.mtiles * p.ntiles;          // tiles per group
-    const long blocks_all = T * G;
+    const long blocks_all = (long)p.mtiles * p.ntiles * G;
     const int nk = p.Kpad / BK;
-    auto split_for = [&](long nblocks, long rows) {
-        if (!g_splitk_ws || nk < 16) return 1;
-        int S = (int)((slots + nblocks - 1) / nblocks);
+    int S = 1;
+    if (g_splitk_ws && blocks_all * 2 < slots && nk >= 16) {
+        S = (int)((slots + blocks_all - 1) / blocks_all);
         if (S > nk / 8) S = nk / 8;
         if (S > 16) S = 16;
-        while (S > 1 && (size_t)S * G * rows * p.Cout > g_splitk_floats) --S;
-        return S < 2 ? 1 : S;
-    };
-    auto launch = [&](long tile_begin, long ntile, int S, int m_begin) {
-        ConvP q = p;
-        q.tile_begin = (int)tile_begin;
-        q.ksplit = S;
-        q.m_begin = m_begin;
-        q.ws = g_splitk_ws;
-        hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN>), dim3((unsigned)ntile, S, G), dim3(WM * WN * 64), 0, st, q);
-        if (S > 1) {
-            const long MN = (long)(q.M - m_begin) * q.Cout;
-            int blocks = (int)((MN + 255) / 256);
-            if (blocks > 2048) blocks = 2048;
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks, G), dim3(256), 0, st, q, S, G);
-        }
-    };
-    launch(0, T, blocks_all * 2 < slots ? split_for(blocks_all, p.M) : 1, 0);
+        while (S > 1 && (size_t)S * G * p.M * p.Cout > g_splitk_floats) --S;
+        if (S < 2) S = 1;
+    }
+    p.ksplit = S;
+    p.ws = g_splitk_ws;
+    const dim3 grid(p.mtiles * p.ntiles, S, G), block(WM * WN * 64);
+    if (S > 1) {
+        hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, true>), grid, block, 0, st, p);
+        const long MN = (long)p.M * p.Cout;
+        int blocks = (int)((MN + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks, G), dim3(256), 0, st, p, S, G);
+    } else {
+        hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, false>), grid, block, 0, st, p);
+    }
     QB_CHECK(hipGetLastError());
     return 0;
 }
@@ -422,13 +367,6 @@ int launch_conv(const ConvP& p, int G, hipStream_t st) {
     if (p.Cout <= 64) return run<256, 64, 4, 1>(p, G, st);
     const long tiles128 = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * G;
     if (tiles128 < 512) return run<64, 64, 2, 2>(p, G, st);
-    if (g_dbg) {
-        ConvP q = p;
-        q.dbg = g_dbg;
-        q.mtiles = (q.M + 127) / 128; q.ntiles = (q.Cout + 127) / 128; q.order = g_order; q.vec_out = (q.Cout % 4 == 0) && (q.out_cs % 4 == 0) && !q.scale && !q.res; q.ksplit = 1; q.tile_begin = 0; q.m_begin = 0;
-        hipLaunchKernelGGL((conv_igemm_f32<128, 128, 2, 2, true>), dim3(q.mtiles * q.ntiles, 1, G), dim3(256), 0, st, q);
-        return 0;
-    }
     return run<128, 128, 2, 2>(p, G, st);
 }
 

@@ -619,7 +619,6 @@ int quber_finalize_weights(quber_ctx* c) {
 }
 
 double quber_forward_flops(quber_ctx* c) { return c ? c->flops : 0.0; }
-void quber_set_debug_buffer(void* dev_ptr) { set_conv_dbg(dev_ptr); }
 void quber_set_tuning(int32_t key, int32_t value) {
     if (key == 2) {   // stand-alone conv op: allocate (value != 0) or drop the split-K workspace
         if (value && !g_op_ws) {
