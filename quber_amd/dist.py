@@ -17,10 +17,16 @@ def shard_range(n_items, rank, world):
     return start, start + q + (1 if rank < r else 0)
 
 
+def _comm_device(device):
+    """gloo (CPU rehearsals of the multi-rank path) moves host tensors; nccl = RCCL moves device tensors."""
+    return torch.device("cpu") if dist.get_backend() == "gloo" else torch.device(device)
+
+
 def broadcast_state_dict(sd, specs, src=0, device="cpu"):
     """sd: name -> numpy array on `src` (ignored elsewhere); specs: ordered name -> (shape, kind).  Returns the
     full state_dict on every rank after ONE broadcast of the concatenated fp32 vector."""
     total = int(sum(int(np.prod(s)) for s, _ in specs.values()))
+    device = _comm_device(device)
     if dist.get_rank() == src:
         flat = torch.from_numpy(np.concatenate([np.asarray(sd[k], np.float32).ravel() for k in specs])).to(device)
     else:
@@ -43,8 +49,9 @@ def gather_label_maps(local, counts, dst=0):
     pad = local
     if local.shape[0] < bmax:
         pad = torch.cat([local, local.new_full((bmax - local.shape[0],) + tuple(local.shape[1:]), -1)])
+    pad = pad.contiguous().to(_comm_device(pad.device))
     bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-    dist.gather(pad.contiguous(), bufs, dst=dst)
+    dist.gather(pad, bufs, dst=dst)
     if rank != dst:
         return None
     return torch.cat([b[:c] for b, c in zip(bufs, counts)])
