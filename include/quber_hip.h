@@ -124,6 +124,13 @@ int quber_postprocess(quber_ctx* ctx, const float* dev_logits, int32_t n_planes,
 int quber_extract_masks(quber_ctx* ctx, const float* dev_panoptic, const float* dev_labels, int32_t batch,
                         int32_t max_inst, uint8_t* dev_masks, void* stream);
 
+/* adapter pre-processing - depth normalisation.  Replaces normalize_depth (eval/preprocess_utils.py:12-28) and the
+ * zero-depth bookkeeping of eval/refiner_model.py:250.
+ *   dev_depth: uint16 [n] (is_float32 = 0, e.g. PNG millimetres, evaluated in float64 like numpy) or f32 [n]
+ *   -> dev_out3 u8 [n][3] (the value replicated to 3 channels), dev_zero u8 [n] = (depth == 0), may be NULL */
+int quber_normalize_depth(const void* dev_depth, int32_t is_float32, int64_t n_pixels, double min_val, double max_val,
+                          uint8_t* dev_out3, uint8_t* dev_zero, void* stream);
+
 /* ---- introspection / kernel-level entry points used by the parity tests and the benchmark ---- */
 /* device pointer + NHWC geometry of a named intermediate of the last quber_forward ("res2", "res3", "res5", "y", ...) */
 int quber_debug_tensor(quber_ctx* ctx, const char* name, float** dev_ptr, int32_t* dims4, int32_t* channel_stride);

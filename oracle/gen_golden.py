@@ -74,6 +74,18 @@ def main():
     mw[:100, 6, 10] = 255
     save("fgunion_wrap", masks=mw, fg=util.masks_to_fg_mask(mw))
 
+    # ---------------------------------------------------------------- normalize_depth (8f rank 1)
+    pre = load("ref_pre", "eval/preprocess_utils.py")          # imports cv2 at module top; normalize_depth is numpy only
+    rng = np.random.default_rng(21)
+    d16 = rng.integers(0, 3000, (60, 80)).astype(np.uint16)
+    d16[:3, :5] = 0
+    d16[10, :9] = [249, 250, 251, 1499, 1500, 1501, 65535, 1, 875]
+    save("depthnorm_u16", depth=d16, out=pre.normalize_depth(d16.copy()), lo=np.array(250.0), hi=np.array(1500.0))
+    d32 = rng.uniform(0, 2.5, (60, 80)).astype(np.float32)
+    d32[:2, :4] = 0
+    d32[5, :6] = [0.25, 0.2500001, 1.5, 1.4999999, 0.7431, 1e-8]
+    save("depthnorm_f32", depth=d32, out=pre.normalize_depth(d32.copy(), 0.25, 1.5), lo=np.array(0.25), hi=np.array(1.5))
+
     # ---------------------------------------------------------------- find_instance_center (a8)
     def ctr_case(name, c):
         c = torch.as_tensor(c, dtype=torch.float32).reshape(1, *c.shape[-2:])

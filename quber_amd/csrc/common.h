@@ -64,6 +64,9 @@ int launch_add_channels(const View& a, const View& b, const View& out, int B, hi
 int launch_upsample_logits(const float* q, float* out, int B, int nch, int h, int w, int scale, int OH, int OW,
                            unsigned mul_mask, hipStream_t st);
 
+int launch_normalize_depth(const void* depth, int is_float, long n, double lo, double hi, uint8_t* out3, uint8_t* zero,
+                           hipStream_t st);
+
 int launch_encode(const uint8_t* masks, int B, int N, int H, int W, const float* gauss, int sigma,
                   void* ws, float* out, hipStream_t st);
 size_t encode_ws_bytes(int B, int N, int H, int W);

@@ -735,6 +735,13 @@ int quber_extract_masks(quber_ctx* c, const float* pan, const float* labels, int
                                 (hipStream_t)stream);
 }
 
+int quber_normalize_depth(const void* depth, int32_t is_float32, int64_t n_pixels, double min_val, double max_val,
+                          uint8_t* out3, uint8_t* zero, void* stream) {
+    if (!depth || !out3 || n_pixels <= 0) return fail("bad argument to quber_normalize_depth");
+    if (!(max_val > min_val)) return fail("normalize_depth: max_val must exceed min_val");
+    return launch_normalize_depth(depth, is_float32, n_pixels, min_val, max_val, out3, zero, (hipStream_t)stream);
+}
+
 int quber_debug_tensor(quber_ctx* c, const char* name, float** ptr, int32_t* dims4, int32_t* cs) {
     if (!c || !name) return fail("null argument");
     auto it = c->taps.find(name);

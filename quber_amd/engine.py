@@ -63,6 +63,24 @@ def make_config(height=480, width=640, max_batch=1, max_instances=64, cfg=None, 
     return qc
 
 
+def normalize_depth(depth, min_val=250.0, max_val=1500.0):
+    """depth: device tensor uint16 / int16-viewed-as-uint16 / float32 [..., H, W] -> (u8 [..., H, W, 3], zero mask u8 [..., H, W]).
+    Device-side eval/preprocess_utils.py:12-28."""
+    lib = _lib.load()
+    assert depth.is_cuda and depth.is_contiguous()
+    if depth.dtype == torch.float32:
+        is_float = 1
+    elif depth.dtype in (torch.uint16, torch.int16):
+        is_float = 0
+    else:
+        raise TypeError("normalize_depth expects uint16 or float32 depth")
+    out = torch.empty(tuple(depth.shape) + (3,), dtype=torch.uint8, device=depth.device)
+    zero = torch.empty(tuple(depth.shape), dtype=torch.uint8, device=depth.device)
+    _lib.check(lib.quber_normalize_depth(_ptr(depth), is_float, depth.numel(), float(min_val), float(max_val), _ptr(out),
+                                         _ptr(zero), _stream()))
+    return out, zero
+
+
 class Engine:
     """One context on the current device.  All methods are asynchronous on torch's current stream."""
 

@@ -2,8 +2,9 @@
 ``MaskRefiner(config_file, weights_file, dataset).predict(rgb_path, depth_path, initial_masks, fg_mask)
 -> (refined_masks bool [K,H,W] | [], output dict, seconds, fg_mask)``.
 
-Built: file loading, resize to 640x480, ``normalize_depth`` (eval/preprocess_utils.py:12-28), nearest depth
-resize, the HIP predictor, the OCID zero-depth masking (refiner_model.py:279-288).
+Built: file loading, resize to 640x480, ``normalize_depth`` (eval/preprocess_utils.py:12-28; on the device for
+uint16 / float32 depth, bit-exact against the imported reference function), nearest depth resize, the HIP predictor,
+the OCID zero-depth masking (refiner_model.py:279-288).
 The ``dataset == 'armbench'`` branch (refiner_model.py:226-244: RGB only, shortest edge 800 / longest 1333, nearest
 resize of the masks) is built too; any frame size is accepted by the HIP path.
 Not built yet (DESIGN.md "next"): ``cv2.inpaint`` TELEA depth in-painting (zero-depth
@@ -70,7 +71,14 @@ class MaskRefiner:
         if rgb.shape[:2] != (H, W):
             rgb = np.asarray(Image.fromarray(np.ascontiguousarray(rgb)).resize((W, H), Image.BILINEAR))
         zero_depth = np.where(depth == 0)
-        depth = normalize_depth(depth, 0.25, 1.5) if "npy" in depth_path else normalize_depth(depth)
+        lo, hi = (0.25, 1.5) if "npy" in depth_path else (250.0, 1500.0)
+        if depth.ndim == 2 and depth.dtype in (np.uint16, np.float32):
+            import torch
+            from .. import engine as qengine
+            d = torch.from_numpy(np.ascontiguousarray(depth)).to(self.refiner_predictor.device)
+            depth = qengine.normalize_depth(d, lo, hi)[0].cpu().numpy()
+        else:
+            depth = normalize_depth(depth, lo, hi)
         if depth.shape[:2] != (H, W):
             depth = _resize_nearest(depth, W, H)
         initial_masks = np.asarray(initial_masks)

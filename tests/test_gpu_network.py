@@ -157,3 +157,22 @@ def test_network_vs_oracle_full_frame_and_predictor():
         assert inst.pred_masks.dtype == torch.bool and list(inst.pred_classes) == list(o["classes"])
     else:
         assert "instances" not in r
+
+
+def test_adapter_from_files(tmp_path):
+    """eval/refiner_model.py:MaskRefiner drop-in: paths in, (masks, output, seconds, fg_mask) out."""
+    from PIL import Image
+    from quber_amd.eval.refiner_model import MaskRefiner
+    sc = synth.make_scene(9, 480, 640, 6)
+    Image.fromarray(sc["rgb"][:, :, ::-1].copy()).save(tmp_path / "rgb.png")
+    depth_mm = (sc["depth"][:, :, 0].astype(np.uint16) * 5 + 300)
+    depth_mm[:10, :10] = 0
+    Image.fromarray(depth_mm).save(tmp_path / "depth.png")
+    np.save(tmp_path / "depth.npy", depth_mm.astype(np.float32) / 1000.0)
+    ref = MaskRefiner(None, None, dataset="OCID")
+    for dpath in ("depth.png", "depth.npy"):
+        masks, out, secs, fg = ref.predict(str(tmp_path / "rgb.png"), str(tmp_path / dpath), sc["masks"] != 0, None)
+        assert fg is None and secs > 0 and "sem_seg" in out and "panoptic_seg" in out
+        if len(masks):
+            assert masks.dtype == np.bool_ and masks.shape[1:] == (480, 640)
+            assert not masks[:, :10, :10].any()            # OCID zero-depth masking (refiner_model.py:279-288)

@@ -178,6 +178,26 @@ def test_postprocess_batch_is_per_frame():
         np.testing.assert_array_equal(pan[i], ref["panoptic"].numpy())
 
 
+# --------------------------------------------------------------------------------------------- adapter pre-processing
+@pytest.mark.parametrize("path", golden("depthnorm"), ids=os.path.basename)
+def test_normalize_depth_golden(path):
+    z = np.load(path)
+    out, zero = engine.normalize_depth(dev(z["depth"]), float(z["lo"]), float(z["hi"]))
+    np.testing.assert_array_equal(out.cpu().numpy(), z["out"])
+    np.testing.assert_array_equal(zero.cpu().numpy().astype(bool), z["depth"] == 0)
+
+
+def test_normalize_depth_full_frame_vs_oracle():
+    from oracle import adapter_np
+    rng = np.random.default_rng(0)
+    d = rng.integers(0, 4000, (2, 480, 640)).astype(np.uint16)
+    out, _ = engine.normalize_depth(dev(d))
+    np.testing.assert_array_equal(out.cpu().numpy(), np.stack([adapter_np.normalize_depth(x) for x in d]))
+    f = rng.uniform(0, 3, (480, 640)).astype(np.float32)
+    out, _ = engine.normalize_depth(dev(f), 0.25, 1.5)
+    np.testing.assert_array_equal(out.cpu().numpy(), adapter_np.normalize_depth(f, 0.25, 1.5))
+
+
 # --------------------------------------------------------------------------------------------- kernel-level ops
 def _conv_case(B, H, W, Cin, Cout, k, stride, dil, affine, residual, relu, seed=0):
     lib = _lib.load()

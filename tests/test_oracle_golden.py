@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from conftest import golden, load_encode_case
-from oracle import encode_np, errmaps_np, postproc_ref
+from oracle import adapter_np, encode_np, errmaps_np, postproc_ref
 
 
 @pytest.mark.parametrize("path", golden("encode"), ids=os.path.basename)
@@ -80,3 +80,10 @@ def test_quadruple_is_one_hot():
     e = errmaps_np.explicit_error_maps(init.astype(np.uint8), gt.astype(np.uint8))
     assert e.shape == (2, 4, 96, 128)
     np.testing.assert_array_equal(e.sum(1), np.ones((2, 96, 128), np.uint8))
+
+
+@pytest.mark.parametrize("path", golden("depthnorm"), ids=os.path.basename)
+def test_normalize_depth(path):
+    z = np.load(path)
+    got = adapter_np.normalize_depth(z["depth"], float(z["lo"]), float(z["hi"]))
+    np.testing.assert_array_equal(got, z["out"])
