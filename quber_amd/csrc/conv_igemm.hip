@@ -309,9 +309,6 @@ __global__ void splitk_reduce_kernel(const ConvP p, int S, int G) {
 }
 
 static int g_order = 0;
-static float* g_splitk_ws = nullptr;
-static size_t g_splitk_floats = 0;
-void set_conv_splitk_workspace(float* ws, size_t floats) { g_splitk_ws = ws; g_splitk_floats = floats; }
 void set_conv_order(int v) { g_order = v; }
 
 template <int BM, int BN, int WM, int WN>
@@ -332,15 +329,14 @@ static int run(ConvP p, int G, hipStream_t st) {
     const long blocks_all = (long)p.mtiles * p.ntiles * G;
     const int nk = p.Kpad / BK;
     int S = 1;
-    if (g_splitk_ws && blocks_all * 2 < slots && nk >= 16) {
+    if (p.ws && blocks_all * 2 < slots && nk >= 16) {
         S = (int)((slots + blocks_all - 1) / blocks_all);
         if (S > nk / 8) S = nk / 8;
         if (S > 16) S = 16;
-        while (S > 1 && (size_t)S * G * p.M * p.Cout > g_splitk_floats) --S;
+        while (S > 1 && (size_t)S * G * p.M * p.Cout > p.ws_floats) --S;
         if (S < 2) S = 1;
     }
     p.ksplit = S;
-    p.ws = g_splitk_ws;
     const dim3 grid(p.mtiles * p.ntiles, S, G), block(WM * WN * 64);
     if (S > 1) {
         hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, true>), grid, block, 0, st, p);

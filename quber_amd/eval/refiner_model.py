@@ -75,7 +75,7 @@ class MaskRefiner:
         if depth.ndim == 2 and depth.dtype in (np.uint16, np.float32):
             import torch
             from .. import engine as qengine
-            d = torch.from_numpy(np.ascontiguousarray(depth)).to(self.refiner_predictor.device)
+            d = torch.from_numpy(np.array(depth)).to(self.refiner_predictor.device)
             depth = qengine.normalize_depth(d, lo, hi)[0].cpu().numpy()
         else:
             depth = normalize_depth(depth, lo, hi)
