@@ -38,7 +38,10 @@ typedef struct quber_config {
     int32_t stuff_area;              /* PANOPTIC_DEEPLAB.STUFF_AREA (2048) */
     int32_t min_instance_area;       /* post_processing.py:145 (512) */
     int32_t label_divisor;           /* register_uoais_sim_panoptic.py:177-186 (1000) */
-    int32_t with_network;            /* 0: only the encode / error-map / post-processing kernels are usable */
+    int32_t with_network;            /* 0: only the encode / error-map / post-processing kernels are usable;
+                                        1: the refiner network; 2: the LMFFNet foreground network of the post-filter
+                                           (foreground_segmentation/lmffnet.py; quber_forward then maps (bgr, depth) to
+                                           3 class planes [B][3][H][W], dev_offsets is ignored) */
     float center_threshold;          /* PANOPTIC_DEEPLAB.CENTER_THRESHOLD (0.3) */
     float boundary_ratio;            /* explicit_error_estimation/util.py:92 dilation_ratio (0.01) */
     float pixel_mean[6];             /* MODEL.PIXEL_MEAN */
@@ -123,6 +126,14 @@ int quber_postprocess(quber_ctx* ctx, const float* dev_logits, int32_t n_planes,
  *   -> dev_masks u8 [B][max_inst][H][W] in {0,1} (all zero for slots beyond the frame's count) */
 int quber_extract_masks(quber_ctx* ctx, const float* dev_panoptic, const float* dev_labels, int32_t batch,
                         int32_t max_inst, uint8_t* dev_masks, void* stream);
+
+/* post-filter of eval/refiner_model.py:273-277 on LMFFNet logits (foreground_segmentation/predictor.py:85,98):
+ *   dev_fg_logits f32 [B][n_classes][HW] -> dev_fg_mask u8 [B][HW] = (argmax == fg_class)
+ *   dev_masks u8 [B][n_masks][HW] (may be NULL with n_masks = 0)
+ *   -> dev_counts u64 [B][n_masks][2] = (|mask & fg|, |mask|); the caller keeps masks with inter / area > 0.3 */
+int quber_foreground_filter(const float* dev_fg_logits, int32_t n_classes, int32_t fg_class, const uint8_t* dev_masks,
+                            int32_t batch, int32_t n_masks, int64_t hw, uint8_t* dev_fg_mask, uint64_t* dev_counts,
+                            void* stream);
 
 /* adapter pre-processing - depth normalisation.  Replaces normalize_depth (eval/preprocess_utils.py:12-28) and the
  * zero-depth bookkeeping of eval/refiner_model.py:250.

@@ -23,6 +23,7 @@ struct ConvP {
     const float* scale;  // [G][Cout] or null
     const float* shift;  // [G][Cout] or null
     const float* res;    // residual view or null
+    const float* prelu;  // [G][Cout] PReLU slopes or null (LMFFNet's BN+PReLU epilogue)
     float* out;
     int B, H, W, Cin, in_cs;
     int OH, OW, Cout, out_cs;
@@ -66,6 +67,21 @@ int launch_upsample_logits(const float* q, float* out, int B, int nch, int h, in
 
 int launch_normalize_depth(const void* depth, int is_float, long n, double lo, double hi, uint8_t* out3, uint8_t* zero,
                            hipStream_t st);
+
+// LMFFNet foreground network + post-filter (lmff.hip)
+int launch_lmff_preprocess(const uint8_t* bgr, const uint8_t* depth, long pixels, float* x, hipStream_t st);
+int launch_dwconv3x3(const View& in, const View& out, int B, int dil, const float* w9, const float* scale,
+                     const float* shift, const float* slope, hipStream_t st);
+int launch_pool_s2(const View& in, const View& out, int B, int mode /*0 avg 3x3/2/1, 1 max 2x2/2*/, hipStream_t st);
+int launch_affine_prelu(const View& a, const View* b, const View& out, int B, const float* scale, const float* shift,
+                        const float* slope, hipStream_t st);
+int launch_pmca(const View& x, int B, const float* w2x2, const float* fc0, const float* alpha, const float* fc2, float* wts,
+                hipStream_t st);
+int launch_scale_channels(const View& in, const float* wts, const View& out, int B, hipStream_t st);
+int launch_mad_gate(const View& o, const View& att, float* q, int B, int C, hipStream_t st);
+int launch_argmax_fg(const float* logits, int B, long HW, int nc, int cls, uint8_t* fg, hipStream_t st);
+int launch_mask_overlap(const uint8_t* masks, const uint8_t* fg, int B, int K, long HW, unsigned long long* counts,
+                        hipStream_t st);
 
 int launch_encode(const uint8_t* masks, int B, int N, int H, int W, const float* gauss, int sigma,
                   void* ws, float* out, hipStream_t st);

@@ -235,6 +235,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
     const float* __restrict__ scale = (p.scale && !SPLIT) ? p.scale + g * p.ss_gs : nullptr;
     const float* __restrict__ shift = (p.shift && !SPLIT) ? p.shift + g * p.ss_gs : nullptr;
     const bool relu = p.relu && !SPLIT;
+    const float* __restrict__ prelu = (p.prelu && !SPLIT) ? p.prelu + g * p.ss_gs : nullptr;   // per-channel PReLU slopes
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -268,6 +269,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
                     if (relu) {
                         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                     }
+                    if (prelu) {
+                        const float4 sl = *reinterpret_cast<const float4*>(prelu + n);
+                        v.x = v.x > 0.f ? v.x : v.x * sl.x; v.y = v.y > 0.f ? v.y : v.y * sl.y;
+                        v.z = v.z > 0.f ? v.z : v.z * sl.z; v.w = v.w > 0.f ? v.w : v.w * sl.w;
+                    }
                     *reinterpret_cast<float4*>(out + (long)m * out_cs + n) = v;
                 }
             }
@@ -280,6 +286,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
                     if (scale) v = fmaf(v, scale[n], shift[n]);
                     if (res) v += res[(long)m * p.res_cs + n];
                     if (relu) v = fmaxf(v, 0.f);
+                    if (prelu) v = v > 0.f ? v : v * prelu[n];
                     out[(long)m * out_cs + n] = v;
                 }
             }
@@ -304,6 +311,7 @@ __global__ void splitk_reduce_kernel(const ConvP p, int S, int G) {
         if (scale) v = fmaf(v, scale[n], shift[n]);
         if (res) v += res[m * p.res_cs + n];
         if (p.relu) v = fmaxf(v, 0.f);
+        if (p.prelu) v = v > 0.f ? v : v * p.prelu[g * p.ss_gs + n];
         out[m * p.out_cs + n] = v;
     }
 }
@@ -318,7 +326,8 @@ static int run(ConvP p, int G, hipStream_t st) {
     p.order = g_order;
     p.vec_out = (p.Cout % 4 == 0) && (p.out_cs % 4 == 0) && (((uintptr_t)p.out & 15) == 0) && (p.out_gs % 4 == 0) &&
                 (!p.res || ((p.res_cs % 4 == 0) && (((uintptr_t)p.res & 15) == 0) && (p.res_gs % 4 == 0))) &&
-                (!p.scale || ((((uintptr_t)p.scale & 15) == 0) && (p.ss_gs % 4 == 0)));
+                (!p.scale || ((((uintptr_t)p.scale & 15) == 0) && (p.ss_gs % 4 == 0))) &&
+                (!p.prelu || ((((uintptr_t)p.prelu & 15) == 0) && (p.ss_gs % 4 == 0)));
     // Work distribution.  `slots` blocks are resident at once (256 CUs x blocks per CU for this tile shape).  With
     // fewer than half a round of tiles (small batches) K is split so that about one round of blocks exists; the partial
     // tiles are combined in a fixed order by splitk_reduce_kernel (deterministic).  Splitting only the ragged last

@@ -1,0 +1,305 @@
+// Element-wise / pooling / depthwise kernels of the LMFFNet foreground network (reference
+// foreground_segmentation/lmffnet.py) and of the refiner's post-filter (eval/refiner_model.py:273-277).
+// The network is ~3 GFLOP per 640x480 frame and its channel counts (38, 134, 262, 26, 3) are not multiples of 4,
+// so these kernels are plain one-element-per-lane NHWC loops over (pixel, channel); the dense convolutions go
+// through conv_igemm_f32 with a BN + PReLU epilogue.
+#include "common.h"
+
+namespace quber {
+
+static inline int grid_for(long work) {
+    long g = (work + 255) / 256;
+    if (g < 1) g = 1;
+    if (g > 4096) g = 4096;
+    return (int)g;
+}
+
+// predictor.py:79-83: BGR standardised with the RGB statistics in float64 (numpy), depth / 255 in float32
+__global__ void lmff_preprocess_kernel(const uint8_t* __restrict__ bgr, const uint8_t* __restrict__ depth, long pixels,
+                                       float* __restrict__ x) {
+    const double mean[3] = {0.485, 0.456, 0.406}, sd[3] = {0.229, 0.224, 0.225};
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < pixels; i += (long)gridDim.x * blockDim.x) {
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            v[c] = (float)(((double)bgr[3 * i + c] / 255.0 - mean[c]) / sd[c]);
+            v[3 + c] = (float)depth[3 * i + c] / 255.f;
+        }
+        v[6] = 0.f; v[7] = 0.f;
+        float4* dst = reinterpret_cast<float4*>(x + i * 8);
+        dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+        dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+
+int launch_lmff_preprocess(const uint8_t* bgr, const uint8_t* depth, long pixels, float* x, hipStream_t st) {
+    hipLaunchKernelGGL(lmff_preprocess_kernel, dim3(grid_for(pixels)), dim3(256), 0, st, bgr, depth, pixels, x);
+    QB_CHECK(hipGetLastError());
+    return 0;
+}
+
+// depthwise 3x3 (dilation d, padding d) + folded BN + PReLU
+__global__ void dwconv3x3_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C,
+                                 int in_cs, int out_cs, int dil, const float* __restrict__ w9,
+                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                 const float* __restrict__ slope) {
+    const long total = (long)B * H * W * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = i % C;
+        long pix = i / C;
+        const int x = pix % W;
+        pix /= W;
+        const int y = pix % H;
+        const int b = pix / H;
+        float acc = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = y + (ky - 1) * dil;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = x + (kx - 1) * dil;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                acc = fmaf(in[((long)(b * H + iy) * W + ix) * in_cs + c], w9[c * 9 + ky * 3 + kx], acc);
+            }
+        }
+        float v = fmaf(acc, scale[c], shift[c]);
+        v = v > 0.f ? v : v * slope[c];
+        out[((long)(b * H + y) * W + x) * out_cs + c] = v;
+    }
+}
+
+int launch_dwconv3x3(const View& in, const View& out, int B, int dil, const float* w9, const float* scale,
+                     const float* shift, const float* slope, hipStream_t st) {
+    const long total = (long)B * in.H * in.W * in.C;
+    hipLaunchKernelGGL(dwconv3x3_kernel, dim3(grid_for(total)), dim3(256), 0, st, in.p, out.p, B, in.H, in.W, in.C, in.cs,
+                       out.cs, dil, w9, scale, shift, slope);
+    QB_CHECK(hipGetLastError());
+    return 0;
+}
+
+// mode 0: AvgPool2d(3, stride 2, padding 1), count_include_pad (divide by 9);  mode 1: MaxPool2d(2, stride 2)
+__global__ void pool_s2_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C,
+                               int in_cs, int OH, int OW, int out_cs, int mode) {
+    const long total = (long)B * OH * OW * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = i % C;
+        long pix = i / C;
+        const int ox = pix % OW;
+        pix /= OW;
+        const int oy = pix % OH;
+        const int b = pix / OH;
+        float r;
+        if (mode == 0) {
+            float s = 0.f;
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int iy = 2 * oy + dy, ix = 2 * ox + dx;
+                    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) s += in[((long)(b * H + iy) * W + ix) * in_cs + c];
+                }
+            r = s / 9.f;
+        } else {
+            r = -INFINITY;
+            for (int dy = 0; dy < 2; ++dy)
+                for (int dx = 0; dx < 2; ++dx) r = fmaxf(r, in[((long)(b * H + 2 * oy + dy) * W + 2 * ox + dx) * in_cs + c]);
+        }
+        out[((long)(b * OH + oy) * OW + ox) * out_cs + c] = r;
+    }
+}
+
+int launch_pool_s2(const View& in, const View& out, int B, int mode, hipStream_t st) {
+    const long total = (long)B * out.H * out.W * in.C;
+    hipLaunchKernelGGL(pool_s2_kernel, dim3(grid_for(total)), dim3(256), 0, st, in.p, out.p, B, in.H, in.W, in.C, in.cs,
+                       out.H, out.W, out.cs, mode);
+    QB_CHECK(hipGetLastError());
+    return 0;
+}
+
+// y = prelu((a [+ b]) * scale + shift)   (BNPReLU on a concatenation, and SEM_B's bn_relu_1(output + input))
+__global__ void affine_prelu_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                    long pixels, int C, int a_cs, int b_cs, int out_cs, const float* __restrict__ scale,
+                                    const float* __restrict__ shift, const float* __restrict__ slope) {
+    const long total = pixels * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / C;
+        const int c = (int)(i - pix * C);
+        float v = a[pix * a_cs + c];
+        if (b) v += b[pix * b_cs + c];
+        v = fmaf(v, scale[c], shift[c]);
+        out[pix * out_cs + c] = v > 0.f ? v : v * slope[c];
+    }
+}
+
+int launch_affine_prelu(const View& a, const View* b, const View& out, int B, const float* scale, const float* shift,
+                        const float* slope, hipStream_t st) {
+    const long pixels = (long)B * a.H * a.W;
+    hipLaunchKernelGGL(affine_prelu_kernel, dim3(grid_for(pixels * a.C)), dim3(256), 0, st, a.p, b ? b->p : nullptr, out.p,
+                       pixels, a.C, a.cs, b ? b->cs : 0, out.cs, scale, shift, slope);
+    QB_CHECK(hipGetLastError());
+    return 0;
+}
+
+// PMCA (lmffnet.py:172-191): w = sigmoid(fc2(prelu(fc0(dw2x2(adaptive_pool_2x2(x)) + global_pool(x))))); one block per frame
+__global__ __launch_bounds__(256) void pmca_kernel(const float* __restrict__ x, int H, int W, int C, int cs,
+                                                   const float* __restrict__ w2x2, const float* __restrict__ fc0,
+                                                   const float* __restrict__ alpha, const float* __restrict__ fc2,
+                                                   float* __restrict__ wts) {
+    __shared__ float s[128], hidden[16];
+    __shared__ double part[4][128 * 5];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float* base = x + (long)b * H * W * cs;
+    // adaptive bins of a 2-way split: [0, ceil(n/2)) and [floor(n/2), n)
+    const int hy1 = (H + 1) / 2, ly1 = H / 2, hx1 = (W + 1) / 2, lx1 = W / 2;
+    const int lanes = 256 / C;   // C in {64, 128}: 4 or 2 pixel lanes per channel
+    const int lane = t / C;
+    const int c = t % C;
+    double q[5] = {0, 0, 0, 0, 0};
+    if (t < lanes * C) {
+        for (int p = lane; p < H * W; p += lanes) {
+            const int y = p / W, xx = p - y * W;
+            const double v = base[(long)p * cs + c];
+            q[4] += v;
+            const bool t0 = y < hy1, t1 = y >= ly1, l0 = xx < hx1, l1 = xx >= lx1;
+            if (t0 && l0) q[0] += v;
+            if (t0 && l1) q[1] += v;
+            if (t1 && l0) q[2] += v;
+            if (t1 && l1) q[3] += v;
+        }
+        for (int k = 0; k < 5; ++k) part[lane][c * 5 + k] = q[k];
+    }
+    __syncthreads();
+    if (t < C) {
+        double a[5];
+        for (int k = 0; k < 5; ++k) {
+            a[k] = 0;
+            for (int l = 0; l < lanes; ++l) a[k] += part[l][t * 5 + k];
+        }
+        const double n00 = (double)hy1 * hx1, n01 = (double)hy1 * (W - lx1), n10 = (double)(H - ly1) * hx1,
+                     n11 = (double)(H - ly1) * (W - lx1);
+        const float p00 = (float)(a[0] / n00), p01 = (float)(a[1] / n01), p10 = (float)(a[2] / n10), p11 = (float)(a[3] / n11);
+        float o1 = 0.f;
+        o1 = fmaf(p00, w2x2[t * 4 + 0], o1);
+        o1 = fmaf(p01, w2x2[t * 4 + 1], o1);
+        o1 = fmaf(p10, w2x2[t * 4 + 2], o1);
+        o1 = fmaf(p11, w2x2[t * 4 + 3], o1);
+        s[t] = o1 + (float)(a[4] / ((double)H * W));
+    }
+    __syncthreads();
+    const int R = C / 8;
+    if (t < R) {
+        float h = 0.f;
+        for (int k = 0; k < C; ++k) h = fmaf(s[k], fc0[t * C + k], h);
+        hidden[t] = h > 0.f ? h : h * alpha[0];
+    }
+    __syncthreads();
+    if (t < C) {
+        float o = 0.f;
+        for (int k = 0; k < R; ++k) o = fmaf(hidden[k], fc2[t * R + k], o);
+        wts[(long)b * C + t] = 1.f / (1.f + expf(-o));
+    }
+}
+
+int launch_pmca(const View& x, int B, const float* w2x2, const float* fc0, const float* alpha, const float* fc2, float* wts,
+                hipStream_t st) {
+    if (x.C != 64 && x.C != 128) return fail("pmca: expects 64 or 128 channels");
+    hipLaunchKernelGGL(pmca_kernel, dim3(B), dim3(256), 0, st, x.p, x.H, x.W, x.C, x.cs, w2x2, fc0, alpha, fc2, wts);
+    QB_CHECK(hipGetLastError());
+    return 0;
+}
+
+__global__ void scale_channels_kernel(const float* __restrict__ in, const float* __restrict__ wts, float* __restrict__ out,
+                                      int B, long HW, int C, int in_cs, int out_cs) {
+    const long total = (long)B * HW * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / C;
+        const int c = (int)(i - pix * C);
+        const long b = pix / HW;
+        out[pix * out_cs + c] = wts[b * C + c] * in[pix * in_cs + c];
+    }
+}
+
+int launch_scale_channels(const View& in, const float* wts, const View& out, int B, hipStream_t st) {
+    const long HW = (long)in.H * in.W;
+    hipLaunchKernelGGL(scale_channels_kernel, dim3(grid_for((long)B * HW * in.C)), dim3(256), 0, st, in.p, wts, out.p, B, HW,
+                       in.C, in.cs, out.cs);
+    QB_CHECK(hipGetLastError());
+    return 0;
+}
+
+// MAD gate (lmffnet.py:268-277): q[b][c][pix] = o[pix][c] * sigmoid(att[pix][c])  (NHWC in, planar out)
+__global__ void mad_gate_kernel(const float* __restrict__ o, const float* __restrict__ att, float* __restrict__ q, int B,
+                                long HW, int C, int o_cs, int a_cs) {
+    const long total = (long)B * HW * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / C;
+        const int c = (int)(i - pix * C);
+        const long b = pix / HW, p = pix - b * HW;
+        const float a = 1.f / (1.f + expf(-att[pix * a_cs + c]));
+        q[(b * C + c) * HW + p] = o[pix * o_cs + c] * a;
+    }
+}
+
+int launch_mad_gate(const View& o, const View& att, float* q, int B, int C, hipStream_t st) {
+    const long HW = (long)o.H * o.W;
+    hipLaunchKernelGGL(mad_gate_kernel, dim3(grid_for((long)B * HW * C)), dim3(256), 0, st, o.p, att.p, q, B, HW, C, o.cs,
+                       att.cs);
+    QB_CHECK(hipGetLastError());
+    return 0;
+}
+
+// predictor.py:85,98: argmax over the class planes (first maximum wins), foreground = class `cls`
+__global__ void argmax_fg_kernel(const float* __restrict__ logits, int B, long HW, int nc, int cls, uint8_t* __restrict__ fg) {
+    const long total = (long)B * HW;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / HW, p = i - b * HW;
+        const float* l = logits + b * nc * HW + p;
+        int best = 0;
+        float bv = l[0];
+        for (int c = 1; c < nc; ++c) {
+            const float v = l[c * HW];
+            if (v > bv) { bv = v; best = c; }
+        }
+        fg[i] = best == cls ? 1 : 0;
+    }
+}
+
+int launch_argmax_fg(const float* logits, int B, long HW, int nc, int cls, uint8_t* fg, hipStream_t st) {
+    hipLaunchKernelGGL(argmax_fg_kernel, dim3(grid_for((long)B * HW)), dim3(256), 0, st, logits, B, HW, nc, cls, fg);
+    QB_CHECK(hipGetLastError());
+    return 0;
+}
+
+// eval/refiner_model.py:274-277: per refined mask, |mask & fg| and |mask|   -> counts[b][k][2]
+__global__ __launch_bounds__(256) void mask_overlap_kernel(const uint8_t* __restrict__ masks, const uint8_t* __restrict__ fg,
+                                                           long HW, int K, unsigned long long* __restrict__ counts) {
+    const int k = blockIdx.y, b = blockIdx.z;
+    const uint8_t* m = masks + ((long)b * K + k) * HW;
+    const uint8_t* f = fg + (long)b * HW;
+    unsigned inter = 0, area = 0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < HW; i += (long)gridDim.x * blockDim.x) {
+        const bool on = m[i] != 0;
+        area += on;
+        inter += on && f[i] != 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        inter += __shfl_down(inter, o);
+        area += __shfl_down(area, o);
+    }
+    if ((threadIdx.x & 63) == 0 && area) {
+        atomicAdd(&counts[((long)b * K + k) * 2], (unsigned long long)inter);
+        atomicAdd(&counts[((long)b * K + k) * 2 + 1], (unsigned long long)area);
+    }
+}
+
+int launch_mask_overlap(const uint8_t* masks, const uint8_t* fg, int B, int K, long HW, unsigned long long* counts,
+                        hipStream_t st) {
+    QB_CHECK(hipMemsetAsync(counts, 0, sizeof(unsigned long long) * 2 * B * K, st));
+    int bx = (int)((HW + 256 * 16 - 1) / (256 * 16));
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(mask_overlap_kernel, dim3(bx, K, B), dim3(256), 0, st, masks, fg, HW, K, counts);
+    QB_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace quber

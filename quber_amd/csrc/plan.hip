@@ -138,63 +138,40 @@ struct Builder {
     }
 
     // ---- ops ----
-    // `names`: one conv key prefix per group (e.g. "backbone.rgb_backbone.stem.conv1")
-    void conv(const std::vector<std::string>& names, const View& in, int cin_real, const View& out, int k, int stride,
-              int pad, int dil, Affine af, const View* res, bool relu) {
-        const int G = (int)names.size();
+    // Emits one (grouped) convolution launch.  w[g] = OIHW host weights of group g; scale/shift/prelu are
+    // [G*Cout] per-channel epilogue vectors (prelu may be empty).
+    void emit_conv(const std::string& name, const std::vector<const float*>& w, const View& in, int cin_real,
+                   const View& out, int k, int stride, int pad, int dil, bool affine, const std::vector<float>& scale,
+                   const std::vector<float>& shift, const std::vector<float>& prelu, const View* res, bool relu) {
+        const int G = (int)w.size();
         const int Cin = in.C, Cout = out.C;
         const int K = k * k * Cin, Kpad = (K + 31) / 32 * 32;
         const int kmode = (k > 1 && Cin % 32 == 0) ? 1 : 0;   // slice-major K order for the 3x3 layers
-        std::vector<float> packed, scale, shift;
-        if (!dry) {
-            packed.assign((size_t)G * Cout * Kpad, 0.f);
-            scale.assign((size_t)G * Cout, 1.f);
-            shift.assign((size_t)G * Cout, 0.f);
+        const int OH = (in.H + 2 * pad - dil * (k - 1) - 1) / stride + 1;
+        const int OW = (in.W + 2 * pad - dil * (k - 1) - 1) / stride + 1;
+        if (dry) return;
+        c->flops += 2.0 * OH * OW * (double)cin_real * k * k * Cout * G;
+        if (OH != out.H || OW != out.W) {
+            if (err.empty()) err = "internal: conv output geometry mismatch at " + name;
+            return;
         }
-        for (int g = 0; g < G; ++g) {
-            const std::string& n = names[g];
-            const float* w = hw(n + ".weight", (int64_t)Cout * cin_real * k * k);
-            const float *bias = nullptr, *bw = nullptr, *bb = nullptr, *bm = nullptr, *bv = nullptr;
-            if (af == AF_BIAS || af == AF_BIAS_BN) bias = hw(n + ".bias", Cout);
-            if (af == AF_FROZEN_BN || af == AF_BIAS_BN) {
-                bw = hw(n + ".norm.weight", Cout);
-                bb = hw(n + ".norm.bias", Cout);
-                bm = hw(n + ".norm.running_mean", Cout);
-                bv = hw(n + ".norm.running_var", Cout);
-            }
-            if (dry || !w) continue;
+        for (const float* p : w)
+            if (!p) return;   // a missing weight was already reported
+        std::vector<float> packed((size_t)G * Cout * Kpad, 0.f);
+        for (int g = 0; g < G; ++g)
             for (int o = 0; o < Cout; ++o) {
                 float* dst = &packed[((size_t)g * Cout + o) * Kpad];
                 for (int ci = 0; ci < cin_real; ++ci)
                     for (int t = 0; t < k * k; ++t) {
                         const size_t kk = kmode ? ((size_t)(ci / 32) * k * k + t) * 32 + ci % 32 : (size_t)t * Cin + ci;
-                        dst[kk] = w[((size_t)o * cin_real + ci) * k * k + t];
+                        dst[kk] = w[g][((size_t)o * cin_real + ci) * k * k + t];
                     }
-                float sc = 1.f, sh = 0.f;
-                if (af == AF_FROZEN_BN || af == AF_BIAS_BN) {
-                    if (!bw || !bb || !bm || !bv) continue;
-                    sc = bw[o] * (1.0f / sqrtf(bv[o] + 1e-5f));
-                    sh = bb[o] - bm[o] * sc;
-                    if (af == AF_BIAS_BN && bias) sh = fmaf(bias[o], sc, sh);
-                } else if (af == AF_BIAS && bias) {
-                    sh = bias[o];
-                }
-                scale[(size_t)g * Cout + o] = sc;
-                shift[(size_t)g * Cout + o] = sh;
             }
-        }
-        const int OH = (in.H + 2 * pad - dil * (k - 1) - 1) / stride + 1;
-        const int OW = (in.W + 2 * pad - dil * (k - 1) - 1) / stride + 1;
-        if (!dry) c->flops += 2.0 * OH * OW * (double)cin_real * k * k * Cout * G;
-        if (dry) return;
-        if (OH != out.H || OW != out.W) {
-            if (err.empty()) err = "internal: conv output geometry mismatch at " + names[0];
-            return;
-        }
         ConvP p{};
         p.in = in.p; p.w = upload(packed);
-        p.scale = af == AF_NONE ? nullptr : upload(scale);
-        p.shift = af == AF_NONE ? nullptr : upload(shift);
+        p.scale = affine ? upload(scale) : nullptr;
+        p.shift = affine ? upload(shift) : nullptr;
+        p.prelu = prelu.empty() ? nullptr : upload(prelu);
         p.res = res ? res->p : nullptr;
         p.out = out.p;
         p.H = in.H; p.W = in.W; p.Cin = Cin; p.in_cs = in.cs;
@@ -213,7 +190,42 @@ struct Builder {
             p.ws = ctx->splitk_ws;
             p.ws_floats = ctx->splitk_floats;
             return launch_conv(p, G, st);
-        }, OP_CONV, names[0], 2.0 * OH * OW * (double)cin_real * k * k * Cout * G, 1});
+        }, OP_CONV, name, 2.0 * OH * OW * (double)cin_real * k * k * Cout * G, 1});
+    }
+
+    // refiner convolutions: `names` = one detectron2 Conv2d key prefix per group (e.g. "backbone.rgb_backbone.stem.conv1")
+    void conv(const std::vector<std::string>& names, const View& in, int cin_real, const View& out, int k, int stride,
+              int pad, int dil, Affine af, const View* res, bool relu) {
+        const int G = (int)names.size(), Cout = out.C;
+        std::vector<float> scale((size_t)G * Cout, 1.f), shift((size_t)G * Cout, 0.f);
+        std::vector<const float*> w;
+        for (int g = 0; g < G; ++g) {
+            const std::string& n = names[g];
+            w.push_back(hw(n + ".weight", (int64_t)Cout * cin_real * k * k));
+            const float *bias = nullptr, *bw = nullptr, *bb = nullptr, *bm = nullptr, *bv = nullptr;
+            if (af == AF_BIAS || af == AF_BIAS_BN) bias = hw(n + ".bias", Cout);
+            if (af == AF_FROZEN_BN || af == AF_BIAS_BN) {
+                bw = hw(n + ".norm.weight", Cout);
+                bb = hw(n + ".norm.bias", Cout);
+                bm = hw(n + ".norm.running_mean", Cout);
+                bv = hw(n + ".norm.running_var", Cout);
+            }
+            if (dry) continue;
+            for (int o = 0; o < Cout; ++o) {
+                float sc = 1.f, sh = 0.f;
+                if (af == AF_FROZEN_BN || af == AF_BIAS_BN) {
+                    if (!bw || !bb || !bm || !bv) continue;
+                    sc = bw[o] * (1.0f / sqrtf(bv[o] + 1e-5f));
+                    sh = bb[o] - bm[o] * sc;
+                    if (af == AF_BIAS_BN && bias) sh = fmaf(bias[o], sc, sh);
+                } else if (af == AF_BIAS && bias) {
+                    sh = bias[o];
+                }
+                scale[(size_t)g * Cout + o] = sc;
+                shift[(size_t)g * Cout + o] = sh;
+            }
+        }
+        emit_conv(names[0], w, in, cin_real, out, k, stride, pad, dil, af != AF_NONE, scale, shift, {}, res, relu);
     }
 
     // GroupNorm(32) + ReLU from `in` into `out` (possibly a concat slice); names = norm key prefixes per group
@@ -490,9 +502,205 @@ struct Builder {
     }
 };
 
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// LMFFNet launch plan (reference foreground_segmentation/lmffnet.py:283-341; keys = that module's state_dict keys)
+namespace {
+
+struct BnP {   // folded BatchNorm(eps 1e-3) + PReLU vectors, padded with identity / zero slope
+    std::vector<float> scale, shift, slope;
+};
+
+struct LmffBuilder {
+    Builder& b;
+    quber_ctx* c;
+    bool dry;
+    explicit LmffBuilder(Builder& bb) : b(bb), c(bb.c), dry(bb.dry) {}
+
+    BnP bnp(const std::string& n, int C, int Cpad = 0) {
+        BnP r;
+        const float* w = b.hw(n + ".bn.weight", C);
+        const float* bi = b.hw(n + ".bn.bias", C);
+        const float* m = b.hw(n + ".bn.running_mean", C);
+        const float* v = b.hw(n + ".bn.running_var", C);
+        const float* a = b.hw(n + ".acti.weight", C);
+        if (Cpad < C) Cpad = C;
+        r.scale.assign(Cpad, 1.f); r.shift.assign(Cpad, 0.f); r.slope.assign(Cpad, 0.f);
+        if (dry || !w || !bi || !m || !v || !a) return r;
+        for (int i = 0; i < C; ++i) {
+            r.scale[i] = w[i] * (1.0f / sqrtf(v[i] + 1e-3f));
+            r.shift[i] = bi[i] - m[i] * r.scale[i];
+            r.slope[i] = a[i];
+        }
+        return r;
+    }
+    // dense conv (+ optional fused BN+PReLU): key prefix n -> n.conv.weight, n.bn_prelu.*
+    void conv(const std::string& n, const View& in, int cin_real, const View& out, int k, int stride, bool fused) {
+        const int Cout = out.C;
+        const float* w = b.hw(n + ".conv.weight", (int64_t)Cout * cin_real * k * k);
+        BnP e;
+        if (fused) e = bnp(n + ".bn_prelu", Cout);
+        b.emit_conv(n, {w}, in, cin_real, out, k, stride, k == 3 ? 1 : 0, 1, fused, e.scale, e.shift,
+                    fused ? e.slope : std::vector<float>(), nullptr, false);
+    }
+    void dwconv(const std::string& n, const View& in, const View& out, int dil) {
+        const int C = in.C;
+        const float* w = b.hw(n + ".conv.weight", (int64_t)C * 9);
+        BnP e = bnp(n + ".bn_prelu", C);
+        if (dry || !w) return;
+        const float* dw = b.upload(std::vector<float>(w, w + (size_t)C * 9));
+        const float *ds = b.upload(e.scale), *dh = b.upload(e.shift), *dl = b.upload(e.slope);
+        b.op([=](int B, hipStream_t st) { return launch_dwconv3x3(in, out, B, dil, dw, ds, dh, dl, st); });
+    }
+    void affine(const std::string& n, const View& a, const View* add, const View& out) {
+        BnP e = bnp(n, a.C);
+        if (dry) return;
+        const float *ds = b.upload(e.scale), *dh = b.upload(e.shift), *dl = b.upload(e.slope);
+        const bool has = add != nullptr;
+        const View addv = has ? *add : View();
+        b.op([=](int B, hipStream_t st) { return launch_affine_prelu(a, has ? &addv : nullptr, out, B, ds, dh, dl, st); });
+    }
+    void pool(const View& in, const View& out, int mode) {
+        b.op([=](int B, hipStream_t st) { return launch_pool_s2(in, out, B, mode, st); });
+    }
+    // SEM_B (lmffnet.py:80-113)
+    View sem(const std::string& n, const View& x, int dil, const View& out) {
+        const int C = x.C, h = x.H, w = x.W;
+        View t = b.make(C / 2, h, w), u = b.make(C / 2, h, w), v = b.make(C / 2, h, w), r = b.make(C, h, w);
+        conv(n + ".conv3x3", x, C, t, 3, 1, true);
+        dwconv(n + ".dconv_left", Builder::slice(t, 0, C / 4), Builder::slice(u, 0, C / 4), 1);
+        dwconv(n + ".dconv_right", Builder::slice(t, C / 4, C / 4), Builder::slice(u, C / 4, C / 4), dil);
+        conv(n + ".conv3x3_resume.conv3x3", u, C / 2, v, 3, 1, true);
+        conv(n + ".conv3x3_resume.conv1x1_resume", v, C / 2, r, 1, 1, false);
+        affine(n + ".bn_relu_1", r, &x, out);
+        return out;
+    }
+    // PMCA (lmffnet.py:172-191): channel attention of `x`, written scaled into `out`
+    void pmca(const std::string& n, const View& x, const View& out) {
+        const int C = x.C;
+        const float* w2 = b.hw(n + ".conv2x2.conv.weight", (int64_t)C * 4);
+        const float* f0 = b.hw(n + ".SE_Block.fc.0.weight", (int64_t)(C / 8) * C);
+        const float* al = b.hw(n + ".SE_Block.fc.1.weight", 1);
+        const float* f2 = b.hw(n + ".SE_Block.fc.2.weight", (int64_t)C * (C / 8));
+        if (dry || !w2 || !f0 || !al || !f2) return;
+        const float* dw2 = b.upload(std::vector<float>(w2, w2 + C * 4));
+        const float* df0 = b.upload(std::vector<float>(f0, f0 + (C / 8) * C));
+        const float* dal = b.upload(std::vector<float>(al, al + 1));
+        const float* df2 = b.upload(std::vector<float>(f2, f2 + C * (C / 8)));
+        float* wts = (float*)b.dalloc_bytes(sizeof(float) * (size_t)b.Bmax * C);
+        b.op([=](int B, hipStream_t st) {
+            int rc = launch_pmca(x, B, dw2, df0, dal, df2, wts, st);
+            if (rc) return rc;
+            return launch_scale_channels(x, wts, out, B, st);
+        });
+    }
+
+    void build() {
+        const int H = b.H, W = b.W, h2 = H / 2, w2 = W / 2, h4 = H / 4, w4 = W / 4, h8 = H / 8, w8 = W / 8;
+        const int ncls = 3;
+        View X = b.make(8, H, W);
+        if (!dry) c->X = X.p;
+        View x6 = Builder::slice(X, 0, 6);
+        // Init block
+        View i0 = b.make(32, h2, w2), i1 = b.make(32, h2, w2);
+        View A = b.make(40, h2, w2);                       // [init(32) | down_1(6) | pad]
+        conv("Init_Block.init_conv.0", X, 6, i0, 3, 2, true);
+        conv("Init_Block.init_conv.1", i0, 32, i1, 3, 1, true);
+        conv("Init_Block.init_conv.2", i1, 32, Builder::slice(A, 0, 32), 3, 1, true);
+        View dn1 = Builder::slice(A, 32, 6);
+        pool(x6, dn1, 0);
+        // FFM-A
+        View An = b.make(40, h2, w2), ffa = b.make(40, h2, w2);
+        affine("FFM_A.bn_prelu", Builder::slice(A, 0, 38), nullptr, Builder::slice(An, 0, 38));
+        conv("FFM_A.conv1x1", An, 38, Builder::slice(ffa, 0, 38), 1, 1, false);
+        // downsample 1: conv(38 -> 26) | maxpool(38) -> 64
+        View D = b.make(64, h4, w4), d1 = b.make(64, h4, w4);
+        conv("downsample_1.conv3x3", ffa, 38, Builder::slice(D, 0, 26), 3, 2, false);
+        pool(Builder::slice(ffa, 0, 38), Builder::slice(D, 26, 38), 1);
+        affine("downsample_1.bn_prelu", D, nullptr, d1);
+        // SEM-B block 1 -> FFM-B1 input [sem(64) | pmca(d1)(64) | down_2(6) | pad]
+        View Bc = b.make(136, h4, w4);
+        View cur = d1;
+        static const int dil1[3] = {2, 2, 2};
+        for (int i = 0; i < 3; ++i) {
+            View out = i == 2 ? Builder::slice(Bc, 0, 64) : b.make(64, h4, w4);
+            cur = sem("SEM_B_Block1.SEM_B_Block.SEM_Block_1" + std::to_string(i), cur, dil1[i], out);
+        }
+        pmca("FFM_B1.PMCA", d1, Builder::slice(Bc, 64, 64));
+        View dn2 = Builder::slice(Bc, 128, 6);
+        {
+            View tmp = b.make(8, h2, w2);
+            View t6 = Builder::slice(tmp, 0, 6);
+            pool(x6, t6, 0);
+            pool(t6, dn2, 0);
+        }
+        View Bn = b.make(136, h4, w4), fb1 = b.make(136, h4, w4);
+        affine("FFM_B1.bn_prelu", Builder::slice(Bc, 0, 134), nullptr, Builder::slice(Bn, 0, 134));
+        conv("FFM_B1.conv1x1", Bn, 134, Builder::slice(fb1, 0, 134), 1, 1, false);
+        // downsample 2 (134 -> 128, no concat) + BN/PReLU fused
+        View d2 = b.make(128, h8, w8);
+        {
+            const float* w = b.hw("downsample_2.conv3x3.conv.weight", (int64_t)128 * 134 * 9);
+            BnP e = bnp("downsample_2.bn_prelu", 128);
+            b.emit_conv("downsample_2.conv3x3", {w}, fb1, 134, d2, 3, 2, 1, 1, true, e.scale, e.shift, e.slope, nullptr, false);
+        }
+        View Cc = b.make(264, h8, w8);
+        cur = d2;
+        static const int dil2[8] = {4, 4, 8, 8, 16, 16, 32, 32};
+        for (int i = 0; i < 8; ++i) {
+            View out = i == 7 ? Builder::slice(Cc, 0, 128) : b.make(128, h8, w8);
+            cur = sem("SEM_B_Block2.SEM_B_Block.SEM_Block_2" + std::to_string(i), cur, dil2[i], out);
+        }
+        pmca("FFM_B2.PMCA", d2, Builder::slice(Cc, 128, 128));
+        {
+            View t1 = b.make(8, h2, w2), t2 = b.make(8, h4, w4);
+            View a6 = Builder::slice(t1, 0, 6), b6 = Builder::slice(t2, 0, 6);
+            pool(x6, a6, 0);
+            pool(a6, b6, 0);
+            pool(b6, Builder::slice(Cc, 256, 6), 0);
+        }
+        View Cn = b.make(264, h8, w8), fb2 = b.make(264, h8, w8);
+        affine("FFM_B2.bn_prelu", Builder::slice(Cc, 0, 262), nullptr, Builder::slice(Cn, 0, 262));
+        conv("FFM_B2.conv1x1", Cn, 262, Builder::slice(fb2, 0, 262), 1, 1, false);
+        // MAD (lmffnet.py:232-280)
+        View cat48 = b.make(48, h4, w4), dl = b.make(32, h8, w8), dwa = b.make(48, h4, w4), att = b.make(4, h4, w4);
+        conv("MAD.mid_layer_1x1", fb1, 134, Builder::slice(cat48, 0, 16), 1, 1, false);
+        conv("MAD.deep_layer_1x1", fb2, 262, dl, 1, 1, false);
+        {
+            View dst = Builder::slice(cat48, 16, 32);
+            b.op([=](int B, hipStream_t st) { return launch_bilinear(dl, dst, B, st); });
+        }
+        dwconv("MAD.DwConv1", cat48, dwa, 1);
+        conv("MAD.PwConv1", dwa, 48, Builder::slice(att, 0, ncls), 1, 1, false);
+        View dwb = b.make(264, h8, w8), o8 = b.make(4, h8, w8), o4 = b.make(4, h4, w4);
+        dwconv("MAD.DwConv2", Builder::slice(fb2, 0, 262), Builder::slice(dwb, 0, 262), 1);
+        conv("MAD.PwConv2", dwb, 262, Builder::slice(o8, 0, ncls), 1, 1, false);
+        b.op([=](int B, hipStream_t st) { return launch_bilinear(o8, o4, B, st); });
+        if (!dry) c->q = (float*)b.dalloc_bytes(sizeof(float) * (size_t)b.Bmax * ncls * h4 * w4);
+        float* q = c->q;
+        quber_ctx* ctx = c;
+        b.op([=](int B, hipStream_t st) {
+            int rc = launch_mad_gate(o4, att, q, B, ncls, st);
+            if (rc) return rc;
+            return launch_upsample_logits(q, ctx->cur_out, B, ncls, h4, w4, 4, ctx->cfg.height, ctx->cfg.width, 0u, st);
+        });
+        if (!dry) {
+            c->taps["ffm_a"] = Builder::slice(ffa, 0, 38);
+            c->taps["d1"] = d1;
+            c->taps["ffm_b1"] = Builder::slice(fb1, 0, 134);
+            c->taps["ffm_b2"] = Builder::slice(fb2, 0, 262);
+        }
+    }
+};
+
 int check_cfg(const quber_config& c) {
     if (c.height <= 0 || c.width <= 0) return fail("height and width must be positive");
     if (c.with_network && (c.height < 16 || c.width < 16)) return fail("frames smaller than 16 x 16 are not supported");
+    if (c.with_network == 2) {
+        if (c.height % 8 || c.width % 8) return fail("LMFFNet needs height and width to be multiples of 8");
+        return c.max_batch >= 1 ? 0 : fail("max_batch must be >= 1");
+    }
     if (c.max_batch < 1) return fail("max_batch must be >= 1");
     if (c.max_instances < 1 || c.max_instances > 254) return fail("max_instances must be in 1..254");
     if (c.resnet_depth != 50 && c.resnet_depth != 101 && c.resnet_depth != 152) return fail("resnet_depth must be 50, 101 or 152");
@@ -574,7 +782,10 @@ int quber_create(const quber_config* cfg, quber_ctx** out) {
         quber_destroy(c);
         return fail(e);
     }
-    if (cfg->with_network) {
+    if (cfg->with_network == 2) {
+        Builder dry(c, true);
+        LmffBuilder(dry).build();
+    } else if (cfg->with_network) {
         Builder dry(c, true);
         dry.build();
     }
@@ -610,7 +821,13 @@ int quber_finalize_weights(quber_ctx* c) {
     if (c->finalized) return fail("weights already finalized");
     Builder b(c, false);
     c->flops = 0.0;
-    b.build();
+    if (c->cfg.with_network == 2) {
+        c->splitk_floats = (size_t)4 << 20;
+        c->splitk_ws = (float*)b.dalloc_bytes(sizeof(float) * c->splitk_floats);
+        LmffBuilder(b).build();
+    } else {
+        b.build();
+    }
     if (!b.err.empty()) {
         c->ops.clear();
         return fail(b.err);
@@ -672,6 +889,14 @@ int quber_forward(quber_ctx* c, const uint8_t* bgr, const uint8_t* depth, const 
                   float* logits, void* stream) {
     if (check_batch(c, batch)) return -1;
     if (!c->finalized) return fail("quber_forward before quber_finalize_weights");
+    if (c->cfg.with_network == 2) {   // LMFFNet: (bgr, depth) -> 3 class planes; `offs` is unused
+        if (!bgr || !depth || !logits) return fail("null tensor");
+        hipStream_t s2 = (hipStream_t)stream;
+        c->cur_out = logits;
+        int r2 = launch_lmff_preprocess(bgr, depth, (long)batch * c->cfg.height * c->cfg.width, c->X, s2);
+        for (size_t i = 0; !r2 && i < c->ops.size(); ++i) r2 = c->ops[i].run(batch, s2);
+        return r2;
+    }
     if (!bgr || (!depth && c->cfg.streams == 2) || !offs || !logits) return fail("null tensor");
     hipStream_t st = (hipStream_t)stream;
     c->cur_out = logits;
@@ -734,6 +959,16 @@ int quber_extract_masks(quber_ctx* c, const float* pan, const float* labels, int
     if (check_batch(c, batch)) return -1;
     return launch_extract_masks(pan, labels, batch, c->cfg.height, c->cfg.width, c->cfg.top_k, max_inst, masks,
                                 (hipStream_t)stream);
+}
+
+int quber_foreground_filter(const float* fg_logits, int32_t n_classes, int32_t fg_class, const uint8_t* masks,
+                            int32_t batch, int32_t n_masks, int64_t hw, uint8_t* fg_mask, uint64_t* counts, void* stream) {
+    if (!fg_logits || !fg_mask || batch < 1 || hw < 1 || n_classes < 2) return fail("bad argument to quber_foreground_filter");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = launch_argmax_fg(fg_logits, batch, hw, n_classes, fg_class, fg_mask, st);
+    if (rc || n_masks == 0) return rc;
+    if (!masks || !counts) return fail("null masks / counts");
+    return launch_mask_overlap(masks, fg_mask, batch, n_masks, hw, (unsigned long long*)counts, st);
 }
 
 int quber_normalize_depth(const void* depth, int32_t is_float32, int64_t n_pixels, double min_val, double max_val,

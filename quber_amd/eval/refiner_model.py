@@ -7,10 +7,11 @@ uint16 / float32 depth, bit-exact against the imported reference function), near
 the OCID zero-depth masking (refiner_model.py:279-288).
 The ``dataset == 'armbench'`` branch (refiner_model.py:226-244: RGB only, shortest edge 800 / longest 1333, nearest
 resize of the masks) is built too; any frame size is accepted by the HIP path.
-Not built yet (DESIGN.md "next"): ``cv2.inpaint`` TELEA depth in-painting (zero-depth
-pixels are left at 0 here; frames without zero depth are unaffected because the reference only rewrites
-zero pixels, preprocess_utils.py:63) and the LMFFNet foreground post-filter (``fg_mask`` is returned as None
-and no mask is dropped).  cv2 / imageio are absent, so images are read with PIL and resized with PIL's
+The LMFFNet foreground post-filter (refiner_model.py:273-277) runs on the HIP path too when ``foreground_filter=True``
+(the reference always applies it; it is opt-in here because the reference's ``rgbd_lmffnet.pth`` is not available and
+seeded weights give a meaningless foreground).
+Not built: ``cv2.inpaint`` TELEA depth in-painting (zero-depth pixels are left at 0 here; frames without
+zero depth are unaffected because the reference only rewrites zero pixels, preprocess_utils.py:63).  cv2 / imageio are absent, so images are read with PIL and resized with PIL's
 bilinear filter, which is not bit-identical to cv2.resize.
 """
 import time
@@ -50,9 +51,14 @@ def resize_shortest_edge_shape(oldh, oldw, short_edge_length=800, max_size=1333)
 
 
 class MaskRefiner:
-    def __init__(self, config_file=None, weights_file=None, dataset="OSD", device="cuda:0"):
+    def __init__(self, config_file=None, weights_file=None, dataset="OSD", device="cuda:0", foreground_filter=False,
+                 lmffnet_weights="./foreground_segmentation/rgbd_lmffnet.pth"):
         self.refiner_predictor = MaskRefinerPredictor(config_file, weights_file=weights_file, device=device)
         self.dataset = dataset
+        self.lmffnet = None
+        if foreground_filter:
+            from ..foreground.predictor import lmffNet
+            self.lmffnet = lmffNet(lmffnet_weights, device=device)
 
     def predict(self, rgb_path, depth_path, initial_masks, fg_mask=None):
         rgb = np.asarray(Image.open(rgb_path).convert("RGB"))[:, :, ::-1]        # BGR like cv2.imread
@@ -91,9 +97,21 @@ class MaskRefiner:
             refined = []
         else:
             refined = output["instances"].to("cpu").pred_masks.numpy()
+        fg = None
+        if self.lmffnet is not None:
+            import torch
+            from ..foreground.predictor import filter_masks
+            dev = self.refiner_predictor.device
+            b = torch.from_numpy(np.ascontiguousarray(rgb)[None]).to(dev)
+            d = torch.from_numpy(np.ascontiguousarray(depth)[None]).to(dev)
+            m = torch.from_numpy(np.ascontiguousarray(refined, dtype=np.uint8)[None]).to(dev) if len(refined) else None
+            fg_t, counts = self.lmffnet.net.foreground(b, d, m)
+            fg = fg_t[0].cpu().numpy().astype(bool)
+            if len(refined):
+                refined = np.asarray(filter_masks(refined, counts[0]))
         elapsed = time.time() - start
         if self.dataset == "OCID" and len(refined):
             refined = refined.copy()
             for m in refined:
                 m[zero_depth] = False
-        return refined, output, elapsed, None
+        return refined, output, elapsed, fg

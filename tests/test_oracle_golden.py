@@ -87,3 +87,15 @@ def test_normalize_depth(path):
     z = np.load(path)
     got = adapter_np.normalize_depth(z["depth"], float(z["lo"]), float(z["hi"]))
     np.testing.assert_array_equal(got, z["out"])
+
+
+@pytest.mark.parametrize("path", golden("lmffnet"), ids=os.path.basename)
+def test_lmffnet_oracle_matches_reference(path):
+    from oracle import lmffnet_torch as L
+    from quber_amd import lmff_arch
+    z = np.load(path)
+    w = {k: torch.from_numpy(v) for k, v in lmff_arch.init_state_dict(seed=int(z["seed"])).items()}
+    with torch.no_grad():
+        got = L.forward(L.preprocess(z["rgb"], z["depth"]), w)[0].numpy()
+    np.testing.assert_allclose(got, z["logits"], rtol=0, atol=1e-5)
+    assert len(w) == 402 and sum(v.numel() for v in w.values()) == 1356859 - 65     # the reference state_dict minus its 65 num_batches_tracked counters
