@@ -33,7 +33,6 @@ struct ConvP {
     int relu;
     int M;               // B*OH*OW
     int mtiles, ntiles;
-    int order;           // tile-order experiment knob
     int vec_out;         // 16-byte epilogue accesses are legal for this launch
     float* ws;           // split-K workspace (partial tiles [ksplit][G][M][Cout]); null = never split
     size_t ws_floats;    // its capacity
@@ -48,7 +47,6 @@ int fail(const std::string& msg);
 
 // launchers (all asynchronous on `st`, no allocation, no synchronisation)
 int launch_conv(const ConvP& p, int G, hipStream_t st);
-void set_conv_order(int v);   // tile-order experiment knob
 int launch_preprocess(const uint8_t* rgb, const uint8_t* depth, const float* offs, float* x, int B, int Bcap,
                       int H, int W, const float* mean6, const float* std6, int streams, hipStream_t st);
 int launch_maxpool3x3s2(const View& in, const View& out, int B, int G, hipStream_t st);

@@ -63,18 +63,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
         const int bid = blockIdx.x, nblk = gridDim.x;
         const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-        if (p.order == 1) tile = bid;
     }
-    int nt = tile % p.ntiles;
-    int mt = tile / p.ntiles;
-    if (p.order == 2) {
-        // groups of 8 m-tiles x all n-tiles, m fastest inside the group
-        const int gsz = 8 * p.ntiles;
-        const int grp = tile / gsz, within = tile - grp * gsz;
-        const int rows = min(8, p.mtiles - grp * 8);
-        mt = grp * 8 + within % rows;
-        nt = within / rows;
-    }
+    const int nt = tile % p.ntiles;
+    const int mt = tile / p.ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
 
     const float* __restrict__ in = p.in + (long)g * p.in_gs;
@@ -316,14 +307,11 @@ __global__ void splitk_reduce_kernel(const ConvP p, int S, int G) {
     }
 }
 
-static int g_order = 0;
-void set_conv_order(int v) { g_order = v; }
 
 template <int BM, int BN, int WM, int WN>
 static int run(ConvP p, int G, hipStream_t st) {
     p.mtiles = (p.M + BM - 1) / BM;
     p.ntiles = (p.Cout + BN - 1) / BN;
-    p.order = g_order;
     p.vec_out = (p.Cout % 4 == 0) && (p.out_cs % 4 == 0) && (((uintptr_t)p.out & 15) == 0) && (p.out_gs % 4 == 0) &&
                 (!p.res || ((p.res_cs % 4 == 0) && (((uintptr_t)p.res & 15) == 0) && (p.res_gs % 4 == 0))) &&
                 (!p.scale || ((((uintptr_t)p.scale & 15) == 0) && (p.ss_gs % 4 == 0))) &&

@@ -848,7 +848,6 @@ void quber_set_tuning(int32_t key, int32_t value) {
             g_op_ws = nullptr;
         }
     }
-    if (key == 1) set_conv_order(value);
 }
 
 int quber_num_ops(quber_ctx* c) { return c ? (int)c->ops.size() : 0; }
