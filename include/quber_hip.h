@@ -127,6 +127,16 @@ int quber_postprocess(quber_ctx* ctx, const float* dev_logits, int32_t n_planes,
 int quber_extract_masks(quber_ctx* ctx, const float* dev_panoptic, const float* dev_labels, int32_t batch,
                         int32_t max_inst, uint8_t* dev_masks, void* stream);
 
+/* evaluation support - all pairwise overlap counts of two label maps in one pass.  Replaces the per-pair
+ * np.count_nonzero loops of eval/evaluation.py:180-199 (multilabel_metrics).
+ *   dev_pred, dev_gt i32 [n_pixels], label values in 0..65535, at most `cap` (<= 1024) distinct values per map
+ *   workspace (quber_contingency_workspace_bytes(cap) bytes, device) receives, in this order:
+ *     u32 flags[2][65536] | u64 table[cap][cap] (row = gt index, column = pred index) | i32 labels[2][cap] (sorted unique
+ *     values: [0] pred, [1] gt) | i32 counts[4] = (n_pred, n_gt, out-of-range flag, 0) | u16 lut[2][65536] */
+int64_t quber_contingency_workspace_bytes(int32_t cap);
+int quber_label_contingency(const int32_t* dev_pred, const int32_t* dev_gt, int64_t n_pixels, int32_t cap,
+                            void* dev_workspace, void* stream);
+
 /* post-filter of eval/refiner_model.py:273-277 on LMFFNet logits (foreground_segmentation/predictor.py:85,98):
  *   dev_fg_logits f32 [B][n_classes][HW] -> dev_fg_mask u8 [B][HW] = (argmax == fg_class)
  *   dev_masks u8 [B][n_masks][HW] (may be NULL with n_masks = 0)

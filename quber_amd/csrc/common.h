@@ -81,6 +81,9 @@ int launch_argmax_fg(const float* logits, int B, long HW, int nc, int cls, uint8
 int launch_mask_overlap(const uint8_t* masks, const uint8_t* fg, int B, int K, long HW, unsigned long long* counts,
                         hipStream_t st);
 
+int launch_contingency(const int* pred, const int* gt, long n, int cap, void* ws, hipStream_t st);
+size_t contingency_ws_bytes(int cap);
+
 int launch_encode(const uint8_t* masks, int B, int N, int H, int W, const float* gauss, int sigma,
                   void* ws, float* out, hipStream_t st);
 size_t encode_ws_bytes(int B, int N, int H, int W);

@@ -960,6 +960,14 @@ int quber_extract_masks(quber_ctx* c, const float* pan, const float* labels, int
                                 (hipStream_t)stream);
 }
 
+int64_t quber_contingency_workspace_bytes(int32_t cap) { return (int64_t)contingency_ws_bytes(cap); }
+
+int quber_label_contingency(const int32_t* pred, const int32_t* gt, int64_t n_pixels, int32_t cap, void* workspace,
+                            void* stream) {
+    if (!pred || !gt || !workspace || n_pixels < 1 || cap < 1 || cap > 1024) return fail("bad argument to quber_label_contingency");
+    return launch_contingency(pred, gt, n_pixels, cap, workspace, (hipStream_t)stream);
+}
+
 int quber_foreground_filter(const float* fg_logits, int32_t n_classes, int32_t fg_class, const uint8_t* masks,
                             int32_t batch, int32_t n_masks, int64_t hw, uint8_t* fg_mask, uint64_t* counts, void* stream) {
     if (!fg_logits || !fg_mask || batch < 1 || hw < 1 || n_classes < 2) return fail("bad argument to quber_foreground_filter");

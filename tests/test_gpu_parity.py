@@ -178,6 +178,43 @@ def test_postprocess_batch_is_per_frame():
         np.testing.assert_array_equal(pan[i], ref["panoptic"].numpy())
 
 
+# --------------------------------------------------------------------------------------------- evaluation metrics (8f rank 3)
+@pytest.mark.parametrize("path", golden("metrics"), ids=os.path.basename)
+def test_multilabel_metrics_golden(path):
+    import json
+    from quber_amd.eval.evaluation import contingency, multilabel_metrics
+    z = np.load(path)
+    exp = json.loads(str(z["result"]))
+    got = multilabel_metrics(z["pred"], z["gt"], 0, 1, compute_boundary_stuff=False)
+    assert set(got) == set(exp)
+    for k, v in exp.items():
+        if v is None:
+            assert got[k] is None, k
+        else:
+            assert float(got[k]) == v, (k, got[k], v)
+    lp, lg, table = contingency(z["pred"], z["gt"])
+    np.testing.assert_array_equal(lp, np.unique(z["pred"]))
+    np.testing.assert_array_equal(lg, np.unique(z["gt"]))
+    for i, gi in enumerate(lg):
+        for j, pj in enumerate(lp):
+            assert table[i, j] == np.count_nonzero((z["gt"] == gi) & (z["pred"] == pj))
+
+
+def test_contingency_many_labels_and_errors():
+    from quber_amd.eval.evaluation import contingency
+    rng = np.random.default_rng(0)
+    p = rng.integers(0, 200, (240, 320)).astype(np.int32) * 7            # 200 distinct labels: global-atomic path
+    g = rng.integers(0, 150, (240, 320)).astype(np.int32) * 11
+    lp, lg, table = contingency(p, g)
+    np.testing.assert_array_equal(lp, np.unique(p))
+    np.testing.assert_array_equal(lg, np.unique(g))
+    exp = np.zeros((len(lg), len(lp)), np.int64)
+    np.add.at(exp, (np.searchsorted(lg, g.ravel()), np.searchsorted(lp, p.ravel())), 1)
+    np.testing.assert_array_equal(table, exp)
+    with pytest.raises(ValueError):
+        contingency(np.full((8, 8), 70000, np.int32), np.zeros((8, 8), np.int32))
+
+
 # --------------------------------------------------------------------------------------------- adapter pre-processing
 @pytest.mark.parametrize("path", golden("depthnorm"), ids=os.path.basename)
 def test_normalize_depth_golden(path):

@@ -99,3 +99,31 @@ def test_lmffnet_oracle_matches_reference(path):
         got = L.forward(L.preprocess(z["rgb"], z["depth"]), w)[0].numpy()
     np.testing.assert_allclose(got, z["logits"], rtol=0, atol=1e-5)
     assert len(w) == 402 and sum(v.numel() for v in w.values()) == 1356859 - 65     # the reference state_dict minus its 65 num_batches_tracked counters
+
+
+def _same_metrics(got, exp):
+    assert set(got) == set(exp)
+    for k, v in exp.items():
+        if v is None:
+            assert got[k] is None, k
+        else:
+            assert float(got[k]) == v, (k, got[k], v)
+
+
+@pytest.mark.parametrize("path", golden("metrics"), ids=os.path.basename)
+def test_metrics_oracle_matches_reference(path):
+    import json
+    from oracle import metrics_np
+    z = np.load(path)
+    _same_metrics(metrics_np.multilabel_metrics(z["pred"], z["gt"]), json.loads(str(z["result"])))
+
+
+def test_munkres_matches_vendored_solver():
+    import json
+    from conftest import GOLDEN
+    from quber_amd.eval.assignment import munkres_assign
+    z = np.load(os.path.join(GOLDEN, "munkres_cases.npz"))
+    exp = json.load(open(os.path.join(GOLDEN, "munkres_expected.json")))
+    for k in z.files:
+        m = z[k]
+        assert [list(a) for a in munkres_assign(m.max() - m)] == exp[k], k
