@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""rocprofv3 --pmc pass (SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT)
+joined with the launch plan -> per-layer MFMA utilisation table (markdown)."""
+import collections
+import csv
+import json
+import sys
+
+plan_json, counters_csv = sys.argv[1:3]
+meta = json.load(open(plan_json))
+convs = [p for p in meta["plan"] if p[1] == "conv"]
+B = meta["batch"]
+d = collections.OrderedDict()
+for r in csv.DictReader(open(counters_csv)):
+    if "conv_igemm" not in r["Kernel_Name"] or "splitk" in r["Kernel_Name"]:
+        continue
+    x = d.setdefault(r["Dispatch_Id"], {"ns": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})
+    x[r["Counter_Name"]] = float(r["Counter_Value"])
+rows = list(d.values())[-len(convs):]
+print("| layer | ms | TFLOP/s | MFMA busy (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs)) | eff. clock GHz | mean waves per CU | LDS bank conflicts |")
+print("|---|---|---|---|---|---|---|")
+tb = ta = tf = tn = 0.0
+for c, v in zip(convs, rows):
+    cyc = v["GRBM_GUI_ACTIVE"] / 8
+    busy = v["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024)
+    waves = v["SQ_WAVE_CYCLES"] * 4 / cyc / 256
+    fl = c[2] * B
+    tb += v["SQ_VALU_MFMA_BUSY_CYCLES"]; ta += cyc * 1024; tf += fl; tn += v["ns"]
+    if fl / 1e9 > 60 * B / 16 or "stem" in c[0]:
+        print("| %s | %.3f | %.1f | %.2f | %.2f | %.1f | %d |" % (c[0].replace("backbone.", "b.").replace("ins_embed_head.", "h."),
+              v["ns"] / 1e6, fl / v["ns"] / 1e3, busy, cyc / v["ns"], waves, v["SQ_LDS_BANK_CONFLICT"]))
+print("| **all %d convolution launches** | %.3f | %.1f | %.2f | | | |" % (len(convs), tn / 1e6, tf / tn / 1e3, tb / ta))
