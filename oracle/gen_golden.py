@@ -1,10 +1,13 @@
-"""Generates tests/golden/*.npz by RUNNING the two reference modules that import in the build container.
+"""Generates tests/golden/* by RUNNING the reference modules that import in the build container.
 
-Run once, here (the GPU box has no /root/reference):   python oracle/gen_golden.py
+Run once, here (the GPU box has no /root/reference):   python oracle/gen_golden.py [post|lmffnet|metrics ...]
 
   * maskrefiner/modeling/mask_refiner/post_processing.py  (torch only; loaded by file path)
   * explicit_error_estimation/util.py                     (cv2 / segmentation_models_pytorch are imported at
     module top but unused by the two functions called; empty stand-in modules are registered for the import)
+  * eval/preprocess_utils.py (normalize_depth), foreground_segmentation/lmffnet.py (torch only),
+    eval/evaluation.py + eval/munkres.py (cv2 / eval/utilities.py are imported at module top but untouched with
+    compute_boundary_stuff=False; empty stand-ins)
 
 Only inputs and the reference's outputs are stored.
 """
@@ -31,17 +34,97 @@ def load(name, rel):
     return mod
 
 
+def save(name, **kw):
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **kw)
+    print("wrote", name, {k: getattr(v, "shape", None) for k, v in kw.items()})
+
+
+def gen_lmffnet():
+    """lmffnet_*.npz: logits of the reference LMFFNet(classes=3).eval() with quber_amd.lmff_arch's seeded weights."""
+    from oracle import lmffnet_torch as L
+    from quber_amd import lmff_arch
+    m = load("ref_lmff", "foreground_segmentation/lmffnet.py")
+    net = m.LMFFNet(classes=3).eval()
+    sd = lmff_arch.init_state_dict(seed=0)
+    ref_keys = [k for k in net.state_dict() if "num_batches" not in k]
+    assert set(ref_keys) == set(sd) and all(tuple(net.state_dict()[k].shape) == sd[k].shape for k in ref_keys)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    for (h, wd, seed) in [(64, 96, 1), (120, 160, 2)]:
+        sc = synth.make_scene(seed, h, wd, 3)
+        with torch.no_grad():
+            ref = net(L.preprocess(sc["rgb"], sc["depth"]))
+        save(f"lmffnet_{h}x{wd}", rgb=sc["rgb"], depth=sc["depth"], logits=ref[0].numpy(), seed=np.array(0))
+
+
+def gen_metrics():
+    """metrics_*.npz: dictionaries returned by the reference multilabel_metrics(compute_boundary_stuff=False);
+    munkres_cases.npz / munkres_expected.json: assignments of the vendored eval/munkres.py on tie-heavy matrices."""
+    import json
+    sys.path.insert(0, os.path.join(REF, "eval"))
+    for n in ("cv2", "utilities"):
+        sys.modules.setdefault(n, types.ModuleType(n))
+    m = load("ref_eval", "eval/evaluation.py")
+    import munkres
+
+    def labelmap(masks):
+        out = np.zeros(masks.shape[1:], np.int32)
+        for i, mk in enumerate(masks):
+            out[mk != 0] = i + 1
+        return out
+
+    run = lambda p, g: m.multilabel_metrics(p, g, 0, 1, compute_boundary_stuff=False)
+    cases = {}
+    for name, (h, w, n, seed, drop, extra) in {"scene_a": (96, 128, 6, 1, 0, 0), "scene_b": (120, 160, 9, 2, 2, 0),
+                                               "scene_c": (96, 128, 5, 3, 0, 3), "scene_big": (480, 640, 20, 4, 1, 1)}.items():
+        r = np.random.default_rng(seed)
+        gt_m, init_m = synth.make_masks(r, n, h, w)
+        gt = labelmap(gt_m)
+        pm = list(init_m)[drop:]          # missing predictions
+        for _ in range(extra):            # spurious predictions
+            z = np.zeros((h, w), bool)
+            y0, x0 = int(r.integers(0, h - 12)), int(r.integers(0, w - 12))
+            z[y0:y0 + 10, x0:x0 + 10] = True
+            pm.append(z)
+        pred = labelmap(np.array(pm))
+        cases[name] = (pred, gt, run(pred, gt))
+    z = np.zeros((32, 48), np.int32)
+    one = z.copy()
+    one[4:20, 5:30] = 3
+    two = z.copy()
+    two[0:10, 0:10] = 1
+    two[20:30, 30:40] = 7
+    cases["none_pred"] = (z, one, run(z, one))
+    cases["none_gt"] = (one, z, run(one, z))
+    cases["none_both"] = (z, z, run(z, z))
+    cases["disjoint"] = (two, one, run(two, one))
+    for k, (p, g, res) in cases.items():
+        save("metrics_" + k, pred=p, gt=g,
+             result=np.array(json.dumps({a: (None if b is None else float(b)) for a, b in res.items()})))
+    mats = {f"m{t}": np.round(np.random.default_rng(100 + t).random((np.random.default_rng(t).integers(1, 8),
+                                                                    np.random.default_rng(50 + t).integers(1, 8))), 1)
+            for t in range(40)}
+    save("munkres_cases", **mats)
+    json.dump({k: munkres.Munkres().compute(x.max() - x.copy()) for k, x in mats.items()},
+              open(os.path.join(OUT, "munkres_expected.json"), "w"))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    what = sys.argv[1:] or ["post", "lmffnet", "metrics"]
+    if "lmffnet" in what:
+        gen_lmffnet()
+    if "metrics" in what:
+        gen_metrics()
+    if "post" in what:
+        gen_post()
+
+
+def gen_post():
     post = load("ref_post", "maskrefiner/modeling/mask_refiner/post_processing.py")
     for n in ("cv2", "segmentation_models_pytorch"):
         sys.modules.setdefault(n, types.ModuleType(n))
     util = load("ref_eee_util", "explicit_error_estimation/util.py")
     gen = util.PerturbedInputOffsetGenerator(sigma=10)
-
-    def save(name, **kw):
-        np.savez_compressed(os.path.join(OUT, name + ".npz"), **kw)
-        print("wrote", name, {k: getattr(v, "shape", None) for k, v in kw.items()})
 
     # ---------------------------------------------------------------- encode (a1) + fg-union (a2)
     def enc_case(name, masks):
