@@ -157,7 +157,9 @@ int quber_normalize_depth(const void* dev_depth, int32_t is_float32, int64_t n_p
 int quber_debug_tensor(quber_ctx* ctx, const char* name, float** dev_ptr, int32_t* dims4, int32_t* channel_stride);
 /* algorithmic FLOPs of one forward at batch 1 (2 * MACs of every convolution) */
 double quber_forward_flops(quber_ctx* ctx);
-/* test-harness knob: key 2 = give the stand-alone quber_op_conv2d a split-K workspace (value != 0) or drop it (0) */
+/* test-harness knobs: key 2 = give the stand-alone quber_op_conv2d a split-K workspace (value != 0) or drop it (0);
+ * key 3 = force the number of K partitions of convolutions that have a workspace (0 = automatic);
+ * key 4 = force the convolution tile shape (1 = 64x64, 2 = 128x128, 4 = 256x32; 0 = automatic) */
 void quber_set_tuning(int32_t key, int32_t value);
 /* the launch plan of quber_forward, in execution order (after the input pre-processing kernel):
  * kind 0 = convolution, 1 = GroupNorm, 2 = other; flops = algorithmic FLOPs at batch 1 */

@@ -37,6 +37,7 @@ struct ConvP {
     float* ws;           // split-K workspace (partial tiles [ksplit][G][M][Cout]); null = never split
     size_t ws_floats;    // its capacity
     int ksplit;          // number of K partitions (grid.y); 1 = direct epilogue
+    int kchunk;          // K-slices per partition
     int kmode;           // 0: k = (tap, c)   1: k = (c/32, tap, c%32)  (weights packed accordingly)
     long in_gs, out_gs, res_gs, w_gs;
     int ss_gs;
@@ -47,6 +48,7 @@ int fail(const std::string& msg);
 
 // launchers (all asynchronous on `st`, no allocation, no synchronisation)
 int launch_conv(const ConvP& p, int G, hipStream_t st);
+extern int g_force_split, g_force_tile;
 int launch_preprocess(const uint8_t* rgb, const uint8_t* depth, const float* offs, float* x, int B, int Bcap,
                       int H, int W, const float* mean6, const float* std6, int streams, hipStream_t st);
 int launch_maxpool3x3s2(const View& in, const View& out, int B, int G, hipStream_t st);

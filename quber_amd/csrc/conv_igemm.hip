@@ -30,11 +30,13 @@ constexpr int BK = 32;
 constexpr int PITCH = 36;
 
 // Main-loop variants that were measured and rejected (profiles/r01c_conv_variants.md): double-buffered LDS with one
-// barrier per K-slice, a a per-block s_setprio stagger, and 256x128 / 128x256 tiles (8 waves, or 4 waves of 128x64) were all 1-25 % slower
-// than this single-buffer, register-prefetch loop at 3 blocks per CU.
-// SPLIT: blockIdx.y owns a range of K-slices and writes a raw partial tile (split-K for launches that cannot fill the
-// chip).  Kept as a separate instantiation: with the K range a run-time quantity hipcc allocates ~50 more VGPRs for
-// the main loop and the kernel drops from 3 to 2 waves per SIMD.
+// barrier per K-slice, a per-block s_setprio stagger, and 256x128 / 128x256 tiles (8 waves, or 4 waves of 128x64) were
+// all 1-25 % slower than this single-buffer, register-prefetch loop at 3 blocks per CU; a 256x64 tile (2 blocks per
+// CU) lost to 64x64 on every layer with 33-64 output channels (profiles/r01i_conv_sweep_*.md).
+// SPLIT: blockIdx.y owns p.kchunk consecutive K-slices and writes a raw partial tile (split-K for launches that cannot
+// fill the chip, or whose tile count is an awkward multiple of the resident slots).  The K range is derived without a
+// division (host-computed kchunk): a 64-bit division here costs hipcc ~50 VGPRs over the whole kernel and a wave per
+// SIMD; as written both instantiations allocate the same registers.
 template <int BM, int BN, int WM, int WN, bool SPLIT>
 __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
     constexpr int NTH = WM * WN * 64;
@@ -68,8 +70,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
     const int mt = tile / p.ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
 
+    int k_begin = 0, nk = p.Kpad / BK;     // first K-slice and number of K-slices of this block
+    if constexpr (SPLIT) {
+        k_begin = blockIdx.y * p.kchunk;
+        nk = min(nk - k_begin, p.kchunk);
+    }
     const float* __restrict__ in = p.in + (long)g * p.in_gs;
-    const float* __restrict__ wt = p.w + (long)g * p.w_gs;
+    const float* __restrict__ wt = p.w + (long)g * p.w_gs + (long)k_begin * BK;
 
     // ---- loader state ----
     // Each thread owns one 16-byte column (4 consecutive k) of AL A-rows and BL B-rows.  Its position inside the
@@ -103,12 +110,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
     for (int i = 0; i < BL; ++i) {
         const int n = n0 + lrow + RPP * i;
         wrow[i] = wt + (long)(n < p.Cout ? n : 0) * p.Kpad + kq;   // columns >= Cout are never stored
-    }
-    int k_begin = 0, nk = p.Kpad / BK;
-    if constexpr (SPLIT) {
-        const int nk_all = p.Kpad / BK;
-        k_begin = (int)((long)blockIdx.y * nk_all / p.ksplit);
-        nk = (int)((long)(blockIdx.y + 1) * nk_all / p.ksplit);
     }
     int kc, kx, ky;
     if (p.kmode) {
@@ -201,10 +202,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
             }
     };
-    gload(k_begin);
+    gload(0);
     lstore(0);
     __syncthreads();
-    for (int kt = k_begin; kt < nk; ++kt) {
+    for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) gload(kt + 1);
 #pragma unroll
         for (int ks = 0; ks < BK / 8; ++ks) mma(0, ks);
@@ -287,60 +288,111 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
 }
 
 // sums the split-K partial tiles in a fixed order (deterministic) and applies the fused epilogue
+template <int V>
 __global__ void splitk_reduce_kernel(const ConvP p, int S, int G) {
+    using vec = __attribute__((ext_vector_type(V))) float;
     const int g = blockIdx.y;
     const long MN = (long)p.M * p.Cout;
     const float* __restrict__ scale = p.scale ? p.scale + g * p.ss_gs : nullptr;
     const float* __restrict__ shift = p.shift ? p.shift + g * p.ss_gs : nullptr;
+    const float* __restrict__ prelu = p.prelu ? p.prelu + g * p.ss_gs : nullptr;
     const float* __restrict__ res = p.res ? p.res + (long)g * p.res_gs : nullptr;
     float* __restrict__ out = p.out + (long)g * p.out_gs;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < MN; i += (long)gridDim.x * blockDim.x) {
+    for (long i = (blockIdx.x * (long)blockDim.x + threadIdx.x) * V; i < MN; i += (long)gridDim.x * blockDim.x * V) {
         const long m = i / p.Cout;
         const int n = (int)(i - m * p.Cout);
-        float v = 0.f;
-        for (int s = 0; s < S; ++s) v += p.ws[((long)s * G + g) * MN + i];
-        if (scale) v = fmaf(v, scale[n], shift[n]);
-        if (res) v += res[m * p.res_cs + n];
-        if (p.relu) v = fmaxf(v, 0.f);
-        if (p.prelu) v = v > 0.f ? v : v * p.prelu[g * p.ss_gs + n];
-        out[m * p.out_cs + n] = v;
+        vec v = *reinterpret_cast<const vec*>(p.ws + (long)g * MN + i);
+        for (int s = 1; s < S; ++s) v += *reinterpret_cast<const vec*>(p.ws + ((long)s * G + g) * MN + i);
+        float o[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float x = V == 1 ? v[0] : v[e];
+            if (scale) x = fmaf(x, scale[n + e], shift[n + e]);
+            if (res) x += res[m * p.res_cs + n + e];
+            if (p.relu) x = fmaxf(x, 0.f);
+            if (prelu) x = x > 0.f ? x : x * prelu[n + e];
+            o[e] = x;
+        }
+        if constexpr (V == 4) {
+            *reinterpret_cast<vec*>(out + m * p.out_cs + n) = vec{o[0], o[1], o[2], o[3]};
+        } else {
+            out[m * p.out_cs + n] = o[0];
+        }
     }
 }
 
+int g_force_tile = 0;     // test-harness knobs (quber_set_tuning keys 4 / 3): force the tile shape / the number of K partitions
+int g_force_split = 0;
+
+// ---- work distribution -------------------------------------------------------------------------------------------
+// A launch is (tile shape, S = number of K partitions).  `bpc` blocks of a tile shape are resident per CU (registers /
+// LDS), so 256*bpc blocks run at once and a launch whose block count is an awkward multiple of that leaves CUs idle in
+// its last round; with few blocks (small batches) most of the chip idles throughout.  Splitting K trades that for a
+// second pass over the output (partial tiles -> splitk_reduce_kernel, fixed summation order: deterministic).
+// The choice is a small cost model fitted to a sweep of every convolution shape of the refiner at 1-16 frames
+// (tools/conv_sweep.py, profiles/r01i_conv_sweep_*.md): cost in K-slice units of one CU-round,
+//     (nk/S + c) * W(blocks per CU)  [+ lat + (2S+1) * outputs * per_float   if S > 1]
+// where W counts rounds, a partly filled last round being cheaper than a full one (a lone block runs faster).
+struct SplitModel { double c, thr1, thr2, per_float, lat; };
+constexpr SplitModel kModel3 = {3.9, 0.74, 0.995, 1.09e-7, 13.7};   // 3 resident blocks per CU (128x128, 256x32)
+constexpr SplitModel kModel7 = {7.5, 0.0, 0.0, 6.05e-7, 40.0};      // 7 resident blocks per CU (64x64)
+constexpr int kMinSlicesPerSplit = 6;
+
+static double launch_cost(long blocks, int nk, double outputs, int S, int bpc, const SplitModel& m) {
+    const long per_cu = (blocks * S + 255) / 256;
+    const long q = per_cu / bpc, rem = per_cu % bpc;
+    double W = (double)bpc * q;
+    if (rem) W += bpc == 3 ? (rem == 1 ? 1.0 / m.thr1 : 2.0 / m.thr2) : (rem > 0.55 * bpc ? (double)rem : 0.55 * bpc);
+    double t = ((double)nk / S + m.c) * W;
+    if (S > 1) t += m.lat + (2.0 * S + 1.0) * outputs * m.per_float;
+    return t;
+}
+
+static int choose_split(const ConvP& p, int G, int BM, int BN, int bpc) {
+    const int nk = p.Kpad / BK;
+    if (!p.ws) return 1;
+    const long blocks = (long)((p.M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN) * G;
+    const double outputs = (double)G * p.M * p.Cout;
+    const SplitModel& m = bpc == 3 ? kModel3 : kModel7;
+    int best = 1;
+    double best_t = launch_cost(blocks, nk, outputs, 1, bpc, m);
+    for (int S = 2; S <= 16 && nk / S >= kMinSlicesPerSplit; ++S) {
+        if ((double)S * outputs > (double)p.ws_floats) break;
+        const double t = launch_cost(blocks, nk, outputs, S, bpc, m);
+        if (t < 0.97 * best_t) { best_t = t; best = S; }
+    }
+    return best;
+}
 
 template <int BM, int BN, int WM, int WN>
-static int run(ConvP p, int G, hipStream_t st) {
+static int run(ConvP p, int G, int S, hipStream_t st) {
     p.mtiles = (p.M + BM - 1) / BM;
     p.ntiles = (p.Cout + BN - 1) / BN;
     p.vec_out = (p.Cout % 4 == 0) && (p.out_cs % 4 == 0) && (((uintptr_t)p.out & 15) == 0) && (p.out_gs % 4 == 0) &&
                 (!p.res || ((p.res_cs % 4 == 0) && (((uintptr_t)p.res & 15) == 0) && (p.res_gs % 4 == 0))) &&
                 (!p.scale || ((((uintptr_t)p.scale & 15) == 0) && (p.ss_gs % 4 == 0))) &&
                 (!p.prelu || ((((uintptr_t)p.prelu & 15) == 0) && (p.ss_gs % 4 == 0)));
-    // Work distribution.  `slots` blocks are resident at once (256 CUs x blocks per CU for this tile shape).  With
-    // fewer than half a round of tiles (small batches) K is split so that about one round of blocks exists; the partial
-    // tiles are combined in a fixed order by splitk_reduce_kernel (deterministic).  Splitting only the ragged last
-    // round of larger launches was measured too (profiles/r01g_tail_split.md): +1..3 % on some layers, -2 % on
-    // others, because a lone block on a CU already runs ~1.5x faster than one of three - not kept.
-    constexpr int BPC = (BM == 64) ? 7 : (BM * BN == 256 * 64 ? 2 : 3);   // resident blocks per CU (registers / LDS)
-    const long slots = 256L * BPC;
-    const long blocks_all = (long)p.mtiles * p.ntiles * G;
     const int nk = p.Kpad / BK;
-    int S = 1;
-    if (p.ws && blocks_all * 2 < slots && nk >= 16) {
-        S = (int)((slots + blocks_all - 1) / blocks_all);
-        if (S > nk / 8) S = nk / 8;
-        if (S > 16) S = 16;
-        while (S > 1 && (size_t)S * G * p.M * p.Cout > p.ws_floats) --S;
-        if (S < 2) S = 1;
-    }
+    if (p.ws && g_force_split > 0) S = g_force_split;
+    if (!p.ws || S < 1) S = 1;
+    if (S > nk) S = nk;
+    while (S > 1 && (size_t)S * G * p.M * p.Cout > p.ws_floats) --S;
+    p.kchunk = (nk + S - 1) / S;
+    S = (nk + p.kchunk - 1) / p.kchunk;        // no empty partitions
     p.ksplit = S;
     const dim3 grid(p.mtiles * p.ntiles, S, G), block(WM * WN * 64);
     if (S > 1) {
         hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, true>), grid, block, 0, st, p);
         const long MN = (long)p.M * p.Cout;
-        int blocks = (int)((MN + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks, G), dim3(256), 0, st, p, S, G);
+        if (p.vec_out) {
+            int blocks = (int)((MN / 4 + 255) / 256);
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(blocks, G), dim3(256), 0, st, p, S, G);
+        } else {
+            int blocks = (int)((MN + 255) / 256);
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(blocks, G), dim3(256), 0, st, p, S, G);
+        }
     } else {
         hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, false>), grid, block, 0, st, p);
     }
@@ -356,12 +408,22 @@ int launch_conv(const ConvP& p, int G, hipStream_t st) {
     if (p.M <= 0 || p.Cout <= 0) return fail("conv: empty problem");
     if (p.kmode && (p.Cin % BK || p.K != p.Kpad)) return fail("conv: slice-major weights need Cin % 32 == 0");
     if ((p.scale == nullptr) != (p.shift == nullptr)) return fail("conv: scale and shift go together");
-    if (p.Cout <= 32) return run<256, 32, 4, 1>(p, G, st);
-    if (p.Cout <= 64) return run<256, 64, 4, 1>(p, G, st);
+    switch (g_force_tile) {
+        case 1: return run<64, 64, 2, 2>(p, G, 1, st);
+        case 2: return run<128, 128, 2, 2>(p, G, 1, st);
+        case 4: return run<256, 32, 4, 1>(p, G, 1, st);
+        default: break;
+    }
+    // Tile shape (sweep: profiles/r01i_conv_sweep_*.md).  <= 32 output channels: 256x32.  <= 64 channels, and the
+    // memory-bound residual 1x1 layers with a short K (res2-4 conv3): 64x64, whose 7 resident blocks per CU keep more
+    // loads in flight.  Otherwise 128x128, split when the model says so; 64x64 again for launches too small for that.
+    const int nk = p.Kpad / BK;
+    if (p.Cout <= 32) return run<256, 32, 4, 1>(p, G, choose_split(p, G, 256, 32, 3), st);
+    if (p.Cout <= 64 || (p.res && nk <= 8 && p.Cout >= 128)) return run<64, 64, 2, 2>(p, G, choose_split(p, G, 64, 64, 7), st);
     const long tiles128 = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * G;
-    // (128x128 tiles with K split 3 ways were tried for the 300-tile ASPP layers: 76 vs 100 TFLOP/s for 64x64 tiles)
-    if (tiles128 < 512) return run<64, 64, 2, 2>(p, G, st);
-    return run<128, 128, 2, 2>(p, G, st);
+    const int s128 = choose_split(p, G, 128, 128, 3);
+    if (tiles128 < 64 || (tiles128 < 384 && s128 == 1)) return run<64, 64, 2, 2>(p, G, choose_split(p, G, 64, 64, 7), st);
+    return run<128, 128, 2, 2>(p, G, s128, st);
 }
 
 }  // namespace quber

@@ -274,7 +274,7 @@ struct Builder {
         };
         if (!dry) c->gn_stats = (double*)dalloc_bytes(sizeof(double) * 2 * 64 * Bmax * 4);
         if (!dry) {
-            c->splitk_floats = (size_t)16 << 20;   // 64 MiB of partial tiles (only small-batch launches split K)
+            c->splitk_floats = (size_t)40 << 20;   // 160 MiB of partial tiles: S x blocks stays near 1-2 rounds of 128x128 tiles at any batch
             c->splitk_ws = (float*)dalloc_bytes(sizeof(float) * c->splitk_floats);
         }
 
@@ -731,7 +731,7 @@ int check_cfg(const quber_config& c) {
 }  // namespace
 
 static float* g_op_ws = nullptr;
-static const size_t g_op_ws_floats = (size_t)16 << 20;
+static const size_t g_op_ws_floats = (size_t)256 << 20;   // 1 GiB, test harness only
 
 extern "C" {
 
@@ -848,6 +848,8 @@ void quber_set_tuning(int32_t key, int32_t value) {
             g_op_ws = nullptr;
         }
     }
+    if (key == 4) g_force_tile = value;    // force the tile shape: 1 = 64x64, 2 = 128x128, 4 = 256x32 (0 = automatic)
+    if (key == 3) g_force_split = value;   // force the number of K partitions of every convolution with a workspace (0 = automatic)
 }
 
 int quber_num_ops(quber_ctx* c) { return c ? (int)c->ops.size() : 0; }
