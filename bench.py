@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-gather", action="store_true", help="skip the per-step RCCL gather of label maps")
     ap.add_argument("--graph", action="store_true", help="capture the step's ~330 launches in one hipGraph and replay it")
+    ap.add_argument("--tuning", default="", help="A/B knobs for quber_set_tuning, e.g. 5=0 (include/quber_hip.h)")
     return ap.parse_args()
 
 
@@ -106,6 +107,9 @@ def main():
 
     eng = engine.Engine(engine.make_config(H, W, max_batch=B, max_instances=max(N, 1)), dev)
     eng.load_state_dict(sd)
+    for kv in filter(None, a.tuning.split(",")):
+        k, v = kv.split("=")
+        eng.lib.quber_set_tuning(int(k), int(v))
 
     # ---- synthetic inputs, resident in HBM before the timed region; each rank has its own frames ----
     batch = synth.make_batch(7 + rank, B, H, W, N)

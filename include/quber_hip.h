@@ -159,6 +159,8 @@ int quber_debug_tensor(quber_ctx* ctx, const char* name, float** dev_ptr, int32_
 double quber_forward_flops(quber_ctx* ctx);
 /* test-harness knobs: key 2 = give the stand-alone quber_op_conv2d a split-K workspace (value != 0) or drop it (0);
  * key 3 = force the number of K partitions of convolutions that have a workspace (0 = automatic);
+ * key 5 = split the ragged last round of large convolution launches into K-pieces: when the cost model
+ *         favours it (1, default), never (0), whenever feasible (2);
  * key 4 = force the convolution tile shape (1 = 64x64, 2 = 128x128, 4 = 256x32; 0 = automatic) */
 void quber_set_tuning(int32_t key, int32_t value);
 /* the launch plan of quber_forward, in execution order (after the input pre-processing kernel):

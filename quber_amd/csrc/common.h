@@ -38,6 +38,8 @@ struct ConvP {
     size_t ws_floats;    // its capacity
     int ksplit;          // number of K partitions (grid.y); 1 = direct epilogue
     int kchunk;          // K-slices per partition
+    int nfull, tail_shift;   // split tail: tiles computed whole, log2(pieces per remaining tile)
+    int ws_rows, ws_row0;    // output rows held in the workspace slabs
     int kmode;           // 0: k = (tap, c)   1: k = (c/32, tap, c%32)  (weights packed accordingly)
     long in_gs, out_gs, res_gs, w_gs;
     int ss_gs;
@@ -48,7 +50,7 @@ int fail(const std::string& msg);
 
 // launchers (all asynchronous on `st`, no allocation, no synchronisation)
 int launch_conv(const ConvP& p, int G, hipStream_t st);
-extern int g_force_split, g_force_tile;
+extern int g_force_split, g_force_tile, g_tail_split;
 int launch_preprocess(const uint8_t* rgb, const uint8_t* depth, const float* offs, float* x, int B, int Bcap,
                       int H, int W, const float* mean6, const float* std6, int streams, hipStream_t st);
 int launch_maxpool3x3s2(const View& in, const View& out, int B, int G, hipStream_t st);

@@ -33,11 +33,14 @@ constexpr int PITCH = 36;
 // barrier per K-slice, a per-block s_setprio stagger, and 256x128 / 128x256 tiles (8 waves, or 4 waves of 128x64) were
 // all 1-25 % slower than this single-buffer, register-prefetch loop at 3 blocks per CU; a 256x64 tile (2 blocks per
 // CU) lost to 64x64 on every layer with 33-64 output channels (profiles/r01i_conv_sweep_*.md).
-// SPLIT: blockIdx.y owns p.kchunk consecutive K-slices and writes a raw partial tile (split-K for launches that cannot
-// fill the chip, or whose tile count is an awkward multiple of the resident slots).  The K range is derived without a
-// division (host-computed kchunk): a 64-bit division here costs hipcc ~50 VGPRs over the whole kernel and a wave per
-// SIMD; as written both instantiations allocate the same registers.
-template <int BM, int BN, int WM, int WN, bool SPLIT>
+// MODE 1 (split-K): blockIdx.y owns p.kchunk consecutive K-slices and writes a raw partial tile - for launches that
+// cannot fill the chip, or whose tile count is an awkward multiple of the resident slots.
+// MODE 2 (split tail): the first p.nfull tiles are computed whole; the remaining tiles - the ragged last round of a
+// large launch - are cut into 2^p.tail_shift K-pieces each, appended to the grid, so that the hardware dispatcher hands
+// out short pieces while the last whole tiles drain.
+// The K range is derived without a division (host-computed kchunk): a 64-bit division here costs hipcc ~50 VGPRs over
+// the whole kernel and a wave per SIMD; as written all instantiations allocate the same registers.
+template <int BM, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
     constexpr int NTH = WM * WN * 64;
     constexpr int RPP = NTH / 8;      // tile rows covered by one pass of the loader
@@ -60,19 +63,29 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
 
     // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give every XCD one
     // contiguous run of tiles, n-tile fastest, so neighbouring tiles reuse the same input rows.
-    int tile;
+    int tile, part = 0;                    // part: which K partition this block computes
+    bool raw = MODE == 1;                  // raw partial tile into the workspace instead of the fused epilogue
     {
-        const int bid = blockIdx.x, nblk = gridDim.x;
+        const int bid = blockIdx.x, nblk = MODE == 2 ? p.nfull : gridDim.x;
         const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        if constexpr (MODE == 1) part = blockIdx.y;
+        if constexpr (MODE == 2) {
+            if (bid >= nblk) {
+                const int u = bid - nblk;
+                tile = nblk + (u >> p.tail_shift);
+                part = u & ((1 << p.tail_shift) - 1);
+                raw = true;
+            }
+        }
     }
     const int nt = tile % p.ntiles;
     const int mt = tile / p.ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
 
     int k_begin = 0, nk = p.Kpad / BK;     // first K-slice and number of K-slices of this block
-    if constexpr (SPLIT) {
-        k_begin = blockIdx.y * p.kchunk;
+    if (MODE == 1 || (MODE == 2 && raw)) {
+        k_begin = part * p.kchunk;
         nk = min(nk - k_begin, p.kchunk);
     }
     const float* __restrict__ in = p.in + (long)g * p.in_gs;
@@ -114,7 +127,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
     int kc, kx, ky;
     if (p.kmode) {
         kc = kq; kx = 0; ky = 0;
-        if constexpr (SPLIT) {
+        if (MODE != 0) {
             const int taps = p.kh * p.kw;
             const int cb = k_begin / taps, tap = k_begin - cb * taps;
             kc = cb * BK + kq;
@@ -219,15 +232,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
     // ---- epilogue: y = acc*scale + shift (+ residual) (ReLU) ----
     // The accumulators are transposed through LDS one 32-column tile per wave at a time, so that global
     // stores (and residual loads) are 16 bytes per lane over WN*32 consecutive channels of a pixel.
-    // SPLIT: raw partial tile into slab (split s, group g) = ws[(s*G + g) * M * Cout ...]; the affine, residual and
-    // ReLU are applied by splitk_reduce_kernel after the slabs have been summed
-    float* __restrict__ out = SPLIT ? p.ws + ((long)blockIdx.y * gridDim.z + g) * (long)p.M * p.Cout : p.out + (long)g * p.out_gs;
-    const int out_cs = SPLIT ? p.Cout : p.out_cs;
-    const float* __restrict__ res = (p.res && !SPLIT) ? p.res + (long)g * p.res_gs : nullptr;
-    const float* __restrict__ scale = (p.scale && !SPLIT) ? p.scale + g * p.ss_gs : nullptr;
-    const float* __restrict__ shift = (p.shift && !SPLIT) ? p.shift + g * p.ss_gs : nullptr;
-    const bool relu = p.relu && !SPLIT;
-    const float* __restrict__ prelu = (p.prelu && !SPLIT) ? p.prelu + g * p.ss_gs : nullptr;   // per-channel PReLU slopes
+    // raw: partial tile into slab (partition s, group g) = ws[(s*G + g) * ws_rows * Cout ...], rows counted from
+    // ws_row0; the affine, residual and ReLU are applied by splitk_reduce_kernel after the slabs have been summed
+    float* __restrict__ out = raw ? p.ws + (((long)part * gridDim.z + g) * p.ws_rows - p.ws_row0) * (long)p.Cout
+                                  : p.out + (long)g * p.out_gs;
+    const int out_cs = raw ? p.Cout : p.out_cs;
+    const float* __restrict__ res = (p.res && !raw) ? p.res + (long)g * p.res_gs : nullptr;
+    const float* __restrict__ scale = (p.scale && !raw) ? p.scale + g * p.ss_gs : nullptr;
+    const float* __restrict__ shift = (p.shift && !raw) ? p.shift + g * p.ss_gs : nullptr;
+    const bool relu = p.relu && !raw;
+    const float* __restrict__ prelu = (p.prelu && !raw) ? p.prelu + g * p.ss_gs : nullptr;   // per-channel PReLU slopes
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -292,15 +306,16 @@ template <int V>
 __global__ void splitk_reduce_kernel(const ConvP p, int S, int G) {
     using vec = __attribute__((ext_vector_type(V))) float;
     const int g = blockIdx.y;
-    const long MN = (long)p.M * p.Cout;
+    const long MN = (long)p.ws_rows * p.Cout;          // the rows [ws_row0, ws_row0 + ws_rows) were computed in pieces
     const float* __restrict__ scale = p.scale ? p.scale + g * p.ss_gs : nullptr;
     const float* __restrict__ shift = p.shift ? p.shift + g * p.ss_gs : nullptr;
     const float* __restrict__ prelu = p.prelu ? p.prelu + g * p.ss_gs : nullptr;
     const float* __restrict__ res = p.res ? p.res + (long)g * p.res_gs : nullptr;
     float* __restrict__ out = p.out + (long)g * p.out_gs;
     for (long i = (blockIdx.x * (long)blockDim.x + threadIdx.x) * V; i < MN; i += (long)gridDim.x * blockDim.x * V) {
-        const long m = i / p.Cout;
-        const int n = (int)(i - m * p.Cout);
+        const long mr = i / p.Cout;
+        const int n = (int)(i - mr * p.Cout);
+        const long m = mr + p.ws_row0;
         vec v = *reinterpret_cast<const vec*>(p.ws + (long)g * MN + i);
         for (int s = 1; s < S; ++s) v += *reinterpret_cast<const vec*>(p.ws + ((long)s * G + g) * MN + i);
         float o[V];
@@ -323,6 +338,7 @@ __global__ void splitk_reduce_kernel(const ConvP p, int S, int G) {
 
 int g_force_tile = 0;     // test-harness knobs (quber_set_tuning keys 4 / 3): force the tile shape / the number of K partitions
 int g_force_split = 0;
+int g_tail_split = 1;      // key 5: split the ragged last round of large launches when the model favours it (1), never (0), whenever feasible (2)
 
 // ---- work distribution -------------------------------------------------------------------------------------------
 // A launch is (tile shape, S = number of K partitions).  `bpc` blocks of a tile shape are resident per CU (registers /
@@ -380,21 +396,58 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
     p.kchunk = (nk + S - 1) / S;
     S = (nk + p.kchunk - 1) / p.kchunk;        // no empty partitions
     p.ksplit = S;
-    const dim3 grid(p.mtiles * p.ntiles, S, G), block(WM * WN * 64);
-    if (S > 1) {
-        hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, true>), grid, block, 0, st, p);
-        const long MN = (long)p.M * p.Cout;
+    p.ws_rows = p.M;
+    p.ws_row0 = 0;
+    p.nfull = p.mtiles * p.ntiles;
+    p.tail_shift = 0;
+    const dim3 block(WM * WN * 64);
+    auto reduce = [&](int parts) {
+        const long MN = (long)p.ws_rows * p.Cout;
         if (p.vec_out) {
             int blocks = (int)((MN / 4 + 255) / 256);
             if (blocks > 2048) blocks = 2048;
-            hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(blocks, G), dim3(256), 0, st, p, S, G);
+            hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(blocks, G), dim3(256), 0, st, p, parts, G);
         } else {
             int blocks = (int)((MN + 255) / 256);
             if (blocks > 2048) blocks = 2048;
-            hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(blocks, G), dim3(256), 0, st, p, S, G);
+            hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(blocks, G), dim3(256), 0, st, p, parts, G);
         }
+    };
+    // Split tail: with more than one round of tiles, cut the tiles of the ragged last round into 2^shift K-pieces that
+    // together fill about one more (short) round; taken when the model prices it below the launch chosen so far.
+    constexpr int BPC = (BM == 64) ? 7 : 3;
+    const long slots = 256L * BPC, tiles = (long)p.mtiles * p.ntiles, blocks_all = tiles * G;
+    if (p.ws && g_tail_split && g_force_split == 0 && BM == 128 && blocks_all > slots && nk >= 32) {
+        const long nfull = (blocks_all / slots) * slots / G / p.ntiles * p.ntiles;    // per group, whole tile rows
+        const long rem = tiles - nfull;
+        int shift = 0;
+        while (shift < 3 && (rem * G << (shift + 1)) <= slots + slots / 8 && (nk >> (shift + 1)) >= 8) ++shift;
+        const long row0 = nfull / p.ntiles * BM;
+        const double rem_outputs = (double)G * (p.M - row0) * p.Cout;
+        if (rem > 0 && shift > 0 && rem_outputs * (1 << shift) <= (double)p.ws_floats) {
+            const double whole = launch_cost(blocks_all, nk, (double)G * p.M * p.Cout, S, BPC, kModel3);
+            const double tail = (nk + kModel3.c) * BPC * ((double)nfull * G / slots) +
+                                launch_cost(rem * G, nk, rem_outputs, 1 << shift, BPC, kModel3);
+            if (tail < 0.995 * whole || g_tail_split == 2) {
+                p.nfull = (int)nfull;
+                p.tail_shift = shift;
+                p.kchunk = (nk + (1 << shift) - 1) >> shift;
+                p.ws_row0 = (int)row0;
+                p.ws_rows = p.M - (int)row0;
+                // every piece owns at least one K-slice: (2^shift - 1) * kchunk < nk because nk >= 8 * 2^shift
+                hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 2>), dim3((unsigned)(nfull + (rem << shift)), 1, G), block, 0,
+                                   st, p);
+                reduce(1 << shift);
+                QB_CHECK(hipGetLastError());
+                return 0;
+            }
+        }
+    }
+    if (S > 1) {
+        hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 1>), dim3(p.mtiles * p.ntiles, S, G), block, 0, st, p);
+        reduce(S);
     } else {
-        hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, false>), grid, block, 0, st, p);
+        hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 0>), dim3(p.mtiles * p.ntiles, 1, G), block, 0, st, p);
     }
     QB_CHECK(hipGetLastError());
     return 0;

@@ -849,6 +849,7 @@ void quber_set_tuning(int32_t key, int32_t value) {
         }
     }
     if (key == 4) g_force_tile = value;    // force the tile shape: 1 = 64x64, 2 = 128x128, 4 = 256x32 (0 = automatic)
+    if (key == 5) g_tail_split = value;    // split the ragged last round of large convolution launches (default 1)
     if (key == 3) g_force_split = value;   // force the number of K partitions of every convolution with a workspace (0 = automatic)
 }
 

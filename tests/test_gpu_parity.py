@@ -286,11 +286,12 @@ def test_conv_igemm_vs_torch(case):
 
 @pytest.mark.parametrize("case", [
     # split-K (needs the op workspace) and launches around the one-round boundary
-    (4, 120, 160, 64, 128, 3, 1, 1, True, True, True),      # 600 tiles of 128x128: below one round, above half
-    (8, 120, 160, 32, 128, 3, 1, 2, True, False, True),     # 1200 tiles: one full round + a 432-tile tail
-    (9, 120, 160, 32, 256, 1, 1, 1, False, False, False),   # 2700 tiles: three full rounds + tail
+    (4, 120, 160, 64, 128, 3, 1, 1, True, True, True),      # 600 tiles of 128x128 (below one round): K split in two
+    (8, 120, 160, 128, 128, 3, 1, 2, True, False, True),    # 1200 tiles: one round whole + a 432-tile tail in 2 K-pieces
+    (9, 120, 160, 32, 256, 1, 1, 1, False, False, False),   # 2700 tiles, K too short to split
     (1, 30, 40, 512, 256, 3, 1, 6, True, False, True),      # 76 tiles of 64x64, K = 4608: split-K
-    (2, 60, 80, 256, 64, 3, 1, 1, True, True, True),        # 256x64 tiles
+    (2, 60, 80, 256, 64, 3, 1, 1, True, True, True),        # 64x64 tiles, 64 output channels
+    (1, 120, 160, 128, 32, 3, 1, 1, True, False, True),     # 256x32 tiles, 75 blocks: split-K
 ])
 def test_conv_split_paths_vs_torch(case):
     lib = _lib.load()
@@ -299,6 +300,57 @@ def test_conv_split_paths_vs_torch(case):
         assert _conv_case(*case) < 2e-6
     finally:
         lib.quber_set_tuning(2, 0)
+
+
+@pytest.mark.parametrize("case", [
+    # B, H, W, Cin, Cout, k, dil, residual: split tail (MODE 2) against the same launch computed whole
+    (6, 119, 160, 128, 256, 3, 1, True),     # 1786 tiles (ragged M, 2 n-tiles): 1536 whole + 250 in 2 pieces
+    (8, 108, 128, 256, 128, 3, 1, False),    # 864 tiles: 768 whole + 96 in 8 pieces
+    (7, 120, 160, 1024, 128, 1, 1, True),    # 1x1, K = 1024: 1050 tiles, 282 in 2 pieces
+    (8, 100, 128, 136, 128, 3, 2, False),    # tap-major K order (Cin % 32 != 0, K tail), dilation 2: 800 tiles, 32 in 4 pieces
+])
+def test_conv_split_tail_equals_whole(case):
+    B, H, W, Cin, Cout, k, dil, residual = case
+    lib = _lib.load()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
+    w = torch.randn(Cout, Cin, k, k, device="cuda", generator=g) / np.sqrt(Cin * k * k)
+    sc, sh = torch.rand(Cout, device="cuda", generator=g) + 0.5, torch.randn(Cout, device="cuda", generator=g)
+    r = torch.randn(B, H, W, Cout, device="cuda", generator=g) if residual else None
+    packed = torch.empty(Cout * ((k * k * Cin + 31) // 32 * 32), device="cuda")
+    outs = []
+    lib.quber_set_tuning(2, 1)
+    try:
+        for tail in (0, 2):               # never / whenever feasible
+            lib.quber_set_tuning(5, tail)
+            y = torch.full((B, H, W, Cout), float("nan"), device="cuda")
+            _lib.check(lib.quber_op_conv2d(p(x), B, H, W, Cin, p(w), Cout, k, 1, dil * (k // 2), dil, p(sc), p(sh), p(r), 1,
+                                           p(packed), p(y), st))
+            outs.append(y)
+    finally:
+        lib.quber_set_tuning(5, 1)
+        lib.quber_set_tuning(2, 0)
+    whole, tail = outs
+    assert torch.isfinite(tail).all()
+    assert not torch.equal(whole, tail)          # the tail really was summed in pieces
+    err = (whole - tail).abs().max().item() / max(1.0, whole.abs().max().item())
+    assert err < 2e-6
+    # and the whole-tile launch is right on a sample of output pixels (float64 on the host)
+    idx = torch.randint(0, B * H * W, (64,), generator=torch.Generator().manual_seed(1))
+    pd = dil * (k // 2)
+    xp = torch.nn.functional.pad(x.cpu().double(), (0, 0, pd, pd, pd, pd))
+    wc = w.cpu().double()
+    for i in idx.tolist():
+        b, rem = divmod(i, H * W)
+        oy, ox = divmod(rem, W)
+        patch = xp[b, oy:oy + dil * (k - 1) + 1:dil, ox:ox + dil * (k - 1) + 1:dil, :]      # [k, k, Cin]
+        ref = torch.einsum("yxc,ocyx->o", patch, wc) * sc.cpu().double() + sh.cpu().double()
+        if residual:
+            ref = ref + r[b, oy, ox].cpu().double()
+        ref = ref.relu()
+        assert (whole[b, oy, ox].cpu().double() - ref).abs().max().item() < 2e-5
 
 
 def test_groupnorm_bilinear_maxpool_vs_torch():
