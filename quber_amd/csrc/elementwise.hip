@@ -150,15 +150,20 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     if (t < groups * 2) atomicAdd(&stats[((long)(g * B + b) * groups) * 2 + t], acc[t]);
 }
 
+static int gn_pixels_per_block(int HW, int C, int B, int G) {
+    // ~64K floats per block at large batch, but never fewer than ~1000 blocks in flight at small batch
+    int ppb = 65536 / C;
+    const long want = ((long)HW * B * G + 1023) / 1024;
+    if (ppb > want) ppb = (int)want;
+    if (ppb < 8) ppb = 8;
+    return ppb;
+}
+
 int launch_gn_stats(const View& in, int B, int G, int groups, double* stats, hipStream_t st) {
     if (groups > 64 || in.C % groups || in.C % 4) return fail("groupnorm: unsupported channel/group count");
     const int HW = in.H * in.W;
     QB_CHECK(hipMemsetAsync(stats, 0, sizeof(double) * 2 * groups * B * G, st));
-    // pixels per block: ~64K floats each at large batch, but never fewer than ~1000 blocks in flight at small batch
-    int ppb = 65536 / in.C;
-    const long want = ((long)HW * B * G + 1023) / 1024;
-    if (ppb > want) ppb = (int)want;
-    if (ppb < 8) ppb = 8;
+    const int ppb = gn_pixels_per_block(HW, in.C, B, G);
     const int chunks = (HW + ppb - 1) / ppb;
     hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks, B, G), dim3(256), 0, st, in.p, HW, in.C, in.cs, in.gs,
                        (long)HW * in.cs, groups, ppb, stats, B);
@@ -166,63 +171,66 @@ int launch_gn_stats(const View& in, int B, int G, int groups, double* stats, hip
     return 0;
 }
 
-// mean / rstd per (launch group, sample, norm group) from the fp64 sums; written over the sums as two floats
-__global__ void gn_finalize_kernel(double* __restrict__ stats, int count, double n, float eps) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    const double mean = stats[2 * i] / n;
-    double var = stats[2 * i + 1] / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    float2 mr;
-    mr.x = (float)mean;
-    mr.y = (float)(1.0 / sqrt(var + (double)eps));
-    *reinterpret_cast<float2*>(&stats[2 * i]) = mr;       // first 8 bytes of the 16-byte slot
-}
-
-// y = relu(x*scale + bias), scale = rstd*gamma, bias = beta - mean*scale  (torch's GroupNorm CPU form)
-__global__ void gn_apply_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int HW, int C, int in_cs,
-                                int out_cs, long in_gs, long out_gs, int groups, const double* __restrict__ stats,
-                                const float* __restrict__ gamma, const float* __restrict__ beta, int param_gs,
-                                int relu) {
-    const int g = blockIdx.y;
-    in += g * in_gs;
-    out += g * out_gs;
+// y = relu(x*scale + bias), scale = rstd*gamma, bias = beta - mean*scale  (torch's GroupNorm CPU form).
+// mean / rstd come from the fp64 sums of gn_stats_kernel.  A thread keeps one 16-byte channel column: its four
+// (scale, bias) pairs are computed once, the pixel loop is load - fma - store with no index arithmetic beyond an add.
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int HW,
+                                                       int C, int in_cs, int out_cs, long in_gs, long out_gs, int groups,
+                                                       const double* __restrict__ stats, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int param_gs, int relu, int ppb,
+                                                       double n, float eps) {
+    const int t = threadIdx.x;
+    const int b = blockIdx.y, g = blockIdx.z;
+    in += g * in_gs + (long)b * HW * in_cs;
+    out += g * out_gs + (long)b * HW * out_cs;
     gamma += g * param_gs;
     beta += g * param_gs;
+    const double* sbase = stats + ((long)(g * B + b) * groups) * 2;
     const int C4 = C >> 2, cpg = C / groups;
-    const long total = (long)B * HW * C4;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c4 = i % C4;
-        const long pix = i / C4;
-        const int b = pix / HW;
-        const float4 v = *reinterpret_cast<const float4*>(in + pix * in_cs + c4 * 4);
+    const int p0 = blockIdx.x * ppb;
+    const int p1 = min(HW, p0 + ppb);
+    const int colsper = min(C4, 256);
+    const int rows = 256 / colsper;
+    const int col = t % colsper, row = t / colsper;
+    for (int cp = 0; cp < C4; cp += colsper) {
+        const int c4 = cp + col;
+        if (row >= rows || c4 >= C4) continue;
         const float4 ga = *reinterpret_cast<const float4*>(gamma + c4 * 4);
         const float4 be = *reinterpret_cast<const float4*>(beta + c4 * 4);
-        const float e[4] = {v.x, v.y, v.z, v.w}, gm[4] = {ga.x, ga.y, ga.z, ga.w}, bt[4] = {be.x, be.y, be.z, be.w};
-        const double* sbase = stats + ((long)(g * B + b) * groups) * 2;
-        float o[4];
+        const float gm[4] = {ga.x, ga.y, ga.z, ga.w}, bt[4] = {be.x, be.y, be.z, be.w};
+        float sc[4], bi[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float2 mr = *reinterpret_cast<const float2*>(sbase + 2 * ((c4 * 4 + j) / cpg));
-            const float sc = mr.y * gm[j];
-            const float bi = bt[j] - mr.x * sc;
-            float y = fmaf(e[j], sc, bi);
-            if (relu) y = fmaxf(y, 0.f);
-            o[j] = y;
+            const int grp = (c4 * 4 + j) / cpg;
+            const double mean = sbase[2 * grp] / n;
+            double var = sbase[2 * grp + 1] / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+            sc[j] = rstd * gm[j];
+            bi[j] = bt[j] - (float)mean * sc[j];
         }
-        *reinterpret_cast<float4*>(out + pix * out_cs + c4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        for (int pix = p0 + row; pix < p1; pix += rows) {
+            const float4 v = *reinterpret_cast<const float4*>(in + (long)pix * in_cs + c4 * 4);
+            float4 o;
+            o.x = fmaf(v.x, sc[0], bi[0]);
+            o.y = fmaf(v.y, sc[1], bi[1]);
+            o.z = fmaf(v.z, sc[2], bi[2]);
+            o.w = fmaf(v.w, sc[3], bi[3]);
+            if (relu) {
+                o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+            }
+            *reinterpret_cast<float4*>(out + (long)pix * out_cs + c4 * 4) = o;
+        }
     }
 }
 
 int launch_gn_apply(const View& in, const View& out, int B, int G, int groups, const double* stats,
                     const float* gamma, const float* beta, int param_gs, float eps, int relu, hipStream_t st) {
     const int HW = in.H * in.W;
-    const int count = G * B * groups;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((count + 255) / 256), dim3(256), 0, st, const_cast<double*>(stats), count,
+    const int ppb = gn_pixels_per_block(HW, in.C, B, G);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((HW + ppb - 1) / ppb, B, G), dim3(256), 0, st, in.p, out.p, B, HW, in.C,
+                       in.cs, out.cs, in.gs, out.gs, groups, stats, gamma, beta, param_gs, relu, ppb,
                        (double)HW * (in.C / groups), eps);
-    const long total = (long)B * HW * (in.C / 4);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(cap_grid(total, 256), G), dim3(256), 0, st, in.p, out.p, B, HW, in.C,
-                       in.cs, out.cs, in.gs, out.gs, groups, stats, gamma, beta, param_gs, relu);
     QB_CHECK(hipGetLastError());
     return 0;
 }
