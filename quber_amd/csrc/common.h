@@ -54,7 +54,8 @@ extern int g_force_split, g_force_tile, g_tail_split;
 int launch_preprocess(const uint8_t* rgb, const uint8_t* depth, const float* offs, float* x, int B, int Bcap,
                       int H, int W, const float* mean6, const float* std6, int streams, hipStream_t st);
 int launch_maxpool3x3s2(const View& in, const View& out, int B, int G, hipStream_t st);
-int launch_gn_stats(const View& in, int B, int G, int groups, double* stats, hipStream_t st);
+int launch_zero(void* p, size_t bytes, hipStream_t st);
+int launch_gn_stats(const View& in, int B, int G, int groups, double* stats, hipStream_t st, bool zero = true);
 int launch_gn_apply(const View& in, const View& out, int B, int G, int groups, const double* stats,
                     const float* gamma, const float* beta, int param_gs, float eps, int relu, hipStream_t st);
 int launch_bilinear(const View& in, const View& out, int B, hipStream_t st);

@@ -159,10 +159,29 @@ static int gn_pixels_per_block(int HW, int C, int B, int G) {
     return ppb;
 }
 
-int launch_gn_stats(const View& in, int B, int G, int groups, double* stats, hipStream_t st) {
+// Zero fill as a plain kernel: cheaper than the runtime's fill path for the small accumulators of this library and,
+// unlike hipMemsetAsync nodes, replayed correctly when the step is captured in a hipGraph (ROCm 7.2: the captured
+// memsets did not clear the buffers on replay - tests/test_gpu_network.py::test_config2_...).
+__global__ void zero_kernel(unsigned* __restrict__ p, size_t words) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+
+int launch_zero(void* p, size_t bytes, hipStream_t st) {
+    if (((uintptr_t)p & 3) || (bytes & 3)) return fail("zero fill: 4-byte granularity");
+    if (!bytes) return 0;
+    const size_t words = bytes / 4;
+    hipLaunchKernelGGL(zero_kernel, dim3(cap_grid((long)words, 256)), dim3(256), 0, st, (unsigned*)p, words);
+    QB_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_gn_stats(const View& in, int B, int G, int groups, double* stats, hipStream_t st, bool zero) {
     if (groups > 64 || in.C % groups || in.C % 4) return fail("groupnorm: unsupported channel/group count");
     const int HW = in.H * in.W;
-    QB_CHECK(hipMemsetAsync(stats, 0, sizeof(double) * 2 * groups * B * G, st));
+    if (zero) {
+        const int rc = launch_zero(stats, sizeof(double) * 2 * groups * B * G, st);
+        if (rc) return rc;
+    }
     const int ppb = gn_pixels_per_block(HW, in.C, B, G);
     const int chunks = (HW + ppb - 1) / ppb;
     hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks, B, G), dim3(256), 0, st, in.p, HW, in.C, in.cs, in.gs,

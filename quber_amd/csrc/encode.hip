@@ -173,10 +173,9 @@ int launch_encode(const uint8_t* masks, int B, int N, int H, int W, const float*
     uint8_t* last = reinterpret_cast<uint8_t*>(ws);
     MaskStat* stats = reinterpret_cast<MaskStat*>(last + (((size_t)B * HW + 15) & ~(size_t)15));
     if (N == 0) {
-        QB_CHECK(hipMemsetAsync(out, 0, sizeof(float) * 3 * HW * B, st));
-        return 0;
+        return launch_zero(out, sizeof(float) * 3 * HW * B, st);
     }
-    QB_CHECK(hipMemsetAsync(stats, 0, sizeof(MaskStat) * (size_t)B * N, st));
+    if (int rc = launch_zero(stats, sizeof(MaskStat) * (size_t)B * N, st)) return rc;
     if (W % ENC_PIX == 0 && ((uintptr_t)masks & 15) == 0) {
         const int blocks = (int)((HW / ENC_PIX + 255) / 256);
         hipLaunchKernelGGL(encode_reduce_kernel, dim3(blocks, B), dim3(256), sizeof(unsigned) * 3 * N, st, masks, N, H,

@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void mask_overlap_kernel(const uint8_t* __rest
 
 int launch_mask_overlap(const uint8_t* masks, const uint8_t* fg, int B, int K, long HW, unsigned long long* counts,
                         hipStream_t st) {
-    QB_CHECK(hipMemsetAsync(counts, 0, sizeof(unsigned long long) * 2 * B * K, st));
+    if (int rc = launch_zero(counts, sizeof(unsigned long long) * 2 * B * K, st)) return rc;
     int bx = (int)((HW + 256 * 16 - 1) / (256 * 16));
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(mask_overlap_kernel, dim3(bx, K, B), dim3(256), 0, st, masks, fg, HW, K, counts);

@@ -90,7 +90,7 @@ int launch_contingency(const int* pred, const int* gt, long n, int cap, void* ws
     int* labels = reinterpret_cast<int*>(w); w += sizeof(int) * 2 * cap;
     int* counts = reinterpret_cast<int*>(w); w += sizeof(int) * 4;
     unsigned short* lut = reinterpret_cast<unsigned short*>(w);
-    QB_CHECK(hipMemsetAsync(ws, 0, contingency_ws_bytes(cap), st));
+    if (int rc = launch_zero(ws, contingency_ws_bytes(cap), st)) return rc;
     int blocks = (int)((n + 255) / 256);
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(label_presence_kernel, dim3(blocks), dim3(256), 0, st, pred, gt, n, flags, counts + 2);

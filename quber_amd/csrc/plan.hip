@@ -37,6 +37,9 @@ int fail(const std::string& m) {
 
 using namespace quber;
 
+constexpr int GN_SLOTS = 64;
+static inline size_t gn_slot_doubles(int max_batch) { return (size_t)2 * 32 * max_batch * 4; }
+
 enum OpKind { OP_CONV = 0, OP_NORM = 1, OP_OTHER = 2, OP_KINDS = 3 };
 struct Op {
     std::function<int(int, hipStream_t)> run;
@@ -57,7 +60,8 @@ struct quber_ctx {
     void* enc_ws = nullptr;
     uint8_t* err_ws = nullptr;
     void* post_ws = nullptr;
-    double* gn_stats = nullptr;
+    double* gn_stats = nullptr;   // [GN_SLOTS][launch group <= 4][max_batch][32 groups][sum, sum of squares]
+    int gn_slots = 0;
     float* splitk_ws = nullptr;
     size_t splitk_floats = 0;
     float* X = nullptr;   // [2][Bmax][H][W][8]
@@ -242,9 +246,11 @@ struct Builder {
         if (dry) return;
         const float* dg = upload(gamma);
         const float* db = upload(beta);
-        double* stats = c->gn_stats;
+        // every GroupNorm owns a slot of the sum accumulators; one launch at the start of the forward clears them all
+        if (c->gn_slots >= GN_SLOTS) { if (err.empty()) err = "more GroupNorm layers than accumulator slots"; return; }
+        double* stats = c->gn_stats + (size_t)c->gn_slots++ * gn_slot_doubles(c->cfg.max_batch);
         c->ops.push_back({[=](int B, hipStream_t st) {
-            int rc = launch_gn_stats(in, B, G, 32, stats, st);
+            int rc = launch_gn_stats(in, B, G, 32, stats, st, false);
             if (rc) return rc;
             return launch_gn_apply(in, out, B, G, 32, stats, dg, db, C, 1e-5f, 1, st);
         }, OP_NORM, names[0], 0.0, 2});
@@ -272,7 +278,13 @@ struct Builder {
             if (NS == 1) return {"backbone." + tail};
             return {R + tail, D + (stage_prefix ? "depth_" : "") + tail};
         };
-        if (!dry) c->gn_stats = (double*)dalloc_bytes(sizeof(double) * 2 * 64 * Bmax * 4);
+        if (!dry) {
+            c->gn_stats = (double*)dalloc_bytes(sizeof(double) * GN_SLOTS * gn_slot_doubles(Bmax));
+            quber_ctx* ctx = c;
+            op([ctx](int, hipStream_t st) {
+                return launch_zero(ctx->gn_stats, sizeof(double) * ctx->gn_slots * gn_slot_doubles(ctx->cfg.max_batch), st);
+            });
+        }
         if (!dry) {
             c->splitk_floats = (size_t)40 << 20;   // 160 MiB of partial tiles: S x blocks stays near 1-2 rounds of 128x128 tiles at any batch
             c->splitk_ws = (float*)dalloc_bytes(sizeof(float) * c->splitk_floats);

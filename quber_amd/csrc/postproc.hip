@@ -363,7 +363,7 @@ int launch_postprocess(const float* logits, int nch, int B, int H, int W, const 
     hipLaunchKernelGGL(nms_kernel, dim3((W + NT - 1) / NT, (H + NT - 1) / NT, B), dim3(256), sizeof(float) * P * P, st,
                        logits, nch, H, W, c.threshold, r, cand);
     hipLaunchKernelGGL(select_kernel, dim3(B), dim3(1024), 0, st, cand, (int)HW, W, c.top_k, c.cap, centers, ncenters);
-    QB_CHECK(hipMemsetAsync(area, 0, (size_t)B * 256 * 4, st));
+    if (int rc = launch_zero(area, (size_t)B * 256 * 4, st)) return rc;
     const int pblocks = (int)((HW + 255) / 256);
     hipLaunchKernelGGL(group_kernel, dim3(pblocks, B), dim3(256), 0, st, logits, nch, H, W, c.cap, centers, ncenters,
                        idmap, area);

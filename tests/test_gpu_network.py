@@ -176,3 +176,68 @@ def test_adapter_from_files(tmp_path):
         if len(masks):
             assert masks.dtype == np.bool_ and masks.shape[1:] == (480, 640)
             assert not masks[:, :10, :10].any()            # OCID zero-depth masking (refiner_model.py:279-288)
+
+
+def test_config2_1280x720_hipgraph_steady_state():
+    """BASELINE.json configs[2]: 1280x720, 30 instances, the whole step captured in one hipGraph.  The replayed graph must
+    give the eager results bit for bit on new inputs (it reads the device buffers, not captured values), the logits match
+    the oracle within 1e-4 and the label map is the oracle's post-processing of those logits."""
+    h, w, n = 720, 1280, 30
+    sd = arch.init_state_dict(seed=4)
+    eng = engine.Engine(engine.make_config(h, w, max_batch=1, max_instances=n), "cuda:0")
+    eng.load_state_dict(sd)
+    dev = "cuda:0"
+    masks = torch.empty((1, n, h, w), dtype=torch.uint8, device=dev)
+    bgr = torch.empty((1, h, w, 3), dtype=torch.uint8, device=dev)
+    depth = torch.empty((1, h, w, 3), dtype=torch.uint8, device=dev)
+    offsets = torch.empty((1, 3, h, w), dtype=torch.float32, device=dev)
+    logits = torch.empty((1, eng.planes, h, w), dtype=torch.float32, device=dev)
+    post = eng.alloc_post(1)
+    max_inst = min(eng.cap, n + 12)
+    out_masks = torch.empty((1, max_inst, h, w), dtype=torch.uint8, device=dev)
+
+    def load(seed):
+        sc = synth.make_scene(seed, h, w, n)
+        masks.copy_(torch.from_numpy(sc["masks"][None]))
+        bgr.copy_(torch.from_numpy(sc["rgb"][None]))
+        depth.copy_(torch.from_numpy(sc["depth"][None]))
+        return sc
+
+    def step():
+        eng.encode(masks, offsets)
+        eng.forward(bgr, depth, offsets, logits)
+        eng.postprocess(logits, post)
+        eng.extract_masks(post, max_inst, out_masks)
+
+    load(11)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    sc = load(12)                      # new frame: the graph was captured on frame 11
+    step()
+    torch.cuda.synchronize()
+    eager = (logits.clone(), post["panoptic"].clone(), post["count"].clone(), out_masks.clone())
+    for t in (logits, post["panoptic"], out_masks):
+        t.zero_()
+    graph.replay()
+    graph.replay()                     # steady state: replays are idempotent
+    torch.cuda.synchronize()
+    assert torch.equal(logits, eager[0]) and torch.equal(post["panoptic"], eager[1])
+    assert torch.equal(post["count"], eager[2]) and torch.equal(out_masks, eager[3])
+    # against the oracle
+    net = oracle_net(sd)
+    offs = encode_np.encode_initial_masks(sc["masks"])[None]
+    np.testing.assert_array_equal(offsets.cpu().numpy(), offs)
+    image = torch.from_numpy(np.concatenate([sc["rgb"], sc["depth"]], -1)).permute(2, 0, 1)[None]
+    with torch.no_grad():
+        ref = net(image, torch.from_numpy(offs))
+    exp = torch.cat([ref["foreground"], ref["center"], ref["offset"], ref["eee_boundary"]], 1)
+    lg = logits.cpu()
+    assert float((lg - exp).abs().max()) < TOL
+    o = postproc_ref.postprocess(lg[0, 0:1], lg[0, 1:2], lg[0, 2:4])
+    np.testing.assert_array_equal(post["panoptic"][0].cpu().numpy(), o["panoptic"].numpy())
