@@ -271,7 +271,7 @@ def _conv_case(B, H, W, Cin, Cout, k, stride, dil, affine, residual, relu, seed=
 @pytest.mark.parametrize("case", [
     # B, H, W, Cin, Cout, k, stride, dil, affine, residual, relu
     (2, 24, 32, 8, 32, 3, 2, 1, True, False, True),        # stem conv1 (K = 72, tail), 256x32 tile
-    (2, 24, 32, 32, 64, 3, 1, 1, True, False, True),       # 256x64 tile
+    (2, 24, 32, 32, 64, 3, 1, 1, True, False, True),       # 64 output channels: 64x64 tiles
     (2, 16, 20, 64, 256, 1, 1, 1, True, True, True),       # bottleneck conv3 + residual
     (1, 30, 40, 256, 128, 1, 2, 1, True, False, True),     # strided 1x1
     (1, 15, 20, 128, 128, 3, 1, 4, True, False, True),     # dilated 3x3

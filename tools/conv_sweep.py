@@ -58,7 +58,7 @@ SHAPES = [
     ("heads x3 3x3 128>32", 3, 120, 160, 128, 32, 3, 1, 1, 0),
 ]
 ALL = []
-TILES = {1: (64, 64, 7), 2: (128, 128, 3), 3: (256, 64, 2), 4: (256, 32, 3)}
+TILES = {1: (64, 64, 7), 2: (128, 128, 3), 4: (256, 32, 3)}    # quber_set_tuning key 4 values -> (BM, BN, blocks per CU)
 
 
 def main():
@@ -103,7 +103,7 @@ def main():
         ref = y.clone()
         results = []
         for tile, (bm, bn, bpc) in TILES.items():
-            if bn < 64 and Cout > 64 or bn == 64 and bm == 256 and Cout > 128:
+            if bn < 64 and Cout > 64:
                 continue
             blocks = ((M + bm - 1) // bm) * ((Cout + bn - 1) // bn)
             for S in (1, 2, 3, 4, 6, 8, 12):
