@@ -118,13 +118,14 @@ struct Builder {
             if (err.empty()) err = "hipMalloc of " + std::to_string(bytes) + " bytes failed";
             return nullptr;
         }
-        hipMemset(p, 0, bytes ? bytes : 16);
         c->allocs.push_back(p);
+        if (hipMemset(p, 0, bytes ? bytes : 16) != hipSuccess && err.empty()) err = "hipMemset of a new buffer failed";
         return p;
     }
     float* upload(const std::vector<float>& v) {
         float* d = (float*)dalloc_bytes(v.size() * sizeof(float));
-        if (d) hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (d && hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess && err.empty())
+            err = "upload of " + std::to_string(v.size()) + " floats failed";
         return d;
     }
     View make(int C, int h, int w, int G = 1) {
@@ -774,9 +775,11 @@ int quber_create(const quber_config* cfg, quber_ctx** out) {
     if (check_cfg(*cfg)) return -1;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device available");
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return fail("hipGetDevice failed");
     quber_ctx* c = new quber_ctx();
     c->cfg = *cfg;
-    hipGetDevice(&c->device);
+    c->device = device;
     const int B = cfg->max_batch, H = cfg->height, W = cfg->width;
     // Gaussian template (predictor.py:246-251): float64 exp rounded to f32
     const int sg = cfg->gaussian_sigma, side = 6 * sg + 3, c0 = 3 * sg + 1;
@@ -807,8 +810,8 @@ int quber_create(const quber_config* cfg, quber_ctx** out) {
 
 void quber_destroy(quber_ctx* c) {
     if (!c) return;
-    for (hipEvent_t e : c->prof_events) hipEventDestroy(e);
-    for (void* p : c->allocs) hipFree(p);
+    for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);   // nothing useful to do with a failure while tearing down
+    for (void* p : c->allocs) (void)hipFree(p);
     delete c;
 }
 
