@@ -303,25 +303,32 @@ int launch_bilinear(const View& in, const View& out, int B, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// global average pool: grid (C/64, B); 256 threads = 64 channels x 4 pixel lanes
+// global average pool: grid (C/64, B); 256 threads = 16 float4 channel columns x 16 pixel lanes, fp64 sums
 __global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ in, float* __restrict__ out, int HW,
                                                       int C, int in_cs, int out_cs) {
-    __shared__ double part[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int lane = threadIdx.x >> 6;
+    __shared__ double part[16][64];
+    const int col = threadIdx.x & 15, lane = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + col * 4;
     const int b = blockIdx.y;
-    double s = 0.0;
-    if (c < C)
-        for (int p = lane; p < HW; p += 4) s += (double)in[((long)b * HW + p) * in_cs + c];
-    part[lane][threadIdx.x & 63] = s;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    if (c < C)      // C % 4 == 0: a float4 column is inside the tensor or entirely outside
+        for (int p = lane; p < HW; p += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(in + ((long)b * HW + p) * in_cs + c);
+            s[0] += (double)v.x; s[1] += (double)v.y; s[2] += (double)v.z; s[3] += (double)v.w;
+        }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) part[lane][col * 4 + e] = s[e];
     __syncthreads();
-    if (lane == 0 && c < C) {
-        s = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
-        out[(long)b * out_cs + c] = (float)(s / (double)HW);
+    if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < C) {
+        double t = 0.0;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) t += part[l][threadIdx.x];
+        out[(long)b * out_cs + blockIdx.x * 64 + threadIdx.x] = (float)(t / (double)HW);
     }
 }
 
 int launch_avgpool(const View& in, const View& out, int B, hipStream_t st) {
+    if (in.C % 4 || in.cs % 4 || ((uintptr_t)in.p & 15)) return fail("avgpool: channels must come in aligned groups of 4");
     hipLaunchKernelGGL(avgpool_kernel, dim3((in.C + 63) / 64, B), dim3(256), 0, st, in.p, out.p, in.H * in.W, in.C,
                        in.cs, out.cs);
     QB_CHECK(hipGetLastError());
@@ -421,33 +428,59 @@ int launch_copy_channels(const View& in, const View& out, int B, hipStream_t st)
 // planar bilinear x`scale` of the predictor logits, cropped to the frame (sem_seg_postprocess, model.py:266-289:
 // when H or W is not a multiple of 16 the x4 map is larger than the image and only its top-left H x W part is
 // kept); channels whose bit is set in mul_mask are multiplied by `scale` afterwards (offsets, model.py:695-700)
-__global__ void upsample_logits_kernel(const float* __restrict__ q, float* __restrict__ out, int planes, int h, int w,
-                                       int nch, int scale, int OH, int OW, unsigned mul_mask) {
+// One thread = V consecutive output pixels of one row of one plane (V = 4 with 16-byte stores when the row length
+// allows); all index arithmetic is 32-bit and per thread, not per element.
+template <int V>
+__global__ __launch_bounds__(256) void upsample_logits_kernel(const float* __restrict__ q, float* __restrict__ out, int h,
+                                                              int w, int nch, int scale, int OH, int OW,
+                                                              unsigned mul_mask) {
+    const int pl = blockIdx.y;                       // plane = frame * nch + channel
+    const unsigned per_row = (unsigned)OW / V;
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= per_row * (unsigned)OH) return;
+    const int oy = idx / per_row;
+    const int ox0 = (idx - oy * per_row) * V;
     const float inv = 1.f / (float)scale;
-    const long total = (long)planes * OH * OW;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int ox = i % OW;
-        long r = i / OW;
-        const int oy = r % OH;
-        const long pl = r / OH;
-        int y0, y1, x0, x1;
-        float ly, lx;
-        bilin_src(oy, inv, h, y0, y1, ly);
-        bilin_src(ox, inv, w, x0, x1, lx);
-        const float* s = q + pl * h * w;
-        const float hy = 1.f - ly, hx = 1.f - lx;
-        float v = hy * (hx * s[y0 * w + x0] + lx * s[y0 * w + x1]) + ly * (hx * s[y1 * w + x0] + lx * s[y1 * w + x1]);
-        if ((mul_mask >> (pl % nch)) & 1u) v *= (float)scale;
-        out[i] = v;
+    int y0, y1;
+    float ly;
+    bilin_src(oy, inv, h, y0, y1, ly);
+    const float hy = 1.f - ly;
+    const float* s0 = q + (long)pl * h * w + (long)y0 * w;
+    const float* s1 = q + (long)pl * h * w + (long)y1 * w;
+    const float mul = ((mul_mask >> (pl % nch)) & 1u) ? (float)scale : 1.f;
+    float o[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        int x0, x1;
+        float lx;
+        bilin_src(ox0 + e, inv, w, x0, x1, lx);
+        const float hx = 1.f - lx;
+        float v = hy * (hx * s0[x0] + lx * s0[x1]) + ly * (hx * s1[x0] + lx * s1[x1]);
+        if (mul != 1.f) v *= mul;
+        o[e] = v;
+    }
+    float* dst = out + ((long)pl * OH + oy) * OW + ox0;
+    if constexpr (V == 4) {
+        *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+        dst[0] = o[0];
     }
 }
 
 int launch_upsample_logits(const float* q, float* out, int B, int nch, int h, int w, int scale, int OH, int OW,
                            unsigned mul_mask, hipStream_t st) {
     if (OH > h * scale || OW > w * scale) return fail("upsample: frame larger than the scaled head map");
-    const long total = (long)B * nch * OH * OW;
-    hipLaunchKernelGGL(upsample_logits_kernel, dim3(cap_grid(total, 256)), dim3(256), 0, st, q, out, B * nch, h, w,
-                       nch, scale, OH, OW, mul_mask);
+    if ((long)OH * OW >= (1L << 31)) return fail("upsample: frame too large");
+    const int planes = B * nch;
+    if (OW % 4 == 0 && ((uintptr_t)out & 15) == 0) {
+        const unsigned n = (unsigned)(OW / 4) * OH;
+        hipLaunchKernelGGL(upsample_logits_kernel<4>, dim3((n + 255) / 256, planes), dim3(256), 0, st, q, out, h, w, nch,
+                           scale, OH, OW, mul_mask);
+    } else {
+        const unsigned n = (unsigned)OW * OH;
+        hipLaunchKernelGGL(upsample_logits_kernel<1>, dim3((n + 255) / 256, planes), dim3(256), 0, st, q, out, h, w, nch,
+                           scale, OH, OW, mul_mask);
+    }
     QB_CHECK(hipGetLastError());
     return 0;
 }

@@ -57,7 +57,14 @@ __global__ __launch_bounds__(1024) void select_kernel(const float* __restrict__ 
     const float* c = cand + (long)b * HW;
     // count strictly positive candidates
     unsigned local = 0;
-    for (int i = t; i < HW; i += 1024) local += c[i] > 0.f;
+    if ((HW & 3) == 0) {
+        for (int i = 4 * t; i < HW; i += 4096) {
+            const float4 v = *reinterpret_cast<const float4*>(c + i);
+            local += (v.x > 0.f) + (v.y > 0.f) + (v.z > 0.f) + (v.w > 0.f);
+        }
+    } else {
+        for (int i = t; i < HW; i += 1024) local += c[i] > 0.f;
+    }
     if (t == 0) s_npos = 0;
     __syncthreads();
     atomicAdd(&s_npos, local);
@@ -93,29 +100,62 @@ __global__ __launch_bounds__(1024) void select_kernel(const float* __restrict__ 
         }
         cut = __uint_as_float(s_prefix);
     }
-    // ordered compaction: thread t owns the contiguous pixel run [t*seg, (t+1)*seg)
-    const int seg = (HW + 1023) / 1024;
-    const int p0 = t * seg, p1 = min(HW, p0 + seg);
-    unsigned n = 0;
-    for (int i = p0; i < p1; ++i) n += c[i] > cut;
-    scan[t] = n;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const unsigned v = t >= o ? scan[t - o] : 0;
-        __syncthreads();
-        scan[t] += v;
-        __syncthreads();
-    }
-    unsigned pos = scan[t] - n;
-    for (int i = p0; i < p1; ++i)
-        if (c[i] > cut) {
-            if ((int)pos < cap) {
-                centers[((long)b * cap + pos) * 2] = i / W;
-                centers[((long)b * cap + pos) * 2 + 1] = i % W;
-            }
-            ++pos;
+    // ordered compaction: wave v owns the contiguous pixel run [v*seg, (v+1)*seg), walked 64 x 4 pixels at a time (lane l
+    // holds 4 consecutive pixels, so lane order is raster order); survivors are at most top_k - 1, so the second walk
+    // skips almost every step on its ballot
+    const int wave = t >> 6, lane = t & 63;
+    const int seg = ((HW + 15) / 16 + 255) / 256 * 256;          // multiple of the 256-pixel step
+    const int p0 = wave * seg, p1 = min(HW, p0 + seg);
+    auto flags = [&](int base) {                                    // bit e: pixel base + 4*lane + e survives
+        const int i = base + 4 * lane;
+        unsigned f = 0;
+        if (i + 3 < p1 && (HW & 3) == 0) {
+            const float4 v = *reinterpret_cast<const float4*>(c + i);
+            f = (v.x > cut ? 1u : 0u) | (v.y > cut ? 2u : 0u) | (v.z > cut ? 4u : 0u) | (v.w > cut ? 8u : 0u);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (i + e < p1 && c[i + e] > cut) f |= 1u << e;
         }
-    if (t == 1023) ncenters[b] = min((int)scan[1023], cap);
+        return f;
+    };
+    unsigned n = 0;
+    for (int base = p0; base < p1; base += 256) n += __popc(flags(base));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+    if (lane == 0) scan[wave] = n;
+    __syncthreads();
+    unsigned pos = 0, total = 0;
+    for (int v = 0; v < 16; ++v) {
+        if (v < wave) pos += scan[v];
+        total += scan[v];
+    }
+    if (n) {
+        for (int base = p0; base < p1; base += 256) {
+            const unsigned f = flags(base);
+            if (__ballot(f != 0) == 0) continue;
+            const unsigned cnt = __popc(f);
+            unsigned incl = cnt;                                    // inclusive scan of the per-lane counts
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned up = __shfl_up(incl, o);
+                if (lane >= o) incl += up;
+            }
+            unsigned at = pos + incl - cnt;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (f & (1u << e)) {
+                    const int i = base + 4 * lane + e;
+                    if ((int)at < cap) {
+                        centers[((long)b * cap + at) * 2] = i / W;
+                        centers[((long)b * cap + at) * 2 + 1] = i % W;
+                    }
+                    ++at;
+                }
+            pos += __shfl(incl, 63);
+        }
+    }
+    if (t == 0) ncenters[b] = min((int)total, cap);
 }
 
 // ---- P3: nearest-centre grouping + instance areas ----
