@@ -40,6 +40,9 @@ struct ConvP {
     int kchunk;          // K-slices per partition
     int nfull, tail_shift;   // split tail: tiles computed whole, log2(pieces per remaining tile)
     int ws_rows, ws_row0;    // output rows held in the workspace slabs
+    double* gn_sum;          // GroupNorm sums of the output [G][B][gn_groups][sum, sum of squares] (accumulated), or null
+    int gn_groups, gn_cpg;   // norm groups, channels per group
+    int ohw;                 // OH * OW
     int kmode;           // 0: k = (tap, c)   1: k = (c/32, tap, c%32)  (weights packed accordingly)
     long in_gs, out_gs, res_gs, w_gs;
     int ss_gs;

@@ -242,6 +242,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
     const float* __restrict__ shift = (p.shift && !raw) ? p.shift + g * p.ss_gs : nullptr;
     const bool relu = p.relu && !raw;
     const float* __restrict__ prelu = (p.prelu && !raw) ? p.prelu + g * p.ss_gs : nullptr;   // per-channel PReLU slopes
+    // GroupNorm sums of the stored values (the layer's consumer is a GroupNorm): fp64 sum and sum of squares per
+    // (image, norm group), gathered per block in LDS.  A tile spans at most two images (host: OH*OW >= BM).
+    __shared__ double gacc[2 * 32 * 2];        // [image b0 / b0+1][group][sum, sum of squares]
+    const bool gn = p.gn_sum != nullptr && !raw;
+    int b0 = 0, m_next = 0;
+    if (gn) {
+        if (t < 128) gacc[t] = 0.0;
+        b0 = m0 / p.ohw;
+        m_next = (b0 + 1) * p.ohw;
+    }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -256,6 +266,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
         const int nb = n0 + j * SW;    // first channel of this pass
         if (p.vec_out) {
             constexpr int CPR = SW / 4;  // float4 chunks per row
+            static_assert(NTH % CPR == 0, "a thread keeps its channel column across the rows of a pass");
+            double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
 #pragma unroll
             for (int c = t; c < BM * CPR; c += NTH) {
                 const int row = c / CPR, q = (c - row * CPR) * 4;
@@ -281,6 +293,23 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
                         v.z = v.z > 0.f ? v.z : v.z * sl.z; v.w = v.w > 0.f ? v.w : v.w * sl.w;
                     }
                     *reinterpret_cast<float4*>(out + (long)m * out_cs + n) = v;
+                    if (gn) {
+                        const double a = (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+                        const double b = (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+                        if (m < m_next) { s0 += a; q0 += b; } else { s1 += a; q1 += b; }
+                    }
+                }
+            }
+            if (gn) {
+                const int n = nb + (t % CPR) * 4;
+                if (n < p.Cout) {
+                    const int grp = n / p.gn_cpg;
+                    atomicAdd(&gacc[grp * 2], s0);
+                    atomicAdd(&gacc[grp * 2 + 1], q0);
+                    if (s1 != 0.0 || q1 != 0.0) {
+                        atomicAdd(&gacc[64 + grp * 2], s1);
+                        atomicAdd(&gacc[64 + grp * 2 + 1], q1);
+                    }
                 }
             }
         } else {
@@ -299,11 +328,21 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
         }
         if (j + 1 < TN) __syncthreads();
     }
+    if (gn) {
+        __syncthreads();
+        if (t < 128) {
+            const double v = gacc[t];
+            const int b = b0 + (t >> 6);
+            if (v != 0.0 && b < p.B)
+                atomicAdd(&p.gn_sum[(((long)g * p.B + b) * p.gn_groups) * 2 + (t & 63)], v);
+        }
+    }
 }
 
-// sums the split-K partial tiles in a fixed order (deterministic) and applies the fused epilogue
+// sums the split-K partial tiles in a fixed order (deterministic) and applies the fused epilogue; block x owns the
+// contiguous element range [x*chunk, (x+1)*chunk) so that, with GroupNorm sums requested, it meets at most two images
 template <int V>
-__global__ void splitk_reduce_kernel(const ConvP p, int S, int G) {
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvP p, int S, int G, long chunk) {
     using vec = __attribute__((ext_vector_type(V))) float;
     const int g = blockIdx.y;
     const long MN = (long)p.ws_rows * p.Cout;          // the rows [ws_row0, ws_row0 + ws_rows) were computed in pieces
@@ -312,7 +351,18 @@ __global__ void splitk_reduce_kernel(const ConvP p, int S, int G) {
     const float* __restrict__ prelu = p.prelu ? p.prelu + g * p.ss_gs : nullptr;
     const float* __restrict__ res = p.res ? p.res + (long)g * p.res_gs : nullptr;
     float* __restrict__ out = p.out + (long)g * p.out_gs;
-    for (long i = (blockIdx.x * (long)blockDim.x + threadIdx.x) * V; i < MN; i += (long)gridDim.x * blockDim.x * V) {
+    const long i0 = blockIdx.x * chunk, i1 = min(MN, i0 + chunk);
+    __shared__ double gacc[2 * 32 * 2];
+    const bool gn = p.gn_sum != nullptr;
+    int b0 = 0;
+    long m_next = 0;
+    if (gn) {
+        if (threadIdx.x < 128) gacc[threadIdx.x] = 0.0;
+        b0 = (int)((i0 / p.Cout + p.ws_row0) / p.ohw);
+        m_next = (long)(b0 + 1) * p.ohw;
+        __syncthreads();
+    }
+    for (long i = i0 + (long)threadIdx.x * V; i < i1; i += 256 * V) {
         const long mr = i / p.Cout;
         const int n = (int)(i - mr * p.Cout);
         const long m = mr + p.ws_row0;
@@ -330,8 +380,24 @@ __global__ void splitk_reduce_kernel(const ConvP p, int S, int G) {
         }
         if constexpr (V == 4) {
             *reinterpret_cast<vec*>(out + m * p.out_cs + n) = vec{o[0], o[1], o[2], o[3]};
+            if (gn) {   // host: V == 4 and 4 | channels per group whenever sums are requested
+                const double a = (double)o[0] + (double)o[1] + (double)o[2] + (double)o[3];
+                const double b = (double)o[0] * o[0] + (double)o[1] * o[1] + (double)o[2] * o[2] + (double)o[3] * o[3];
+                const int slot = (m < m_next ? 0 : 64) + (n / p.gn_cpg) * 2;
+                atomicAdd(&gacc[slot], a);
+                atomicAdd(&gacc[slot + 1], b);
+            }
         } else {
             out[m * p.out_cs + n] = o[0];
+        }
+    }
+    if (gn) {
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const double v = gacc[threadIdx.x];
+            const int b = b0 + (threadIdx.x >> 6);
+            if (v != 0.0 && b < p.B)
+                atomicAdd(&p.gn_sum[(((long)g * p.B + b) * p.gn_groups) * 2 + (threadIdx.x & 63)], v);
         }
     }
 }
@@ -388,6 +454,17 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
                 (!p.res || ((p.res_cs % 4 == 0) && (((uintptr_t)p.res & 15) == 0) && (p.res_gs % 4 == 0))) &&
                 (!p.scale || ((((uintptr_t)p.scale & 15) == 0) && (p.ss_gs % 4 == 0))) &&
                 (!p.prelu || ((((uintptr_t)p.prelu & 15) == 0) && (p.ss_gs % 4 == 0)));
+    // GroupNorm sums in the epilogue: 16-byte stores, whole float4s inside one norm group, at most 32 groups, and images
+    // of at least one tile of rows (a tile then meets at most two images); otherwise a separate pass over the output
+    const bool gn_sep = p.gn_sum && !(p.vec_out && p.gn_cpg % 4 == 0 && p.gn_groups <= 32 && p.ohw >= BM && p.ohw >= 8);
+    double* const gn_sum = p.gn_sum;
+    if (gn_sep) p.gn_sum = nullptr;
+    auto gn_separate = [&]() {
+        if (!gn_sep) return 0;
+        View o;
+        o.p = p.out; o.B = p.B; o.H = p.OH; o.W = p.OW; o.C = p.Cout; o.cs = p.out_cs; o.gs = p.out_gs;
+        return launch_gn_stats(o, p.B, G, p.gn_groups, gn_sum, st, false);
+    };
     const int nk = p.Kpad / BK;
     if (p.ws && g_force_split > 0) S = g_force_split;
     if (!p.ws || S < 1) S = 1;
@@ -403,15 +480,16 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
     const dim3 block(WM * WN * 64);
     auto reduce = [&](int parts) {
         const long MN = (long)p.ws_rows * p.Cout;
-        if (p.vec_out) {
-            int blocks = (int)((MN / 4 + 255) / 256);
-            if (blocks > 2048) blocks = 2048;
-            hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(blocks, G), dim3(256), 0, st, p, parts, G);
-        } else {
-            int blocks = (int)((MN + 255) / 256);
-            if (blocks > 2048) blocks = 2048;
-            hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(blocks, G), dim3(256), 0, st, p, parts, G);
-        }
+        const int V = p.vec_out ? 4 : 1;
+        long chunk = (MN + 2047) / 2048;                       // at most 2048 blocks ...
+        if (chunk < 256L * V * 4) chunk = 256L * V * 4;        // ... of at least 4 elements-vectors per thread
+        chunk = (chunk + V - 1) / V * V;
+        if (p.gn_sum && chunk / p.Cout + 2 > p.ohw) chunk = (long)(p.ohw - 2) * p.Cout / V * V;   // at most two images per block
+        const int blocks = (int)((MN + chunk - 1) / chunk);
+        if (p.vec_out)
+            hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(blocks, G), dim3(256), 0, st, p, parts, G, chunk);
+        else
+            hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(blocks, G), dim3(256), 0, st, p, parts, G, chunk);
     };
     // Split tail: with more than one round of tiles, cut the tiles of the ragged last round into 2^shift K-pieces that
     // together fill about one more (short) round; taken when the model prices it below the launch chosen so far.
@@ -439,7 +517,7 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
                                    st, p);
                 reduce(1 << shift);
                 QB_CHECK(hipGetLastError());
-                return 0;
+                return gn_separate();
             }
         }
     }
@@ -450,7 +528,7 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
         hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 0>), dim3(p.mtiles * p.ntiles, 1, G), block, 0, st, p);
     }
     QB_CHECK(hipGetLastError());
-    return 0;
+    return gn_separate();
 }
 
 int launch_conv(const ConvP& p, int G, hipStream_t st) {

@@ -18,6 +18,7 @@
 
 #include <functional>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -82,9 +83,13 @@ constexpr int BLOCKS50[4] = {3, 4, 6, 3}, BLOCKS101[4] = {3, 4, 23, 3}, BLOCKS15
 
 enum Affine { AF_NONE, AF_FROZEN_BN, AF_BIAS, AF_BIAS_BN };
 
+struct GnFuse { double* sums = nullptr; int groups = 0; };
+struct LastConv { std::shared_ptr<GnFuse> fuse; const float* out = nullptr; int G = 0, C = 0; };
+
 struct Builder {
     quber_ctx* c;
     bool dry;
+    LastConv last_conv;
     std::string err;
     int Bmax, H, W;
 
@@ -188,12 +193,19 @@ struct Builder {
         p.kmode = kmode;
         p.in_gs = in.gs; p.out_gs = out.gs; p.res_gs = res ? res->gs : 0;
         p.w_gs = (long)Cout * Kpad; p.ss_gs = Cout;
+        p.ohw = OH * OW;
         quber_ctx* ctx = c;
-        c->ops.push_back({[p, G, ctx](int B, hipStream_t st) mutable {
+        // a GroupNorm that consumes this output may ask the convolution for its sums (gn_relu fills `fuse` in)
+        auto fuse = std::make_shared<GnFuse>();
+        last_conv = {fuse, out.p, G, Cout};
+        c->ops.push_back({[p, G, ctx, fuse](int B, hipStream_t st) mutable {
             p.B = B;
             p.M = B * p.OH * p.OW;
             p.ws = ctx->splitk_ws;
             p.ws_floats = ctx->splitk_floats;
+            p.gn_sum = fuse->sums;
+            p.gn_groups = fuse->groups;
+            p.gn_cpg = fuse->groups ? p.Cout / fuse->groups : 0;
             return launch_conv(p, G, st);
         }, OP_CONV, name, 2.0 * OH * OW * (double)cin_real * k * k * Cout * G, 1});
     }
@@ -250,11 +262,20 @@ struct Builder {
         // every GroupNorm owns a slot of the sum accumulators; one launch at the start of the forward clears them all
         if (c->gn_slots >= GN_SLOTS) { if (err.empty()) err = "more GroupNorm layers than accumulator slots"; return; }
         double* stats = c->gn_stats + (size_t)c->gn_slots++ * gn_slot_doubles(c->cfg.max_batch);
+        // the producer is the convolution emitted just before: it accumulates the sums while it stores its output
+        const bool fused = last_conv.fuse && last_conv.out == in.p && last_conv.G == G && last_conv.C == C;
+        if (fused) {
+            last_conv.fuse->sums = stats;
+            last_conv.fuse->groups = 32;
+            last_conv.fuse.reset();
+        }
         c->ops.push_back({[=](int B, hipStream_t st) {
-            int rc = launch_gn_stats(in, B, G, 32, stats, st, false);
-            if (rc) return rc;
+            if (!fused) {
+                int rc = launch_gn_stats(in, B, G, 32, stats, st, false);
+                if (rc) return rc;
+            }
             return launch_gn_apply(in, out, B, G, 32, stats, dg, db, C, 1e-5f, 1, st);
-        }, OP_NORM, names[0], 0.0, 2});
+        }, OP_NORM, names[0], 0.0, fused ? 1 : 2});
     }
 
     void op(std::function<int(int, hipStream_t)> f) {
