@@ -201,7 +201,9 @@ def main():
                        "instances_out_per_frame_mean": float(count.mean())},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "conv_igemm_f32 (all instantiations)", "launches_per_step": conv_n,
+                         "kernel": "conv_igemm_f32 (all instantiations; the timed launches include the fused affine / residual / "
+                                   "ReLU epilogue, the GroupNorm sums of the output and the split-K reduce pass)",
+                         "launches_per_step": conv_n,
                          "avg_launch_ms": cms / max(conv_n, 1), "flops_per_launch": flops / max(conv_n, 1),
                          "forward_ms": {"conv": cms, "groupnorm": float(np.median(norm_ms)),
                                         "other": float(np.median(other_ms))}},
