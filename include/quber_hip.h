@@ -159,6 +159,8 @@ int quber_debug_tensor(quber_ctx* ctx, const char* name, float** dev_ptr, int32_
 double quber_forward_flops(quber_ctx* ctx);
 /* test-harness knobs: key 2 = give the stand-alone quber_op_conv2d a split-K workspace (value != 0) or drop it (0);
  * key 3 = force the number of K partitions of convolutions that have a workspace (0 = automatic);
+ * key 7 = smallest input width (channels) routed to the Winograd path (default 256);
+ * key 6 = Winograd F(2x2,3x3) path of the eligible 3x3 layers: 0 = where it pays (default), 1 = never, 2 = always;
  * key 5 = split the ragged last round of large convolution launches into K-pieces: when the cost model
  *         favours it (1, default), never (0), whenever feasible (2);
  * key 4 = force the convolution tile shape (1 = 64x64, 2 = 128x128, 4 = 256x32; 0 = automatic) */
@@ -172,6 +174,13 @@ int quber_op_conv2d(const float* dev_x, int32_t batch, int32_t h, int32_t w, int
                     int32_t cout, int32_t ksize, int32_t stride, int32_t pad, int32_t dil, const float* dev_scale,
                     const float* dev_shift, const float* dev_residual, int32_t relu, float* dev_packed_scratch,
                     float* dev_y, void* stream);
+/* the same for a 3x3 / stride 1 / pad 1 convolution through the Winograd F(2x2,3x3) path (cin >= 256 and a multiple
+ * of 32, cout >= 128): dev_u_scratch holds 16*cout*cin floats (transformed weights), dev_ws at least
+ * 16 * batch * ceil(h/2) * ceil(w/2) * (cin + cout) floats */
+int quber_op_conv3x3_winograd(const float* dev_x, int32_t batch, int32_t h, int32_t w, int32_t cin,
+                              const float* dev_w_oihw, int32_t cout, const float* dev_scale, const float* dev_shift,
+                              int32_t relu, float* dev_u_scratch, float* dev_ws, int64_t ws_floats, float* dev_y,
+                              void* stream);
 int quber_op_groupnorm(const float* dev_x, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t groups,
                        const float* dev_gamma, const float* dev_beta, float eps, int32_t relu,
                        double* dev_stats_scratch, float* dev_y, void* stream);

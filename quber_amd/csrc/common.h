@@ -51,8 +51,27 @@ struct ConvP {
 void set_error(const std::string& msg);
 int fail(const std::string& msg);
 
+// one 3x3 / stride 1 / pad 1 convolution through Winograd F(2x2,3x3) (winograd.hip)
+struct WinoP {
+    View in, out;            // NHWC views; groups via View::gs
+    const float* u;          // transformed weights [G][16][Cout][Cin]
+    const float* scale;      // per-channel affine of the epilogue ([G][Cout], stride ss_gs) or null
+    const float* shift;
+    int ss_gs, relu;
+    float* ws;               // V | M workspace (winograd_ws_floats)
+    size_t ws_floats;
+    float* splitk_ws;        // forwarded to the grouped GEMM launch
+    size_t splitk_floats;
+};
+
 // launchers (all asynchronous on `st`, no allocation, no synchronisation)
 int launch_conv(const ConvP& p, int G, hipStream_t st);
+int launch_conv_winograd(const WinoP& q, int B, int G, hipStream_t st);
+int launch_winograd_weights(const float* w_oihw, int Cout, int Cin, float* u, hipStream_t st);
+void winograd_weights_host(const float* w_oihw, int Cout, int Cin, float* u);
+bool winograd_eligible(int k, int stride, int pad, int dil, int Cin, int Cout);
+size_t winograd_ws_floats(int B, int H, int W, int Cin, int Cout, int G);
+extern int g_winograd, g_wino_min_cin;
 extern int g_force_split, g_force_tile, g_tail_split;
 int launch_preprocess(const uint8_t* rgb, const uint8_t* depth, const float* offs, float* x, int B, int Bcap,
                       int H, int W, const float* mean6, const float* std6, int streams, hipStream_t st);

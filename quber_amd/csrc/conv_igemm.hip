@@ -402,6 +402,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvP p, int S
     }
 }
 
+int g_winograd = 0;       // key 6: Winograd path for the eligible 3x3 layers: 0 = where it pays, 1 = never, 2 = always
 int g_force_tile = 0;     // test-harness knobs (quber_set_tuning keys 4 / 3): force the tile shape / the number of K partitions
 int g_force_split = 0;
 int g_tail_split = 1;      // key 5: split the ragged last round of large launches when the model favours it (1), never (0), whenever feasible (2)

@@ -65,6 +65,8 @@ struct quber_ctx {
     int gn_slots = 0;
     float* splitk_ws = nullptr;
     size_t splitk_floats = 0;
+    float* wino_ws = nullptr;     // V | M of the Winograd layers (sized for the largest one at max_batch)
+    size_t wino_floats = 0;
     float* X = nullptr;   // [2][Bmax][H][W][8]
     float* q = nullptr;   // [Bmax][planes][H/4][W/4]
     const uint8_t* cur_bgr = nullptr;
@@ -195,10 +197,29 @@ struct Builder {
         p.w_gs = (long)Cout * Kpad; p.ss_gs = Cout;
         p.ohw = OH * OW;
         quber_ctx* ctx = c;
+        // Winograd F(2x2,3x3) alternative for the wide plain 3x3 layers; chosen per launch (batch) in the lambda below
+        WinoP wq{};
+        const bool wino = winograd_eligible(k, stride, pad, dil, Cin, Cout) && cin_real == Cin && !res && prelu.empty();
+        if (wino) {
+            std::vector<float> u((size_t)G * 16 * Cout * Cin);
+            for (int g = 0; g < G; ++g) winograd_weights_host(w[g], Cout, Cin, &u[(size_t)g * 16 * Cout * Cin]);
+            wq.in = in; wq.out = out; wq.u = upload(u);
+            wq.scale = p.scale; wq.shift = p.shift; wq.ss_gs = Cout; wq.relu = relu;
+            const size_t need = winograd_ws_floats(Bmax, in.H, in.W, Cin, Cout, G);
+            if (need > c->wino_floats) c->wino_floats = need;
+        }
         // a GroupNorm that consumes this output may ask the convolution for its sums (gn_relu fills `fuse` in)
         auto fuse = std::make_shared<GnFuse>();
         last_conv = {fuse, out.p, G, Cout};
-        c->ops.push_back({[p, G, ctx, fuse](int B, hipStream_t st) mutable {
+        c->ops.push_back({[p, G, ctx, fuse, wq, wino](int B, hipStream_t st) mutable {
+            // Winograd pays once the 16 GEMMs have a few thousand tile rows each (sweep: profiles/r01l_winograd.md)
+            if (wino && ctx->wino_ws && g_winograd != 1 && (g_winograd == 2 || (long)B * ((p.H + 1) / 2) * ((p.W + 1) / 2) >= 4096)) {
+                wq.ws = ctx->wino_ws; wq.ws_floats = ctx->wino_floats;
+                wq.splitk_ws = ctx->splitk_ws; wq.splitk_floats = ctx->splitk_floats;
+                int rc = launch_conv_winograd(wq, B, G, st);
+                if (rc || !fuse->sums) return rc;
+                return launch_gn_stats(wq.out, B, G, fuse->groups, fuse->sums, st, false);
+            }
             p.B = B;
             p.M = B * p.OH * p.OW;
             p.ws = ctx->splitk_ws;
@@ -864,6 +885,7 @@ int quber_finalize_weights(quber_ctx* c) {
     } else {
         b.build();
     }
+    if (c->wino_floats) c->wino_ws = (float*)b.dalloc_bytes(sizeof(float) * c->wino_floats);
     if (!b.err.empty()) {
         c->ops.clear();
         return fail(b.err);
@@ -885,6 +907,8 @@ void quber_set_tuning(int32_t key, int32_t value) {
         }
     }
     if (key == 4) g_force_tile = value;    // force the tile shape: 1 = 64x64, 2 = 128x128, 4 = 256x32 (0 = automatic)
+    if (key == 7) g_wino_min_cin = value;  // smallest input width eligible for the Winograd path (default 256)
+    if (key == 6) g_winograd = value;      // Winograd F(2x2,3x3) for the eligible 3x3 layers: 0 = where it pays, 1 = never, 2 = always
     if (key == 5) g_tail_split = value;    // split the ragged last round of large convolution launches (default 1)
     if (key == 3) g_force_split = value;   // force the number of K partitions of every convolution with a workspace (0 = automatic)
 }
@@ -1078,6 +1102,24 @@ int quber_op_conv2d(const float* x, int32_t B, int32_t h, int32_t w, int32_t cin
     p.ws = g_op_ws;
     p.ws_floats = g_op_ws ? g_op_ws_floats : 0;
     return launch_conv(p, 1, st);
+}
+
+static View mkview(const float* p, int B, int h, int w, int c);
+
+int quber_op_conv3x3_winograd(const float* x, int32_t B, int32_t h, int32_t w, int32_t cin, const float* w_oihw, int32_t cout,
+                              const float* scale, const float* shift, int32_t relu, float* u, float* ws, int64_t ws_floats,
+                              float* y, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!winograd_eligible(3, 1, 1, 1, cin, cout)) return fail("winograd: unsupported channel counts");
+    if ((scale == nullptr) != (shift == nullptr)) return fail("winograd: scale and shift go together");
+    int rc = launch_winograd_weights(w_oihw, cout, cin, u, st);
+    if (rc) return rc;
+    WinoP q{};
+    q.in = mkview(x, B, h, w, cin); q.out = mkview(y, B, h, w, cout);
+    q.u = u; q.scale = scale; q.shift = shift; q.ss_gs = 0; q.relu = relu;
+    q.ws = ws; q.ws_floats = (size_t)ws_floats;
+    q.splitk_ws = g_op_ws; q.splitk_floats = g_op_ws ? g_op_ws_floats : 0;
+    return launch_conv_winograd(q, B, 1, st);
 }
 
 static View mkview(const float* p, int B, int h, int w, int c) {

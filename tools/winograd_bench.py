@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Direct implicit-GEMM vs Winograd F(2x2,3x3) on the eligible 3x3 layers of the refiner (stand-alone ops)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from quber_amd import _lib  # noqa: E402
+
+lib = _lib.load()
+lib.quber_set_tuning(2, 1)
+lib.quber_set_tuning(7, 32)
+st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+print(f"| layer ({F} frames) | GFLOP | direct ms | TF/s | winograd ms | effective TF/s | speed-up |")
+print("|---|---|---|---|---|---|---|")
+for name, ipf, H, W, Cin, Cout in [("fusion_res2 3x3 256>256 @120x160", 1, 120, 160, 256, 256),
+                                   ("fusion_res3 3x3 512>512 @60x80", 1, 60, 80, 512, 512),
+                                   ("res4.conv2 3x3 256>256 @30x40 (2 streams)", 2, 30, 40, 256, 256),
+                                   ("decoder.res3.fuse0 3x3 320>128 @60x80", 1, 60, 80, 320, 128),
+                                   ("decoder.res2.fuse0 3x3 160>128 @120x160", 1, 120, 160, 160, 128),
+                                   ("head 3x3 128>128 @120x160", 1, 120, 160, 128, 128),
+                                   ("heads x3 3x3 128>128 @120x160", 3, 120, 160, 128, 128),
+                                   ("head 3x3 128>32 @120x160", 1, 120, 160, 128, 32),
+                                   ("res3.conv2 3x3 128>128 @60x80 (2 streams)", 2, 60, 80, 128, 128),
+                                   ("res2.conv2 3x3 64>64 @120x160 (2 streams)", 2, 120, 160, 64, 64),
+                                   ("stem.conv3 3x3 32>64 @240x320 (2 streams)", 2, 240, 320, 32, 64)]:
+    B = ipf * F
+    x = torch.randn(B, H, W, Cin, device="cuda")
+    w = torch.randn(Cout, Cin, 3, 3, device="cuda") / np.sqrt(Cin * 9)
+    sc, sh = torch.rand(Cout, device="cuda") + 0.5, torch.randn(Cout, device="cuda")
+    y = torch.empty(B, H, W, Cout, device="cuda")
+    packed = torch.empty(Cout * 9 * Cin, device="cuda")
+    tiles = B * ((H + 1) // 2) * ((W + 1) // 2)
+    u = torch.empty(16 * Cout * Cin, device="cuda")
+    ws = torch.empty(16 * tiles * (Cin + Cout), device="cuda")
+    fl = 2.0 * B * H * W * Cin * 9 * Cout
+
+    def timed(fn):
+        ts = []
+        for rd in range(6):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            if rd:
+                ts.append(e0.elapsed_time(e1) / 3)
+        return float(np.median(ts))
+
+    td = timed(lambda: _lib.check(lib.quber_op_conv2d(p(x), B, H, W, Cin, p(w), Cout, 3, 1, 1, 1, p(sc), p(sh), p(None), 1,
+                                                      p(packed), p(y), st)))
+    try:
+        tw = timed(lambda: _lib.check(lib.quber_op_conv3x3_winograd(p(x), B, H, W, Cin, p(w), Cout, p(sc), p(sh), 1, p(u), p(ws),
+                                                                    ws.numel(), p(y), st)))
+        print("| %s | %.1f | %.3f | %.1f | %.3f | %.1f | %.2fx |" % (name, fl / 1e9, td, fl / td / 1e9, tw, fl / tw / 1e9, td / tw), flush=True)
+    except Exception as e:
+        print("| %s | %.1f | %.3f | %.1f | n/a (%s) | | |" % (name, fl / 1e9, td, fl / td / 1e9, str(e)[:40]), flush=True)
