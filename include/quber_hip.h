@@ -157,6 +157,9 @@ int quber_normalize_depth(const void* dev_depth, int32_t is_float32, int64_t n_p
 int quber_debug_tensor(quber_ctx* ctx, const char* name, float** dev_ptr, int32_t* dims4, int32_t* channel_stride);
 /* algorithmic FLOPs of one forward at batch 1 (2 * MACs of every convolution) */
 double quber_forward_flops(quber_ctx* ctx);
+/* FLOPs the matrix pipe actually executes per forward at batch 1: the layers routed through Winograd F(2x2,3x3)
+ * count 16/36 of their algorithmic FLOPs (transform additions not counted) */
+double quber_forward_flops_executed(quber_ctx* ctx);
 /* test-harness knobs: key 2 = give the stand-alone quber_op_conv2d a split-K workspace (value != 0) or drop it (0);
  * key 3 = force the number of K partitions of convolutions that have a workspace (0 = automatic);
  * key 7 = smallest input width (channels) routed to the Winograd path (default 256);

@@ -51,6 +51,7 @@ SIGNATURES = {
     "quber_normalize_depth": (C.c_int, [_P, _I, C.c_int64, C.c_double, C.c_double, _P, _P, _P]),
     "quber_debug_tensor": (C.c_int, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(_I * 4), C.POINTER(_I)]),
     "quber_forward_flops": (C.c_double, [_P]),
+    "quber_forward_flops_executed": (C.c_double, [_P]),
     "quber_set_tuning": (None, [_I, _I]),
     "quber_num_ops": (C.c_int, [_P]),
     "quber_op_info": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(_I), C.POINTER(C.c_double), C.POINTER(_I)]),

@@ -58,6 +58,8 @@ struct WinoP {
     const float* scale;      // per-channel affine of the epilogue ([G][Cout], stride ss_gs) or null
     const float* shift;
     int ss_gs, relu;
+    double* gn_sum;          // GroupNorm sums of the output to accumulate ([G][B][gn_groups][2]) or null
+    int gn_groups;
     float* ws;               // V | M workspace (winograd_ws_floats)
     size_t ws_floats;
     float* splitk_ws;        // forwarded to the grouped GEMM launch

@@ -74,6 +74,7 @@ struct quber_ctx {
     const float* cur_off = nullptr;
     float* cur_out = nullptr;
     double flops = 0.0;
+    double wino_flops = 0.0;      // algorithmic FLOPs (batch 1) of the layers that take the Winograd path
     std::vector<hipEvent_t> prof_events;
     bool finalized = false;
     int device = 0;
@@ -207,18 +208,20 @@ struct Builder {
             wq.scale = p.scale; wq.shift = p.shift; wq.ss_gs = Cout; wq.relu = relu;
             const size_t need = winograd_ws_floats(Bmax, in.H, in.W, Cin, Cout, G);
             if (need > c->wino_floats) c->wino_floats = need;
+            c->wino_flops += 2.0 * OH * OW * (double)cin_real * k * k * Cout * G;
         }
         // a GroupNorm that consumes this output may ask the convolution for its sums (gn_relu fills `fuse` in)
         auto fuse = std::make_shared<GnFuse>();
         last_conv = {fuse, out.p, G, Cout};
         c->ops.push_back({[p, G, ctx, fuse, wq, wino](int B, hipStream_t st) mutable {
-            // Winograd pays once the 16 GEMMs have a few thousand tile rows each (sweep: profiles/r01l_winograd.md)
-            if (wino && ctx->wino_ws && g_winograd != 1 && (g_winograd == 2 || (long)B * ((p.H + 1) / 2) * ((p.W + 1) / 2) >= 4096)) {
+            // Winograd F(2x2,3x3) wins on every eligible layer (>= 128 channels in and out) at every batch size
+            // (profiles/r01l_winograd.md); frames of a handful of tiles stay on the direct kernel
+            const long trows = (long)B * ((p.H + 1) / 2) * ((p.W + 1) / 2);
+            if (wino && ctx->wino_ws && g_winograd != 1 && (g_winograd == 2 || trows >= 256)) {
                 wq.ws = ctx->wino_ws; wq.ws_floats = ctx->wino_floats;
                 wq.splitk_ws = ctx->splitk_ws; wq.splitk_floats = ctx->splitk_floats;
-                int rc = launch_conv_winograd(wq, B, G, st);
-                if (rc || !fuse->sums) return rc;
-                return launch_gn_stats(wq.out, B, G, fuse->groups, fuse->sums, st, false);
+                wq.gn_sum = fuse->sums; wq.gn_groups = fuse->groups;
+                return launch_conv_winograd(wq, B, G, st);
             }
             p.B = B;
             p.M = B * p.OH * p.OW;
@@ -878,6 +881,7 @@ int quber_finalize_weights(quber_ctx* c) {
     if (c->finalized) return fail("weights already finalized");
     Builder b(c, false);
     c->flops = 0.0;
+    c->wino_flops = 0.0;
     if (c->cfg.with_network == 2) {
         c->splitk_floats = (size_t)4 << 20;
         c->splitk_ws = (float*)b.dalloc_bytes(sizeof(float) * c->splitk_floats);
@@ -897,6 +901,11 @@ int quber_finalize_weights(quber_ctx* c) {
 }
 
 double quber_forward_flops(quber_ctx* c) { return c ? c->flops : 0.0; }
+double quber_forward_flops_executed(quber_ctx* c) {
+    if (!c) return 0.0;
+    // Winograd F(2x2,3x3) layers multiply 16 instead of 36 times per 2x2 output tile and channel pair
+    return g_winograd == 1 ? c->flops : c->flops - c->wino_flops * (1.0 - 16.0 / 36.0);
+}
 void quber_set_tuning(int32_t key, int32_t value) {
     if (key == 2) {   // stand-alone conv op: allocate (value != 0) or drop the split-K workspace
         if (value && !g_op_ws) {

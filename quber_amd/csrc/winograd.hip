@@ -16,7 +16,7 @@
 
 namespace quber {
 
-int g_wino_min_cin = 256;   // key 7 (test harness): smallest input width routed to this path
+int g_wino_min_cin = 128;   // key 7 (test harness): smallest input width routed to this path
 
 // tile (ty, tx) of image b covers output rows 2ty..2ty+1, columns 2tx..2tx+1 and reads input rows 2ty-1..2ty+2
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ in, int B, int H, int W, int C4, int in_cs,
@@ -67,23 +67,30 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
     }
 }
 
+// A block handles OUT_ITERS groups of tiles; with `gn_sum` it also accumulates the GroupNorm sums of what it stores
+// (fp64, LDS per block, one global atomic per (image, group) per block - as the direct kernel's epilogue does).
+constexpr int OUT_ITERS = 4;
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ m, long m_gs, int B, int OH, int OW, int C4,
                                                           int TH, int TW, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int ss_gs, int relu,
-                                                          float* __restrict__ out, int out_cs, long out_gs) {
+                                                          float* __restrict__ out, int out_cs, long out_gs,
+                                                          double* __restrict__ gn_sum, int gn_groups, int gn_cpg) {
     const int g = blockIdx.z;
     m += g * m_gs;
     out += g * out_gs;
     const int tpb = 256 / C4;
     const int c4 = tpb ? threadIdx.x % C4 : blockIdx.y * 256 + threadIdx.x;
     const long tiles = (long)B * TH * TW;
-    const long tile = tpb ? (long)blockIdx.x * tpb + threadIdx.x / C4 : blockIdx.x;
-    if (tile >= tiles || c4 >= C4 || (tpb && (int)(threadIdx.x / C4) >= tpb)) return;
-    const int tx = tile % TW;
-    const long r = tile / TW;
-    const int ty = r % TH;
-    const int b = r / TH;
-    const float* src = m + tile * (long)(C4 * 4) + c4 * 4;
+    const int step = tpb ? tpb : 1;                  // tiles per iteration
+    const long tile0 = (long)blockIdx.x * step * OUT_ITERS;
+    const bool lane_ok = c4 < C4 && (!tpb || (int)(threadIdx.x / C4) < tpb);
+    __shared__ double gacc[2 * 32 * 2];              // [image b0 / b0+1][group][sum, sum of squares]
+    const int b0 = (int)(tile0 / ((long)TH * TW));
+    if (gn_sum) {
+        if (threadIdx.x < 128) gacc[threadIdx.x] = 0.0;
+        __syncthreads();
+    }
+    double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
     const long ps = tiles * (long)(C4 * 4);
     auto add3 = [](const float4& a, const float4& b, const float4& c) {
         return make_float4(a.x + b.x + c.x, a.y + b.y + c.y, a.z + b.z + c.z, a.w + b.w + c.w);
@@ -91,38 +98,64 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     auto sub3 = [](const float4& a, const float4& b, const float4& c) {
         return make_float4(a.x - b.x - c.x, a.y - b.y - c.y, a.z - b.z - c.z, a.w - b.w - c.w);
     };
-    float4 s[2][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {                    // A^T M
-        const float4 m0 = *reinterpret_cast<const float4*>(src + (0 * 4 + j) * ps);
-        const float4 m1 = *reinterpret_cast<const float4*>(src + (1 * 4 + j) * ps);
-        const float4 m2 = *reinterpret_cast<const float4*>(src + (2 * 4 + j) * ps);
-        const float4 m3 = *reinterpret_cast<const float4*>(src + (3 * 4 + j) * ps);
-        s[0][j] = add3(m0, m1, m2);
-        s[1][j] = sub3(m1, m2, m3);
-    }
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (scale) {
+    if (scale && lane_ok) {
         sc = *reinterpret_cast<const float4*>(scale + g * ss_gs + c4 * 4);
         sh = *reinterpret_cast<const float4*>(shift + g * ss_gs + c4 * 4);
     }
+    for (int it = 0; it < OUT_ITERS; ++it) {
+        const long tile = tile0 + (long)it * step + (tpb ? threadIdx.x / C4 : 0);
+        if (!lane_ok || tile >= tiles) continue;
+        const int tx = tile % TW;
+        const long r = tile / TW;
+        const int ty = r % TH;
+        const int b = r / TH;
+        const float* src = m + tile * (long)(C4 * 4) + c4 * 4;
+        float4 s[2][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int oy = 2 * ty + i;
-        if (oy >= OH) continue;
+        for (int j = 0; j < 4; ++j) {                // A^T M
+            const float4 m0 = *reinterpret_cast<const float4*>(src + (0 * 4 + j) * ps);
+            const float4 m1 = *reinterpret_cast<const float4*>(src + (1 * 4 + j) * ps);
+            const float4 m2 = *reinterpret_cast<const float4*>(src + (2 * 4 + j) * ps);
+            const float4 m3 = *reinterpret_cast<const float4*>(src + (3 * 4 + j) * ps);
+            s[0][j] = add3(m0, m1, m2);
+            s[1][j] = sub3(m1, m2, m3);
+        }
+        double a = 0.0, q = 0.0;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int ox = 2 * tx + j;
-            if (ox >= OW) continue;
-            float4 y = j == 0 ? add3(s[i][0], s[i][1], s[i][2]) : sub3(s[i][1], s[i][2], s[i][3]);   // (A^T M) A
-            if (scale) {
-                y.x = fmaf(y.x, sc.x, sh.x); y.y = fmaf(y.y, sc.y, sh.y);
-                y.z = fmaf(y.z, sc.z, sh.z); y.w = fmaf(y.w, sc.w, sh.w);
+        for (int i = 0; i < 2; ++i) {
+            const int oy = 2 * ty + i;
+            if (oy >= OH) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int ox = 2 * tx + j;
+                if (ox >= OW) continue;
+                float4 y = j == 0 ? add3(s[i][0], s[i][1], s[i][2]) : sub3(s[i][1], s[i][2], s[i][3]);   // (A^T M) A
+                if (scale) {
+                    y.x = fmaf(y.x, sc.x, sh.x); y.y = fmaf(y.y, sc.y, sh.y);
+                    y.z = fmaf(y.z, sc.z, sh.z); y.w = fmaf(y.w, sc.w, sh.w);
+                }
+                if (relu) {
+                    y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
+                }
+                *reinterpret_cast<float4*>(out + (((long)b * OH + oy) * OW + ox) * out_cs + c4 * 4) = y;
+                a += (double)y.x + (double)y.y + (double)y.z + (double)y.w;
+                q += (double)y.x * y.x + (double)y.y * y.y + (double)y.z * y.z + (double)y.w * y.w;
             }
-            if (relu) {
-                y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
-            }
-            *reinterpret_cast<float4*>(out + (((long)b * OH + oy) * OW + ox) * out_cs + c4 * 4) = y;
+        }
+        if (b == b0) { s0 += a; q0 += q; } else { s1 += a; q1 += q; }
+    }
+    if (gn_sum) {
+        if (lane_ok) {
+            const int grp = c4 * 4 / gn_cpg;
+            if (s0 != 0.0 || q0 != 0.0) { atomicAdd(&gacc[grp * 2], s0); atomicAdd(&gacc[grp * 2 + 1], q0); }
+            if (s1 != 0.0 || q1 != 0.0) { atomicAdd(&gacc[64 + grp * 2], s1); atomicAdd(&gacc[64 + grp * 2 + 1], q1); }
+        }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const double v = gacc[threadIdx.x];
+            const int b = b0 + (threadIdx.x >> 6);
+            if (v != 0.0 && b < B) atomicAdd(&gn_sum[(((long)g * B + b) * gn_groups) * 2 + (threadIdx.x & 63)], v);
         }
     }
 }
@@ -172,7 +205,7 @@ int launch_winograd_weights(const float* w_oihw, int Cout, int Cin, float* u, hi
 
 bool winograd_eligible(int k, int stride, int pad, int dil, int Cin, int Cout) {
     return k == 3 && stride == 1 && pad == 1 && dil == 1 && Cin % 32 == 0 && Cout % 4 == 0 && Cin >= g_wino_min_cin &&
-           Cout >= 32 && (Cin / 4 <= 256 || (Cin / 4) % 256 == 0) && (Cout / 4 <= 256 || (Cout / 4) % 256 == 0);
+           Cout >= 128 && (Cin / 4 <= 256 || (Cin / 4) % 256 == 0) && (Cout / 4 <= 256 || (Cout / 4) % 256 == 0);
 }
 
 size_t winograd_ws_floats(int B, int H, int W, int Cin, int Cout, int G) {
@@ -210,9 +243,17 @@ int launch_conv_winograd(const WinoP& q, int B, int G, hipStream_t st) {
     p.ws = q.splitk_ws; p.ws_floats = q.splitk_floats;
     int rc = launch_conv(p, G * 16, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(wino_output_kernel, grid(Cout / 4), dim3(256), 0, st, m, 16 * tiles * Cout, B, H, W, Cout / 4, TH, TW,
-                       q.scale, q.shift, q.ss_gs, q.relu, out.p, out.cs, out.gs);
+    // GroupNorm sums in the output transform when a block's tiles meet at most two images and float4s stay inside a group
+    const int C4o = Cout / 4, per_iter = C4o <= 256 ? 256 / C4o : 1;
+    const bool gn_here = q.gn_sum && q.gn_groups > 0 && q.gn_groups <= 32 && (Cout / q.gn_groups) % 4 == 0 &&
+                         (long)TH * TW >= (long)per_iter * OUT_ITERS;
+    dim3 og = grid(C4o);
+    og.x = (og.x + OUT_ITERS - 1) / OUT_ITERS;
+    hipLaunchKernelGGL(wino_output_kernel, og, dim3(256), 0, st, m, 16 * tiles * Cout, B, H, W, C4o, TH, TW, q.scale, q.shift,
+                       q.ss_gs, q.relu, out.p, out.cs, out.gs, gn_here ? q.gn_sum : nullptr, q.gn_groups,
+                       q.gn_groups ? Cout / q.gn_groups : 1);
     QB_CHECK(hipGetLastError());
+    if (q.gn_sum && !gn_here) return launch_gn_stats(out, B, G, q.gn_groups, q.gn_sum, st, false);
     return 0;
 }
 

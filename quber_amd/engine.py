@@ -147,6 +147,9 @@ class Engine:
     def forward_flops(self):
         return self.lib.quber_forward_flops(self.h)
 
+    def forward_flops_executed(self):
+        return self.lib.quber_forward_flops_executed(self.h)
+
     # ---- hot path ----
     def encode(self, masks, out=None):
         """masks u8 [B,N,H,W] (device) -> f32 [B,3,H,W]."""

@@ -30,21 +30,33 @@ def run(a):
 
 
 def report(a):
+    """One row per convolution op: its conv_igemm launch plus the launches that belong to it (Winograd input / output
+    transforms, split-K reduce), taken from the last forward in the trace."""
     meta = json.load(open(a.plan))
     plan, B = meta["plan"], meta["batch"]
     convs = [p for p in plan if p[1] == "conv"]
-    rows = [r for r in csv.DictReader(open(a.trace)) if "conv_igemm" in r["Kernel_Name"]]
-    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    allk = sorted(csv.DictReader(open(a.trace)), key=lambda r: int(r["Start_Timestamp"]))
+    idx = [i for i, r in enumerate(allk) if "conv_igemm" in r["Kernel_Name"]]
     n = len(convs)
-    assert len(rows) % n == 0 and len(rows) >= n, (len(rows), n)
-    last = rows[-n:]
+    assert len(idx) % n == 0 and len(idx) >= n, (len(idx), n)
+    dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
     tot_t = tot_f = 0.0
-    out = ["| # | layer (first weight key) | tile | GFLOP (batch %d) | ms | TFLOP/s |" % B, "|---|---|---|---|---|---|"]
-    for i, (c, r) in enumerate(zip(convs, last)):
-        ms = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+    out = ["| # | layer (first weight key) | path, GEMM tile | GFLOP (batch %d, algorithmic) | ms | TFLOP/s |" % B,
+           "|---|---|---|---|---|---|"]
+    for i, (c, k) in enumerate(zip(convs, idx[-n:])):
+        r = allk[k]
+        ms, path = dur(r), "direct"
+        if k > 0 and "wino_input" in allk[k - 1]["Kernel_Name"]:
+            ms += dur(allk[k - 1])
+            path = "winograd"
+        nxt = k + 1
+        while nxt < len(allk) and any(t in allk[nxt]["Kernel_Name"] for t in ("splitk_reduce", "wino_output")):
+            ms += dur(allk[nxt])
+            nxt += 1
         fl = c[2] * B
         tile = r["Kernel_Name"].split("<")[1].split(">")[0].replace(" ", "")
-        out.append("| %d | %s | %s | %.1f | %.3f | %.1f |" % (i, c[0].replace("backbone.", "b.").replace("ins_embed_head.", "h."), tile, fl / 1e9, ms, fl / ms / 1e9))
+        out.append("| %d | %s | %s %s | %.1f | %.3f | %.1f |" % (i, c[0].replace("backbone.", "b.").replace("ins_embed_head.", "h."),
+                                                               path, tile, fl / 1e9, ms, fl / ms / 1e9))
         tot_t += ms
         tot_f += fl
     out.append("| | **all convolutions** | | %.1f | %.3f | %.1f |" % (tot_f / 1e9, tot_t, tot_f / tot_t / 1e9))
