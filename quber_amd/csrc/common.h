@@ -58,6 +58,7 @@ struct WinoP {
     const float* scale;      // per-channel affine of the epilogue ([G][Cout], stride ss_gs) or null
     const float* shift;
     int ss_gs, relu;
+    int dil;                 // dilation (= padding)
     double* gn_sum;          // GroupNorm sums of the output to accumulate ([G][B][gn_groups][2]) or null
     int gn_groups;
     float* ws;               // V | M workspace (winograd_ws_floats)
@@ -72,8 +73,9 @@ int launch_conv_winograd(const WinoP& q, int B, int G, hipStream_t st);
 int launch_winograd_weights(const float* w_oihw, int Cout, int Cin, float* u, hipStream_t st);
 void winograd_weights_host(const float* w_oihw, int Cout, int Cin, float* u);
 bool winograd_eligible(int k, int stride, int pad, int dil, int Cin, int Cout);
-size_t winograd_ws_floats(int B, int H, int W, int Cin, int Cout, int G);
-extern int g_winograd, g_wino_min_cin;
+size_t winograd_ws_floats(int B, int H, int W, int Cin, int Cout, int G, int dil);
+double winograd_mac_ratio(int H, int W, int dil);
+extern int g_winograd, g_wino_min_cin, g_wino_max_ratio;
 extern int g_force_split, g_force_tile, g_tail_split;
 int launch_preprocess(const uint8_t* rgb, const uint8_t* depth, const float* offs, float* x, int B, int Bcap,
                       int H, int W, const float* mean6, const float* std6, int streams, hipStream_t st);

@@ -75,6 +75,7 @@ struct quber_ctx {
     float* cur_out = nullptr;
     double flops = 0.0;
     double wino_flops = 0.0;      // algorithmic FLOPs (batch 1) of the layers that take the Winograd path
+    double wino_saved = 0.0;      // ... and the part of them the path does not execute
     std::vector<hipEvent_t> prof_events;
     bool finalized = false;
     int device = 0;
@@ -200,15 +201,18 @@ struct Builder {
         quber_ctx* ctx = c;
         // Winograd F(2x2,3x3) alternative for the wide plain 3x3 layers; chosen per launch (batch) in the lambda below
         WinoP wq{};
-        const bool wino = winograd_eligible(k, stride, pad, dil, Cin, Cout) && cin_real == Cin && !res && prelu.empty();
+        // (a dilated layer pads its short phases to whole tiles: only taken while that keeps >= 1.5x fewer multiplies)
+        const bool wino = winograd_eligible(k, stride, pad, dil, Cin, Cout) && cin_real == Cin && !res && prelu.empty() &&
+                          winograd_mac_ratio(in.H, in.W, dil) <= (double)g_wino_max_ratio / 100.0;
         if (wino) {
             std::vector<float> u((size_t)G * 16 * Cout * Cin);
             for (int g = 0; g < G; ++g) winograd_weights_host(w[g], Cout, Cin, &u[(size_t)g * 16 * Cout * Cin]);
             wq.in = in; wq.out = out; wq.u = upload(u);
-            wq.scale = p.scale; wq.shift = p.shift; wq.ss_gs = Cout; wq.relu = relu;
-            const size_t need = winograd_ws_floats(Bmax, in.H, in.W, Cin, Cout, G);
+            wq.scale = p.scale; wq.shift = p.shift; wq.ss_gs = Cout; wq.relu = relu; wq.dil = dil;
+            const size_t need = winograd_ws_floats(Bmax, in.H, in.W, Cin, Cout, G, dil);
             if (need > c->wino_floats) c->wino_floats = need;
             c->wino_flops += 2.0 * OH * OW * (double)cin_real * k * k * Cout * G;
+            c->wino_saved += 2.0 * OH * OW * (double)cin_real * k * k * Cout * G * (1.0 - winograd_mac_ratio(in.H, in.W, dil));
         }
         // a GroupNorm that consumes this output may ask the convolution for its sums (gn_relu fills `fuse` in)
         auto fuse = std::make_shared<GnFuse>();
@@ -216,7 +220,7 @@ struct Builder {
         c->ops.push_back({[p, G, ctx, fuse, wq, wino](int B, hipStream_t st) mutable {
             // Winograd F(2x2,3x3) wins on every eligible layer (>= 128 channels in and out) at every batch size
             // (profiles/r01l_winograd.md); frames of a handful of tiles stay on the direct kernel
-            const long trows = (long)B * ((p.H + 1) / 2) * ((p.W + 1) / 2);
+            const long trows = (long)B * p.H * p.W / 4;
             if (wino && ctx->wino_ws && g_winograd != 1 && (g_winograd == 2 || trows >= 256)) {
                 wq.ws = ctx->wino_ws; wq.ws_floats = ctx->wino_floats;
                 wq.splitk_ws = ctx->splitk_ws; wq.splitk_floats = ctx->splitk_floats;
@@ -882,6 +886,7 @@ int quber_finalize_weights(quber_ctx* c) {
     Builder b(c, false);
     c->flops = 0.0;
     c->wino_flops = 0.0;
+    c->wino_saved = 0.0;
     if (c->cfg.with_network == 2) {
         c->splitk_floats = (size_t)4 << 20;
         c->splitk_ws = (float*)b.dalloc_bytes(sizeof(float) * c->splitk_floats);
@@ -904,7 +909,7 @@ double quber_forward_flops(quber_ctx* c) { return c ? c->flops : 0.0; }
 double quber_forward_flops_executed(quber_ctx* c) {
     if (!c) return 0.0;
     // Winograd F(2x2,3x3) layers multiply 16 instead of 36 times per 2x2 output tile and channel pair
-    return g_winograd == 1 ? c->flops : c->flops - c->wino_flops * (1.0 - 16.0 / 36.0);
+    return g_winograd == 1 ? c->flops : c->flops - c->wino_saved;
 }
 void quber_set_tuning(int32_t key, int32_t value) {
     if (key == 2) {   // stand-alone conv op: allocate (value != 0) or drop the split-K workspace
@@ -916,6 +921,7 @@ void quber_set_tuning(int32_t key, int32_t value) {
         }
     }
     if (key == 4) g_force_tile = value;    // force the tile shape: 1 = 64x64, 2 = 128x128, 4 = 256x32 (0 = automatic)
+    if (key == 8) g_wino_max_ratio = value;   // Winograd only while executed / direct multiplies <= value % (default 67)
     if (key == 7) g_wino_min_cin = value;  // smallest input width eligible for the Winograd path (default 256)
     if (key == 6) g_winograd = value;      // Winograd F(2x2,3x3) for the eligible 3x3 layers: 0 = where it pays, 1 = never, 2 = always
     if (key == 5) g_tail_split = value;    // split the ragged last round of large convolution launches (default 1)
@@ -1116,16 +1122,16 @@ int quber_op_conv2d(const float* x, int32_t B, int32_t h, int32_t w, int32_t cin
 static View mkview(const float* p, int B, int h, int w, int c);
 
 int quber_op_conv3x3_winograd(const float* x, int32_t B, int32_t h, int32_t w, int32_t cin, const float* w_oihw, int32_t cout,
-                              const float* scale, const float* shift, int32_t relu, float* u, float* ws, int64_t ws_floats,
-                              float* y, void* stream) {
+                              int32_t dil, const float* scale, const float* shift, int32_t relu, float* u, float* ws,
+                              int64_t ws_floats, float* y, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    if (!winograd_eligible(3, 1, 1, 1, cin, cout)) return fail("winograd: unsupported channel counts");
+    if (!winograd_eligible(3, 1, dil, dil, cin, cout)) return fail("winograd: unsupported channel counts");
     if ((scale == nullptr) != (shift == nullptr)) return fail("winograd: scale and shift go together");
     int rc = launch_winograd_weights(w_oihw, cout, cin, u, st);
     if (rc) return rc;
     WinoP q{};
     q.in = mkview(x, B, h, w, cin); q.out = mkview(y, B, h, w, cout);
-    q.u = u; q.scale = scale; q.shift = shift; q.ss_gs = 0; q.relu = relu;
+    q.u = u; q.scale = scale; q.shift = shift; q.ss_gs = 0; q.relu = relu; q.dil = dil;
     q.ws = ws; q.ws_floats = (size_t)ws_floats;
     q.splitk_ws = g_op_ws; q.splitk_floats = g_op_ws ? g_op_ws_floats : 0;
     return launch_conv_winograd(q, B, 1, st);

@@ -16,34 +16,41 @@
 
 namespace quber {
 
-int g_wino_min_cin = 128;   // key 7 (test harness): smallest input width routed to this path
+int g_wino_min_cin = 128;
+int g_wino_max_ratio = 67;   // key 8: executed / direct multiplies (%) up to which a (dilated) layer takes this path   // key 7 (test harness): smallest input width routed to this path
 
 // tile (ty, tx) of image b covers output rows 2ty..2ty+1, columns 2tx..2tx+1 and reads input rows 2ty-1..2ty+2
+// With dilation d the layer is d*d independent dense convolutions on the phase sub-images in[d*Y + py][d*X + px]
+// (TH x TW tiles each, the same for every phase; tiles beyond a shorter phase read zeros and store nothing).
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ in, int B, int H, int W, int C4, int in_cs,
-                                                         long in_gs, int TH, int TW, float* __restrict__ v, long v_gs) {
+                                                         long in_gs, int TH, int TW, int d, float* __restrict__ v, long v_gs) {
     const int g = blockIdx.z;
     in += g * in_gs;
     v += g * v_gs;
     const int tpb = 256 / C4;                        // tiles per block; C4 > 256 (host: then a multiple of 256): grid.y column blocks
     const int c4 = tpb ? threadIdx.x % C4 : blockIdx.y * 256 + threadIdx.x;
-    const long tiles = (long)B * TH * TW;
+    const long tiles = (long)B * d * d * TH * TW;
     const long tile = tpb ? (long)blockIdx.x * tpb + threadIdx.x / C4 : blockIdx.x;
     if (tile >= tiles || c4 >= C4 || (tpb && (int)(threadIdx.x / C4) >= tpb)) return;
     const int tx = tile % TW;
-    const long r = tile / TW;
+    long r = tile / TW;
     const int ty = r % TH;
-    const int b = r / TH;
+    r /= TH;
+    const int px = r % d;
+    r /= d;
+    const int py = r % d;
+    const int b = r / d;
     const float* base = in + (long)b * H * W * in_cs + c4 * 4;
-    float4 d[4][4];
+    float4 dd[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int y = 2 * ty - 1 + i;
+        const int y = d * (2 * ty - 1 + i) + py;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int x = 2 * tx - 1 + j;
-            d[i][j] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
-                          ? *reinterpret_cast<const float4*>(base + ((long)y * W + x) * in_cs)
-                          : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int x = d * (2 * tx - 1 + j) + px;
+            dd[i][j] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+                           ? *reinterpret_cast<const float4*>(base + ((long)y * W + x) * in_cs)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     auto sub = [](const float4& a, const float4& b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); };
@@ -51,10 +58,10 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
     float4 t[4][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {                    // B^T d
-        t[0][j] = sub(d[0][j], d[2][j]);
-        t[1][j] = add(d[1][j], d[2][j]);
-        t[2][j] = sub(d[2][j], d[1][j]);
-        t[3][j] = sub(d[1][j], d[3][j]);
+        t[0][j] = sub(dd[0][j], dd[2][j]);
+        t[1][j] = add(dd[1][j], dd[2][j]);
+        t[2][j] = sub(dd[2][j], dd[1][j]);
+        t[3][j] = sub(dd[1][j], dd[3][j]);
     }
     float* dst = v + tile * (long)(C4 * 4) + c4 * 4;
     const long ps = tiles * (long)(C4 * 4);          // position stride
@@ -71,7 +78,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 // (fp64, LDS per block, one global atomic per (image, group) per block - as the direct kernel's epilogue does).
 constexpr int OUT_ITERS = 4;
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ m, long m_gs, int B, int OH, int OW, int C4,
-                                                          int TH, int TW, const float* __restrict__ scale,
+                                                          int TH, int TW, int d, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int ss_gs, int relu,
                                                           float* __restrict__ out, int out_cs, long out_gs,
                                                           double* __restrict__ gn_sum, int gn_groups, int gn_cpg) {
@@ -80,12 +87,13 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     out += g * out_gs;
     const int tpb = 256 / C4;
     const int c4 = tpb ? threadIdx.x % C4 : blockIdx.y * 256 + threadIdx.x;
-    const long tiles = (long)B * TH * TW;
+    const long per_img = (long)d * d * TH * TW;
+    const long tiles = (long)B * per_img;
     const int step = tpb ? tpb : 1;                  // tiles per iteration
     const long tile0 = (long)blockIdx.x * step * OUT_ITERS;
     const bool lane_ok = c4 < C4 && (!tpb || (int)(threadIdx.x / C4) < tpb);
     __shared__ double gacc[2 * 32 * 2];              // [image b0 / b0+1][group][sum, sum of squares]
-    const int b0 = (int)(tile0 / ((long)TH * TW));
+    const int b0 = (int)(tile0 / per_img);
     if (gn_sum) {
         if (threadIdx.x < 128) gacc[threadIdx.x] = 0.0;
         __syncthreads();
@@ -107,9 +115,13 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
         const long tile = tile0 + (long)it * step + (tpb ? threadIdx.x / C4 : 0);
         if (!lane_ok || tile >= tiles) continue;
         const int tx = tile % TW;
-        const long r = tile / TW;
+        long r = tile / TW;
         const int ty = r % TH;
-        const int b = r / TH;
+        r /= TH;
+        const int px = r % d;
+        r /= d;
+        const int py = r % d;
+        const int b = r / d;
         const float* src = m + tile * (long)(C4 * 4) + c4 * 4;
         float4 s[2][4];
 #pragma unroll
@@ -124,11 +136,11 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
         double a = 0.0, q = 0.0;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int oy = 2 * ty + i;
+            const int oy = d * (2 * ty + i) + py;
             if (oy >= OH) continue;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int ox = 2 * tx + j;
+                const int ox = d * (2 * tx + j) + px;
                 if (ox >= OW) continue;
                 float4 y = j == 0 ? add3(s[i][0], s[i][1], s[i][2]) : sub3(s[i][1], s[i][2], s[i][3]);   // (A^T M) A
                 if (scale) {
@@ -203,33 +215,41 @@ int launch_winograd_weights(const float* w_oihw, int Cout, int Cin, float* u, hi
     return 0;
 }
 
+// tiles per image: d*d phases of ceil(ceil(H/d)/2) x ceil(ceil(W/d)/2) tiles
+static inline long wino_tiles(int H, int W, int d) { return (long)d * d * (((H + d - 1) / d + 1) / 2) * (((W + d - 1) / d + 1) / 2); }
+
 bool winograd_eligible(int k, int stride, int pad, int dil, int Cin, int Cout) {
-    return k == 3 && stride == 1 && pad == 1 && dil == 1 && Cin % 32 == 0 && Cout % 4 == 0 && Cin >= g_wino_min_cin &&
+    return k == 3 && stride == 1 && dil >= 1 && pad == dil && Cin % 32 == 0 && Cout % 4 == 0 && Cin >= g_wino_min_cin &&
            Cout >= 128 && (Cin / 4 <= 256 || (Cin / 4) % 256 == 0) && (Cout / 4 <= 256 || (Cout / 4) % 256 == 0);
 }
 
-size_t winograd_ws_floats(int B, int H, int W, int Cin, int Cout, int G) {
-    const size_t tiles = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2);
+size_t winograd_ws_floats(int B, int H, int W, int Cin, int Cout, int G, int dil) {
+    const size_t tiles = (size_t)B * wino_tiles(H, W, dil);
     return (size_t)G * 16 * tiles * (size_t)(Cin + Cout);
 }
+
+// executed multiplies relative to the direct kernel: 16 per tile against 36 per four REAL outputs; the padded tiles of
+// a dilated layer's short phases eat into the 2.25x
+double winograd_mac_ratio(int H, int W, int dil) { return 16.0 * wino_tiles(H, W, dil) / (9.0 * H * W); }
 
 int launch_conv_winograd(const WinoP& q, int B, int G, hipStream_t st) {
     const View& in = q.in;
     const View& out = q.out;
     const int H = in.H, W = in.W, Cin = in.C, Cout = out.C;
-    if (!winograd_eligible(3, 1, 1, 1, Cin, Cout) || out.H != H || out.W != W) return fail("winograd: unsupported geometry");
+    const int d = q.dil;
+    if (!winograd_eligible(3, 1, d, d, Cin, Cout) || out.H != H || out.W != W) return fail("winograd: unsupported geometry");
     if (in.cs % 4 || out.cs % 4 || ((uintptr_t)in.p & 15) || ((uintptr_t)out.p & 15) || (in.gs & 3) || (out.gs & 3))
         return fail("winograd: operands must be 16-byte aligned");
-    const int TH = (H + 1) / 2, TW = (W + 1) / 2;
-    const long tiles = (long)B * TH * TW;
+    const int TH = ((H + d - 1) / d + 1) / 2, TW = ((W + d - 1) / d + 1) / 2;
+    const long tiles = (long)B * wino_tiles(H, W, d);
     if (tiles * 16 >= (1L << 31) / 2) return fail("winograd: too many tiles");
-    if (winograd_ws_floats(B, H, W, Cin, Cout, G) > q.ws_floats) return fail("winograd: workspace too small");
+    if (winograd_ws_floats(B, H, W, Cin, Cout, G, d) > q.ws_floats) return fail("winograd: workspace too small");
     float* v = q.ws;
     float* m = q.ws + (size_t)G * 16 * tiles * Cin;
     auto grid = [&](int C4) {
         return C4 <= 256 ? dim3((unsigned)((tiles + 256 / C4 - 1) / (256 / C4)), 1, G) : dim3((unsigned)tiles, C4 / 256, G);
     };
-    hipLaunchKernelGGL(wino_input_kernel, grid(Cin / 4), dim3(256), 0, st, in.p, B, H, W, Cin / 4, in.cs, in.gs, TH, TW, v,
+    hipLaunchKernelGGL(wino_input_kernel, grid(Cin / 4), dim3(256), 0, st, in.p, B, H, W, Cin / 4, in.cs, in.gs, TH, TW, d, v,
                        16 * tiles * Cin);
     QB_CHECK(hipGetLastError());
     ConvP p{};
@@ -246,10 +266,10 @@ int launch_conv_winograd(const WinoP& q, int B, int G, hipStream_t st) {
     // GroupNorm sums in the output transform when a block's tiles meet at most two images and float4s stay inside a group
     const int C4o = Cout / 4, per_iter = C4o <= 256 ? 256 / C4o : 1;
     const bool gn_here = q.gn_sum && q.gn_groups > 0 && q.gn_groups <= 32 && (Cout / q.gn_groups) % 4 == 0 &&
-                         (long)TH * TW >= (long)per_iter * OUT_ITERS;
+                         wino_tiles(H, W, d) >= (long)per_iter * OUT_ITERS;
     dim3 og = grid(C4o);
     og.x = (og.x + OUT_ITERS - 1) / OUT_ITERS;
-    hipLaunchKernelGGL(wino_output_kernel, og, dim3(256), 0, st, m, 16 * tiles * Cout, B, H, W, C4o, TH, TW, q.scale, q.shift,
+    hipLaunchKernelGGL(wino_output_kernel, og, dim3(256), 0, st, m, 16 * tiles * Cout, B, H, W, C4o, TH, TW, d, q.scale, q.shift,
                        q.ss_gs, q.relu, out.p, out.cs, out.gs, gn_here ? q.gn_sum : nullptr, q.gn_groups,
                        q.gn_groups ? Cout / q.gn_groups : 1);
     QB_CHECK(hipGetLastError());

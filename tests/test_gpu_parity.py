@@ -354,14 +354,18 @@ def test_conv_split_tail_equals_whole(case):
 
 
 @pytest.mark.parametrize("case", [
-    # B, H, W, Cin, Cout, affine, relu: the Winograd F(2x2,3x3) path against float64 (host) on sampled output pixels
-    (2, 30, 40, 256, 256, True, True),
-    (1, 31, 45, 512, 512, True, False),       # odd frame: ragged last tile row and column
-    (3, 12, 16, 256, 128, False, False),
-    (1, 9, 7, 1024, 256, True, True),         # C4 = 256: one tile per block
+    # B, H, W, Cin, Cout, dilation, affine, relu: the Winograd F(2x2,3x3) path against float64 (host) on sampled pixels
+    (2, 30, 40, 256, 256, 1, True, True),
+    (1, 31, 45, 512, 512, 1, True, False),       # odd frame: ragged last tile row and column
+    (3, 12, 16, 256, 128, 1, False, False),
+    (1, 9, 7, 1024, 256, 1, True, True),         # C4 = 256: one tile per block
+    (2, 30, 40, 512, 512, 2, True, True),        # res5 conv2: 4 phase sub-images of 15 x 20
+    (1, 30, 40, 512, 512, 8, True, True),        # dilation 8: 64 phases of 4 x 5 (ragged: 30 = 3*8 + 6)
+    (1, 23, 37, 128, 128, 4, False, False),      # phases of unequal size
+    (1, 30, 40, 2048, 256, 6, True, True),       # ASPP d = 6
 ])
 def test_conv3x3_winograd_vs_float64(case):
-    B, H, W, Cin, Cout, affine, relu = case
+    B, H, W, Cin, Cout, dil, affine, relu = case
     lib = _lib.load()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
@@ -370,28 +374,28 @@ def test_conv3x3_winograd_vs_float64(case):
     w = torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) / np.sqrt(Cin * 9)
     sc = torch.rand(Cout, device="cuda", generator=g) + 0.5 if affine else None
     sh = torch.randn(Cout, device="cuda", generator=g) if affine else None
-    tiles = B * ((H + 1) // 2) * ((W + 1) // 2)
+    tiles = B * dil * dil * ((-(-H // dil) + 1) // 2) * ((-(-W // dil) + 1) // 2)
     u = torch.empty(16 * Cout * Cin, device="cuda")
     ws = torch.empty(16 * tiles * (Cin + Cout), device="cuda")
     y = torch.full((B, H, W, Cout), float("nan"), device="cuda")
-    _lib.check(lib.quber_op_conv3x3_winograd(p(x), B, H, W, Cin, p(w), Cout, p(sc), p(sh), int(relu), p(u), p(ws),
+    _lib.check(lib.quber_op_conv3x3_winograd(p(x), B, H, W, Cin, p(w), Cout, dil, p(sc), p(sh), int(relu), p(u), p(ws),
                                              ws.numel(), p(y), st))
     assert torch.isfinite(y).all()
     # the direct kernel on the same input agrees to a few ulps of the accumulated magnitude ...
     packed = torch.empty(Cout * 9 * Cin, device="cuda")
     yd = torch.empty_like(y)
-    _lib.check(lib.quber_op_conv2d(p(x), B, H, W, Cin, p(w), Cout, 3, 1, 1, 1, p(sc), p(sh), p(None), int(relu), p(packed),
+    _lib.check(lib.quber_op_conv2d(p(x), B, H, W, Cin, p(w), Cout, 3, 1, dil, dil, p(sc), p(sh), p(None), int(relu), p(packed),
                                    p(yd), st))
     scale = max(1.0, yd.abs().max().item())
     assert (y - yd).abs().max().item() / scale < 1e-5
     # ... and both are right: float64 on the host for every border pixel class and a random sample
-    xp = torch.nn.functional.pad(x.cpu().double(), (0, 0, 1, 1, 1, 1))
+    xp = torch.nn.functional.pad(x.cpu().double(), (0, 0, dil, dil, dil, dil))
     wc = w.cpu().double()
     pts = [(0, 0, 0), (B - 1, H - 1, W - 1), (0, H - 1, 0), (B - 1, 0, W - 1), (0, H // 2, W - 1), (0, H - 1, W // 2)]
     rng = np.random.default_rng(0)
     pts += [(int(rng.integers(B)), int(rng.integers(H)), int(rng.integers(W))) for _ in range(40)]
     for (b, oy, ox) in pts:
-        ref = torch.einsum("yxc,ocyx->o", xp[b, oy:oy + 3, ox:ox + 3, :], wc)
+        ref = torch.einsum("yxc,ocyx->o", xp[b, oy:oy + 2 * dil + 1:dil, ox:ox + 2 * dil + 1:dil, :], wc)
         if affine:
             ref = ref * sc.cpu().double() + sh.cpu().double()
         if relu:

@@ -19,7 +19,13 @@ p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 print(f"| layer ({F} frames) | GFLOP | direct ms | TF/s | winograd ms | effective TF/s | speed-up |")
 print("|---|---|---|---|---|---|---|")
-for name, ipf, H, W, Cin, Cout in [("fusion_res2 3x3 256>256 @120x160", 1, 120, 160, 256, 256),
+for name, ipf, H, W, Cin, Cout, *rest in [("fusion_res2 3x3 256>256 @120x160", 1, 120, 160, 256, 256),
+                                   ("res5.conv2 3x3 d2 512>512 @30x40 (2 streams)", 2, 30, 40, 512, 512, 2),
+                                   ("res5.conv2 3x3 d4 512>512 @30x40 (2 streams)", 2, 30, 40, 512, 512, 4),
+                                   ("res5.conv2 3x3 d8 512>512 @30x40 (2 streams)", 2, 30, 40, 512, 512, 8),
+                                   ("aspp 3x3 d6 2048>256 @30x40", 1, 30, 40, 2048, 256, 6),
+                                   ("aspp 3x3 d12 2048>256 @30x40", 1, 30, 40, 2048, 256, 12),
+                                   ("aspp 3x3 d18 2048>256 @30x40", 1, 30, 40, 2048, 256, 18),
                                    ("fusion_res3 3x3 512>512 @60x80", 1, 60, 80, 512, 512),
                                    ("res4.conv2 3x3 256>256 @30x40 (2 streams)", 2, 30, 40, 256, 256),
                                    ("decoder.res3.fuse0 3x3 320>128 @60x80", 1, 60, 80, 320, 128),
@@ -31,12 +37,13 @@ for name, ipf, H, W, Cin, Cout in [("fusion_res2 3x3 256>256 @120x160", 1, 120, 
                                    ("res2.conv2 3x3 64>64 @120x160 (2 streams)", 2, 120, 160, 64, 64),
                                    ("stem.conv3 3x3 32>64 @240x320 (2 streams)", 2, 240, 320, 32, 64)]:
     B = ipf * F
+    d = rest[0] if rest else 1
     x = torch.randn(B, H, W, Cin, device="cuda")
     w = torch.randn(Cout, Cin, 3, 3, device="cuda") / np.sqrt(Cin * 9)
     sc, sh = torch.rand(Cout, device="cuda") + 0.5, torch.randn(Cout, device="cuda")
     y = torch.empty(B, H, W, Cout, device="cuda")
     packed = torch.empty(Cout * 9 * Cin, device="cuda")
-    tiles = B * ((H + 1) // 2) * ((W + 1) // 2)
+    tiles = B * d * d * ((-(-H // d) + 1) // 2) * ((-(-W // d) + 1) // 2)
     u = torch.empty(16 * Cout * Cin, device="cuda")
     ws = torch.empty(16 * tiles * (Cin + Cout), device="cuda")
     fl = 2.0 * B * H * W * Cin * 9 * Cout
@@ -54,10 +61,10 @@ for name, ipf, H, W, Cin, Cout in [("fusion_res2 3x3 256>256 @120x160", 1, 120, 
                 ts.append(e0.elapsed_time(e1) / 3)
         return float(np.median(ts))
 
-    td = timed(lambda: _lib.check(lib.quber_op_conv2d(p(x), B, H, W, Cin, p(w), Cout, 3, 1, 1, 1, p(sc), p(sh), p(None), 1,
+    td = timed(lambda: _lib.check(lib.quber_op_conv2d(p(x), B, H, W, Cin, p(w), Cout, 3, 1, d, d, p(sc), p(sh), p(None), 1,
                                                       p(packed), p(y), st)))
     try:
-        tw = timed(lambda: _lib.check(lib.quber_op_conv3x3_winograd(p(x), B, H, W, Cin, p(w), Cout, p(sc), p(sh), 1, p(u), p(ws),
+        tw = timed(lambda: _lib.check(lib.quber_op_conv3x3_winograd(p(x), B, H, W, Cin, p(w), Cout, d, p(sc), p(sh), 1, p(u), p(ws),
                                                                     ws.numel(), p(y), st)))
         print("| %s | %.1f | %.3f | %.1f | %.3f | %.1f | %.2fx |" % (name, fl / 1e9, td, fl / td / 1e9, tw, fl / tw / 1e9, td / tw), flush=True)
     except Exception as e:
