@@ -8,32 +8,40 @@ import json
 import sys
 
 
-def conv_rows(path, counter, n):
-    d = collections.OrderedDict()
+FAMILY = ("conv_igemm", "wino_input", "wino_output", "splitk_reduce")
+
+
+def family_bytes(path, counter):
+    """-> {kernel family: counter sum} over the trace (the profiled run does ONE forward: layer_profile.py run --iters 1)"""
+    seen, out = set(), collections.Counter()
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == counter and "conv_igemm" in r["Kernel_Name"]:
-            d[r["Dispatch_Id"]] = float(r["Counter_Value"])
-    v = list(d.values())
-    assert len(v) >= n and len(v) % n == 0, (len(v), n)
-    return v[-n:]
+        if r["Counter_Name"] != counter or r["Dispatch_Id"] in seen:
+            continue
+        for fam in FAMILY:
+            if fam in r["Kernel_Name"]:
+                seen.add(r["Dispatch_Id"])
+                out[fam] += float(r["Counter_Value"])
+    return out
 
 
 def main(plan_json, fetch_csv, write_csv, out_json):
     meta = json.load(open(plan_json))
+    assert meta["iters"] == 1, "profile a single forward (layer_profile.py run --iters 1)"
     convs = [p for p in meta["plan"] if p[1] == "conv"]
-    B = meta["batch"]
-    f = conv_rows(fetch_csv, "FETCH_SIZE", len(convs))
-    w = conv_rows(write_csv, "WRITE_SIZE", len(convs))
-    layers = []
-    for c, a, b in zip(convs, f, w):
-        layers.append({"layer": c[0], "flops": c[2] * B, "fetch_bytes": a * 1024 * 2, "write_bytes": b * 1024})
-    tot = sum(l["fetch_bytes"] + l["write_bytes"] for l in layers)
-    out = {"batch": B, "launches": len(layers), "bytes_per_launch": tot / len(layers),
-           "fetch_bytes_total": sum(l["fetch_bytes"] for l in layers), "write_bytes_total": sum(l["write_bytes"] for l in layers),
-           "note": "HBM-side bytes of the conv_igemm_f32 launches of one forward; FETCH_SIZE x2 (gfx950 correction), "
-                   "WRITE_SIZE as read; separate --pmc passes", "layers": layers}
+    f = family_bytes(fetch_csv, "FETCH_SIZE")
+    w = family_bytes(write_csv, "WRITE_SIZE")
+    fam = {k: {"fetch_bytes": f[k] * 1024 * 2, "write_bytes": w[k] * 1024} for k in FAMILY}
+    tot = sum(v["fetch_bytes"] + v["write_bytes"] for v in fam.values())
+    out = {"batch": meta["batch"], "launches": len(convs), "bytes_per_launch": tot / len(convs),
+           "fetch_bytes_total": sum(v["fetch_bytes"] for v in fam.values()),
+           "write_bytes_total": sum(v["write_bytes"] for v in fam.values()),
+           "note": "HBM-side bytes of one forward's convolution ops (GEMM launches, Winograd input / output transforms, "
+                   "split-K reduce passes) divided by the number of convolution ops; FETCH_SIZE x2 (gfx950 correction), "
+                   "WRITE_SIZE as read; separate --pmc passes", "by_kernel_family": fam}
     json.dump(out, open(out_json, "w"), indent=1)
     print("bytes_per_launch %.1f MB, fetch %.1f GB, write %.1f GB" % (out["bytes_per_launch"] / 1e6, out["fetch_bytes_total"] / 1e9, out["write_bytes_total"] / 1e9))
+    for k, v in fam.items():
+        print("   %-14s fetch %.2f GB  write %.2f GB" % (k, v["fetch_bytes"] / 1e9, v["write_bytes"] / 1e9))
 
 
 if __name__ == "__main__":
