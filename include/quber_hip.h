@@ -162,6 +162,7 @@ double quber_forward_flops(quber_ctx* ctx);
 double quber_forward_flops_executed(quber_ctx* ctx);
 /* test-harness knobs: key 2 = give the stand-alone quber_op_conv2d a split-K workspace (value != 0) or drop it (0);
  * key 3 = force the number of K partitions of convolutions that have a workspace (0 = automatic);
+ * key 9 = Winograd output tile edge of the eligible layers: 0 = automatic (default), 2, 4 (acts at plan time);
  * key 8 = Winograd only while its multiplies are <= value % of the direct kernel's (dilated layers; default 67);
  * key 7 = smallest input width (channels) routed to the Winograd path (default 256);
  * key 6 = Winograd F(2x2,3x3) path of the eligible 3x3 layers: 0 = where it pays (default), 1 = never, 2 = always;
@@ -178,11 +179,12 @@ int quber_op_conv2d(const float* dev_x, int32_t batch, int32_t h, int32_t w, int
                     int32_t cout, int32_t ksize, int32_t stride, int32_t pad, int32_t dil, const float* dev_scale,
                     const float* dev_shift, const float* dev_residual, int32_t relu, float* dev_packed_scratch,
                     float* dev_y, void* stream);
-/* the same for a 3x3 / stride 1 / pad = dilation convolution through the Winograd F(2x2,3x3) path (cin >= 128 and a
- * multiple of 32, cout >= 128): dev_u_scratch holds 16*cout*cin floats (transformed weights), dev_ws at least
- * 16 * batch * dil^2 * ceil(ceil(h/dil)/2) * ceil(ceil(w/dil)/2) * (cin + cout) floats */
+/* the same for a 3x3 / stride 1 / pad = dilation convolution through the Winograd F(m x m, 3x3) path, m = 2 or 4
+ * (cin >= 128 and a multiple of 32, cout >= 128): with P = (m+2)^2, dev_u_scratch holds P*cout*cin floats (transformed
+ * weights), dev_ws at least P * batch * dil^2 * ceil(ceil(h/dil)/m) * ceil(ceil(w/dil)/m) * (cin + cout) floats */
 int quber_op_conv3x3_winograd(const float* dev_x, int32_t batch, int32_t h, int32_t w, int32_t cin,
-                              const float* dev_w_oihw, int32_t cout, int32_t dil, const float* dev_scale, const float* dev_shift,
+                              const float* dev_w_oihw, int32_t cout, int32_t dil, int32_t m, const float* dev_scale,
+                              const float* dev_shift,
                               int32_t relu, float* dev_u_scratch, float* dev_ws, int64_t ws_floats, float* dev_y,
                               void* stream);
 int quber_op_groupnorm(const float* dev_x, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t groups,

@@ -59,6 +59,7 @@ struct WinoP {
     const float* shift;
     int ss_gs, relu;
     int dil;                 // dilation (= padding)
+    int m;                   // output tile edge: 2 = F(2x2,3x3), 4 = F(4x4,3x3)
     double* gn_sum;          // GroupNorm sums of the output to accumulate ([G][B][gn_groups][2]) or null
     int gn_groups;
     float* ws;               // V | M workspace (winograd_ws_floats)
@@ -70,12 +71,12 @@ struct WinoP {
 // launchers (all asynchronous on `st`, no allocation, no synchronisation)
 int launch_conv(const ConvP& p, int G, hipStream_t st);
 int launch_conv_winograd(const WinoP& q, int B, int G, hipStream_t st);
-int launch_winograd_weights(const float* w_oihw, int Cout, int Cin, float* u, hipStream_t st);
-void winograd_weights_host(const float* w_oihw, int Cout, int Cin, float* u);
+int launch_winograd_weights(const float* w_oihw, int Cout, int Cin, int m, float* u, hipStream_t st);
+void winograd_weights_host(const float* w_oihw, int Cout, int Cin, int m, float* u);
 bool winograd_eligible(int k, int stride, int pad, int dil, int Cin, int Cout);
-size_t winograd_ws_floats(int B, int H, int W, int Cin, int Cout, int G, int dil);
-double winograd_mac_ratio(int H, int W, int dil);
-extern int g_winograd, g_wino_min_cin, g_wino_max_ratio;
+size_t winograd_ws_floats(int B, int H, int W, int Cin, int Cout, int G, int dil, int m);
+double winograd_mac_ratio(int H, int W, int dil, int m);
+extern int g_winograd, g_wino_min_cin, g_wino_max_ratio, g_wino_variant;
 extern int g_force_split, g_force_tile, g_tail_split;
 int launch_preprocess(const uint8_t* rgb, const uint8_t* depth, const float* offs, float* x, int B, int Bcap,
                       int H, int W, const float* mean6, const float* std6, int streams, hipStream_t st);

@@ -201,20 +201,29 @@ struct Builder {
         quber_ctx* ctx = c;
         // Winograd F(2x2,3x3) alternative for the wide plain 3x3 layers; chosen per launch (batch) in the lambda below
         WinoP wq{};
-        // (a dilated layer pads its short phases to whole tiles: only taken while that keeps >= 1.5x fewer multiplies)
-        const bool wino = winograd_eligible(k, stride, pad, dil, Cin, Cout) && cin_real == Cin && !res && prelu.empty() &&
-                          winograd_mac_ratio(in.H, in.W, dil) <= (double)g_wino_max_ratio / 100.0;
+        // (ragged frames and a dilated layer's short phases are padded to whole tiles: a variant is only taken while it
+        // still executes <= g_wino_max_ratio % of the direct multiplies; m = 4 preferred when both qualify)
+        bool wino = winograd_eligible(k, stride, pad, dil, Cin, Cout) && cin_real == Cin && !res && prelu.empty();
+        int wm = 0;
         if (wino) {
-            std::vector<float> u((size_t)G * 16 * Cout * Cin);
-            for (int g = 0; g < G; ++g) winograd_weights_host(w[g], Cout, Cin, &u[(size_t)g * 16 * Cout * Cin]);
+            const double lim = (double)g_wino_max_ratio / 100.0;
+            const double r4 = winograd_mac_ratio(in.H, in.W, dil, 4), r2 = winograd_mac_ratio(in.H, in.W, dil, 2);
+            if (g_wino_variant != 2 && r4 <= lim && r4 < r2) wm = 4;
+            else if (g_wino_variant != 4 && r2 <= lim) wm = 2;
+            else if (g_wino_variant == 4 && r4 <= lim) wm = 4;
+            wino = wm != 0;
+        }
+        if (wino) {
+            const int P = (wm + 2) * (wm + 2);
+            std::vector<float> u((size_t)G * P * Cout * Cin);
+            for (int g = 0; g < G; ++g) winograd_weights_host(w[g], Cout, Cin, wm, &u[(size_t)g * P * Cout * Cin]);
             wq.in = in; wq.out = out; wq.u = upload(u);
-            wq.scale = p.scale; wq.shift = p.shift; wq.ss_gs = Cout; wq.relu = relu; wq.dil = dil;
-            const size_t need = winograd_ws_floats(Bmax, in.H, in.W, Cin, Cout, G, dil);
+            wq.scale = p.scale; wq.shift = p.shift; wq.ss_gs = Cout; wq.relu = relu; wq.dil = dil; wq.m = wm;
+            const size_t need = winograd_ws_floats(Bmax, in.H, in.W, Cin, Cout, G, dil, wm);
             if (need > c->wino_floats) c->wino_floats = need;
             c->wino_flops += 2.0 * OH * OW * (double)cin_real * k * k * Cout * G;
-            c->wino_saved += 2.0 * OH * OW * (double)cin_real * k * k * Cout * G * (1.0 - winograd_mac_ratio(in.H, in.W, dil));
+            c->wino_saved += 2.0 * OH * OW * (double)cin_real * k * k * Cout * G * (1.0 - winograd_mac_ratio(in.H, in.W, dil, wm));
         }
-        // a GroupNorm that consumes this output may ask the convolution for its sums (gn_relu fills `fuse` in)
         auto fuse = std::make_shared<GnFuse>();
         last_conv = {fuse, out.p, G, Cout};
         c->ops.push_back({[p, G, ctx, fuse, wq, wino](int B, hipStream_t st) mutable {
@@ -921,6 +930,7 @@ void quber_set_tuning(int32_t key, int32_t value) {
         }
     }
     if (key == 4) g_force_tile = value;    // force the tile shape: 1 = 64x64, 2 = 128x128, 4 = 256x32 (0 = automatic)
+    if (key == 9) g_wino_variant = value;     // Winograd output tile edge for the eligible layers: 0 = automatic, 2, 4
     if (key == 8) g_wino_max_ratio = value;   // Winograd only while executed / direct multiplies <= value % (default 67)
     if (key == 7) g_wino_min_cin = value;  // smallest input width eligible for the Winograd path (default 256)
     if (key == 6) g_winograd = value;      // Winograd F(2x2,3x3) for the eligible 3x3 layers: 0 = where it pays, 1 = never, 2 = always
@@ -1122,16 +1132,17 @@ int quber_op_conv2d(const float* x, int32_t B, int32_t h, int32_t w, int32_t cin
 static View mkview(const float* p, int B, int h, int w, int c);
 
 int quber_op_conv3x3_winograd(const float* x, int32_t B, int32_t h, int32_t w, int32_t cin, const float* w_oihw, int32_t cout,
-                              int32_t dil, const float* scale, const float* shift, int32_t relu, float* u, float* ws,
+                              int32_t dil, int32_t m, const float* scale, const float* shift, int32_t relu, float* u, float* ws,
                               int64_t ws_floats, float* y, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (!winograd_eligible(3, 1, dil, dil, cin, cout)) return fail("winograd: unsupported channel counts");
     if ((scale == nullptr) != (shift == nullptr)) return fail("winograd: scale and shift go together");
-    int rc = launch_winograd_weights(w_oihw, cout, cin, u, st);
+    if (m != 2 && m != 4) return fail("winograd: the output tile edge is 2 or 4");
+    int rc = launch_winograd_weights(w_oihw, cout, cin, m, u, st);
     if (rc) return rc;
     WinoP q{};
     q.in = mkview(x, B, h, w, cin); q.out = mkview(y, B, h, w, cout);
-    q.u = u; q.scale = scale; q.shift = shift; q.ss_gs = 0; q.relu = relu; q.dil = dil;
+    q.u = u; q.scale = scale; q.shift = shift; q.ss_gs = 0; q.relu = relu; q.dil = dil; q.m = m;
     q.ws = ws; q.ws_floats = (size_t)ws_floats;
     q.splitk_ws = g_op_ws; q.splitk_floats = g_op_ws ? g_op_ws_floats : 0;
     return launch_conv_winograd(q, B, 1, st);

@@ -1,29 +1,88 @@
-// Winograd F(2x2, 3x3) path for the wide 3x3 / stride 1 / dilation 1 convolutions of the refiner (fp32 throughout).
+// Winograd F(m x m, 3x3) path, m = 2 or 4, for the wide 3x3 / stride 1 convolutions of the refiner (fp32 throughout).
 //
 // The reference computes these layers as plain convolutions (detectron2 Conv2d -> F.conv2d;
-// maskrefiner/modeling/backbone/resnet.py:472-485 fusion_res*.conv0/1, resnet.py:441-447 res4 conv2).  The same sum is
-// regrouped: every 2x2 output tile needs 16 multiplies per (cin, cout) pair instead of 36,
-//     Y = A^T [ (G g G^T) .* (B^T d B) ] A,       d = 4x4 input patch, g = 3x3 filter,
-// so the matrix pipe does 2.25x less work.  Pipeline per layer:
-//   1. wino_input_kernel   d -> V = B^T d B          NHWC input  -> V[g][16][tile][Cin]      (HBM-bound, writes 4x the input)
-//   2. conv_igemm_f32      M[p] = V[p] x U[p]^T       16 (x groups) independent GEMMs, launched as ONE grouped 1x1
+// maskrefiner/modeling/backbone/resnet.py:472-485 fusion_res*.conv0/1, resnet.py:441-447 res3-5 conv2, the
+// DeepLabV3+ / head 3x3s of model.py:369-458).  The same sum is regrouped: an m x m output tile needs (m+2)^2
+// multiplies per (cin, cout) pair instead of 9 m^2,
+//     Y = A^T [ (G g G^T) .* (B^T d B) ] A,       d = (m+2)^2 input patch, g = 3x3 filter,
+// so the matrix pipe does 2.25x (m = 2) or 4x (m = 4) less work.  Pipeline per layer, P = (m+2)^2:
+//   1. wino_input_kernel   d -> V = B^T d B          NHWC input  -> V[g][P][tile][Cin]     (HBM-bound)
+//   2. conv_igemm_f32      M[p] = V[p] x U[p]^T       P (x groups) independent GEMMs, launched as ONE grouped 1x1
 //                                                      "convolution" over blockIdx.z (conv_igemm.hip, unchanged)
-//   3. wino_output_kernel  Y = A^T M A, affine, ReLU  M[g][16][tile][Cout] -> NHWC output (any channel-slice view)
-// All transform matrices have entries in {0, +-1, +-1/2}; the result differs from the direct kernel by a few 1e-7
-// relative (different summation grouping), well inside the 1e-4 bar, and the path is only taken where it wins:
-// Cin >= 256 (transform traffic grows with C, GEMM work with C^2) and enough tiles to fill the chip.
+//   3. wino_output_kernel  Y = A^T M A, affine, ReLU  M[g][P][tile][Cout] -> NHWC output (any channel-slice view),
+//                                                      GroupNorm sums of the stored values on request
+// m = 2: all transform entries are in {0, +-1, +-1/2}; the result is as accurate as the direct kernel.
+// m = 4 (Lavin & Gray's points 0, +-1, +-2, inf): entries up to 8 / down to 1/24 cost about one decimal digit
+// (tests/test_gpu_parity.py::test_conv3x3_winograd_vs_float64 bounds it); see DESIGN.md for where each is used.
+// With dilation d the layer is d*d independent dense convolutions on the phase sub-images in[d*Y + py][d*X + px]
+// (TH x TW tiles each, the same for every phase; tiles beyond a shorter phase read zeros and store nothing).
 #include "common.h"
 
 namespace quber {
 
-int g_wino_min_cin = 128;
-int g_wino_max_ratio = 67;   // key 8: executed / direct multiplies (%) up to which a (dilated) layer takes this path   // key 7 (test harness): smallest input width routed to this path
+int g_wino_min_cin = 128;     // key 7 (test harness): smallest input width routed to this path
+int g_wino_max_ratio = 67;    // key 8: executed / direct multiplies (%) up to which a (dilated) layer takes this path
+int g_wino_variant = 0;       // key 9: output tile edge m for the eligible layers: 0 = automatic, 2, 4
 
-// tile (ty, tx) of image b covers output rows 2ty..2ty+1, columns 2tx..2tx+1 and reads input rows 2ty-1..2ty+2
-// With dilation d the layer is d*d independent dense convolutions on the phase sub-images in[d*Y + py][d*X + px]
-// (TH x TW tiles each, the same for every phase; tiles beyond a shorter phase read zeros and store nothing).
+namespace {
+
+__device__ inline float4 f4(float a) { return make_float4(a, a, a, a); }
+__device__ inline float4 operator+(const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ inline float4 operator-(const float4& a, const float4& b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ inline float4 operator*(float s, const float4& a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
+
+// y = B^T x  (one dimension)
+template <int O>
+__device__ inline void bt(const float4* x, float4* y) {
+    if constexpr (O == 2) {
+        y[0] = x[0] - x[2];
+        y[1] = x[1] + x[2];
+        y[2] = x[2] - x[1];
+        y[3] = x[1] - x[3];
+    } else {
+        y[0] = (4.f * x[0] - 5.f * x[2]) + x[4];
+        y[1] = (x[3] + x[4]) - 4.f * (x[1] + x[2]);
+        y[2] = (x[4] - x[3]) + 4.f * (x[1] - x[2]);
+        y[3] = (x[4] - x[2]) + 2.f * (x[3] - x[1]);
+        y[4] = (x[4] - x[2]) + 2.f * (x[1] - x[3]);
+        y[5] = (4.f * x[1] - 5.f * x[3]) + x[5];
+    }
+}
+
+// y = A^T x  (one dimension)
+template <int O>
+__device__ inline void at(const float4* x, float4* y) {
+    if constexpr (O == 2) {
+        y[0] = (x[0] + x[1]) + x[2];
+        y[1] = (x[1] - x[2]) - x[3];
+    } else {
+        const float4 a = x[1] + x[2], b = x[1] - x[2], c = x[3] + x[4], d = x[3] - x[4];
+        y[0] = (x[0] + a) + c;
+        y[1] = b + 2.f * d;
+        y[2] = a + 4.f * c;
+        y[3] = (b + 8.f * d) + x[5];
+    }
+}
+
+// tile index -> image, phase and tile position
+struct TileAt { int b, py, px, ty, tx; };
+__device__ inline TileAt locate(long tile, int TH, int TW, int d) {
+    TileAt t;
+    t.tx = tile % TW;
+    long r = tile / TW;
+    t.ty = r % TH;
+    r /= TH;
+    t.px = r % d;
+    r /= d;
+    t.py = r % d;
+    t.b = (int)(r / d);
+    return t;
+}
+
+template <int O>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ in, int B, int H, int W, int C4, int in_cs,
                                                          long in_gs, int TH, int TW, int d, float* __restrict__ v, long v_gs) {
+    constexpr int T = O + 2;
     const int g = blockIdx.z;
     in += g * in_gs;
     v += g * v_gs;
@@ -32,56 +91,45 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
     const long tiles = (long)B * d * d * TH * TW;
     const long tile = tpb ? (long)blockIdx.x * tpb + threadIdx.x / C4 : blockIdx.x;
     if (tile >= tiles || c4 >= C4 || (tpb && (int)(threadIdx.x / C4) >= tpb)) return;
-    const int tx = tile % TW;
-    long r = tile / TW;
-    const int ty = r % TH;
-    r /= TH;
-    const int px = r % d;
-    r /= d;
-    const int py = r % d;
-    const int b = r / d;
-    const float* base = in + (long)b * H * W * in_cs + c4 * 4;
-    float4 dd[4][4];
+    const TileAt ta = locate(tile, TH, TW, d);
+    const float* base = in + (long)ta.b * H * W * in_cs + c4 * 4;
+    float4 t[T][T];                                  // t = B^T d, one input column at a time
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int y = d * (2 * ty - 1 + i) + py;
+    for (int j = 0; j < T; ++j) {
+        const int x = d * (O * ta.tx - 1 + j) + ta.px;
+        float4 col[T], tc[T];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int x = d * (2 * tx - 1 + j) + px;
-            dd[i][j] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
-                           ? *reinterpret_cast<const float4*>(base + ((long)y * W + x) * in_cs)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < T; ++i) {
+            const int y = d * (O * ta.ty - 1 + i) + ta.py;
+            col[i] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+                         ? *reinterpret_cast<const float4*>(base + ((long)y * W + x) * in_cs)
+                         : f4(0.f);
         }
-    }
-    auto sub = [](const float4& a, const float4& b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); };
-    auto add = [](const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
-    float4 t[4][4];
+        bt<O>(col, tc);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {                    // B^T d
-        t[0][j] = sub(dd[0][j], dd[2][j]);
-        t[1][j] = add(dd[1][j], dd[2][j]);
-        t[2][j] = sub(dd[2][j], dd[1][j]);
-        t[3][j] = sub(dd[1][j], dd[3][j]);
+        for (int i = 0; i < T; ++i) t[i][j] = tc[i];
     }
     float* dst = v + tile * (long)(C4 * 4) + c4 * 4;
     const long ps = tiles * (long)(C4 * 4);          // position stride
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {                    // (B^T d) B
-        *reinterpret_cast<float4*>(dst + (i * 4 + 0) * ps) = sub(t[i][0], t[i][2]);
-        *reinterpret_cast<float4*>(dst + (i * 4 + 1) * ps) = add(t[i][1], t[i][2]);
-        *reinterpret_cast<float4*>(dst + (i * 4 + 2) * ps) = sub(t[i][2], t[i][1]);
-        *reinterpret_cast<float4*>(dst + (i * 4 + 3) * ps) = sub(t[i][1], t[i][3]);
+    for (int i = 0; i < T; ++i) {                    // (B^T d) B
+        float4 row[T];
+        bt<O>(t[i], row);
+#pragma unroll
+        for (int j = 0; j < T; ++j) *reinterpret_cast<float4*>(dst + (i * T + j) * ps) = row[j];
     }
 }
 
 // A block handles OUT_ITERS groups of tiles; with `gn_sum` it also accumulates the GroupNorm sums of what it stores
 // (fp64, LDS per block, one global atomic per (image, group) per block - as the direct kernel's epilogue does).
 constexpr int OUT_ITERS = 4;
+template <int O>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ m, long m_gs, int B, int OH, int OW, int C4,
                                                           int TH, int TW, int d, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int ss_gs, int relu,
                                                           float* __restrict__ out, int out_cs, long out_gs,
                                                           double* __restrict__ gn_sum, int gn_groups, int gn_cpg) {
+    constexpr int T = O + 2;
     const int g = blockIdx.z;
     m += g * m_gs;
     out += g * out_gs;
@@ -100,13 +148,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     }
     double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
     const long ps = tiles * (long)(C4 * 4);
-    auto add3 = [](const float4& a, const float4& b, const float4& c) {
-        return make_float4(a.x + b.x + c.x, a.y + b.y + c.y, a.z + b.z + c.z, a.w + b.w + c.w);
-    };
-    auto sub3 = [](const float4& a, const float4& b, const float4& c) {
-        return make_float4(a.x - b.x - c.x, a.y - b.y - c.y, a.z - b.z - c.z, a.w - b.w - c.w);
-    };
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 sc = f4(1.f), sh = f4(0.f);
     if (scale && lane_ok) {
         sc = *reinterpret_cast<const float4*>(scale + g * ss_gs + c4 * 4);
         sh = *reinterpret_cast<const float4*>(shift + g * ss_gs + c4 * 4);
@@ -114,35 +156,30 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     for (int it = 0; it < OUT_ITERS; ++it) {
         const long tile = tile0 + (long)it * step + (tpb ? threadIdx.x / C4 : 0);
         if (!lane_ok || tile >= tiles) continue;
-        const int tx = tile % TW;
-        long r = tile / TW;
-        const int ty = r % TH;
-        r /= TH;
-        const int px = r % d;
-        r /= d;
-        const int py = r % d;
-        const int b = r / d;
+        const TileAt ta = locate(tile, TH, TW, d);
         const float* src = m + tile * (long)(C4 * 4) + c4 * 4;
-        float4 s[2][4];
+        float4 s[O][T];                              // s = A^T M, one column of positions at a time
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {                // A^T M
-            const float4 m0 = *reinterpret_cast<const float4*>(src + (0 * 4 + j) * ps);
-            const float4 m1 = *reinterpret_cast<const float4*>(src + (1 * 4 + j) * ps);
-            const float4 m2 = *reinterpret_cast<const float4*>(src + (2 * 4 + j) * ps);
-            const float4 m3 = *reinterpret_cast<const float4*>(src + (3 * 4 + j) * ps);
-            s[0][j] = add3(m0, m1, m2);
-            s[1][j] = sub3(m1, m2, m3);
+        for (int j = 0; j < T; ++j) {
+            float4 col[T], sj[O];
+#pragma unroll
+            for (int i = 0; i < T; ++i) col[i] = *reinterpret_cast<const float4*>(src + (i * T + j) * ps);
+            at<O>(col, sj);
+#pragma unroll
+            for (int i = 0; i < O; ++i) s[i][j] = sj[i];
         }
         double a = 0.0, q = 0.0;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int oy = d * (2 * ty + i) + py;
+        for (int i = 0; i < O; ++i) {
+            const int oy = d * (O * ta.ty + i) + ta.py;
+            float4 row[O];
+            at<O>(s[i], row);                        // (A^T M) A
             if (oy >= OH) continue;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int ox = d * (2 * tx + j) + px;
+            for (int j = 0; j < O; ++j) {
+                const int ox = d * (O * ta.tx + j) + ta.px;
                 if (ox >= OW) continue;
-                float4 y = j == 0 ? add3(s[i][0], s[i][1], s[i][2]) : sub3(s[i][1], s[i][2], s[i][3]);   // (A^T M) A
+                float4 y = row[j];
                 if (scale) {
                     y.x = fmaf(y.x, sc.x, sh.x); y.y = fmaf(y.y, sc.y, sh.y);
                     y.z = fmaf(y.z, sc.z, sh.z); y.w = fmaf(y.w, sc.w, sh.w);
@@ -150,12 +187,12 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
                 if (relu) {
                     y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
                 }
-                *reinterpret_cast<float4*>(out + (((long)b * OH + oy) * OW + ox) * out_cs + c4 * 4) = y;
+                *reinterpret_cast<float4*>(out + (((long)ta.b * OH + oy) * OW + ox) * out_cs + c4 * 4) = y;
                 a += (double)y.x + (double)y.y + (double)y.z + (double)y.w;
                 q += (double)y.x * y.x + (double)y.y * y.y + (double)y.z * y.z + (double)y.w * y.w;
             }
         }
-        if (b == b0) { s0 += a; q0 += q; } else { s1 += a; q1 += q; }
+        if (ta.b == b0) { s0 += a; q0 += q; } else { s1 += a; q1 += q; }
     }
     if (gn_sum) {
         if (lane_ok) {
@@ -172,85 +209,110 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     }
 }
 
-// U[p = i*4+j][o][c] = (G g G^T)[i][j] of filter (o, c); G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]; fp64, rounded once
-__host__ __device__ static inline void wino_filter(const float* g9, double* u16) {
-    double t[4][3];
-    for (int j = 0; j < 3; ++j) {
-        const double a = g9[0 * 3 + j], b = g9[1 * 3 + j], c = g9[2 * 3 + j];
-        t[0][j] = a;
-        t[1][j] = 0.5 * (a + b + c);
-        t[2][j] = 0.5 * (a - b + c);
-        t[3][j] = c;
-    }
-    for (int i = 0; i < 4; ++i) {
-        const double a = t[i][0], b = t[i][1], c = t[i][2];
-        u16[i * 4 + 0] = a;
-        u16[i * 4 + 1] = 0.5 * (a + b + c);
-        u16[i * 4 + 2] = 0.5 * (a - b + c);
-        u16[i * 4 + 3] = c;
+// one dimension of U = G g G^T, fp64
+template <int O>
+__host__ __device__ inline void gmul(double a, double b, double c, double* y) {
+    if constexpr (O == 2) {
+        y[0] = a;
+        y[1] = 0.5 * (a + b + c);
+        y[2] = 0.5 * (a - b + c);
+        y[3] = c;
+    } else {
+        y[0] = a / 4.0;
+        y[1] = -(a + b + c) / 6.0;
+        y[2] = -(a - b + c) / 6.0;
+        y[3] = a / 24.0 + b / 12.0 + c / 6.0;
+        y[4] = a / 24.0 - b / 12.0 + c / 6.0;
+        y[5] = c;
     }
 }
 
-void winograd_weights_host(const float* w_oihw, int Cout, int Cin, float* u) {
+// U[p = i*T+j] = (G g G^T)[i][j] of one 3x3 filter (row-major g9); computed in fp64 and rounded once by the caller
+template <int O>
+__host__ __device__ inline void wino_filter(const float* g9, double* u) {
+    constexpr int T = O + 2;
+    double t[T][3];
+    for (int j = 0; j < 3; ++j) {
+        double col[T];
+        gmul<O>(g9[0 * 3 + j], g9[1 * 3 + j], g9[2 * 3 + j], col);
+        for (int i = 0; i < T; ++i) t[i][j] = col[i];
+    }
+    for (int i = 0; i < T; ++i) gmul<O>(t[i][0], t[i][1], t[i][2], u + i * T);
+}
+
+template <int O>
+__global__ void wino_weight_kernel(const float* __restrict__ w, int Cout, int Cin, float* __restrict__ u) {
+    constexpr int P = (O + 2) * (O + 2);
+    const long n = (long)Cout * Cin;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        double up[P];
+        wino_filter<O>(w + i * 9, up);
+        for (int p = 0; p < P; ++p) u[p * n + i] = (float)up[p];
+    }
+}
+
+template <int O>
+void weights_host(const float* w_oihw, int Cout, int Cin, float* u) {
+    constexpr int P = (O + 2) * (O + 2);
     for (int o = 0; o < Cout; ++o)
         for (int c = 0; c < Cin; ++c) {
-            double u16[16];
-            wino_filter(w_oihw + ((size_t)o * Cin + c) * 9, u16);
-            for (int p = 0; p < 16; ++p) u[((size_t)p * Cout + o) * Cin + c] = (float)u16[p];
+            double up[P];
+            wino_filter<O>(w_oihw + ((size_t)o * Cin + c) * 9, up);
+            for (int p = 0; p < P; ++p) u[((size_t)p * Cout + o) * Cin + c] = (float)up[p];
         }
 }
 
-__global__ void wino_weight_kernel(const float* __restrict__ w, int Cout, int Cin, float* __restrict__ u) {
-    const long n = (long)Cout * Cin;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        double u16[16];
-        wino_filter(w + i * 9, u16);
-        for (int p = 0; p < 16; ++p) u[p * n + i] = (float)u16[p];
-    }
+// tiles per image: d*d phases of ceil(ceil(H/d)/m) x ceil(ceil(W/d)/m) tiles
+inline int tiles_1d(int n, int d, int m) { return ((n + d - 1) / d + m - 1) / m; }
+inline long wino_tiles(int H, int W, int d, int m) { return (long)d * d * tiles_1d(H, d, m) * tiles_1d(W, d, m); }
+
+}  // namespace
+
+void winograd_weights_host(const float* w_oihw, int Cout, int Cin, int m, float* u) {
+    if (m == 4) weights_host<4>(w_oihw, Cout, Cin, u);
+    else weights_host<2>(w_oihw, Cout, Cin, u);
 }
 
-int launch_winograd_weights(const float* w_oihw, int Cout, int Cin, float* u, hipStream_t st) {
-    hipLaunchKernelGGL(wino_weight_kernel, dim3(256), dim3(256), 0, st, w_oihw, Cout, Cin, u);
+int launch_winograd_weights(const float* w_oihw, int Cout, int Cin, int m, float* u, hipStream_t st) {
+    if (m == 4) hipLaunchKernelGGL(wino_weight_kernel<4>, dim3(256), dim3(256), 0, st, w_oihw, Cout, Cin, u);
+    else hipLaunchKernelGGL(wino_weight_kernel<2>, dim3(256), dim3(256), 0, st, w_oihw, Cout, Cin, u);
     QB_CHECK(hipGetLastError());
     return 0;
 }
-
-// tiles per image: d*d phases of ceil(ceil(H/d)/2) x ceil(ceil(W/d)/2) tiles
-static inline long wino_tiles(int H, int W, int d) { return (long)d * d * (((H + d - 1) / d + 1) / 2) * (((W + d - 1) / d + 1) / 2); }
 
 bool winograd_eligible(int k, int stride, int pad, int dil, int Cin, int Cout) {
     return k == 3 && stride == 1 && dil >= 1 && pad == dil && Cin % 32 == 0 && Cout % 4 == 0 && Cin >= g_wino_min_cin &&
            Cout >= 128 && (Cin / 4 <= 256 || (Cin / 4) % 256 == 0) && (Cout / 4 <= 256 || (Cout / 4) % 256 == 0);
 }
 
-size_t winograd_ws_floats(int B, int H, int W, int Cin, int Cout, int G, int dil) {
-    const size_t tiles = (size_t)B * wino_tiles(H, W, dil);
-    return (size_t)G * 16 * tiles * (size_t)(Cin + Cout);
+size_t winograd_ws_floats(int B, int H, int W, int Cin, int Cout, int G, int dil, int m) {
+    const size_t tiles = (size_t)B * wino_tiles(H, W, dil, m);
+    return (size_t)G * (m + 2) * (m + 2) * tiles * (size_t)(Cin + Cout);
 }
 
-// executed multiplies relative to the direct kernel: 16 per tile against 36 per four REAL outputs; the padded tiles of
-// a dilated layer's short phases eat into the 2.25x
-double winograd_mac_ratio(int H, int W, int dil) { return 16.0 * wino_tiles(H, W, dil) / (9.0 * H * W); }
+// executed multiplies relative to the direct kernel: (m+2)^2 per tile against 9 per REAL output; the padded tiles of
+// ragged frames and of a dilated layer's short phases eat into the 2.25x / 4x
+double winograd_mac_ratio(int H, int W, int dil, int m) {
+    return (double)((m + 2) * (m + 2)) * wino_tiles(H, W, dil, m) / (9.0 * H * W);
+}
 
-int launch_conv_winograd(const WinoP& q, int B, int G, hipStream_t st) {
+template <int O>
+static int run_winograd(const WinoP& q, int B, int G, hipStream_t st) {
+    constexpr int P = (O + 2) * (O + 2);
     const View& in = q.in;
     const View& out = q.out;
-    const int H = in.H, W = in.W, Cin = in.C, Cout = out.C;
-    const int d = q.dil;
-    if (!winograd_eligible(3, 1, d, d, Cin, Cout) || out.H != H || out.W != W) return fail("winograd: unsupported geometry");
-    if (in.cs % 4 || out.cs % 4 || ((uintptr_t)in.p & 15) || ((uintptr_t)out.p & 15) || (in.gs & 3) || (out.gs & 3))
-        return fail("winograd: operands must be 16-byte aligned");
-    const int TH = ((H + d - 1) / d + 1) / 2, TW = ((W + d - 1) / d + 1) / 2;
-    const long tiles = (long)B * wino_tiles(H, W, d);
-    if (tiles * 16 >= (1L << 31) / 2) return fail("winograd: too many tiles");
-    if (winograd_ws_floats(B, H, W, Cin, Cout, G, d) > q.ws_floats) return fail("winograd: workspace too small");
+    const int H = in.H, W = in.W, Cin = in.C, Cout = out.C, d = q.dil;
+    const int TH = tiles_1d(H, d, O), TW = tiles_1d(W, d, O);
+    const long tiles = (long)B * wino_tiles(H, W, d, O);
+    if (tiles * P >= (1L << 31) / 2) return fail("winograd: too many tiles");
+    if (winograd_ws_floats(B, H, W, Cin, Cout, G, d, O) > q.ws_floats) return fail("winograd: workspace too small");
     float* v = q.ws;
-    float* m = q.ws + (size_t)G * 16 * tiles * Cin;
+    float* m = q.ws + (size_t)G * P * tiles * Cin;
     auto grid = [&](int C4) {
         return C4 <= 256 ? dim3((unsigned)((tiles + 256 / C4 - 1) / (256 / C4)), 1, G) : dim3((unsigned)tiles, C4 / 256, G);
     };
-    hipLaunchKernelGGL(wino_input_kernel, grid(Cin / 4), dim3(256), 0, st, in.p, B, H, W, Cin / 4, in.cs, in.gs, TH, TW, d, v,
-                       16 * tiles * Cin);
+    hipLaunchKernelGGL(wino_input_kernel<O>, grid(Cin / 4), dim3(256), 0, st, in.p, B, H, W, Cin / 4, in.cs, in.gs, TH, TW, d,
+                       v, (long)P * tiles * Cin);
     QB_CHECK(hipGetLastError());
     ConvP p{};
     p.in = v; p.w = q.u; p.out = m;
@@ -261,20 +323,30 @@ int launch_conv_winograd(const WinoP& q, int B, int G, hipStream_t st) {
     p.M = (int)tiles; p.ohw = (int)tiles;
     p.in_gs = tiles * Cin; p.out_gs = tiles * Cout; p.w_gs = (long)Cout * Cin;
     p.ws = q.splitk_ws; p.ws_floats = q.splitk_floats;
-    int rc = launch_conv(p, G * 16, st);
+    int rc = launch_conv(p, G * P, st);
     if (rc) return rc;
     // GroupNorm sums in the output transform when a block's tiles meet at most two images and float4s stay inside a group
     const int C4o = Cout / 4, per_iter = C4o <= 256 ? 256 / C4o : 1;
     const bool gn_here = q.gn_sum && q.gn_groups > 0 && q.gn_groups <= 32 && (Cout / q.gn_groups) % 4 == 0 &&
-                         wino_tiles(H, W, d) >= (long)per_iter * OUT_ITERS;
+                         wino_tiles(H, W, d, O) >= (long)per_iter * OUT_ITERS;
     dim3 og = grid(C4o);
     og.x = (og.x + OUT_ITERS - 1) / OUT_ITERS;
-    hipLaunchKernelGGL(wino_output_kernel, og, dim3(256), 0, st, m, 16 * tiles * Cout, B, H, W, C4o, TH, TW, d, q.scale, q.shift,
-                       q.ss_gs, q.relu, out.p, out.cs, out.gs, gn_here ? q.gn_sum : nullptr, q.gn_groups,
+    hipLaunchKernelGGL(wino_output_kernel<O>, og, dim3(256), 0, st, m, (long)P * tiles * Cout, B, H, W, C4o, TH, TW, d, q.scale,
+                       q.shift, q.ss_gs, q.relu, out.p, out.cs, out.gs, gn_here ? q.gn_sum : nullptr, q.gn_groups,
                        q.gn_groups ? Cout / q.gn_groups : 1);
     QB_CHECK(hipGetLastError());
     if (q.gn_sum && !gn_here) return launch_gn_stats(out, B, G, q.gn_groups, q.gn_sum, st, false);
     return 0;
+}
+
+int launch_conv_winograd(const WinoP& q, int B, int G, hipStream_t st) {
+    const View& in = q.in;
+    const View& out = q.out;
+    if (!winograd_eligible(3, 1, q.dil, q.dil, in.C, out.C) || out.H != in.H || out.W != in.W || (q.m != 2 && q.m != 4))
+        return fail("winograd: unsupported geometry");
+    if (in.cs % 4 || out.cs % 4 || ((uintptr_t)in.p & 15) || ((uintptr_t)out.p & 15) || (in.gs & 3) || (out.gs & 3))
+        return fail("winograd: operands must be 16-byte aligned");
+    return q.m == 4 ? run_winograd<4>(q, B, G, st) : run_winograd<2>(q, B, G, st);
 }
 
 }  // namespace quber

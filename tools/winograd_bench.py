@@ -17,8 +17,8 @@ lib.quber_set_tuning(7, 32)
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-print(f"| layer ({F} frames) | GFLOP | direct ms | TF/s | winograd ms | effective TF/s | speed-up |")
-print("|---|---|---|---|---|---|---|")
+print(f"| layer ({F} frames) | GFLOP | direct ms | TF/s | F(2x2) ms | speed-up | F(4x4) ms | speed-up |")
+print("|---|---|---|---|---|---|---|---|")
 for name, ipf, H, W, Cin, Cout, *rest in [("fusion_res2 3x3 256>256 @120x160", 1, 120, 160, 256, 256),
                                    ("res5.conv2 3x3 d2 512>512 @30x40 (2 streams)", 2, 30, 40, 512, 512, 2),
                                    ("res5.conv2 3x3 d4 512>512 @30x40 (2 streams)", 2, 30, 40, 512, 512, 4),
@@ -43,9 +43,6 @@ for name, ipf, H, W, Cin, Cout, *rest in [("fusion_res2 3x3 256>256 @120x160", 1
     sc, sh = torch.rand(Cout, device="cuda") + 0.5, torch.randn(Cout, device="cuda")
     y = torch.empty(B, H, W, Cout, device="cuda")
     packed = torch.empty(Cout * 9 * Cin, device="cuda")
-    tiles = B * d * d * ((-(-H // d) + 1) // 2) * ((-(-W // d) + 1) // 2)
-    u = torch.empty(16 * Cout * Cin, device="cuda")
-    ws = torch.empty(16 * tiles * (Cin + Cout), device="cuda")
     fl = 2.0 * B * H * W * Cin * 9 * Cout
 
     def timed(fn):
@@ -63,9 +60,17 @@ for name, ipf, H, W, Cin, Cout, *rest in [("fusion_res2 3x3 256>256 @120x160", 1
 
     td = timed(lambda: _lib.check(lib.quber_op_conv2d(p(x), B, H, W, Cin, p(w), Cout, 3, 1, d, d, p(sc), p(sh), p(None), 1,
                                                       p(packed), p(y), st)))
-    try:
-        tw = timed(lambda: _lib.check(lib.quber_op_conv3x3_winograd(p(x), B, H, W, Cin, p(w), Cout, d, p(sc), p(sh), 1, p(u), p(ws),
-                                                                    ws.numel(), p(y), st)))
-        print("| %s | %.1f | %.3f | %.1f | %.3f | %.1f | %.2fx |" % (name, fl / 1e9, td, fl / td / 1e9, tw, fl / tw / 1e9, td / tw), flush=True)
-    except Exception as e:
-        print("| %s | %.1f | %.3f | %.1f | n/a (%s) | | |" % (name, fl / 1e9, td, fl / td / 1e9, str(e)[:40]), flush=True)
+    cols = []
+    for m in (2, 4):
+        P = (m + 2) ** 2
+        tiles = B * d * d * ((-(-H // d) + m - 1) // m) * ((-(-W // d) + m - 1) // m)
+        u = torch.empty(P * Cout * Cin, device="cuda")
+        ws = torch.empty(P * tiles * (Cin + Cout), device="cuda")
+        try:
+            tw = timed(lambda: _lib.check(lib.quber_op_conv3x3_winograd(p(x), B, H, W, Cin, p(w), Cout, d, m, p(sc), p(sh), 1, p(u),
+                                                                        p(ws), ws.numel(), p(y), st)))
+            cols.append("%.3f | %.2fx" % (tw, td / tw))
+        except Exception as e:
+            cols.append("n/a | ")
+        del u, ws
+    print("| %s | %.1f | %.3f | %.1f | %s |" % (name, fl / 1e9, td, fl / td / 1e9, " | ".join(cols)), flush=True)
