@@ -79,6 +79,14 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    # QUBER_WINOGRAD = auto (default) | f4 | f2 | off : which fast algorithm the wide 3x3 layers may use.  F(4x4,3x3)
+    # is about one decimal digit less accurate per layer than the direct kernel; "f2" keeps the
+    # direct kernel's accuracy at ~0.8x the throughput, "off" runs every layer as a plain implicit GEMM.
+    mode = os.environ.get("QUBER_WINOGRAD", "auto").lower()
+    if mode not in ("auto", "f4", "f2", "off"):
+        raise QuberError(f"QUBER_WINOGRAD={mode!r}: expected auto, f4, f2 or off")
+    lib.quber_set_tuning(6, 1 if mode == "off" else 0)
+    lib.quber_set_tuning(9, {"f2": 2, "f4": 4}.get(mode, 0))
     _lib = lib
     return lib
 

@@ -76,7 +76,7 @@ void winograd_weights_host(const float* w_oihw, int Cout, int Cin, int m, float*
 bool winograd_eligible(int k, int stride, int pad, int dil, int Cin, int Cout);
 size_t winograd_ws_floats(int B, int H, int W, int Cin, int Cout, int G, int dil, int m);
 double winograd_mac_ratio(int H, int W, int dil, int m);
-extern int g_winograd, g_wino_min_cin, g_wino_max_ratio, g_wino_variant;
+extern int g_winograd, g_wino_min_cin, g_wino_max_ratio, g_wino_variant, g_wino_min_cout;
 extern int g_force_split, g_force_tile, g_tail_split;
 int launch_preprocess(const uint8_t* rgb, const uint8_t* depth, const float* offs, float* x, int B, int Bcap,
                       int H, int W, const float* mean6, const float* std6, int streams, hipStream_t st);

@@ -23,6 +23,7 @@ namespace quber {
 int g_wino_min_cin = 128;     // key 7 (test harness): smallest input width routed to this path
 int g_wino_max_ratio = 67;    // key 8: executed / direct multiplies (%) up to which a (dilated) layer takes this path
 int g_wino_variant = 0;       // key 9: output tile edge m for the eligible layers: 0 = automatic, 2, 4
+int g_wino_min_cout = 128;    // key 10: smallest output width routed to this path
 
 namespace {
 
@@ -282,7 +283,7 @@ int launch_winograd_weights(const float* w_oihw, int Cout, int Cin, int m, float
 
 bool winograd_eligible(int k, int stride, int pad, int dil, int Cin, int Cout) {
     return k == 3 && stride == 1 && dil >= 1 && pad == dil && Cin % 32 == 0 && Cout % 4 == 0 && Cin >= g_wino_min_cin &&
-           Cout >= 128 && (Cin / 4 <= 256 || (Cin / 4) % 256 == 0) && (Cout / 4 <= 256 || (Cout / 4) % 256 == 0);
+           Cout >= g_wino_min_cout && (Cin / 4 <= 256 || (Cin / 4) % 256 == 0) && (Cout / 4 <= 256 || (Cout / 4) % 256 == 0);
 }
 
 size_t winograd_ws_floats(int B, int H, int W, int Cin, int Cout, int G, int dil, int m) {

@@ -14,6 +14,7 @@ from quber_amd import _lib  # noqa: E402
 lib = _lib.load()
 lib.quber_set_tuning(2, 1)
 lib.quber_set_tuning(7, 32)
+lib.quber_set_tuning(10, 32)
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 16
