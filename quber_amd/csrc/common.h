@@ -51,7 +51,17 @@ struct ConvP {
 void set_error(const std::string& msg);
 int fail(const std::string& msg);
 
-// one 3x3 / stride 1 / pad 1 convolution through Winograd F(2x2,3x3) (winograd.hip)
+// GroupNorm (+ ReLU) folded into the Winograd input transform: sums of the input tensor, affine parameters
+struct WinoNorm {
+    const double* stats;     // [G][B][groups][sum, sum of squares] of the tensor being read, or null = no normalisation
+    const float* gamma;
+    const float* beta;
+    int groups, cpg, param_gs, relu;
+    double n;                // elements per (image, group); filled in by the launcher
+    float eps;
+};
+
+// one 3x3 / stride 1 / pad = dilation convolution through Winograd F(m x m, 3x3) (winograd.hip)
 struct WinoP {
     View in, out;            // NHWC views; groups via View::gs
     const float* u;          // transformed weights [G][16][Cout][Cin]
@@ -62,6 +72,7 @@ struct WinoP {
     int m;                   // output tile edge: 2 = F(2x2,3x3), 4 = F(4x4,3x3)
     double* gn_sum;          // GroupNorm sums of the output to accumulate ([G][B][gn_groups][2]) or null
     int gn_groups;
+    WinoNorm norm;           // normalisation of the INPUT applied on load (stats == null: none)
     float* ws;               // V | M workspace (winograd_ws_floats)
     size_t ws_floats;
     float* splitk_ws;        // forwarded to the grouped GEMM launch

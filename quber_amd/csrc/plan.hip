@@ -88,12 +88,22 @@ constexpr int BLOCKS50[4] = {3, 4, 6, 3}, BLOCKS101[4] = {3, 4, 23, 3}, BLOCKS15
 enum Affine { AF_NONE, AF_FROZEN_BN, AF_BIAS, AF_BIAS_BN };
 
 struct GnFuse { double* sums = nullptr; int groups = 0; };
+// a GroupNorm + ReLU whose output has exactly one consumer: if that consumer takes the Winograd path it normalises
+// while loading and the separate apply pass is skipped
+struct DeferredNorm {
+    View in, out;
+    const double* stats = nullptr;
+    const float *gamma = nullptr, *beta = nullptr;
+    int C = 0, G = 0;
+    std::function<bool(int)> absorbed;     // set by the consumer: does it absorb the normalisation at this batch size?
+};
 struct LastConv { std::shared_ptr<GnFuse> fuse; const float* out = nullptr; int G = 0, C = 0; };
 
 struct Builder {
     quber_ctx* c;
     bool dry;
     LastConv last_conv;
+    std::shared_ptr<DeferredNorm> pending_norm;
     std::string err;
     int Bmax, H, W;
 
@@ -224,17 +234,35 @@ struct Builder {
             c->wino_flops += 2.0 * OH * OW * (double)cin_real * k * k * Cout * G;
             c->wino_saved += 2.0 * OH * OW * (double)cin_real * k * k * Cout * G * (1.0 - winograd_mac_ratio(in.H, in.W, dil, wm));
         }
+        // does this launch take the Winograd path?  (frames of a handful of tiles stay on the direct kernel)
+        const int pH = in.H, pW = in.W;
+        auto use_wino = [ctx, wino, pH, pW](int B) {
+            return wino && ctx->wino_ws && g_winograd != 1 && (g_winograd == 2 || (long)B * pH * pW / 4 >= 256);
+        };
+        std::shared_ptr<DeferredNorm> norm;
+        if (wino && pending_norm && pending_norm->out.p == in.p && pending_norm->C == Cin && pending_norm->G == G) {
+            norm = pending_norm;
+            norm->absorbed = use_wino;
+        }
+        pending_norm.reset();
         auto fuse = std::make_shared<GnFuse>();
         last_conv = {fuse, out.p, G, Cout};
-        c->ops.push_back({[p, G, ctx, fuse, wq, wino](int B, hipStream_t st) mutable {
-            // Winograd F(2x2,3x3) wins on every eligible layer (>= 128 channels in and out) at every batch size
-            // (profiles/r01l_winograd.md); frames of a handful of tiles stay on the direct kernel
-            const long trows = (long)B * p.H * p.W / 4;
-            if (wino && ctx->wino_ws && g_winograd != 1 && (g_winograd == 2 || trows >= 256)) {
+        c->ops.push_back({[p, G, ctx, fuse, wq, use_wino, norm](int B, hipStream_t st) mutable {
+            // Winograd F(m x m,3x3) wins on every eligible layer (>= 128 channels in and out) at every batch size
+            // (profiles/r01l_winograd.md)
+            if (use_wino(B)) {
                 wq.ws = ctx->wino_ws; wq.ws_floats = ctx->wino_floats;
                 wq.splitk_ws = ctx->splitk_ws; wq.splitk_floats = ctx->splitk_floats;
                 wq.gn_sum = fuse->sums; wq.gn_groups = fuse->groups;
+                if (norm) {                      // read the producer's pre-normalisation tensor and normalise on load
+                    wq.in = norm->in;
+                    wq.norm = WinoNorm{norm->stats, norm->gamma, norm->beta, 32, 0, norm->C, 1, 0.0, 1e-5f};
+                }
                 return launch_conv_winograd(wq, B, G, st);
+            }
+            if (norm) {                          // direct path: the skipped normalisation pass runs here instead
+                int rc = launch_gn_apply(norm->in, norm->out, B, G, 32, norm->stats, norm->gamma, norm->beta, norm->C, 1e-5f, 1, st);
+                if (rc) return rc;
             }
             p.B = B;
             p.M = B * p.OH * p.OW;
@@ -283,7 +311,7 @@ struct Builder {
     }
 
     // GroupNorm(32) + ReLU from `in` into `out` (possibly a concat slice); names = norm key prefixes per group
-    void gn_relu(const std::vector<std::string>& names, const View& in, const View& out) {
+    void gn_relu(const std::vector<std::string>& names, const View& in, const View& out, bool single_consumer = false) {
         const int G = (int)names.size(), C = in.C;
         std::vector<float> gamma, beta;
         for (int g = 0; g < G; ++g) {
@@ -306,11 +334,18 @@ struct Builder {
             last_conv.fuse->groups = 32;
             last_conv.fuse.reset();
         }
+        std::shared_ptr<DeferredNorm> dn;
+        if (single_consumer && C % 32 == 0 && (C / 32) % 4 == 0) {
+            dn = std::make_shared<DeferredNorm>();
+            dn->in = in; dn->out = out; dn->stats = stats; dn->gamma = dg; dn->beta = db; dn->C = C; dn->G = G;
+        }
+        pending_norm = dn;
         c->ops.push_back({[=](int B, hipStream_t st) {
             if (!fused) {
                 int rc = launch_gn_stats(in, B, G, 32, stats, st, false);
                 if (rc) return rc;
             }
+            if (dn && dn->absorbed && dn->absorbed(B)) return 0;      // the consumer normalises while it loads
             return launch_gn_apply(in, out, B, G, 32, stats, dg, db, C, 1e-5f, 1, st);
         }, OP_NORM, names[0], 0.0, fused ? 1 : 2});
     }
@@ -320,9 +355,10 @@ struct Builder {
     }
 
     // conv (no bias) -> GN -> ReLU, the [d2] Conv2d(norm=GN, activation=relu) pattern
-    void conv_gn(const std::string& n, const View& in, const View& tmp, const View& out, int k, int dil) {
+    void conv_gn(const std::string& n, const View& in, const View& tmp, const View& out, int k, int dil,
+                 bool single_consumer = false) {
         conv({n}, in, in.C, tmp, k, 1, k == 3 ? dil : 0, dil, AF_NONE, nullptr, false);
-        gn_relu({n + ".norm"}, tmp, out);
+        gn_relu({n + ".norm"}, tmp, out, single_consumer);
     }
 
     void build() {
@@ -413,14 +449,14 @@ struct Builder {
                 op([=](int B, hipStream_t st) { return launch_add_channels(ra, rb, a, B, st); });
             } else {
                 conv({n + "conv"}, cat[s], 2 * C, t, 1, 1, 0, 1, AF_BIAS, nullptr, false);
-                gn_relu({n + "gn"}, t, a);
+                gn_relu({n + "gn"}, t, a, s != 3 && cf.backbone_fusion_layers > 0);   // read only by conv0 below
             }
             if (s != 3) {
                 View b2 = make(C, fh, fw);
                 View cur = a, nxt = b2;
                 for (int i = 0; i < cf.backbone_fusion_layers; ++i) {
                     conv({n + "conv" + std::to_string(i)}, cur, C, t, 3, 1, 1, 1, AF_BIAS, nullptr, false);
-                    gn_relu({n + "gn" + std::to_string(i)}, t, nxt);
+                    gn_relu({n + "gn" + std::to_string(i)}, t, nxt, i + 1 < cf.backbone_fusion_layers);   // read only by the next conv
                     std::swap(cur, nxt);
                 }
                 a = cur;
@@ -455,7 +491,7 @@ struct Builder {
             op([=](int B, hipStream_t st) { return launch_bilinear(y5, dst, B, st); });
         }
         View u3 = make(128, F[1].H, F[1].W), y3 = make(128, F[1].H, F[1].W);
-        conv_gn(Hd + "decoder.res3.fuse_conv.0", cat3, t128a, u3, 3, 1);
+        conv_gn(Hd + "decoder.res3.fuse_conv.0", cat3, t128a, u3, 3, 1, true);    // u3 is read only by fuse_conv.1
         conv_gn(Hd + "decoder.res3.fuse_conv.1", u3, t128a, y3, 3, 1);
 
         // ---------------- prediction heads: generic hierarchy (model.py:738-762) ----------------
@@ -497,7 +533,7 @@ struct Builder {
             op([=](int B, hipStream_t st) { return launch_bilinear(y3, dst, B, st); });
         }
         View u2 = make(128, h4, w4);
-        conv_gn(Hd + "decoder.res2.fuse_conv.0", cat2, t128, u2, 3, 1);
+        conv_gn(Hd + "decoder.res2.fuse_conv.0", cat2, t128, u2, 3, 1, true);      // u2 is read only by fuse_conv.1
         View y = nlev > 1 ? slice(YP[1], 0, 128) : make(128, h4, w4);
         conv_gn(Hd + "decoder.res2.fuse_conv.1", u2, t128, y, 3, 1);
         for (int i = 2; i < nlev; ++i) {

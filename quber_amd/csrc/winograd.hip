@@ -80,9 +80,13 @@ __device__ inline TileAt locate(long tile, int TH, int TW, int d) {
     return t;
 }
 
+// `np.stats` set: the input is the PRE-normalisation tensor of a GroupNorm + ReLU whose only consumer is this layer;
+// the normalisation (same arithmetic as gn_apply_kernel) is applied to the in-range pixels as they are loaded, which
+// saves the separate read + write pass over the activations.
 template <int O>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ in, int B, int H, int W, int C4, int in_cs,
-                                                         long in_gs, int TH, int TW, int d, float* __restrict__ v, long v_gs) {
+                                                         long in_gs, int TH, int TW, int d, float* __restrict__ v, long v_gs,
+                                                         const WinoNorm np) {
     constexpr int T = O + 2;
     const int g = blockIdx.z;
     in += g * in_gs;
@@ -94,6 +98,19 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
     if (tile >= tiles || c4 >= C4 || (tpb && (int)(threadIdx.x / C4) >= tpb)) return;
     const TileAt ta = locate(tile, TH, TW, d);
     const float* base = in + (long)ta.b * H * W * in_cs + c4 * 4;
+    float4 nsc = f4(1.f), nbi = f4(0.f);
+    if (np.stats) {
+        const double* sb = np.stats + (((long)g * B + ta.b) * np.groups + c4 * 4 / np.cpg) * 2;
+        const double mean = sb[0] / np.n;
+        double var = sb[1] / np.n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)np.eps));
+        const float4 ga = *reinterpret_cast<const float4*>(np.gamma + g * np.param_gs + c4 * 4);
+        const float4 be = *reinterpret_cast<const float4*>(np.beta + g * np.param_gs + c4 * 4);
+        nsc = make_float4(rstd * ga.x, rstd * ga.y, rstd * ga.z, rstd * ga.w);
+        nbi = make_float4(be.x - (float)mean * nsc.x, be.y - (float)mean * nsc.y, be.z - (float)mean * nsc.z,
+                          be.w - (float)mean * nsc.w);
+    }
     float4 t[T][T];                                  // t = B^T d, one input column at a time
 #pragma unroll
     for (int j = 0; j < T; ++j) {
@@ -102,9 +119,16 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 #pragma unroll
         for (int i = 0; i < T; ++i) {
             const int y = d * (O * ta.ty - 1 + i) + ta.py;
-            col[i] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
-                         ? *reinterpret_cast<const float4*>(base + ((long)y * W + x) * in_cs)
-                         : f4(0.f);
+            const bool inside = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+            float4 px4 = inside ? *reinterpret_cast<const float4*>(base + ((long)y * W + x) * in_cs) : f4(0.f);
+            if (np.stats && inside) {
+                px4.x = fmaf(px4.x, nsc.x, nbi.x); px4.y = fmaf(px4.y, nsc.y, nbi.y);
+                px4.z = fmaf(px4.z, nsc.z, nbi.z); px4.w = fmaf(px4.w, nsc.w, nbi.w);
+                if (np.relu) {
+                    px4.x = fmaxf(px4.x, 0.f); px4.y = fmaxf(px4.y, 0.f); px4.z = fmaxf(px4.z, 0.f); px4.w = fmaxf(px4.w, 0.f);
+                }
+            }
+            col[i] = px4;
         }
         bt<O>(col, tc);
 #pragma unroll
@@ -312,8 +336,14 @@ static int run_winograd(const WinoP& q, int B, int G, hipStream_t st) {
     auto grid = [&](int C4) {
         return C4 <= 256 ? dim3((unsigned)((tiles + 256 / C4 - 1) / (256 / C4)), 1, G) : dim3((unsigned)tiles, C4 / 256, G);
     };
+    WinoNorm np = q.norm;
+    if (np.stats) {
+        if (np.groups <= 0 || Cin % np.groups || (Cin / np.groups) % 4) return fail("winograd: fused GroupNorm needs 4 | channels per group");
+        np.cpg = Cin / np.groups;
+        np.n = (double)H * W * np.cpg;
+    }
     hipLaunchKernelGGL(wino_input_kernel<O>, grid(Cin / 4), dim3(256), 0, st, in.p, B, H, W, Cin / 4, in.cs, in.gs, TH, TW, d,
-                       v, (long)P * tiles * Cin);
+                       v, (long)P * tiles * Cin, np);
     QB_CHECK(hipGetLastError());
     ConvP p{};
     p.in = v; p.w = q.u; p.out = m;
