@@ -574,7 +574,7 @@ struct Builder {
             View xin = x;
             xin.gs = 0;   // every head of the level reads the same features
             conv(h0, xin, 128, g128, 3, 1, 1, 1, AF_NONE, nullptr, false);
-            gn_relu(n0, g128, g128n);
+            gn_relu(n0, g128, g128n, true);          // g128n is read only by head.1
             conv(h1, g128n, 128, g32, 3, 1, 1, 1, AF_NONE, nullptr, false);
             gn_relu(n1, g32, feat);
             int act_off = 128 + (cf.fusion_feat ? 32 * G : 0);
@@ -966,7 +966,7 @@ void quber_set_tuning(int32_t key, int32_t value) {
         }
     }
     if (key == 4) g_force_tile = value;    // force the tile shape: 1 = 64x64, 2 = 128x128, 4 = 256x32 (0 = automatic)
-    if (key == 10) g_wino_min_cout = value;   // smallest output width eligible for the Winograd path (default 128)
+    if (key == 10) g_wino_min_cout = value;   // smallest output width eligible for the Winograd path (default 32)
     if (key == 9) g_wino_variant = value;     // Winograd output tile edge for the eligible layers: 0 = automatic, 2, 4
     if (key == 8) g_wino_max_ratio = value;   // Winograd only while executed / direct multiplies <= value % (default 67)
     if (key == 7) g_wino_min_cin = value;  // smallest input width eligible for the Winograd path (default 256)
