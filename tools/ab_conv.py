@@ -14,6 +14,10 @@ from quber_amd import _lib  # noqa: E402
 from tools.conv_bench import LAYERS  # noqa: E402
 
 libs = {"old": C.CDLL(sys.argv[1]), "new": C.CDLL(_lib.LIB_PATH)}
+if len(sys.argv) > 2:       # extra "key=value" tuning knobs applied to the first library only
+    for kv in sys.argv[2:]:
+        k, v = kv.split("=")
+        libs["old"].quber_set_tuning(int(k), int(v))
 for lib in libs.values():
     lib.quber_op_conv2d.restype = C.c_int
     lib.quber_op_conv2d.argtypes = _lib.SIGNATURES["quber_op_conv2d"][1]
