@@ -162,6 +162,8 @@ double quber_forward_flops(quber_ctx* ctx);
 double quber_forward_flops_executed(quber_ctx* ctx);
 /* test-harness knobs: key 2 = give the stand-alone quber_op_conv2d a split-K workspace (value != 0) or drop it (0);
  * key 3 = force the number of K partitions of convolutions that have a workspace (0 = automatic);
+ * key 11 = stand-alone conv op only: dilated 3x3 layers in tap-major K order with the zero-padding filter rows skipped;
+ * key 10 = smallest output width routed to the Winograd path (default 32);
  * key 9 = Winograd output tile edge of the eligible layers: 0 = automatic (default), 2, 4 (acts at plan time);
  * key 8 = Winograd only while its multiplies are <= value % of the direct kernel's (dilated layers; default 67);
  * key 7 = smallest input width (channels) routed to the Winograd path (default 256);

@@ -44,6 +44,7 @@ struct ConvP {
     int gn_groups, gn_cpg;   // norm groups, channels per group
     int ohw;                 // OH * OW
     int kmode;           // 0: k = (tap, c)   1: k = (c/32, tap, c%32)  (weights packed accordingly)
+    int skip_rows;       // kmode 0 only: blocks skip the filter rows that are padding for all their output rows
     long in_gs, out_gs, res_gs, w_gs;
     int ss_gs;
 };

@@ -33,6 +33,8 @@ constexpr int PITCH = 36;
 // barrier per K-slice, a per-block s_setprio stagger, and 256x128 / 128x256 tiles (8 waves, or 4 waves of 128x64) were
 // all 1-25 % slower than this single-buffer, register-prefetch loop at 3 blocks per CU; a 256x64 tile (2 blocks per
 // CU) lost to 64x64 on every layer with 33-64 output channels (profiles/r01i_conv_sweep_*.md).
+// MODE 3 / 4: the direct / split-K launch of a dilated layer in tap-major K order whose blocks skip the filter rows that
+// are zero padding for all their output rows (ASPP d = 18 on a 30-row map: 58 % of the multiplies are with padding).
 // MODE 1 (split-K): blockIdx.y owns p.kchunk consecutive K-slices and writes a raw partial tile - for launches that
 // cannot fill the chip, or whose tile count is an awkward multiple of the resident slots.
 // MODE 2 (split tail): the first p.nfull tiles are computed whole; the remaining tiles - the ragged last round of a
@@ -64,12 +66,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
     // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give every XCD one
     // contiguous run of tiles, n-tile fastest, so neighbouring tiles reuse the same input rows.
     int tile, part = 0;                    // part: which K partition this block computes
-    bool raw = MODE == 1;                  // raw partial tile into the workspace instead of the fused epilogue
+    bool raw = MODE == 1 || MODE == 4;     // raw partial tile into the workspace instead of the fused epilogue
     {
         const int bid = blockIdx.x, nblk = MODE == 2 ? p.nfull : gridDim.x;
         const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-        if constexpr (MODE == 1) part = blockIdx.y;
+        if constexpr (MODE == 1 || MODE == 4) part = blockIdx.y;
         if constexpr (MODE == 2) {
             if (bid >= nblk) {
                 const int u = bid - nblk;
@@ -87,6 +89,29 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
     if (MODE == 1 || (MODE == 2 && raw)) {
         k_begin = part * p.kchunk;
         nk = min(nk - k_begin, p.kchunk);
+    }
+    if constexpr (MODE == 3 || MODE == 4) {
+        // Skip the filter rows that fall in the zero padding for every output row of this tile (dilated layers: with
+        // dilation 18 on a 30-row map 58 % of the multiplies are with padding).  Tap-major K order (host: kmode 0,
+        // Cin % 32 == 0): the K-slices of filter row ky are contiguous, so the valid rows are one K range.
+        const int oy_lo = (m0 % p.ohw) / p.OW;
+        const int last = min(m0 + BM, p.M) - 1;
+        const bool one_image = m0 / p.ohw == last / p.ohw;
+        const int oy_hi = one_image ? (last % p.ohw) / p.OW : p.OH - 1;
+        const int oy_min = one_image ? oy_lo : 0;
+        int ky_lo = 0, ky_hi = p.kh - 1;
+        while (ky_lo < ky_hi && oy_hi * p.stride - p.pad + ky_lo * p.dil < 0) ++ky_lo;
+        while (ky_hi > ky_lo && oy_min * p.stride - p.pad + ky_hi * p.dil >= p.H) --ky_hi;
+        const int per_row = p.kw * (p.Cin / BK);
+        k_begin = ky_lo * per_row;
+        nk = (ky_hi - ky_lo + 1) * per_row;
+        if constexpr (MODE == 4) {               // the valid range again in gridDim.y partitions (a trailing one may be empty)
+            const int chunk = (nk + (int)gridDim.y - 1) / (int)gridDim.y;
+            const int done = min(part * chunk, nk);
+            k_begin += done;
+            nk = min(nk - done, chunk);
+            if (nk == 0) k_begin = ky_lo * per_row;   // keep the (unused) prologue loads inside the weight rows
+        }
     }
     const float* __restrict__ in = p.in + (long)g * p.in_gs;
     const float* __restrict__ wt = p.w + (long)g * p.w_gs + (long)k_begin * BK;
@@ -522,9 +547,13 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
             }
         }
     }
+    const bool skip = BM != 256 && p.skip_rows && p.kmode == 0 && p.kh > 1 && p.Cin % BK == 0 && p.K == p.Kpad && p.ohw > 0;
     if (S > 1) {
-        hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 1>), dim3(p.mtiles * p.ntiles, S, G), block, 0, st, p);
+        if (skip) hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 4>), dim3(p.mtiles * p.ntiles, S, G), block, 0, st, p);
+        else hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 1>), dim3(p.mtiles * p.ntiles, S, G), block, 0, st, p);
         reduce(S);
+    } else if (skip) {
+        hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 3>), dim3(p.mtiles * p.ntiles, 1, G), block, 0, st, p);
     } else {
         hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 0>), dim3(p.mtiles * p.ntiles, 1, G), block, 0, st, p);
     }

@@ -170,7 +170,13 @@ struct Builder {
         const int G = (int)w.size();
         const int Cin = in.C, Cout = out.C;
         const int K = k * k * Cin, Kpad = (K + 31) / 32 * 32;
-        const int kmode = (k > 1 && Cin % 32 == 0) ? 1 : 0;   // slice-major K order for the 3x3 layers
+        const int OHp = (in.H + 2 * pad - dil * (k - 1) - 1) / stride + 1;
+        // dilated 3x3 whose top / bottom filter rows are padding for >= 20 % of the (row, tap) pairs and that cannot take the
+        // Winograd path: tap-major K order so that blocks can skip those rows (conv_igemm.hip MODE 3 / 4)
+        const bool skip_rows = k == 3 && stride == 1 && dil > 1 && Cin % 32 == 0 && cin_real == Cin && 10 * 2 * pad >= 2 * 3 * OHp &&
+                               !(winograd_eligible(k, stride, pad, dil, Cin, out.C) && !res && prelu.empty() &&
+                                 std::min(winograd_mac_ratio(in.H, in.W, dil, 4), winograd_mac_ratio(in.H, in.W, dil, 2)) <= g_wino_max_ratio / 100.0 && g_winograd != 1);
+        const int kmode = (k > 1 && Cin % 32 == 0 && !skip_rows) ? 1 : 0;   // slice-major K order for the 3x3 layers
         const int OH = (in.H + 2 * pad - dil * (k - 1) - 1) / stride + 1;
         const int OW = (in.W + 2 * pad - dil * (k - 1) - 1) / stride + 1;
         if (dry) return;
@@ -205,6 +211,7 @@ struct Builder {
         p.kh = k; p.kw = k; p.stride = stride; p.pad = pad; p.dil = dil;
         p.relu = relu;
         p.kmode = kmode;
+        p.skip_rows = skip_rows;
         p.in_gs = in.gs; p.out_gs = out.gs; p.res_gs = res ? res->gs : 0;
         p.w_gs = (long)Cout * Kpad; p.ss_gs = Cout;
         p.ohw = OH * OW;
@@ -838,6 +845,7 @@ int check_cfg(const quber_config& c) {
 }  // namespace
 
 static float* g_op_ws = nullptr;
+static int g_op_skip_rows = 0;
 static const size_t g_op_ws_floats = (size_t)256 << 20;   // 1 GiB, test harness only
 
 extern "C" {
@@ -966,6 +974,7 @@ void quber_set_tuning(int32_t key, int32_t value) {
         }
     }
     if (key == 4) g_force_tile = value;    // force the tile shape: 1 = 64x64, 2 = 128x128, 4 = 256x32 (0 = automatic)
+    if (key == 11) g_op_skip_rows = value;    // stand-alone conv op: tap-major K order with padded filter rows skipped (dilated 3x3)
     if (key == 10) g_wino_min_cout = value;   // smallest output width eligible for the Winograd path (default 32)
     if (key == 9) g_wino_variant = value;     // Winograd output tile edge for the eligible layers: 0 = automatic, 2, 4
     if (key == 8) g_wino_max_ratio = value;   // Winograd only while executed / direct multiplies <= value % (default 67)
@@ -1148,7 +1157,8 @@ int quber_op_conv2d(const float* x, int32_t B, int32_t h, int32_t w, int32_t cin
                     const float* residual, int32_t relu, float* packed, float* y, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int K = k * k * cin, Kpad = (K + 31) / 32 * 32;
-    const int kmode = (k > 1 && cin % 32 == 0) ? 1 : 0;
+    const bool skip_rows = g_op_skip_rows && k == 3 && stride == 1 && dil > 1 && cin % 32 == 0;
+    const int kmode = (k > 1 && cin % 32 == 0 && !skip_rows) ? 1 : 0;
     hipLaunchKernelGGL(pack_oihw_kernel, dim3(256), dim3(256), 0, st, w_oihw, cout, cin, k, Kpad, kmode, packed);
     ConvP p{};
     p.in = x; p.w = packed; p.scale = scale; p.shift = shift; p.res = residual; p.out = y;
@@ -1158,7 +1168,9 @@ int quber_op_conv2d(const float* x, int32_t B, int32_t h, int32_t w, int32_t cin
     p.Cout = cout; p.out_cs = cout; p.res_cs = cout; p.K = K; p.Kpad = Kpad;
     p.kh = k; p.kw = k; p.stride = stride; p.pad = pad; p.dil = dil; p.relu = relu;
     p.kmode = kmode;
+    p.skip_rows = skip_rows;
     p.M = B * p.OH * p.OW;
+    p.ohw = p.OH * p.OW;
     p.w_gs = 0; p.ss_gs = 0;
     // the stand-alone op splits K only when the test harness asked for a workspace (tuning key 2)
     p.ws = g_op_ws;

@@ -303,6 +303,44 @@ def test_conv_split_paths_vs_torch(case):
 
 
 @pytest.mark.parametrize("case", [
+    # B, H, W, Cin, Cout, dil: dilated 3x3 whose blocks skip the filter rows that are all padding (MODE 3 direct, MODE 4 split)
+    (16, 30, 40, 256, 256, 18),      # ASPP d = 18 geometry: 300 tiles -> split-K over the valid rows
+    (64, 30, 40, 128, 128, 12),      # 600 tiles
+    (40, 31, 37, 64, 128, 18),       # ragged map: tiles straddle images
+    (100, 30, 40, 96, 128, 20),      # more than one round of tiles: no split (MODE 3)
+])
+def test_conv_skip_padded_filter_rows(case):
+    B, H, W, Cin, Cout, dil = case
+    lib = _lib.load()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) / np.sqrt(Cin * 9)
+    sc, sh = torch.rand(Cout, device="cuda", generator=g) + 0.5, torch.randn(Cout, device="cuda", generator=g)
+    packed = torch.empty(Cout * 9 * Cin, device="cuda")
+    outs = []
+    lib.quber_set_tuning(2, 1)
+    try:
+        for skip in (0, 1):
+            lib.quber_set_tuning(11, skip)
+            y = torch.full((B, H, W, Cout), float("nan"), device="cuda")
+            _lib.check(lib.quber_op_conv2d(p(x), B, H, W, Cin, p(w), Cout, 3, 1, dil, dil, p(sc), p(sh), p(None), 1, p(packed),
+                                           p(y), st))
+            outs.append(y)
+    finally:
+        lib.quber_set_tuning(11, 0)
+        lib.quber_set_tuning(2, 0)
+    dense, skipped = outs
+    assert torch.isfinite(skipped).all()
+    err = (dense - skipped).abs().max().item() / max(1.0, dense.abs().max().item())
+    assert err < 2e-6
+    ref = torch.nn.functional.conv2d(x[:2].permute(0, 3, 1, 2).cpu().double(), w.cpu().double(), None, 1, dil, dil)
+    ref = (ref * sc.cpu().double().view(1, -1, 1, 1) + sh.cpu().double().view(1, -1, 1, 1)).relu().permute(0, 2, 3, 1)
+    assert (skipped[:2].cpu().double() - ref).abs().max().item() / max(1.0, ref.abs().max().item()) < 2e-6
+
+
+@pytest.mark.parametrize("case", [
     # B, H, W, Cin, Cout, k, dil, residual: split tail (MODE 2) against the same launch computed whole
     (6, 119, 160, 128, 256, 3, 1, True),     # 1786 tiles (ragged M, 2 n-tiles): 1536 whole + 250 in 2 pieces
     (8, 108, 128, 256, 128, 3, 1, False),    # 864 tiles: 768 whole + 96 in 8 pieces
