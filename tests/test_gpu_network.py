@@ -241,3 +241,33 @@ def test_config2_1280x720_hipgraph_steady_state():
     assert float((lg - exp).abs().max()) < TOL
     o = postproc_ref.postprocess(lg[0, 0:1], lg[0, 1:2], lg[0, 2:4])
     np.testing.assert_array_equal(post["panoptic"][0].cpu().numpy(), o["panoptic"].numpy())
+
+
+def test_winograd_modes_agree():
+    """The three convolution algorithms (direct only, Winograd F(2x2,3x3), F(4x4,3x3): quber_set_tuning keys 6 / 9, the
+    C-level form of QUBER_WINOGRAD) give the same logits within the 1e-4 bar, and the library reports how many of the
+    algorithmic FLOPs each one executes."""
+    from quber_amd import _lib
+    lib = _lib.load()
+    h, w, b = 128, 160, 2
+    sd = arch.init_state_dict(seed=6)
+    batch, offs = inputs(9, b, h, w, 5)
+    bgr, dep, off = torch.from_numpy(batch["rgb"]).cuda(), torch.from_numpy(batch["depth"]).cuda(), torch.from_numpy(offs).cuda()
+    outs, ratios = {}, {}
+    try:
+        for name, (k6, k9) in {"off": (1, 0), "f2": (0, 2), "f4": (0, 4)}.items():
+            lib.quber_set_tuning(6, k6)
+            lib.quber_set_tuning(9, k9)
+            eng = engine.Engine(engine.make_config(h, w, max_batch=b), "cuda:0")
+            eng.load_state_dict(sd)
+            outs[name] = eng.forward(bgr, dep, off).cpu()
+            ratios[name] = eng.forward_flops_executed() / eng.forward_flops()
+            del eng
+    finally:
+        lib.quber_set_tuning(6, 0)
+        lib.quber_set_tuning(9, 0)
+    assert ratios["off"] == 1.0 and ratios["f4"] < ratios["f2"] < 1.0
+    assert 0.5 < ratios["f4"] < 0.75 and 0.65 < ratios["f2"] < 0.85
+    for name in ("f2", "f4"):
+        assert float((outs[name] - outs["off"]).abs().max()) < TOL, name
+    assert not torch.equal(outs["f4"], outs["off"])        # the path really was different
