@@ -12,7 +12,8 @@
 //   3. wino_output_kernel  Y = A^T M A, affine, ReLU  M[g][P][tile][Cout] -> NHWC output (any channel-slice view),
 //                                                      GroupNorm sums of the stored values on request
 // m = 2: all transform entries are in {0, +-1, +-1/2}; the result is as accurate as the direct kernel.
-// m = 4 (Lavin & Gray's points 0, +-1, +-2, inf): entries up to 8 / down to 1/24 cost about one decimal digit
+// m = 4 (interpolation points 0, +-3/4, +-3/2, inf - Lavin & Gray's 0, +-1, +-2 scaled by 3/4, which measured 2.7x less
+// fp32 error): about half a decimal digit less accurate than the direct kernel
 // (tests/test_gpu_parity.py::test_conv3x3_winograd_vs_float64 bounds it); see DESIGN.md for where each is used.
 // With dilation d the layer is d*d independent dense convolutions on the phase sub-images in[d*Y + py][d*X + px]
 // (TH x TW tiles each, the same for every phase; tiles beyond a shorter phase read zeros and store nothing).
@@ -41,12 +42,15 @@ __device__ inline void bt(const float4* x, float4* y) {
         y[2] = x[2] - x[1];
         y[3] = x[1] - x[3];
     } else {
-        y[0] = (4.f * x[0] - 5.f * x[2]) + x[4];
-        y[1] = (x[3] + x[4]) - 4.f * (x[1] + x[2]);
-        y[2] = (x[4] - x[3]) + 4.f * (x[1] - x[2]);
-        y[3] = (x[4] - x[2]) + 2.f * (x[3] - x[1]);
-        y[4] = (x[4] - x[2]) + 2.f * (x[1] - x[3]);
-        y[5] = (4.f * x[1] - 5.f * x[3]) + x[5];
+        // points 0, +-3/4, +-3/2, inf (all constants dyadic, hence exact in fp32)
+        const float4 e1 = x[4] - 2.25f * x[2], o1 = 0.75f * x[3] - 1.6875f * x[1];
+        const float4 e2 = x[4] - 0.5625f * x[2], o2 = 1.5f * x[3] - 0.84375f * x[1];
+        y[0] = (1.265625f * x[0] - 2.8125f * x[2]) + x[4];
+        y[1] = e1 + o1;
+        y[2] = e1 - o1;
+        y[3] = e2 + o2;
+        y[4] = e2 - o2;
+        y[5] = (1.265625f * x[1] - 2.8125f * x[3]) + x[5];
     }
 }
 
@@ -59,9 +63,9 @@ __device__ inline void at(const float4* x, float4* y) {
     } else {
         const float4 a = x[1] + x[2], b = x[1] - x[2], c = x[3] + x[4], d = x[3] - x[4];
         y[0] = (x[0] + a) + c;
-        y[1] = b + 2.f * d;
-        y[2] = a + 4.f * c;
-        y[3] = (b + 8.f * d) + x[5];
+        y[1] = 0.75f * b + 1.5f * d;
+        y[2] = 0.5625f * a + 2.25f * c;
+        y[3] = (0.421875f * b + 3.375f * d) + x[5];
     }
 }
 
@@ -243,11 +247,11 @@ __host__ __device__ inline void gmul(double a, double b, double c, double* y) {
         y[2] = 0.5 * (a - b + c);
         y[3] = c;
     } else {
-        y[0] = a / 4.0;
-        y[1] = -(a + b + c) / 6.0;
-        y[2] = -(a - b + c) / 6.0;
-        y[3] = a / 24.0 + b / 12.0 + c / 6.0;
-        y[4] = a / 24.0 - b / 12.0 + c / 6.0;
+        y[0] = a * (64.0 / 81.0);
+        y[1] = -a * (128.0 / 243.0) - b * (32.0 / 81.0) - c * (8.0 / 27.0);
+        y[2] = -a * (128.0 / 243.0) + b * (32.0 / 81.0) - c * (8.0 / 27.0);
+        y[3] = a * (32.0 / 243.0) + b * (16.0 / 81.0) + c * (8.0 / 27.0);
+        y[4] = a * (32.0 / 243.0) - b * (16.0 / 81.0) + c * (8.0 / 27.0);
         y[5] = c;
     }
 }

@@ -405,7 +405,7 @@ def test_conv_split_tail_equals_whole(case):
 @pytest.mark.parametrize("m", [2, 4])
 def test_conv3x3_winograd_vs_float64(case, m):
     B, H, W, Cin, Cout, dil, affine, relu = case
-    tol = 1e-5 if m == 2 else 6e-5        # F(4x4,3x3): transform entries up to 8 and down to 1/24 cost about a digit
+    tol = 1e-5 if m == 2 else 2e-5        # F(4x4,3x3) on the points 0, +-3/4, +-3/2, inf: within ~4x of the direct kernel
     lib = _lib.load()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
