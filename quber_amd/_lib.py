@@ -80,7 +80,7 @@ def load():
         fn.restype = res
         fn.argtypes = args
     # QUBER_WINOGRAD = auto (default) | f4 | f2 | off : which fast algorithm the wide 3x3 layers may use.  F(4x4,3x3)
-    # is about one decimal digit less accurate per layer than the direct kernel; "f2" keeps the
+    # is within ~4x of the direct kernel's rounding error per layer; "f2" keeps the
     # direct kernel's accuracy at ~0.8x the throughput, "off" runs every layer as a plain implicit GEMM.
     mode = os.environ.get("QUBER_WINOGRAD", "auto").lower()
     if mode not in ("auto", "f4", "f2", "off"):
