@@ -118,7 +118,7 @@ int launch_pool_s2(const View& in, const View& out, int B, int mode /*0 avg 3x3/
 int launch_affine_prelu(const View& a, const View* b, const View& out, int B, const float* scale, const float* shift,
                         const float* slope, hipStream_t st);
 int launch_pmca(const View& x, int B, const float* w2x2, const float* fc0, const float* alpha, const float* fc2, float* wts,
-                hipStream_t st);
+                double* sums /* [B][C][5] scratch */, hipStream_t st);
 int launch_scale_channels(const View& in, const float* wts, const View& out, int B, hipStream_t st);
 int launch_mad_gate(const View& o, const View& att, float* q, int B, int C, hipStream_t st);
 int launch_argmax_fg(const float* logits, int B, long HW, int nc, int cls, uint8_t* fg, hipStream_t st);

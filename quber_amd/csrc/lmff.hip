@@ -38,20 +38,25 @@ int launch_lmff_preprocess(const uint8_t* bgr, const uint8_t* depth, long pixels
     return 0;
 }
 
-// depthwise 3x3 (dilation d, padding d) + folded BN + PReLU
-__global__ void dwconv3x3_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C,
-                                 int in_cs, int out_cs, int dil, const float* __restrict__ w9,
-                                 const float* __restrict__ scale, const float* __restrict__ shift,
-                                 const float* __restrict__ slope) {
-    const long total = (long)B * H * W * C;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = i % C;
-        long pix = i / C;
+// depthwise 3x3 (dilation d, padding d) + folded BN + PReLU.  V channels per thread (V = 4: 16-byte accesses when the
+// channel count and strides allow; V = 1 otherwise, e.g. the 262-channel MAD layer); 32-bit index arithmetic.
+template <int V>
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W,
+                                                        int C, int in_cs, int out_cs, int dil, const float* __restrict__ w9,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        const float* __restrict__ slope) {
+    const unsigned CV = C / V, total = (unsigned)B * H * W * CV;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned cv = i % CV;
+        unsigned pix = i / CV;
         const int x = pix % W;
         pix /= W;
         const int y = pix % H;
         const int b = pix / H;
-        float acc = 0.f;
+        const int c = cv * V;
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = 0.f;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int iy = y + (ky - 1) * dil;
@@ -60,20 +65,42 @@ __global__ void dwconv3x3_kernel(const float* __restrict__ in, float* __restrict
             for (int kx = 0; kx < 3; ++kx) {
                 const int ix = x + (kx - 1) * dil;
                 if ((unsigned)ix >= (unsigned)W) continue;
-                acc = fmaf(in[((long)(b * H + iy) * W + ix) * in_cs + c], w9[c * 9 + ky * 3 + kx], acc);
+                const float* src = in + ((long)(b * H + iy) * W + ix) * in_cs + c;
+                if constexpr (V == 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(src);
+                    acc[0] = fmaf(v.x, w9[(c + 0) * 9 + ky * 3 + kx], acc[0]);
+                    acc[1] = fmaf(v.y, w9[(c + 1) * 9 + ky * 3 + kx], acc[1]);
+                    acc[2] = fmaf(v.z, w9[(c + 2) * 9 + ky * 3 + kx], acc[2]);
+                    acc[3] = fmaf(v.w, w9[(c + 3) * 9 + ky * 3 + kx], acc[3]);
+                } else {
+                    acc[0] = fmaf(src[0], w9[c * 9 + ky * 3 + kx], acc[0]);
+                }
             }
         }
-        float v = fmaf(acc, scale[c], shift[c]);
-        v = v > 0.f ? v : v * slope[c];
-        out[((long)(b * H + y) * W + x) * out_cs + c] = v;
+        float o[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float v = fmaf(acc[e], scale[c + e], shift[c + e]);
+            o[e] = v > 0.f ? v : v * slope[c + e];
+        }
+        float* dst = out + ((long)(b * H + y) * W + x) * out_cs + c;
+        if constexpr (V == 4) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        else dst[0] = o[0];
     }
 }
+
+static inline bool vec4_ok(const View& v) { return v.C % 4 == 0 && v.cs % 4 == 0 && ((uintptr_t)v.p & 15) == 0; }
 
 int launch_dwconv3x3(const View& in, const View& out, int B, int dil, const float* w9, const float* scale,
                      const float* shift, const float* slope, hipStream_t st) {
     const long total = (long)B * in.H * in.W * in.C;
-    hipLaunchKernelGGL(dwconv3x3_kernel, dim3(grid_for(total)), dim3(256), 0, st, in.p, out.p, B, in.H, in.W, in.C, in.cs,
-                       out.cs, dil, w9, scale, shift, slope);
+    if (total >= (1L << 31)) return fail("dwconv: tensor too large");
+    if (vec4_ok(in) && vec4_ok(out))
+        hipLaunchKernelGGL(dwconv3x3_kernel<4>, dim3(grid_for(total / 4)), dim3(256), 0, st, in.p, out.p, B, in.H, in.W, in.C,
+                           in.cs, out.cs, dil, w9, scale, shift, slope);
+    else
+        hipLaunchKernelGGL(dwconv3x3_kernel<1>, dim3(grid_for(total)), dim3(256), 0, st, in.p, out.p, B, in.H, in.W, in.C, in.cs,
+                           out.cs, dil, w9, scale, shift, slope);
     QB_CHECK(hipGetLastError());
     return 0;
 }
@@ -116,64 +143,115 @@ int launch_pool_s2(const View& in, const View& out, int B, int mode, hipStream_t
 }
 
 // y = prelu((a [+ b]) * scale + shift)   (BNPReLU on a concatenation, and SEM_B's bn_relu_1(output + input))
-__global__ void affine_prelu_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
-                                    long pixels, int C, int a_cs, int b_cs, int out_cs, const float* __restrict__ scale,
-                                    const float* __restrict__ shift, const float* __restrict__ slope) {
-    const long total = pixels * C;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long pix = i / C;
-        const int c = (int)(i - pix * C);
-        float v = a[pix * a_cs + c];
-        if (b) v += b[pix * b_cs + c];
-        v = fmaf(v, scale[c], shift[c]);
-        out[pix * out_cs + c] = v > 0.f ? v : v * slope[c];
+template <int V>
+__global__ __launch_bounds__(256) void affine_prelu_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           float* __restrict__ out, unsigned pixels, int C, int a_cs, int b_cs,
+                                                           int out_cs, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, const float* __restrict__ slope) {
+    const unsigned CV = C / V, total = pixels * CV;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned pix = i / CV;
+        const int c = (int)(i - pix * CV) * V;
+        float v[V];
+        if constexpr (V == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(a + (long)pix * a_cs + c);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            if (b) {
+                const float4 u = *reinterpret_cast<const float4*>(b + (long)pix * b_cs + c);
+                v[0] += u.x; v[1] += u.y; v[2] += u.z; v[3] += u.w;
+            }
+        } else {
+            v[0] = a[(long)pix * a_cs + c];
+            if (b) v[0] += b[(long)pix * b_cs + c];
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float y = fmaf(v[e], scale[c + e], shift[c + e]);
+            v[e] = y > 0.f ? y : y * slope[c + e];
+        }
+        float* dst = out + (long)pix * out_cs + c;
+        if constexpr (V == 4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        else dst[0] = v[0];
     }
 }
 
 int launch_affine_prelu(const View& a, const View* b, const View& out, int B, const float* scale, const float* shift,
                         const float* slope, hipStream_t st) {
     const long pixels = (long)B * a.H * a.W;
-    hipLaunchKernelGGL(affine_prelu_kernel, dim3(grid_for(pixels * a.C)), dim3(256), 0, st, a.p, b ? b->p : nullptr, out.p,
-                       pixels, a.C, a.cs, b ? b->cs : 0, out.cs, scale, shift, slope);
+    if (pixels * a.C >= (1L << 31)) return fail("affine: tensor too large");
+    const bool vec = vec4_ok(a) && vec4_ok(out) && (!b || (b->cs % 4 == 0 && ((uintptr_t)b->p & 15) == 0));
+    if (vec)
+        hipLaunchKernelGGL(affine_prelu_kernel<4>, dim3(grid_for(pixels * a.C / 4)), dim3(256), 0, st, a.p, b ? b->p : nullptr,
+                           out.p, (unsigned)pixels, a.C, a.cs, b ? b->cs : 0, out.cs, scale, shift, slope);
+    else
+        hipLaunchKernelGGL(affine_prelu_kernel<1>, dim3(grid_for(pixels * a.C)), dim3(256), 0, st, a.p, b ? b->p : nullptr, out.p,
+                           (unsigned)pixels, a.C, a.cs, b ? b->cs : 0, out.cs, scale, shift, slope);
     QB_CHECK(hipGetLastError());
     return 0;
 }
 
-// PMCA (lmffnet.py:172-191): w = sigmoid(fc2(prelu(fc0(dw2x2(adaptive_pool_2x2(x)) + global_pool(x))))); one block per frame
-__global__ __launch_bounds__(256) void pmca_kernel(const float* __restrict__ x, int H, int W, int C, int cs,
-                                                   const float* __restrict__ w2x2, const float* __restrict__ fc0,
-                                                   const float* __restrict__ alpha, const float* __restrict__ fc2,
-                                                   float* __restrict__ wts) {
-    __shared__ float s[128], hidden[16];
-    __shared__ double part[4][128 * 5];
-    const int b = blockIdx.x, t = threadIdx.x;
-    const float* base = x + (long)b * H * W * cs;
-    // adaptive bins of a 2-way split: [0, ceil(n/2)) and [floor(n/2), n)
-    const int hy1 = (H + 1) / 2, ly1 = H / 2, hx1 = (W + 1) / 2, lx1 = W / 2;
-    const int lanes = 256 / C;   // C in {64, 128}: 4 or 2 pixel lanes per channel
-    const int lane = t / C;
-    const int c = t % C;
-    double q[5] = {0, 0, 0, 0, 0};
-    if (t < lanes * C) {
-        for (int p = lane; p < H * W; p += lanes) {
-            const int y = p / W, xx = p - y * W;
-            const double v = base[(long)p * cs + c];
-            q[4] += v;
-            const bool t0 = y < hy1, t1 = y >= ly1, l0 = xx < hx1, l1 = xx >= lx1;
-            if (t0 && l0) q[0] += v;
-            if (t0 && l1) q[1] += v;
-            if (t1 && l0) q[2] += v;
-            if (t1 && l1) q[3] += v;
-        }
-        for (int k = 0; k < 5; ++k) part[lane][c * 5 + k] = q[k];
-    }
+// PMCA (lmffnet.py:172-191): w = sigmoid(fc2(prelu(fc0(dw2x2(adaptive_pool_2x2(x)) + global_pool(x))))).
+// Stage 1 (pmca_sums_kernel): per (frame, channel) the four adaptive-pool quadrant sums - adaptive bins of a 2-way split are
+// [0, ceil(n/2)) and [floor(n/2), n), they overlap by one row / column for odd n - over a grid of row bands: a thread
+// keeps one 16-byte channel column, fp64 partial sums, LDS reduce, one atomic per (channel, quadrant) per block.
+// The global pool is the sum of the quadrants minus the overlaps, so it is accumulated as a fifth sum.
+// Stage 2 (pmca_fc_kernel): the two tiny fully connected layers, one block per frame.
+__global__ __launch_bounds__(256) void pmca_sums_kernel(const float* __restrict__ x, int H, int W, int C, int cs, int rows_per_block,
+                                                        double* __restrict__ sums) {
+    __shared__ double acc[128 * 5];
+    const int b = blockIdx.y, t = threadIdx.x;
+    const int C4 = C >> 2, lanes = 256 / C4;              // C in {64, 128}: 16 or 8 pixel lanes per channel column
+    const int c4 = t % C4, lane = t / C4;
+    for (int i = t; i < C * 5; i += 256) acc[i] = 0.0;
     __syncthreads();
-    if (t < C) {
-        double a[5];
-        for (int k = 0; k < 5; ++k) {
-            a[k] = 0;
-            for (int l = 0; l < lanes; ++l) a[k] += part[l][t * 5 + k];
+    const int hy1 = (H + 1) / 2, ly1 = H / 2, hx1 = (W + 1) / 2, lx1 = W / 2;
+    const int y0 = blockIdx.x * rows_per_block, y1 = min(H, y0 + rows_per_block);
+    const float* base = x + (long)b * H * W * cs + c4 * 4;
+    double q[5][4];
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q[k][e] = 0.0;
+    for (int y = y0; y < y1; ++y) {
+        const bool t0 = y < hy1, t1 = y >= ly1;
+        double l[4] = {0, 0, 0, 0}, r[4] = {0, 0, 0, 0}, a[4] = {0, 0, 0, 0};     // left bin, right bin, whole row
+        for (int xx = lane; xx < W; xx += lanes) {
+            const float4 v = *reinterpret_cast<const float4*>(base + ((long)y * W + xx) * cs);
+            const double d[4] = {(double)v.x, (double)v.y, (double)v.z, (double)v.w};
+            const bool l0 = xx < hx1, l1 = xx >= lx1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[e] += d[e];
+                if (l0) l[e] += d[e];
+                if (l1) r[e] += d[e];
+            }
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            q[4][e] += a[e];
+            if (t0) { q[0][e] += l[e]; q[1][e] += r[e]; }
+            if (t1) { q[2][e] += l[e]; q[3][e] += r[e]; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (q[k][e] != 0.0) atomicAdd(&acc[(c4 * 4 + e) * 5 + k], q[k][e]);
+    __syncthreads();
+    for (int i = t; i < C * 5; i += 256)
+        if (acc[i] != 0.0) atomicAdd(&sums[(long)b * C * 5 + i], acc[i]);
+}
+
+__global__ __launch_bounds__(128) void pmca_fc_kernel(const double* __restrict__ sums, int H, int W, int C,
+                                                      const float* __restrict__ w2x2, const float* __restrict__ fc0,
+                                                      const float* __restrict__ alpha, const float* __restrict__ fc2,
+                                                      float* __restrict__ wts) {
+    __shared__ float s[128], hidden[16];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int hy1 = (H + 1) / 2, ly1 = H / 2, hx1 = (W + 1) / 2, lx1 = W / 2;
+    if (t < C) {
+        const double* a = sums + ((long)b * C + t) * 5;
         const double n00 = (double)hy1 * hx1, n01 = (double)hy1 * (W - lx1), n10 = (double)(H - ly1) * hx1,
                      n11 = (double)(H - ly1) * (W - lx1);
         const float p00 = (float)(a[0] / n00), p01 = (float)(a[1] / n01), p10 = (float)(a[2] / n10), p11 = (float)(a[3] / n11);
@@ -200,9 +278,16 @@ __global__ __launch_bounds__(256) void pmca_kernel(const float* __restrict__ x, 
 }
 
 int launch_pmca(const View& x, int B, const float* w2x2, const float* fc0, const float* alpha, const float* fc2, float* wts,
-                hipStream_t st) {
+                double* sums, hipStream_t st) {
     if (x.C != 64 && x.C != 128) return fail("pmca: expects 64 or 128 channels");
-    hipLaunchKernelGGL(pmca_kernel, dim3(B), dim3(256), 0, st, x.p, x.H, x.W, x.C, x.cs, w2x2, fc0, alpha, fc2, wts);
+    if (x.cs % 4 || ((uintptr_t)x.p & 15)) return fail("pmca: channels must come in aligned groups of 4");
+    int rc = launch_zero(sums, sizeof(double) * (size_t)B * x.C * 5, st);
+    if (rc) return rc;
+    // row bands: about 1000 blocks in flight, at least one row each
+    int rpb = (int)(((long)x.H * B + 1023) / 1024);
+    if (rpb < 1) rpb = 1;
+    hipLaunchKernelGGL(pmca_sums_kernel, dim3((x.H + rpb - 1) / rpb, B), dim3(256), 0, st, x.p, x.H, x.W, x.C, x.cs, rpb, sums);
+    hipLaunchKernelGGL(pmca_fc_kernel, dim3(B), dim3(128), 0, st, sums, x.H, x.W, x.C, w2x2, fc0, alpha, fc2, wts);
     QB_CHECK(hipGetLastError());
     return 0;
 }

@@ -703,8 +703,9 @@ struct LmffBuilder {
         const float* dal = b.upload(std::vector<float>(al, al + 1));
         const float* df2 = b.upload(std::vector<float>(f2, f2 + C * (C / 8)));
         float* wts = (float*)b.dalloc_bytes(sizeof(float) * (size_t)b.Bmax * C);
+        double* sums = (double*)b.dalloc_bytes(sizeof(double) * (size_t)b.Bmax * C * 5);
         b.op([=](int B, hipStream_t st) {
-            int rc = launch_pmca(x, B, dw2, df0, dal, df2, wts, st);
+            int rc = launch_pmca(x, B, dw2, df0, dal, df2, wts, sums, st);
             if (rc) return rc;
             return launch_scale_channels(x, wts, out, B, st);
         });
