@@ -106,38 +106,56 @@ int launch_dwconv3x3(const View& in, const View& out, int B, int dil, const floa
 }
 
 // mode 0: AvgPool2d(3, stride 2, padding 1), count_include_pad (divide by 9);  mode 1: MaxPool2d(2, stride 2)
-__global__ void pool_s2_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C,
-                               int in_cs, int OH, int OW, int out_cs, int mode) {
-    const long total = (long)B * OH * OW * C;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = i % C;
-        long pix = i / C;
+template <int V>
+__global__ __launch_bounds__(256) void pool_s2_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W,
+                                                      int C, int in_cs, int OH, int OW, int out_cs, int mode) {
+    const unsigned CV = C / V, total = (unsigned)B * OH * OW * CV;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const int c = (i % CV) * V;
+        unsigned pix = i / CV;
         const int ox = pix % OW;
         pix /= OW;
         const int oy = pix % OH;
         const int b = pix / OH;
-        float r;
-        if (mode == 0) {
-            float s = 0.f;
-            for (int dy = -1; dy <= 1; ++dy)
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const int iy = 2 * oy + dy, ix = 2 * ox + dx;
-                    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) s += in[((long)(b * H + iy) * W + ix) * in_cs + c];
+        float r[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) r[e] = mode == 0 ? 0.f : -INFINITY;
+        const int lo = mode == 0 ? -1 : 0, hi = 1;
+        for (int dy = lo; dy <= hi; ++dy)
+            for (int dx = lo; dx <= hi; ++dx) {
+                const int iy = 2 * oy + dy, ix = 2 * ox + dx;
+                if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;   // (never out of range for the max pool)
+                const float* src = in + ((long)(b * H + iy) * W + ix) * in_cs + c;
+                float v[V];
+                if constexpr (V == 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(src);
+                    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                } else {
+                    v[0] = src[0];
                 }
-            r = s / 9.f;
-        } else {
-            r = -INFINITY;
-            for (int dy = 0; dy < 2; ++dy)
-                for (int dx = 0; dx < 2; ++dx) r = fmaxf(r, in[((long)(b * H + 2 * oy + dy) * W + 2 * ox + dx) * in_cs + c]);
+#pragma unroll
+                for (int e = 0; e < V; ++e) r[e] = mode == 0 ? r[e] + v[e] : fmaxf(r[e], v[e]);
+            }
+        if (mode == 0) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) r[e] = r[e] / 9.f;
         }
-        out[((long)(b * OH + oy) * OW + ox) * out_cs + c] = r;
+        float* dst = out + ((long)(b * OH + oy) * OW + ox) * out_cs + c;
+        if constexpr (V == 4) *reinterpret_cast<float4*>(dst) = make_float4(r[0], r[1], r[2], r[3]);
+        else dst[0] = r[0];
     }
 }
 
 int launch_pool_s2(const View& in, const View& out, int B, int mode, hipStream_t st) {
     const long total = (long)B * out.H * out.W * in.C;
-    hipLaunchKernelGGL(pool_s2_kernel, dim3(grid_for(total)), dim3(256), 0, st, in.p, out.p, B, in.H, in.W, in.C, in.cs,
-                       out.H, out.W, out.cs, mode);
+    if (total >= (1L << 31)) return fail("pool: tensor too large");
+    if (mode == 1 && (in.H < 2 * out.H || in.W < 2 * out.W)) return fail("pool: max pool window leaves the map");
+    if (vec4_ok(in) && out.cs % 4 == 0 && ((uintptr_t)out.p & 15) == 0)
+        hipLaunchKernelGGL(pool_s2_kernel<4>, dim3(grid_for(total / 4)), dim3(256), 0, st, in.p, out.p, B, in.H, in.W, in.C,
+                           in.cs, out.H, out.W, out.cs, mode);
+    else
+        hipLaunchKernelGGL(pool_s2_kernel<1>, dim3(grid_for(total)), dim3(256), 0, st, in.p, out.p, B, in.H, in.W, in.C, in.cs,
+                           out.H, out.W, out.cs, mode);
     QB_CHECK(hipGetLastError());
     return 0;
 }
