@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-gather", action="store_true", help="skip the per-step RCCL gather of label maps")
     ap.add_argument("--graph", action="store_true", help="capture the step's ~330 launches in one hipGraph and replay it")
+    ap.add_argument("--foreground-filter", action="store_true",
+                    help="also run the reference adapter's LMFFNet foreground post-filter on the refined masks in every "
+                         "step (eval/refiner_model.py:273-277; off for the headline metric, which is the refiner path)")
     ap.add_argument("--tuning", default="", help="A/B knobs for quber_set_tuning, e.g. 5=0 (include/quber_hip.h)")
     return ap.parse_args()
 
@@ -123,11 +126,19 @@ def main():
     out_masks = torch.empty((B, max_inst, H, W), dtype=torch.uint8, device=dev)
     counts = [B] * world
 
+    lmff = None
+    if a.foreground_filter:
+        from quber_amd import lmff_arch
+        from quber_amd.foreground.predictor import LmffEngine
+        lmff = LmffEngine(lmff_arch.init_state_dict(0), H, W, B, device=str(dev))
+
     def gpu_step():
         eng.encode(masks, offsets)
         eng.forward(bgr, depth, offsets, logits)
         eng.postprocess(logits, post)
         eng.extract_masks(post, max_inst, out_masks)
+        if lmff is not None:
+            lmff.foreground(bgr, depth, out_masks)
 
     graph = None
     if a.graph:
@@ -198,6 +209,7 @@ def main():
             "config": {"workload": f"batch={B} {W}x{H} RGB-D, {N} initial instances/frame, ResNet-50 RGB-D refiner "
                                    f"(boundary-error -> fg/centre/offset), encode+network+grouping+mask extraction",
                        "frames_per_step_per_gpu": B, "parallelism": f"dp{world}", "hipgraph": bool(a.graph),
+                       "foreground_filter": bool(a.foreground_filter),
                        "weights": "seeded synthetic (no checkpoint ships with the reference)",
                        "instances_out_per_frame_mean": float(count.mean())},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
