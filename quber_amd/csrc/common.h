@@ -86,6 +86,7 @@ int launch_conv_winograd(const WinoP& q, int B, int G, hipStream_t st);
 int launch_winograd_weights(const float* w_oihw, int Cout, int Cin, int m, float* u, hipStream_t st);
 void winograd_weights_host(const float* w_oihw, int Cout, int Cin, int m, float* u);
 bool winograd_eligible(int k, int stride, int pad, int dil, int Cin, int Cout);
+bool winograd_m6_channels_ok(int Cin, int Cout);
 size_t winograd_ws_floats(int B, int H, int W, int Cin, int Cout, int G, int dil, int m);
 double winograd_mac_ratio(int H, int W, int dil, int m);
 extern int g_winograd, g_wino_min_cin, g_wino_max_ratio, g_wino_variant, g_wino_min_cout;

@@ -216,31 +216,41 @@ struct Builder {
         p.w_gs = (long)Cout * Kpad; p.ss_gs = Cout;
         p.ohw = OH * OW;
         quber_ctx* ctx = c;
-        // Winograd F(2x2,3x3) alternative for the wide plain 3x3 layers; chosen per launch (batch) in the lambda below
-        WinoP wq{};
-        // (ragged frames and a dilated layer's short phases are padded to whole tiles: a variant is only taken while it
-        // still executes <= g_wino_max_ratio % of the direct multiplies; m = 4 preferred when both qualify)
+        // Winograd F(m x m,3x3) alternatives for the wide plain 3x3 layers; chosen per launch (batch) in the lambda below.
+        // Ragged frames and a dilated layer's short phases are padded to whole tiles: a variant qualifies only while it
+        // still executes <= g_wino_max_ratio % of the direct multiplies.  `wq` is the best of m = 4 / 2; `wq6` the 6x6
+        // variant where it executes >= 10 % fewer multiplies still - it costs about half a decimal digit of accuracy and
+        // its 64 small GEMMs only pay on large launches (>= 35 000 output pixels: profiles/r01l_winograd.md).
+        WinoP wq{}, wq6{};
         bool wino = winograd_eligible(k, stride, pad, dil, Cin, Cout) && cin_real == Cin && !res && prelu.empty();
         int wm = 0;
+        bool has6 = false;
         if (wino) {
             const double lim = (double)g_wino_max_ratio / 100.0;
+            const double r6 = winograd_m6_channels_ok(Cin, Cout) ? winograd_mac_ratio(in.H, in.W, dil, 6) : 1e9;
             const double r4 = winograd_mac_ratio(in.H, in.W, dil, 4), r2 = winograd_mac_ratio(in.H, in.W, dil, 2);
-            if (g_wino_variant != 2 && r4 <= lim && r4 < r2) wm = 4;
-            else if (g_wino_variant != 4 && r2 <= lim) wm = 2;
-            else if (g_wino_variant == 4 && r4 <= lim) wm = 4;
+            double best = lim;
+            if (r2 <= best && g_wino_variant != 4 && g_wino_variant != 6) { best = r2; wm = 2; }
+            if (r4 <= best && g_wino_variant != 2) { best = r4; wm = 4; }
+            if (r2 <= lim && wm == 0) { best = r2; wm = 2; }                     // a forced larger variant does not fit: smaller tiles
+            has6 = (g_wino_variant == 0 || g_wino_variant == 6) && r6 <= 0.9 * best;
             wino = wm != 0;
+            if (wino) {
+                c->wino_flops += 2.0 * OH * OW * (double)cin_real * k * k * Cout * G;
+                c->wino_saved += 2.0 * OH * OW * (double)cin_real * k * k * Cout * G * (1.0 - (has6 ? r6 : best));
+            }
         }
-        if (wino) {
-            const int P = (wm + 2) * (wm + 2);
+        auto prepare = [&](WinoP& q, int m) {
+            const int P = (m + 2) * (m + 2);
             std::vector<float> u((size_t)G * P * Cout * Cin);
-            for (int g = 0; g < G; ++g) winograd_weights_host(w[g], Cout, Cin, wm, &u[(size_t)g * P * Cout * Cin]);
-            wq.in = in; wq.out = out; wq.u = upload(u);
-            wq.scale = p.scale; wq.shift = p.shift; wq.ss_gs = Cout; wq.relu = relu; wq.dil = dil; wq.m = wm;
-            const size_t need = winograd_ws_floats(Bmax, in.H, in.W, Cin, Cout, G, dil, wm);
+            for (int g = 0; g < G; ++g) winograd_weights_host(w[g], Cout, Cin, m, &u[(size_t)g * P * Cout * Cin]);
+            q.in = in; q.out = out; q.u = upload(u);
+            q.scale = p.scale; q.shift = p.shift; q.ss_gs = Cout; q.relu = relu; q.dil = dil; q.m = m;
+            const size_t need = winograd_ws_floats(Bmax, in.H, in.W, Cin, Cout, G, dil, m);
             if (need > c->wino_floats) c->wino_floats = need;
-            c->wino_flops += 2.0 * OH * OW * (double)cin_real * k * k * Cout * G;
-            c->wino_saved += 2.0 * OH * OW * (double)cin_real * k * k * Cout * G * (1.0 - winograd_mac_ratio(in.H, in.W, dil, wm));
-        }
+        };
+        if (wino) prepare(wq, wm);
+        if (wino && has6) prepare(wq6, 6);
         // does this launch take the Winograd path?  (frames of a handful of tiles stay on the direct kernel)
         const int pH = in.H, pW = in.W;
         auto use_wino = [ctx, wino, pH, pW](int B) {
@@ -254,10 +264,12 @@ struct Builder {
         pending_norm.reset();
         auto fuse = std::make_shared<GnFuse>();
         last_conv = {fuse, out.p, G, Cout};
-        c->ops.push_back({[p, G, ctx, fuse, wq, use_wino, norm](int B, hipStream_t st) mutable {
+        c->ops.push_back({[p, G, ctx, fuse, this_wq = wq, wq6, has6, use_wino, norm](int B, hipStream_t st) mutable {
             // Winograd F(m x m,3x3) wins on every eligible layer (>= 128 channels in and out) at every batch size
             // (profiles/r01l_winograd.md)
             if (use_wino(B)) {
+                const bool six = has6 && (g_wino_variant == 6 || (long)B * G * p.H * p.W >= 35000);
+                WinoP& wq = six ? wq6 : this_wq;
                 wq.ws = ctx->wino_ws; wq.ws_floats = ctx->wino_floats;
                 wq.splitk_ws = ctx->splitk_ws; wq.splitk_floats = ctx->splitk_floats;
                 wq.gn_sum = fuse->sums; wq.gn_groups = fuse->groups;
@@ -1187,7 +1199,7 @@ int quber_op_conv3x3_winograd(const float* x, int32_t B, int32_t h, int32_t w, i
     hipStream_t st = (hipStream_t)stream;
     if (!winograd_eligible(3, 1, dil, dil, cin, cout)) return fail("winograd: unsupported channel counts");
     if ((scale == nullptr) != (shift == nullptr)) return fail("winograd: scale and shift go together");
-    if (m != 2 && m != 4) return fail("winograd: the output tile edge is 2 or 4");
+    if (m != 2 && m != 4 && m != 6) return fail("winograd: the output tile edge is 2, 4 or 6");
     int rc = launch_winograd_weights(w_oihw, cout, cin, m, u, st);
     if (rc) return rc;
     WinoP q{};

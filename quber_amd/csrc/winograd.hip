@@ -1,11 +1,11 @@
-// Winograd F(m x m, 3x3) path, m = 2 or 4, for the wide 3x3 / stride 1 convolutions of the refiner (fp32 throughout).
+// Winograd F(m x m, 3x3) path, m = 2, 4 or 6, for the wide 3x3 / stride 1 convolutions of the refiner (fp32 throughout).
 //
 // The reference computes these layers as plain convolutions (detectron2 Conv2d -> F.conv2d;
 // maskrefiner/modeling/backbone/resnet.py:472-485 fusion_res*.conv0/1, resnet.py:441-447 res3-5 conv2, the
 // DeepLabV3+ / head 3x3s of model.py:369-458).  The same sum is regrouped: an m x m output tile needs (m+2)^2
 // multiplies per (cin, cout) pair instead of 9 m^2,
 //     Y = A^T [ (G g G^T) .* (B^T d B) ] A,       d = (m+2)^2 input patch, g = 3x3 filter,
-// so the matrix pipe does 2.25x (m = 2) or 4x (m = 4) less work.  Pipeline per layer, P = (m+2)^2:
+// so the matrix pipe does 2.25x (m = 2), 4x (m = 4) or 5.06x (m = 6) less work.  Pipeline per layer, P = (m+2)^2:
 //   1. wino_input_kernel   d -> V = B^T d B          NHWC input  -> V[g][P][tile][Cin]     (HBM-bound)
 //   2. conv_igemm_f32      M[p] = V[p] x U[p]^T       P (x groups) independent GEMMs, launched as ONE grouped 1x1
 //                                                      "convolution" over blockIdx.z (conv_igemm.hip, unchanged)
@@ -15,6 +15,8 @@
 // m = 4 (interpolation points 0, +-3/4, +-3/2, inf - Lavin & Gray's 0, +-1, +-2 scaled by 3/4, which measured 2.7x less
 // fp32 error): about half a decimal digit less accurate than the direct kernel
 // (tests/test_gpu_parity.py::test_conv3x3_winograd_vs_float64 bounds it); see DESIGN.md for where each is used.
+// m = 6 (points 0, +-1, +-2, +-1/2, inf): 64 GEMMs per layer, about a decimal digit less accurate than the direct
+// kernel; taken only where the 6x6 tiles fit the map with little padding.
 // With dilation d the layer is d*d independent dense convolutions on the phase sub-images in[d*Y + py][d*X + px]
 // (TH x TW tiles each, the same for every phase; tiles beyond a shorter phase read zeros and store nothing).
 #include "common.h"
@@ -28,44 +30,85 @@ int g_wino_min_cout = 32;     // key 10: smallest output width routed to this pa
 
 namespace {
 
-__device__ inline float4 f4(float a) { return make_float4(a, a, a, a); }
-__device__ inline float4 operator+(const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ inline float4 operator-(const float4& a, const float4& b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
-__device__ inline float4 operator*(float s, const float4& a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
+// V consecutive channels of one pixel (V = 4: 16-byte accesses; V = 2 for the 8x8 transforms of m = 6, whose 64
+// intermediate values per channel would not fit the register file four channels at a time)
+template <int V>
+struct Vec {
+    float v[V];
+    __device__ inline Vec operator+(const Vec& o) const { Vec r; for (int e = 0; e < V; ++e) r.v[e] = v[e] + o.v[e]; return r; }
+    __device__ inline Vec operator-(const Vec& o) const { Vec r; for (int e = 0; e < V; ++e) r.v[e] = v[e] - o.v[e]; return r; }
+};
+template <int V>
+__device__ inline Vec<V> operator*(float s, const Vec<V>& a) { Vec<V> r; for (int e = 0; e < V; ++e) r.v[e] = s * a.v[e]; return r; }
+template <int V>
+__device__ inline Vec<V> vzero() { Vec<V> r; for (int e = 0; e < V; ++e) r.v[e] = 0.f; return r; }
+template <int V>
+__device__ inline Vec<V> vload(const float* p) {
+    Vec<V> r;
+    if constexpr (V == 4) { const float4 t = *reinterpret_cast<const float4*>(p); r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; }
+    else { const float2 t = *reinterpret_cast<const float2*>(p); r.v[0] = t.x; r.v[1] = t.y; }
+    return r;
+}
+template <int V>
+__device__ inline void vstore(float* p, const Vec<V>& a) {
+    if constexpr (V == 4) *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+    else *reinterpret_cast<float2*>(p) = make_float2(a.v[0], a.v[1]);
+}
 
 // y = B^T x  (one dimension)
-template <int O>
-__device__ inline void bt(const float4* x, float4* y) {
+template <int O, class T>
+__device__ inline void bt(const T* x, T* y) {
     if constexpr (O == 2) {
         y[0] = x[0] - x[2];
         y[1] = x[1] + x[2];
         y[2] = x[2] - x[1];
         y[3] = x[1] - x[3];
-    } else {
+    } else if constexpr (O == 4) {
         // points 0, +-3/4, +-3/2, inf (all constants dyadic, hence exact in fp32)
-        const float4 e1 = x[4] - 2.25f * x[2], o1 = 0.75f * x[3] - 1.6875f * x[1];
-        const float4 e2 = x[4] - 0.5625f * x[2], o2 = 1.5f * x[3] - 0.84375f * x[1];
+        const T e1 = x[4] - 2.25f * x[2], o1 = 0.75f * x[3] - 1.6875f * x[1];
+        const T e2 = x[4] - 0.5625f * x[2], o2 = 1.5f * x[3] - 0.84375f * x[1];
         y[0] = (1.265625f * x[0] - 2.8125f * x[2]) + x[4];
         y[1] = e1 + o1;
         y[2] = e1 - o1;
         y[3] = e2 + o2;
         y[4] = e2 - o2;
         y[5] = (1.265625f * x[1] - 2.8125f * x[3]) + x[5];
+    } else {
+        // points 0, +-1, +-2, +-1/2, inf (Lavin & Gray / wincnn)
+        const T a = (x[2] + x[6]) - 4.25f * x[4], b = (x[1] + x[5]) - 4.25f * x[3];
+        const T c = (0.25f * x[2] - 1.25f * x[4]) + x[6], d = (0.5f * x[1] - 2.5f * x[3]) + 2.f * x[5];
+        const T e = (4.f * x[2] - 5.f * x[4]) + x[6], f = (2.f * x[1] - 2.5f * x[3]) + 0.5f * x[5];
+        y[0] = (x[0] - x[6]) + 5.25f * (x[4] - x[2]);
+        y[1] = a + b;
+        y[2] = a - b;
+        y[3] = c + d;
+        y[4] = c - d;
+        y[5] = e + f;
+        y[6] = e - f;
+        y[7] = (x[7] - x[1]) + 5.25f * (x[3] - x[5]);
     }
 }
 
 // y = A^T x  (one dimension)
-template <int O>
-__device__ inline void at(const float4* x, float4* y) {
+template <int O, class T>
+__device__ inline void at(const T* x, T* y) {
     if constexpr (O == 2) {
         y[0] = (x[0] + x[1]) + x[2];
         y[1] = (x[1] - x[2]) - x[3];
-    } else {
-        const float4 a = x[1] + x[2], b = x[1] - x[2], c = x[3] + x[4], d = x[3] - x[4];
+    } else if constexpr (O == 4) {
+        const T a = x[1] + x[2], b = x[1] - x[2], c = x[3] + x[4], d = x[3] - x[4];
         y[0] = (x[0] + a) + c;
         y[1] = 0.75f * b + 1.5f * d;
         y[2] = 0.5625f * a + 2.25f * c;
         y[3] = (0.421875f * b + 3.375f * d) + x[5];
+    } else {
+        const T s1 = x[1] + x[2], d1 = x[1] - x[2], s2 = x[3] + x[4], d2 = x[3] - x[4], s3 = x[5] + x[6], d3 = x[5] - x[6];
+        y[0] = ((x[0] + s1) + s2) + s3;
+        y[1] = (d1 + 2.f * d2) + 0.5f * d3;
+        y[2] = (s1 + 4.f * s2) + 0.25f * s3;
+        y[3] = (d1 + 8.f * d2) + 0.125f * d3;
+        y[4] = (s1 + 16.f * s2) + 0.0625f * s3;
+        y[5] = ((d1 + 32.f * d2) + 0.03125f * d3) + x[7];
     }
 }
 
@@ -87,88 +130,94 @@ __device__ inline TileAt locate(long tile, int TH, int TW, int d) {
 // `np.stats` set: the input is the PRE-normalisation tensor of a GroupNorm + ReLU whose only consumer is this layer;
 // the normalisation (same arithmetic as gn_apply_kernel) is applied to the in-range pixels as they are loaded, which
 // saves the separate read + write pass over the activations.
-template <int O>
-__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ in, int B, int H, int W, int C4, int in_cs,
+// CV = C / V channel groups; a block holds 256 / CV tiles (CV <= 256) or a tile needs CV / 256 blocks (grid.y).
+template <int O, int V>
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ in, int B, int H, int W, int CV, int in_cs,
                                                          long in_gs, int TH, int TW, int d, float* __restrict__ v, long v_gs,
                                                          const WinoNorm np) {
     constexpr int T = O + 2;
+    using VT = Vec<V>;
     const int g = blockIdx.z;
     in += g * in_gs;
     v += g * v_gs;
-    const int tpb = 256 / C4;                        // tiles per block; C4 > 256 (host: then a multiple of 256): grid.y column blocks
-    const int c4 = tpb ? threadIdx.x % C4 : blockIdx.y * 256 + threadIdx.x;
+    const int tpb = 256 / CV;
+    const int cv = tpb ? threadIdx.x % CV : blockIdx.y * 256 + threadIdx.x;
     const long tiles = (long)B * d * d * TH * TW;
-    const long tile = tpb ? (long)blockIdx.x * tpb + threadIdx.x / C4 : blockIdx.x;
-    if (tile >= tiles || c4 >= C4 || (tpb && (int)(threadIdx.x / C4) >= tpb)) return;
+    const long tile = tpb ? (long)blockIdx.x * tpb + threadIdx.x / CV : blockIdx.x;
+    if (tile >= tiles || cv >= CV || (tpb && (int)(threadIdx.x / CV) >= tpb)) return;
     const TileAt ta = locate(tile, TH, TW, d);
-    const float* base = in + (long)ta.b * H * W * in_cs + c4 * 4;
-    float4 nsc = f4(1.f), nbi = f4(0.f);
+    const int c = cv * V;
+    const float* base = in + (long)ta.b * H * W * in_cs + c;
+    VT nsc, nbi;
     if (np.stats) {
-        const double* sb = np.stats + (((long)g * B + ta.b) * np.groups + c4 * 4 / np.cpg) * 2;
+        const double* sb = np.stats + (((long)g * B + ta.b) * np.groups + c / np.cpg) * 2;
         const double mean = sb[0] / np.n;
         double var = sb[1] / np.n - mean * mean;
         if (var < 0.0) var = 0.0;
         const float rstd = (float)(1.0 / sqrt(var + (double)np.eps));
-        const float4 ga = *reinterpret_cast<const float4*>(np.gamma + g * np.param_gs + c4 * 4);
-        const float4 be = *reinterpret_cast<const float4*>(np.beta + g * np.param_gs + c4 * 4);
-        nsc = make_float4(rstd * ga.x, rstd * ga.y, rstd * ga.z, rstd * ga.w);
-        nbi = make_float4(be.x - (float)mean * nsc.x, be.y - (float)mean * nsc.y, be.z - (float)mean * nsc.z,
-                          be.w - (float)mean * nsc.w);
+        const VT ga = vload<V>(np.gamma + g * np.param_gs + c), be = vload<V>(np.beta + g * np.param_gs + c);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            nsc.v[e] = rstd * ga.v[e];
+            nbi.v[e] = be.v[e] - (float)mean * nsc.v[e];
+        }
     }
-    float4 t[T][T];                                  // t = B^T d, one input column at a time
+    VT t[T][T];                                      // t = B^T d, one input column at a time
 #pragma unroll
     for (int j = 0; j < T; ++j) {
         const int x = d * (O * ta.tx - 1 + j) + ta.px;
-        float4 col[T], tc[T];
+        VT col[T], tc[T];
 #pragma unroll
         for (int i = 0; i < T; ++i) {
             const int y = d * (O * ta.ty - 1 + i) + ta.py;
             const bool inside = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-            float4 px4 = inside ? *reinterpret_cast<const float4*>(base + ((long)y * W + x) * in_cs) : f4(0.f);
+            VT px = inside ? vload<V>(base + ((long)y * W + x) * in_cs) : vzero<V>();
             if (np.stats && inside) {
-                px4.x = fmaf(px4.x, nsc.x, nbi.x); px4.y = fmaf(px4.y, nsc.y, nbi.y);
-                px4.z = fmaf(px4.z, nsc.z, nbi.z); px4.w = fmaf(px4.w, nsc.w, nbi.w);
-                if (np.relu) {
-                    px4.x = fmaxf(px4.x, 0.f); px4.y = fmaxf(px4.y, 0.f); px4.z = fmaxf(px4.z, 0.f); px4.w = fmaxf(px4.w, 0.f);
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    px.v[e] = fmaf(px.v[e], nsc.v[e], nbi.v[e]);
+                    if (np.relu) px.v[e] = fmaxf(px.v[e], 0.f);
                 }
             }
-            col[i] = px4;
+            col[i] = px;
         }
         bt<O>(col, tc);
 #pragma unroll
         for (int i = 0; i < T; ++i) t[i][j] = tc[i];
     }
-    float* dst = v + tile * (long)(C4 * 4) + c4 * 4;
-    const long ps = tiles * (long)(C4 * 4);          // position stride
+    float* dst = v + tile * (long)(CV * V) + c;
+    const long ps = tiles * (long)(CV * V);          // position stride
 #pragma unroll
     for (int i = 0; i < T; ++i) {                    // (B^T d) B
-        float4 row[T];
+        VT row[T];
         bt<O>(t[i], row);
 #pragma unroll
-        for (int j = 0; j < T; ++j) *reinterpret_cast<float4*>(dst + (i * T + j) * ps) = row[j];
+        for (int j = 0; j < T; ++j) vstore<V>(dst + (i * T + j) * ps, row[j]);
     }
 }
 
 // A block handles OUT_ITERS groups of tiles; with `gn_sum` it also accumulates the GroupNorm sums of what it stores
 // (fp64, LDS per block, one global atomic per (image, group) per block - as the direct kernel's epilogue does).
 constexpr int OUT_ITERS = 4;
-template <int O>
-__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ m, long m_gs, int B, int OH, int OW, int C4,
+template <int O, int V>
+__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ m, long m_gs, int B, int OH, int OW, int CV,
                                                           int TH, int TW, int d, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int ss_gs, int relu,
                                                           float* __restrict__ out, int out_cs, long out_gs,
                                                           double* __restrict__ gn_sum, int gn_groups, int gn_cpg) {
     constexpr int T = O + 2;
+    using VT = Vec<V>;
     const int g = blockIdx.z;
     m += g * m_gs;
     out += g * out_gs;
-    const int tpb = 256 / C4;
-    const int c4 = tpb ? threadIdx.x % C4 : blockIdx.y * 256 + threadIdx.x;
+    const int tpb = 256 / CV;
+    const int cv = tpb ? threadIdx.x % CV : blockIdx.y * 256 + threadIdx.x;
+    const int c = cv * V;
     const long per_img = (long)d * d * TH * TW;
     const long tiles = (long)B * per_img;
     const int step = tpb ? tpb : 1;                  // tiles per iteration
     const long tile0 = (long)blockIdx.x * step * OUT_ITERS;
-    const bool lane_ok = c4 < C4 && (!tpb || (int)(threadIdx.x / C4) < tpb);
+    const bool lane_ok = cv < CV && (!tpb || (int)(threadIdx.x / CV) < tpb);
     __shared__ double gacc[2 * 32 * 2];              // [image b0 / b0+1][group][sum, sum of squares]
     const int b0 = (int)(tile0 / per_img);
     if (gn_sum) {
@@ -176,23 +225,23 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
         __syncthreads();
     }
     double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
-    const long ps = tiles * (long)(C4 * 4);
-    float4 sc = f4(1.f), sh = f4(0.f);
+    const long ps = tiles * (long)(CV * V);
+    VT sc, sh;
     if (scale && lane_ok) {
-        sc = *reinterpret_cast<const float4*>(scale + g * ss_gs + c4 * 4);
-        sh = *reinterpret_cast<const float4*>(shift + g * ss_gs + c4 * 4);
+        sc = vload<V>(scale + g * ss_gs + c);
+        sh = vload<V>(shift + g * ss_gs + c);
     }
     for (int it = 0; it < OUT_ITERS; ++it) {
-        const long tile = tile0 + (long)it * step + (tpb ? threadIdx.x / C4 : 0);
+        const long tile = tile0 + (long)it * step + (tpb ? threadIdx.x / CV : 0);
         if (!lane_ok || tile >= tiles) continue;
         const TileAt ta = locate(tile, TH, TW, d);
-        const float* src = m + tile * (long)(C4 * 4) + c4 * 4;
-        float4 s[O][T];                              // s = A^T M, one column of positions at a time
+        const float* src = m + tile * (long)(CV * V) + c;
+        VT s[O][T];                                  // s = A^T M, one column of positions at a time
 #pragma unroll
         for (int j = 0; j < T; ++j) {
-            float4 col[T], sj[O];
+            VT col[T], sj[O];
 #pragma unroll
-            for (int i = 0; i < T; ++i) col[i] = *reinterpret_cast<const float4*>(src + (i * T + j) * ps);
+            for (int i = 0; i < T; ++i) col[i] = vload<V>(src + (i * T + j) * ps);
             at<O>(col, sj);
 #pragma unroll
             for (int i = 0; i < O; ++i) s[i][j] = sj[i];
@@ -201,31 +250,29 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
 #pragma unroll
         for (int i = 0; i < O; ++i) {
             const int oy = d * (O * ta.ty + i) + ta.py;
-            float4 row[O];
+            VT row[O];
             at<O>(s[i], row);                        // (A^T M) A
             if (oy >= OH) continue;
 #pragma unroll
             for (int j = 0; j < O; ++j) {
                 const int ox = d * (O * ta.tx + j) + ta.px;
                 if (ox >= OW) continue;
-                float4 y = row[j];
-                if (scale) {
-                    y.x = fmaf(y.x, sc.x, sh.x); y.y = fmaf(y.y, sc.y, sh.y);
-                    y.z = fmaf(y.z, sc.z, sh.z); y.w = fmaf(y.w, sc.w, sh.w);
+                VT y = row[j];
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    if (scale) y.v[e] = fmaf(y.v[e], sc.v[e], sh.v[e]);
+                    if (relu) y.v[e] = fmaxf(y.v[e], 0.f);
+                    a += (double)y.v[e];
+                    q += (double)y.v[e] * y.v[e];
                 }
-                if (relu) {
-                    y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
-                }
-                *reinterpret_cast<float4*>(out + (((long)ta.b * OH + oy) * OW + ox) * out_cs + c4 * 4) = y;
-                a += (double)y.x + (double)y.y + (double)y.z + (double)y.w;
-                q += (double)y.x * y.x + (double)y.y * y.y + (double)y.z * y.z + (double)y.w * y.w;
+                vstore<V>(out + (((long)ta.b * OH + oy) * OW + ox) * out_cs + c, y);
             }
         }
         if (ta.b == b0) { s0 += a; q0 += q; } else { s1 += a; q1 += q; }
     }
     if (gn_sum) {
         if (lane_ok) {
-            const int grp = c4 * 4 / gn_cpg;
+            const int grp = c / gn_cpg;
             if (s0 != 0.0 || q0 != 0.0) { atomicAdd(&gacc[grp * 2], s0); atomicAdd(&gacc[grp * 2 + 1], q0); }
             if (s1 != 0.0 || q1 != 0.0) { atomicAdd(&gacc[64 + grp * 2], s1); atomicAdd(&gacc[64 + grp * 2 + 1], q1); }
         }
@@ -246,13 +293,22 @@ __host__ __device__ inline void gmul(double a, double b, double c, double* y) {
         y[1] = 0.5 * (a + b + c);
         y[2] = 0.5 * (a - b + c);
         y[3] = c;
-    } else {
+    } else if constexpr (O == 4) {
         y[0] = a * (64.0 / 81.0);
         y[1] = -a * (128.0 / 243.0) - b * (32.0 / 81.0) - c * (8.0 / 27.0);
         y[2] = -a * (128.0 / 243.0) + b * (32.0 / 81.0) - c * (8.0 / 27.0);
         y[3] = a * (32.0 / 243.0) + b * (16.0 / 81.0) + c * (8.0 / 27.0);
         y[4] = a * (32.0 / 243.0) - b * (16.0 / 81.0) + c * (8.0 / 27.0);
         y[5] = c;
+    } else {
+        y[0] = a;
+        y[1] = -(a + b + c) * (2.0 / 9.0);
+        y[2] = -(a - b + c) * (2.0 / 9.0);
+        y[3] = a / 90.0 + b / 45.0 + c * (2.0 / 45.0);
+        y[4] = a / 90.0 - b / 45.0 + c * (2.0 / 45.0);
+        y[5] = (32.0 * a + 16.0 * b + 8.0 * c) / 45.0;
+        y[6] = (32.0 * a - 16.0 * b + 8.0 * c) / 45.0;
+        y[7] = c;
     }
 }
 
@@ -298,15 +354,22 @@ inline long wino_tiles(int H, int W, int d, int m) { return (long)d * d * tiles_
 }  // namespace
 
 void winograd_weights_host(const float* w_oihw, int Cout, int Cin, int m, float* u) {
-    if (m == 4) weights_host<4>(w_oihw, Cout, Cin, u);
+    if (m == 6) weights_host<6>(w_oihw, Cout, Cin, u);
+    else if (m == 4) weights_host<4>(w_oihw, Cout, Cin, u);
     else weights_host<2>(w_oihw, Cout, Cin, u);
 }
 
 int launch_winograd_weights(const float* w_oihw, int Cout, int Cin, int m, float* u, hipStream_t st) {
-    if (m == 4) hipLaunchKernelGGL(wino_weight_kernel<4>, dim3(256), dim3(256), 0, st, w_oihw, Cout, Cin, u);
+    if (m == 6) hipLaunchKernelGGL(wino_weight_kernel<6>, dim3(256), dim3(256), 0, st, w_oihw, Cout, Cin, u);
+    else if (m == 4) hipLaunchKernelGGL(wino_weight_kernel<4>, dim3(256), dim3(256), 0, st, w_oihw, Cout, Cin, u);
     else hipLaunchKernelGGL(wino_weight_kernel<2>, dim3(256), dim3(256), 0, st, w_oihw, Cout, Cin, u);
     QB_CHECK(hipGetLastError());
     return 0;
+}
+
+// m = 6 transforms work on channel pairs: C / 2 threads per tile
+bool winograd_m6_channels_ok(int Cin, int Cout) {
+    return (Cin / 2 <= 256 || (Cin / 2) % 256 == 0) && (Cout / 2 <= 256 || (Cout / 2) % 256 == 0);
 }
 
 bool winograd_eligible(int k, int stride, int pad, int dil, int Cin, int Cout) {
@@ -328,6 +391,7 @@ double winograd_mac_ratio(int H, int W, int dil, int m) {
 template <int O>
 static int run_winograd(const WinoP& q, int B, int G, hipStream_t st) {
     constexpr int P = (O + 2) * (O + 2);
+    constexpr int V = O == 6 ? 2 : 4;                // channels per thread in the transforms
     const View& in = q.in;
     const View& out = q.out;
     const int H = in.H, W = in.W, Cin = in.C, Cout = out.C, d = q.dil;
@@ -337,8 +401,8 @@ static int run_winograd(const WinoP& q, int B, int G, hipStream_t st) {
     if (winograd_ws_floats(B, H, W, Cin, Cout, G, d, O) > q.ws_floats) return fail("winograd: workspace too small");
     float* v = q.ws;
     float* m = q.ws + (size_t)G * P * tiles * Cin;
-    auto grid = [&](int C4) {
-        return C4 <= 256 ? dim3((unsigned)((tiles + 256 / C4 - 1) / (256 / C4)), 1, G) : dim3((unsigned)tiles, C4 / 256, G);
+    auto grid = [&](int CV) {
+        return CV <= 256 ? dim3((unsigned)((tiles + 256 / CV - 1) / (256 / CV)), 1, G) : dim3((unsigned)tiles, CV / 256, G);
     };
     WinoNorm np = q.norm;
     if (np.stats) {
@@ -346,8 +410,8 @@ static int run_winograd(const WinoP& q, int B, int G, hipStream_t st) {
         np.cpg = Cin / np.groups;
         np.n = (double)H * W * np.cpg;
     }
-    hipLaunchKernelGGL(wino_input_kernel<O>, grid(Cin / 4), dim3(256), 0, st, in.p, B, H, W, Cin / 4, in.cs, in.gs, TH, TW, d,
-                       v, (long)P * tiles * Cin, np);
+    hipLaunchKernelGGL((wino_input_kernel<O, V>), grid(Cin / V), dim3(256), 0, st, in.p, B, H, W, Cin / V, in.cs, in.gs, TH, TW,
+                       d, v, (long)P * tiles * Cin, np);
     QB_CHECK(hipGetLastError());
     ConvP p{};
     p.in = v; p.w = q.u; p.out = m;
@@ -360,14 +424,14 @@ static int run_winograd(const WinoP& q, int B, int G, hipStream_t st) {
     p.ws = q.splitk_ws; p.ws_floats = q.splitk_floats;
     int rc = launch_conv(p, G * P, st);
     if (rc) return rc;
-    // GroupNorm sums in the output transform when a block's tiles meet at most two images and float4s stay inside a group
-    const int C4o = Cout / 4, per_iter = C4o <= 256 ? 256 / C4o : 1;
+    // GroupNorm sums in the output transform when a block's tiles meet at most two images and vectors stay inside a group
+    const int CVo = Cout / V, per_iter = CVo <= 256 ? 256 / CVo : 1;
     const bool gn_here = q.gn_sum && q.gn_groups > 0 && q.gn_groups <= 32 && (Cout / q.gn_groups) % 4 == 0 &&
                          wino_tiles(H, W, d, O) >= (long)per_iter * OUT_ITERS;
-    dim3 og = grid(C4o);
+    dim3 og = grid(CVo);
     og.x = (og.x + OUT_ITERS - 1) / OUT_ITERS;
-    hipLaunchKernelGGL(wino_output_kernel<O>, og, dim3(256), 0, st, m, (long)P * tiles * Cout, B, H, W, C4o, TH, TW, d, q.scale,
-                       q.shift, q.ss_gs, q.relu, out.p, out.cs, out.gs, gn_here ? q.gn_sum : nullptr, q.gn_groups,
+    hipLaunchKernelGGL((wino_output_kernel<O, V>), og, dim3(256), 0, st, m, (long)P * tiles * Cout, B, H, W, CVo, TH, TW, d,
+                       q.scale, q.shift, q.ss_gs, q.relu, out.p, out.cs, out.gs, gn_here ? q.gn_sum : nullptr, q.gn_groups,
                        q.gn_groups ? Cout / q.gn_groups : 1);
     QB_CHECK(hipGetLastError());
     if (q.gn_sum && !gn_here) return launch_gn_stats(out, B, G, q.gn_groups, q.gn_sum, st, false);
@@ -377,11 +441,12 @@ static int run_winograd(const WinoP& q, int B, int G, hipStream_t st) {
 int launch_conv_winograd(const WinoP& q, int B, int G, hipStream_t st) {
     const View& in = q.in;
     const View& out = q.out;
-    if (!winograd_eligible(3, 1, q.dil, q.dil, in.C, out.C) || out.H != in.H || out.W != in.W || (q.m != 2 && q.m != 4))
+    if (!winograd_eligible(3, 1, q.dil, q.dil, in.C, out.C) || out.H != in.H || out.W != in.W || (q.m != 2 && q.m != 4 && q.m != 6))
         return fail("winograd: unsupported geometry");
+    if (q.m == 6 && !winograd_m6_channels_ok(in.C, out.C)) return fail("winograd: channel counts unsupported by the 6x6 variant");
     if (in.cs % 4 || out.cs % 4 || ((uintptr_t)in.p & 15) || ((uintptr_t)out.p & 15) || (in.gs & 3) || (out.gs & 3))
         return fail("winograd: operands must be 16-byte aligned");
-    return q.m == 4 ? run_winograd<4>(q, B, G, st) : run_winograd<2>(q, B, G, st);
+    return q.m == 6 ? run_winograd<6>(q, B, G, st) : q.m == 4 ? run_winograd<4>(q, B, G, st) : run_winograd<2>(q, B, G, st);
 }
 
 }  // namespace quber

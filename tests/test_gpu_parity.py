@@ -402,10 +402,11 @@ def test_conv_split_tail_equals_whole(case):
     (1, 23, 37, 128, 128, 4, False, False),      # phases of unequal size
     (1, 30, 40, 2048, 256, 6, True, True),       # ASPP d = 6
 ])
-@pytest.mark.parametrize("m", [2, 4])
+@pytest.mark.parametrize("m", [2, 4, 6])
 def test_conv3x3_winograd_vs_float64(case, m):
     B, H, W, Cin, Cout, dil, affine, relu = case
-    tol = 1e-5 if m == 2 else 2e-5        # F(4x4,3x3) on the points 0, +-3/4, +-3/2, inf: within ~4x of the direct kernel
+    # F(4x4,3x3) on the points 0, +-3/4, +-3/2, inf: within ~4x of the direct kernel; F(6x6,3x3): about a digit
+    tol = {2: 1e-5, 4: 2e-5, 6: 1e-4}[m]
     lib = _lib.load()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)

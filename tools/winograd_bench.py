@@ -18,8 +18,8 @@ lib.quber_set_tuning(10, 32)
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-print(f"| layer ({F} frames) | GFLOP | direct ms | TF/s | F(2x2) ms | speed-up | F(4x4) ms | speed-up |")
-print("|---|---|---|---|---|---|---|---|")
+print(f"| layer ({F} frames) | GFLOP | direct ms | TF/s | F(2x2) ms | speed-up | F(4x4) ms | speed-up | F(6x6) ms | speed-up |")
+print("|---|---|---|---|---|---|---|---|---|---|")
 for name, ipf, H, W, Cin, Cout, *rest in [("fusion_res2 3x3 256>256 @120x160", 1, 120, 160, 256, 256),
                                    ("res5.conv2 3x3 d2 512>512 @30x40 (2 streams)", 2, 30, 40, 512, 512, 2),
                                    ("res5.conv2 3x3 d4 512>512 @30x40 (2 streams)", 2, 30, 40, 512, 512, 4),
@@ -62,7 +62,7 @@ for name, ipf, H, W, Cin, Cout, *rest in [("fusion_res2 3x3 256>256 @120x160", 1
     td = timed(lambda: _lib.check(lib.quber_op_conv2d(p(x), B, H, W, Cin, p(w), Cout, 3, 1, d, d, p(sc), p(sh), p(None), 1,
                                                       p(packed), p(y), st)))
     cols = []
-    for m in (2, 4):
+    for m in (2, 4, 6):
         P = (m + 2) ** 2
         tiles = B * d * d * ((-(-H // d) + m - 1) // m) * ((-(-W // d) + m - 1) // m)
         u = torch.empty(P * Cout * Cin, device="cuda")

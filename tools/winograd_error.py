@@ -12,10 +12,10 @@ for name,gen in [("randn",lambda s: torch.randn(s,device="cuda")),("relu(randn)+
         _lib.check(lib.quber_op_conv2d(p(x),B,H,W,Cin,p(w),Cout,3,1,d,d,p(None),p(None),p(None),0,p(packed),p(yd),st))
         ref=torch.nn.functional.conv2d(x.permute(0,3,1,2).double(), w.double(), None,1,d,d).permute(0,2,3,1)
         out=[]
-        for m in (2,4):
+        for m in (2,4,6):
             P=(m+2)**2; tiles=B*d*d*((-(-H//d)+m-1)//m)*((-(-W//d)+m-1)//m)
             u=torch.empty(P*Cout*Cin,device="cuda"); ws=torch.empty(P*tiles*(Cin+Cout),device="cuda"); y=torch.empty_like(yd)
             _lib.check(lib.quber_op_conv3x3_winograd(p(x),B,H,W,Cin,p(w),Cout,d,m,p(None),p(None),0,p(u),p(ws),ws.numel(),p(y),st))
             out.append(float((y.double()-ref).abs().max()/ref.abs().max()))
         ed=float((yd.double()-ref).abs().max()/ref.abs().max())
-        print(f"{name:18s} C={Cin:4d} d={d}: max err / max|y|  direct {ed:.1e}  F2 {out[0]:.1e}  F4 {out[1]:.1e}   (max|y| {float(ref.abs().max()):.2f}, rms {float(ref.pow(2).mean().sqrt()):.2f})")
+        print(f"{name:18s} C={Cin:4d} d={d}: max err / max|y|  direct {ed:.1e}  F2 {out[0]:.1e}  F4 {out[1]:.1e}  F6 {out[2]:.1e}   (max|y| {float(ref.abs().max()):.2f}, rms {float(ref.pow(2).mean().sqrt()):.2f})")
