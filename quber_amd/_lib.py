@@ -79,9 +79,10 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    # QUBER_WINOGRAD = auto (default) | f4 | f2 | off : which fast algorithm the wide 3x3 layers may use.  F(4x4,3x3)
-    # is within ~4x of the direct kernel's rounding error per layer; "f2" keeps the
-    # direct kernel's accuracy at ~0.8x the throughput, "off" runs every layer as a plain implicit GEMM.
+    # QUBER_WINOGRAD = auto (default) | f4 | f2 | off : the largest Winograd tile the wide 3x3 layers may use.  auto adds
+    # F(6x6,3x3) on large launches (about a decimal digit of rounding error per layer), F(4x4,3x3) is within ~4x of the
+    # direct kernel's error, "f2" keeps the direct kernel's accuracy at ~0.8x the throughput,
+    # "off" runs every layer as a plain implicit GEMM.
     mode = os.environ.get("QUBER_WINOGRAD", "auto").lower()
     if mode not in ("auto", "f4", "f2", "off"):
         raise QuberError(f"QUBER_WINOGRAD={mode!r}: expected auto, f4, f2 or off")
