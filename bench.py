@@ -218,8 +218,8 @@ def main():
                                    "ReLU epilogue, the GroupNorm sums of the output, the split-K reduce pass and, for the "
                                    "Winograd layers, the input / output transforms)",
                          "flops": "algorithmic (2 x MAC of the direct convolution, SURVEY 8d), hence frac > 1 is possible: the wide "
-                                  "3x3 layers run as Winograd F(4x4,3x3) / F(2x2,3x3) and execute 1/4 / 4/9 of their "
-                                  "multiplies - executed_tflops / executed_frac are what the matrix pipe really does",
+                                  "3x3 layers run as Winograd F(6x6,3x3) / F(4x4) / F(2x2) and execute 16/81, 1/4 or 4/9 of "
+                                  "their multiplies - executed_tflops / executed_frac are what the matrix pipe really does",
                          "executed_tflops": executed, "executed_frac": executed / FP32_MFMA_PEAK_TFLOPS,
                          "launches_per_step": conv_n,
                          "avg_launch_ms": cms / max(conv_n, 1), "flops_per_launch": flops / max(conv_n, 1),
