@@ -244,8 +244,8 @@ def test_config2_1280x720_hipgraph_steady_state():
 
 
 def test_winograd_modes_agree():
-    """The three convolution algorithms (direct only, Winograd F(2x2,3x3), F(4x4,3x3): quber_set_tuning keys 6 / 9, the
-    C-level form of QUBER_WINOGRAD) give the same logits within the 1e-4 bar, and the library reports how many of the
+    """The convolution algorithms (direct only, Winograd F(2x2,3x3), F(4x4,3x3), F(6x6,3x3) forced on every layer it fits:
+    quber_set_tuning keys 6 / 9, the C-level form of QUBER_WINOGRAD) give the same logits within the 1e-4 bar, and the library reports how many of the
     algorithmic FLOPs each one executes."""
     from quber_amd import _lib
     lib = _lib.load()
@@ -255,7 +255,7 @@ def test_winograd_modes_agree():
     bgr, dep, off = torch.from_numpy(batch["rgb"]).cuda(), torch.from_numpy(batch["depth"]).cuda(), torch.from_numpy(offs).cuda()
     outs, ratios = {}, {}
     try:
-        for name, (k6, k9) in {"off": (1, 0), "f2": (0, 2), "f4": (0, 4)}.items():
+        for name, (k6, k9) in {"off": (1, 0), "f2": (0, 2), "f4": (0, 4), "f6": (0, 6)}.items():
             lib.quber_set_tuning(6, k6)
             lib.quber_set_tuning(9, k9)
             eng = engine.Engine(engine.make_config(h, w, max_batch=b), "cuda:0")
@@ -266,8 +266,8 @@ def test_winograd_modes_agree():
     finally:
         lib.quber_set_tuning(6, 0)
         lib.quber_set_tuning(9, 0)
-    assert ratios["off"] == 1.0 and ratios["f4"] < ratios["f2"] < 1.0
+    assert ratios["off"] == 1.0 and ratios["f6"] < ratios["f4"] < ratios["f2"] < 1.0
     assert 0.5 < ratios["f4"] < 0.75 and 0.65 < ratios["f2"] < 0.85
-    for name in ("f2", "f4"):
+    for name in ("f2", "f4", "f6"):
         assert float((outs[name] - outs["off"]).abs().max()) < TOL, name
     assert not torch.equal(outs["f4"], outs["off"])        # the path really was different
