@@ -253,8 +253,13 @@ struct Builder {
         if (wino && has6) prepare(wq6, 6);
         // does this launch take the Winograd path?  (frames of a handful of tiles stay on the direct kernel)
         const int pH = in.H, pW = in.W;
-        auto use_wino = [ctx, wino, pH, pW](int B) {
-            return wino && ctx->wino_ws && g_winograd != 1 && (g_winograd == 2 || (long)B * pH * pW / 4 >= 256);
+        // (64-channel layers: only the 6x6 variant on very large launches pays - 1.25x at 16 frames, < 1 at one)
+        const bool narrow = Cin < 128;
+        auto use_wino = [ctx, wino, pH, pW, narrow, has6, G](int B) {
+            if (!wino || !ctx->wino_ws || g_winograd == 1) return false;
+            if (g_winograd == 2) return true;
+            const long px = (long)B * pH * pW;
+            return narrow ? has6 && px * G >= 300000 : px / 4 >= 256;
         };
         std::shared_ptr<DeferredNorm> norm;
         if (wino && pending_norm && pending_norm->out.p == in.p && pending_norm->C == Cin && pending_norm->G == G) {
