@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""Does a hipGraph replay of encode + forward reproduce the eager results on a new frame?  (found the hipMemsetAsync issue)"""
 import sys, numpy as np, torch
 sys.path.insert(0,'/root/repo')
 from quber_amd import arch, engine, synth

@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""ASPP d = 18 layer: dense K loop vs skipping the filter rows that are zero padding (tuning key 11), by split factor."""
 import ctypes as C, sys, numpy as np, torch
 sys.path.insert(0,'/root/repo')
 from quber_amd import _lib
