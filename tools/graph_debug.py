@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Does a hipGraph replay of encode + forward reproduce the eager results on a new frame?  (found the hipMemsetAsync issue)"""
 import sys, numpy as np, torch
-sys.path.insert(0,'/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from quber_amd import arch, engine, synth
 h,w,n=int(sys.argv[1]),int(sys.argv[2]),int(sys.argv[3])
 sd=arch.init_state_dict(seed=4)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """ASPP d = 18 layer: dense K loop vs skipping the filter rows that are zero padding (tuning key 11), by split factor."""
 import ctypes as C, sys, numpy as np, torch
-sys.path.insert(0,'/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from quber_amd import _lib
 lib=_lib.load(); lib.quber_set_tuning(2,1)
 st=C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,5 +1,7 @@
+#!/usr/bin/env python3
+"""Error of the direct kernel and of the three Winograd variants against float64 on one 3x3 layer (profiles/r01l_winograd_error.txt)."""
 import ctypes as C, sys, numpy as np, torch
-sys.path.insert(0,'/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from quber_amd import _lib
 lib=_lib.load(); lib.quber_set_tuning(2,1)
 st=C.c_void_p(torch.cuda.current_stream().cuda_stream)
