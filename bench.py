@@ -5,26 +5,39 @@ RCCL broadcast of the weights at start-up and gather of the refined label maps p
 
 A step = one pass of the hot path over one resident batch:
     encode initial masks -> network (fp32 MFMA) -> grouping / merge / scores -> per-instance masks.
-Prints ONE JSON line on rank 0 (see the contract in the task statement): value = whole-job masks/s,
-`roofline` for the dominant kernel (the implicit-GEMM convolution, MFMA-bound) measured live with HIP
-events on the launch stream, `cpu_baseline` = the oracle (pure-torch CPU restatement of the reference
+Prints ONE JSON line on rank 0: value = whole-job masks/s; `roofline` for the dominant kernel (the implicit-GEMM
+convolution, MFMA-bound) plus one `hbm_stages` entry per HBM-bound stage, all measured live with HIP events on the
+launch stream (quber_profile_begin/end); `cpu_baseline` = the oracle (pure-torch CPU restatement of the reference
 path) timed on this box's host cores over a bounded sample.
+
+`python bench.py --gpus N` with N > 1 and no torchrun environment launches the N ranks itself (child processes
+started BEFORE anything touches the GPU); under the driver's torchrun launch it just joins the group.  A world
+size that differs from --gpus is an error, never a silent 1-rank run.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from quber_amd import arch, dist as qdist, engine, synth  # noqa: E402
-
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide, "Peak BF16/FP16 MFMA" (dense)
+HBM_PEAK_GBPS = 8000.0          # same guide, "HBM3E peak BW" (spec; 6.29 TB/s measured float4 copy)
+
+# stage tags (quber_profile_stage) of the convolution family and of the HBM-bound stages reported in `hbm_stages`
+CONV_GEMM = ("conv_gemm", "wino_gemm")
+CONV_FAMILY = CONV_GEMM + ("splitk_reduce", "wino_input", "wino_output")
+HBM_STAGES = ("encode_reduce", "encode_paint", "errmaps_pack", "errmaps_erode", "errmaps_quadruple", "preprocess", "wino_input",
+              "wino_output", "splitk_reduce", "gn_stats", "gn_apply", "maxpool", "bilinear", "predictor", "upsample_logits",
+              "post_nms", "post_select", "post_group", "post_paint_stats", "extract_masks")
 
 
 def parse():
@@ -36,57 +49,190 @@ def parse():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--instances", type=int, default=20)
-    ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--dtype", default="f32", choices=("f32", "bf16"),
+                    help="arithmetic of the convolutions: f32 (headline; exact fp32 MFMA) or bf16 operands with fp32 "
+                         "accumulation (BASELINE.json configs[4] stand-in; its own tolerance, see DESIGN.md)")
+    ap.add_argument("--heads", default="loud", choices=("loud", "faithful"),
+                    help="loud: O(1) predictors + calibrated centre bias so post-processing sees K ~ N instances per frame; "
+                         "faithful: the reference's N(0, 0.001) predictor init (K = 0)")
+    ap.add_argument("--cpu-frames", type=int, default=10, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-grad-frames", type=int, default=3, help="frames timed as the reference runs (autograd graph built)")
     ap.add_argument("--no-gather", action="store_true", help="skip the per-step RCCL gather of label maps")
     ap.add_argument("--graph", action="store_true", help="capture the step's ~330 launches in one hipGraph and replay it")
+    ap.add_argument("--host-io", action="store_true",
+                    help="host-inclusive mode: inputs start in pinned host memory and the refined masks end there every step "
+                         "(double-buffered H2D / D2H on copy streams, as the reference's timed region includes them); "
+                         "reported as host_io, never as `value`")
     ap.add_argument("--foreground-filter", action="store_true",
                     help="also run the reference adapter's LMFFNet foreground post-filter on the refined masks in every "
                          "step (eval/refiner_model.py:273-277; off for the headline metric, which is the refiner path)")
     ap.add_argument("--tuning", default="", help="A/B knobs for quber_set_tuning, e.g. 5=0 (include/quber_hip.h)")
+    ap.add_argument("--dry", action="store_true",
+                    help="no GPU work: exercise the launch / rendezvous / broadcast / gather path only (CPU tests, gloo)")
     return ap.parse_args()
 
 
-def cpu_baseline(sd, h, w, n, frames, eng=None):
-    """The oracle end to end (encode -> network -> grouping -> instances), batch 1 like the reference.
-    With `eng`, the first timed frame is also pushed through the HIP path and compared (the metric's 'IoU delta vs ref')."""
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(a):
+    """--gpus N without a torchrun environment: start the N ranks as child processes and exit with their status.
+    Nothing in this process has touched the GPU (no torch.cuda call, no HIP library loaded)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def source_digest():
+    """sha256 over the kernel sources: measured-traffic files are only trusted for the code they were measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "quber_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_info():
+    model, phys = "unknown", set()
+    try:
+        pid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                phys.add((pid, line.split(":", 1)[1].strip()))
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return model, (min(len(phys), usable) if phys else usable), usable
+
+
+def cpu_baseline(sd, h, w, n, frames, grad_frames, eng=None, batch_eng=None, batch=None):
+    """The oracle end to end (encode -> network -> grouping -> instances), batch 1 like the reference, executed the way the
+    reference executes it (op by op, no folding, the head-fusion stack re-evaluated per key: model.py:760-762).
+    Timed under torch.no_grad() (favours the baseline) and, on fewer frames, with the autograd graph the reference builds
+    (predictor.py:358); `value` is the faster.  With `batch_eng`, frames of the BENCHMARKED batch are compared with the HIP
+    results of the batch-sized engine (the metric's 'IoU delta vs ref')."""
+    import torch
     from oracle import encode_np, postproc_ref
-    from oracle.network_torch import MaskRefinerNet
-    net = MaskRefinerNet().eval()
+    from oracle.network_torch import ArchCfg, MaskRefinerNet
+    from quber_amd import synth
+    model, cores, usable = cpu_info()
+    torch.set_num_threads(cores)
+    net = MaskRefinerNet(ArchCfg(repeat_fusion=True)).eval()
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
-    cores = torch.get_num_threads()
-    times, parity = [], None
-    with torch.no_grad():   # the reference builds an autograd graph (predictor.py:358); no_grad favours the baseline
-        for i in range(frames + 1):
-            sc = synth.make_scene(100 + i, h, w, n)
-            t0 = time.perf_counter()
-            offs = encode_np.encode_initial_masks(sc["masks"])
-            image = torch.from_numpy(np.concatenate([sc["rgb"], sc["depth"]], -1)).permute(2, 0, 1)[None]
+
+    def one(sc, grad):
+        t0 = time.perf_counter()
+        offs = encode_np.encode_initial_masks(sc["masks"])
+        image = torch.from_numpy(np.concatenate([sc["rgb"], sc["depth"]], -1)).permute(2, 0, 1)[None]
+        with torch.enable_grad() if grad else torch.no_grad():
             out = net(image, torch.from_numpy(offs[None]))
-            ref = postproc_ref.postprocess(out["foreground"][0], out["center"][0], out["offset"][0])
-            times.append(time.perf_counter() - t0)
-            if i == 1 and eng is not None:
-                dev = eng.device
-                m = torch.from_numpy(sc["masks"][None]).to(dev)
-                lg = eng.forward(torch.from_numpy(sc["rgb"][None]).to(dev), torch.from_numpy(sc["depth"][None]).to(dev),
-                                 eng.encode(m))
-                pan = eng.postprocess(lg)["panoptic"][0].cpu()
-                exp = torch.cat([out["foreground"], out["center"], out["offset"], out["eee_boundary"]], 1)
-                a, b_ = pan >= 0, ref["panoptic"] >= 0
-                union = int((a | b_).sum())
-                parity = {"max_abs_dlogit": float((lg.cpu() - exp).abs().max()),
-                          "label_map_equal_fraction": float((pan == ref["panoptic"]).float().mean()),
-                          "fg_iou": float((a & b_).sum()) / union if union else 1.0}
-    times = times[1:]                                       # the reference drops the first sample (eval_utils.py:342)
-    med = float(np.median(times))
-    return {"value": n / med, "unit": "refined masks/s", "cores": cores, "kind": "port", "parity_vs_hip": parity,
-            "sample": f"{frames} frames {w}x{h} N={n} batch 1, median {med * 1e3:.0f} ms/frame, torch {torch.__version__} CPU, no_grad"}
+            out = {k: v.detach() for k, v in out.items()}
+        ref = postproc_ref.postprocess(out["foreground"][0], out["center"][0], out["offset"][0])
+        return time.perf_counter() - t0, out, ref
+
+    res = {}
+    for name, grad, cnt in (("no_grad", False, frames), ("grad", True, grad_frames)):
+        if cnt <= 0:
+            continue
+        times = [one(synth.make_scene(100 + i, h, w, n), grad)[0] for i in range(cnt + 1)][1:]   # first sample dropped (eval_utils.py:342)
+        res[name] = {"frames": cnt, "median_ms_per_frame": float(np.median(times)) * 1e3,
+                     "masks_per_s": n / float(np.median(times))}
+    parity = None
+    if batch_eng is not None:
+        # frames 0 and B-1 of the benchmarked batch through the oracle vs the batch-B HIP results already on the device
+        lg_all, pan_all = batch["logits"].cpu(), batch["panoptic"].cpu()
+        dl, eq, iou, ks = [], [], [], []
+        for i in sorted({0, lg_all.shape[0] - 1}):
+            sc = {k: batch["host"][k][i] for k in ("rgb", "depth", "masks")}
+            _, out, ref = one(sc, False)
+            exp = torch.cat([out["foreground"], out["center"], out["offset"], out["eee_boundary"]], 1)[0]
+            dl.append(float((lg_all[i] - exp).abs().max()))
+            a, b_ = pan_all[i] >= 0, ref["panoptic"] >= 0
+            union = int((a | b_).sum())
+            eq.append(float((pan_all[i] == ref["panoptic"]).float().mean()))
+            iou.append(float((a & b_).sum()) / union if union else 1.0)
+            ks.append(len(ref["labels"]))
+        parity = {"engine_batch": int(lg_all.shape[0]), "frames_checked": len(dl), "max_abs_dlogit": max(dl),
+                  "label_map_equal_fraction": min(eq), "fg_iou": min(iou), "oracle_instances_per_frame": ks}
+    best = max(res.values(), key=lambda r: r["masks_per_s"])
+    return {"value": best["masks_per_s"], "unit": "refined masks/s", "cores": cores, "kind": "port",
+            "cpu_model": model, "usable_cpus": usable, "torch": torch.__version__, "variants": res, "parity_vs_hip": parity,
+            "sample": f"{frames} frames {w}x{h} N={n} batch 1 under no_grad + {grad_frames} with the autograd graph, median per "
+                      f"frame, first sample dropped; reference-style execution (fusion stack per key)"}
+
+
+def dry_main(a, world, rank):
+    """CPU rehearsal of everything around the hot path: rendezvous, weight broadcast, frame sharding, label-map gather,
+    max-over-ranks timing, the JSON line.  No GPU, no engine."""
+    import torch
+    import torch.distributed as dist
+    from quber_amd import arch, dist as qdist
+    if world > 1:
+        dist.init_process_group(os.environ.get("QUBER_DIST_BACKEND", "gloo"))
+    specs = arch.param_specs()
+    sd = arch.init_state_dict(seed=0) if rank == 0 else None
+    if world > 1:
+        sd = qdist.broadcast_state_dict(sd, specs, src=0, device="cpu")
+    digest = hashlib.sha256(np.concatenate([np.asarray(sd[k]).ravel()[:64] for k in specs]).tobytes()).hexdigest()[:12]
+    B, H, W = a.batch, 32, 48
+    local = torch.full((B, H, W), float(rank), dtype=torch.float32)
+    t0 = time.perf_counter()
+    got = None
+    for _ in range(a.steps):
+        got = qdist.gather_label_maps(local, [B] * world, dst=0) if world > 1 else local
+    elapsed = time.perf_counter() - t0
+    ranks = [{"rank": rank, "world_size": world, "device": "cpu", "weights": digest}]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        allr = [None] * world
+        dist.all_gather_object(allr, ranks[0])
+        ranks = allr
+    if rank == 0:
+        assert got.shape[0] == world * B and all(float(got[r * B].mean()) == r for r in range(world))
+        assert len({r["weights"] for r in ranks}) == 1, "weight broadcast diverged"
+        print(json.dumps({"metric": "refined masks/sec on 640x480 RGB-D (N=20 inst)", "value": None, "unit": "refined masks/s",
+                          "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+                          "dry": True, "config": {"workload": "dry run: rendezvous + broadcast + gather only"},
+                          "rccl_ranks": ranks}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but the launch environment has WORLD_SIZE={world}; refusing to run "
+                 f"(use `python bench.py --gpus {a.gpus}` alone, or torchrun with --nproc-per-node {a.gpus})")
+    if a.dry:
+        return dry_main(a, world, rank)
+
+    import torch
+    from quber_amd import arch, dist as qdist, engine, synth
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -97,29 +243,51 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
         else:
             dist.init_process_group(backend)
-    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+        if dist.get_world_size() != a.gpus:
+            sys.exit(f"bench.py: process group has {dist.get_world_size()} ranks, expected {a.gpus}")
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
     B, H, W, N = a.batch, a.height, a.width, a.instances
+    loud = a.heads == "loud"
+
+    def make_engine(sd):
+        qc = engine.make_config(H, W, max_batch=B, max_instances=max(N, 1))
+        qc.compute_dtype = 1 if a.dtype == "bf16" else 0
+        e = engine.Engine(qc, dev)
+        for kv in filter(None, a.tuning.split(",")):      # before the plan is built: some knobs act at plan time
+            k, v = kv.split("=")
+            e.lib.quber_set_tuning(int(k), int(v))
+        e.load_state_dict(sd)
+        return e
+
+    # ---- synthetic inputs; each rank has its own frames ----
+    host = synth.make_batch(7 + rank, B, H, W, N)
+    masks = torch.from_numpy(host["masks"]).to(dev)
+    gt_masks = torch.from_numpy(host["gt_masks"]).to(dev)
+    bgr = torch.from_numpy(host["rgb"]).to(dev)
+    depth = torch.from_numpy(host["depth"]).to(dev)
+    offsets = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
 
     # ---- weights: rank 0 owns the checkpoint, the others receive it in one RCCL broadcast ----
     specs = arch.param_specs()
-    sd = arch.init_state_dict(seed=0) if rank == 0 else None
+    center_bias = 0.0
+    if rank == 0:
+        sd = arch.init_state_dict(seed=0, loud_heads=loud)
+        if loud:
+            # centre-head bias such that ~N local maxima per frame pass the 0.3 threshold (arch.calibrate_center_bias):
+            # one forward of rank 0's frames with bias 0, then the weights are rebuilt with the bias
+            eng0 = make_engine(sd)
+            lg0 = eng0.forward(bgr, depth, eng0.encode(masks))
+            center_bias = arch.calibrate_center_bias(lg0[:, 1:2].float().cpu(), N)
+            eng0.close()
+            del eng0, lg0
+            sd = arch.init_state_dict(seed=0, loud_heads=True, center_bias=center_bias)
+    else:
+        sd = None
     if dist is not None:
         sd = qdist.broadcast_state_dict(sd, specs, src=0, device=dev)
+    eng = make_engine(sd)
 
-    eng = engine.Engine(engine.make_config(H, W, max_batch=B, max_instances=max(N, 1)), dev)
-    for kv in filter(None, a.tuning.split(",")):      # before the plan is built: some knobs act at plan time
-        k, v = kv.split("=")
-        eng.lib.quber_set_tuning(int(k), int(v))
-    eng.load_state_dict(sd)
-
-    # ---- synthetic inputs, resident in HBM before the timed region; each rank has its own frames ----
-    batch = synth.make_batch(7 + rank, B, H, W, N)
-    masks = torch.from_numpy(batch["masks"]).to(dev)
-    bgr = torch.from_numpy(batch["rgb"]).to(dev)
-    depth = torch.from_numpy(batch["depth"]).to(dev)
-    offsets = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
     logits = torch.empty((B, eng.planes, H, W), dtype=torch.float32, device=dev)
     post = eng.alloc_post(B)
     max_inst = min(eng.cap, max(N, 1) + 12)
@@ -132,13 +300,13 @@ def main():
         from quber_amd.foreground.predictor import LmffEngine
         lmff = LmffEngine(lmff_arch.init_state_dict(0), H, W, B, device=str(dev))
 
-    def gpu_step():
-        eng.encode(masks, offsets)
-        eng.forward(bgr, depth, offsets, logits)
+    def gpu_step(m=masks, b_=bgr, d_=depth, om=out_masks):
+        eng.encode(m, offsets)
+        eng.forward(b_, d_, offsets, logits)
         eng.postprocess(logits, post)
-        eng.extract_masks(post, max_inst, out_masks)
+        eng.extract_masks(post, max_inst, om)
         if lmff is not None:
-            lmff.foreground(bgr, depth, out_masks)
+            lmff.foreground(b_, d_, om)
 
     graph = None
     if a.graph:
@@ -173,67 +341,183 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    rank_info = {"rank": rank, "world_size": dist.get_world_size() if dist is not None else 1, "device": str(dev),
+                 "device_name": torch.cuda.get_device_name(dev), "backend": dist.get_backend() if dist is not None else None}
+    ranks = [rank_info]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        ranks = [None] * world
+        dist.all_gather_object(ranks, rank_info)
+
+    host_io = None
+    if a.host_io and rank == 0:
+        host_io = host_io_run(a, eng, host, offsets, logits, post, max_inst, dev)
 
     if rank == 0:
-        # ---- roofline of the dominant kernel family: HIP events around every conv launch, on the launch stream ----
-        conv_ms, conv_n, norm_ms, other_ms = [], 0, [], []
-        for _ in range(3):
-            _, prof = eng.forward_profiled(bgr, depth, offsets, logits)
-            conv_ms.append(prof["conv"][0])
-            conv_n = prof["conv"][1]
-            norm_ms.append(prof["norm"][0])
-            other_ms.append(prof["other"][0])
-        cms = float(np.median(conv_ms))
-        flops = eng.forward_flops() * B                       # algorithmic: 2*MAC of every conv, fusion stack once
-        achieved = flops / (cms * 1e-3) / 1e12
-        executed = eng.forward_flops_executed() * B / (cms * 1e-3) / 1e12   # Winograd layers execute 16/36 of their MACs
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "conv_hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("bytes_per_launch")
-            except Exception:
-                traffic = None
-        count = post["count"].cpu().numpy()
-        ms_per_step = elapsed / a.steps * 1e3
-        line = {
-            "metric": "refined masks/sec on 640x480 RGB-D (N=20 inst)",
-            "value": world * B * N * a.steps / elapsed,
-            "unit": "refined masks/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"batch={B} {W}x{H} RGB-D, {N} initial instances/frame, ResNet-50 RGB-D refiner "
-                                   f"(boundary-error -> fg/centre/offset), encode+network+grouping+mask extraction",
-                       "frames_per_step_per_gpu": B, "parallelism": f"dp{world}", "hipgraph": bool(a.graph),
-                       "foreground_filter": bool(a.foreground_filter),
-                       "weights": "seeded synthetic (no checkpoint ships with the reference)",
-                       "instances_out_per_frame_mean": float(count.mean())},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "conv_igemm_f32 (all instantiations; the timed brackets include the fused affine / residual / "
-                                   "ReLU epilogue, the GroupNorm sums of the output, the split-K reduce pass and, for the "
-                                   "Winograd layers, the input / output transforms)",
-                         "flops": "algorithmic (2 x MAC of the direct convolution, SURVEY 8d), hence frac > 1 is possible: the wide "
-                                  "3x3 layers run as Winograd F(6x6,3x3) / F(4x4) / F(2x2) and execute 16/81, 1/4 or 4/9 of "
-                                  "their multiplies - executed_tflops / executed_frac are what the matrix pipe really does",
-                         "executed_tflops": executed, "executed_frac": executed / FP32_MFMA_PEAK_TFLOPS,
-                         "launches_per_step": conv_n,
-                         "avg_launch_ms": cms / max(conv_n, 1), "flops_per_launch": flops / max(conv_n, 1),
-                         "forward_ms": {"conv": cms, "groupnorm": float(np.median(norm_ms)),
-                                        "other": float(np.median(other_ms))}},
-        }
-        if world == 1 and a.cpu_frames > 0:
-            line["cpu_baseline"] = cpu_baseline(sd, H, W, N, a.cpu_frames, eng)
-        else:
-            line["cpu_baseline"] = None
+        line = report(a, eng, world, elapsed, ranks, center_bias, sd, host,
+                      dict(masks=masks, gt_masks=gt_masks, bgr=bgr, depth=depth, offsets=offsets, logits=logits, post=post,
+                           out_masks=out_masks, max_inst=max_inst), gpu_step)
+        if host_io is not None:
+            line["host_io"] = host_io
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def host_io_run(a, eng, host, offsets, logits, post, max_inst, dev):
+    """The reference's timed region (eval/refiner_model.py:265-271) starts with numpy inputs and ends with numpy masks.
+    Pinned staging buffers, two device buffer sets, one H2D and one D2H copy stream: the upload of step i+1 and the
+    download of step i-1 overlap the compute of step i."""
+    import torch
+    B, H, W, N = a.batch, a.height, a.width, a.instances
+    pin = {k: torch.from_numpy(host[k]).pin_memory() for k in ("masks", "rgb", "depth")}
+    dev_in = [{k: torch.empty_like(v, device=dev) for k, v in pin.items()} for _ in range(2)]
+    dev_out = [torch.empty((B, max_inst, H, W), dtype=torch.uint8, device=dev) for _ in range(2)]
+    host_out = [torch.empty((B, max_inst, H, W), dtype=torch.uint8).pin_memory() for _ in range(2)]
+    host_cnt = [torch.empty((B,), dtype=torch.int32).pin_memory() for _ in range(2)]
+    up, down, main = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.current_stream()
+    ev_up = [torch.cuda.Event() for _ in range(2)]
+    ev_done = [torch.cuda.Event() for _ in range(2)]
+    ev_free_in = [torch.cuda.Event() for _ in range(2)]
+    ev_down = [torch.cuda.Event() for _ in range(2)]
+
+    def upload(i):
+        s = i & 1
+        with torch.cuda.stream(up):
+            up.wait_event(ev_free_in[s])            # the compute that last read this input set has finished
+            for k in pin:
+                dev_in[s][k].copy_(pin[k], non_blocking=True)
+            ev_up[s].record(up)
+
+    def run(steps):
+        for s in range(2):
+            ev_free_in[s].record(main)
+            ev_down[s].record(down)
+        upload(0)
+        for i in range(steps):
+            s = i & 1
+            if i + 1 < steps:
+                upload(i + 1)
+            main.wait_event(ev_up[s])
+            main.wait_event(ev_down[s])             # the previous download of this output set has finished
+            eng.encode(dev_in[s]["masks"], offsets)
+            eng.forward(dev_in[s]["rgb"], dev_in[s]["depth"], offsets, logits)
+            eng.postprocess(logits, post)
+            eng.extract_masks(post, max_inst, dev_out[s])
+            ev_free_in[s].record(main)
+            ev_done[s].record(main)
+            with torch.cuda.stream(down):
+                down.wait_event(ev_done[s])
+                host_out[s].copy_(dev_out[s], non_blocking=True)
+                host_cnt[s].copy_(post["count"], non_blocking=True)
+                ev_down[s].record(down)
+        torch.cuda.synchronize()
+
+    run(max(a.warmup, 2))
+    t0 = time.perf_counter()
+    run(a.steps)
+    el = time.perf_counter() - t0
+    per_step_mb = (sum(v.numel() for v in pin.values()) + host_out[0].numel()) / 1e6
+    return {"value": B * N * a.steps / el, "unit": "refined masks/s", "ms_per_step": el / a.steps * 1e3,
+            "pcie_mb_per_step": per_step_mb,
+            "note": "inputs (bgr, depth, initial masks) start in pinned host memory, refined masks u8 [B,max_inst,H,W] end there; "
+                    "double-buffered copy streams; single GPU"}
+
+
+def report(a, eng, world, elapsed, ranks, center_bias, sd, host, t, gpu_step):
+    import torch
+    B, H, W, N = a.batch, a.height, a.width, a.instances
+    # ---- stage profile: HIP events around every kernel of one step (+ the explicit error maps, a2), median of 3 ----
+    runs = []
+    for _ in range(3):
+        eng.profile_begin()
+        gpu_step()
+        eng.error_maps(t["masks"], t["gt_masks"])
+        runs.append(eng.profile_end())
+    stages = {}
+    for k in runs[0]:
+        stages[k] = dict(runs[0][k])
+        stages[k]["ms"] = float(np.median([r[k]["ms"] for r in runs]))
+    fam_ms = sum(stages[k]["ms"] for k in CONV_FAMILY if k in stages)
+    gemm_ms = sum(stages[k]["ms"] for k in CONV_GEMM if k in stages)
+    gemm_n = sum(stages[k]["launches"] for k in CONV_GEMM if k in stages)
+    executed = sum(stages[k]["flops"] for k in CONV_GEMM if k in stages)       # what the matrix pipe multiplies (2*M*K*N per launch)
+    algorithmic = eng.forward_flops() * B                                        # 2 x MAC of the direct convolutions (SURVEY 8d)
+    peak = BF16_MFMA_PEAK_TFLOPS if a.dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS
+    hbm = {}
+    for k in HBM_STAGES:
+        if k in stages and stages[k]["ms"] > 0:
+            s = stages[k]
+            gbps = s["bytes"] / (s["ms"] * 1e-3) / 1e9
+            hbm[k] = {"bytes": s["bytes"], "ms": s["ms"], "launches": s["launches"], "GBps": gbps, "frac": gbps / HBM_PEAK_GBPS}
+    traffic, traffic_note = None, "no measurement on file"
+    tpath = os.path.join(ROOT, "profiles", "conv_hbm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("source_digest") == source_digest() and tj.get("dtype", "f32") == a.dtype:
+                traffic = tj.get("bytes_per_launch")
+                traffic_note = f"rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE per convolution-family launch, measured on kernel sources {tj['source_digest']}"
+            else:
+                traffic_note = "profiles/conv_hbm_traffic.json was measured on other kernel sources (or another dtype): not reported"
+        except Exception:
+            traffic_note = "profiles/conv_hbm_traffic.json unreadable"
+    count = t["post"]["count"].cpu().numpy()
+    ms_per_step = elapsed / a.steps * 1e3
+    ex_tf = executed / (fam_ms * 1e-3) / 1e12 if fam_ms else 0.0
+    line = {
+        "metric": "refined masks/sec on 640x480 RGB-D (N=20 inst)",
+        "value": world * B * N * a.steps / elapsed,
+        "unit": "refined masks/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": f"batch={B} {W}x{H} RGB-D, {N} initial instances/frame, ResNet-50 RGB-D refiner "
+                               f"(boundary-error -> fg/centre/offset), encode+network+grouping+mask extraction",
+                   "frames_per_step_per_gpu": B, "parallelism": f"dp{world}", "hipgraph": bool(a.graph),
+                   "foreground_filter": bool(a.foreground_filter),
+                   "weights": ("seeded synthetic, loud predictors N(0, %.2f), centre bias %.4f calibrated for ~N peaks per frame"
+                               % (arch_sigma(), center_bias)) if a.heads == "loud"
+                              else "seeded synthetic, reference init (predictors N(0, 0.001): K = 0)",
+                   "instances_out_per_frame_mean": float(count.mean()),
+                   "instances_out_per_frame_min_max": [int(count.min()), int(count.max())]},
+        "rccl_ranks": ranks,
+        "roofline": {"bound": "mfma", "achieved": ex_tf, "peak": peak, "unit": "TFLOP/s", "frac": ex_tf / peak,
+                     "traffic": traffic, "traffic_note": traffic_note,
+                     "kernel": "conv_igemm (all instantiations).  achieved = FLOPs the matrix pipe EXECUTES per step (2*M*K*N of "
+                               "every GEMM launch; the Winograd layers' transformed GEMMs count what they multiply, not the direct "
+                               "convolution's 2*MAC) / device time of the whole convolution family (GEMM launches + split-K reduce + "
+                               "Winograd input / output transforms), HIP events on the launch stream",
+                     "gemm_kernel_tflops": executed / (gemm_ms * 1e-3) / 1e12 if gemm_ms else 0.0,
+                     "gemm_kernel_frac": executed / (gemm_ms * 1e-3) / 1e12 / peak if gemm_ms else 0.0,
+                     "algorithmic_tflops": algorithmic / (fam_ms * 1e-3) / 1e12 if fam_ms else 0.0,
+                     "algorithmic_note": "2 x MAC of the direct convolutions (SURVEY 8d: 375.6 GFLOP per 640x480 frame) over the "
+                                         "same time; exceeds `achieved` because Winograd F(m x m,3x3) executes (m+2)^2 / 9m^2 of them",
+                     "executed_over_algorithmic": executed / algorithmic if algorithmic else None,
+                     "gemm_launches_per_step": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
+                     "flops_per_launch": executed / max(gemm_n, 1),
+                     "conv_family_ms": {k: stages[k]["ms"] for k in CONV_FAMILY if k in stages},
+                     "hbm_stages": hbm,
+                     "hbm_note": "bytes = algorithmic (every operand of the stage read / written once), ms = HIP-event device time "
+                                 "per step, frac = GB/s / 8000 (HBM3E spec; 6.3 TB/s is the measured copy ceiling)"},
+        "stage_ms_other": {k: stages[k]["ms"] for k in stages if k not in CONV_FAMILY and k not in hbm},
+    }
+    if world == 1 and a.cpu_frames > 0:
+        bt = {"logits": t["logits"], "panoptic": t["post"]["panoptic"], "host": host}
+        gpu_step()
+        torch.cuda.synchronize()
+        line["cpu_baseline"] = cpu_baseline(sd, H, W, N, a.cpu_frames, a.cpu_grad_frames, eng, eng, bt)
+    else:
+        line["cpu_baseline"] = None
+    return line
+
+
+def arch_sigma():
+    from quber_amd import arch
+    return arch.LOUD_PRED_SIGMA
 
 
 if __name__ == "__main__":

@@ -58,6 +58,8 @@ typedef struct quber_config {
     int32_t fusion_add;              /* MODEL.BACKBONE.FUSION_STRATEGY == "add" (0 = "concat") */
     int32_t streams;                 /* 2: rgb + depth streams (build_resnet_deeplab_rgbd_fusion_backbone); 1: single stream
                                         (build_resnet_deeplab_fusion_backbone: rgb-only or depth-only, pixel_mean[0..2]) */
+    int32_t compute_dtype;           /* arithmetic of the convolutions: 0 = exact fp32 MFMA (default; the 1e-4 parity bar),
+                                        1 = bf16 operands, fp32 accumulation (BASELINE.json configs[4] stand-in; own tolerance) */
 } quber_config;
 
 /* logit planes produced by quber_forward: [fg, centre, off_y, off_x, eee_boundary x classes (if on), eee_mask x classes (if on)] */
@@ -110,6 +112,17 @@ int quber_forward_profiled(quber_ctx* ctx, const uint8_t* dev_bgr, const uint8_t
                            const float* dev_offsets, int32_t batch, float* dev_logits, void* stream,
                            double* kind_ms, int32_t* kind_launches);
 
+/* Stage profile (benchmark use): every quber_* call made on `ctx` by this thread between begin and end brackets each of
+ * its kernels with a HIP-event pair on the launch stream.  quber_profile_end synchronises `stream` and sums, per stage
+ * name ("encode_reduce", "preprocess", "conv_gemm", "wino_input", "wino_gemm", "wino_output", "splitk_reduce",
+ * "gn_apply", "upsample_logits", "post_nms", "post_group", "extract_masks", "errmaps_pack", ...): device milliseconds,
+ * the stage's ALGORITHMIC bytes (every operand read / written once) and FLOPs, and the number of brackets. */
+int quber_profile_begin(quber_ctx* ctx);
+int quber_profile_end(quber_ctx* ctx, void* stream);
+int quber_profile_num_stages(quber_ctx* ctx);
+int quber_profile_stage(quber_ctx* ctx, int index, const char** name, double* ms, double* bytes, double* flops,
+                        int32_t* launches);
+
 /* a8-a11 - centre NMS/top-k, pixel grouping, 512-px merge, scores and boxes.  Replaces get_panoptic_segmentation
  * (maskrefiner/modeling/mask_refiner/post_processing.py:165-221) and the instance loop of model.py:313-356.
  *   dev_logits f32 [B][n_planes][H][W] (planes 0..3 used)
@@ -157,17 +170,20 @@ int quber_normalize_depth(const void* dev_depth, int32_t is_float32, int64_t n_p
 int quber_debug_tensor(quber_ctx* ctx, const char* name, float** dev_ptr, int32_t* dims4, int32_t* channel_stride);
 /* algorithmic FLOPs of one forward at batch 1 (2 * MACs of every convolution) */
 double quber_forward_flops(quber_ctx* ctx);
-/* FLOPs the matrix pipe actually executes per forward at batch 1: the layers routed through Winograd F(2x2,3x3)
- * count 16/36 of their algorithmic FLOPs (transform additions not counted) */
+/* FLOPs the matrix pipe actually executes per forward at batch 1: a layer planned as Winograd F(m x m,3x3) counts
+ * (m+2)^2 / (9 m^2) of its algorithmic FLOPs, padded tiles included (transform additions not counted) */
 double quber_forward_flops_executed(quber_ctx* ctx);
 /* test-harness knobs: key 2 = give the stand-alone quber_op_conv2d a split-K workspace (value != 0) or drop it (0);
  * key 3 = force the number of K partitions of convolutions that have a workspace (0 = automatic);
  * key 11 = stand-alone conv op only: dilated 3x3 layers in tap-major K order with the zero-padding filter rows skipped;
  * key 10 = smallest output width routed to the Winograd path (default 32);
- * key 9 = Winograd output tile edge of the eligible layers: 0 = automatic (default), 2, 4 (acts at plan time);
+ * key 9 = Winograd output tile edge of the eligible layers (acts at plan time): 0 = automatic (default: F(4x4), or F(2x2)
+ *         where its tiles fit the map better; both measure the direct kernel's error), 2, 4, or 6 = opt into F(6x6,3x3)
+ *         where it executes >= 10 % fewer multiplies still (2.5x the error at tap level, +4.5 % throughput at batch 16);
+ *         the algorithm of every layer is fixed at plan time from its geometry alone, never from the batch of a launch;
  * key 8 = Winograd only while its multiplies are <= value % of the direct kernel's (dilated layers; default 67);
  * key 7 = smallest input width (channels) routed to the Winograd path (default 256);
- * key 6 = Winograd F(2x2,3x3) path of the eligible 3x3 layers: 0 = where it pays (default), 1 = never, 2 = always;
+ * key 6 = Winograd path of the eligible 3x3 layers (acts at plan time): 0 = where it pays (default), 1 = never, 2 = always;
  * key 5 = split the ragged last round of large convolution launches into K-pieces: when the cost model
  *         favours it (1, default), never (0), whenever feasible (2);
  * key 4 = force the convolution tile shape (1 = 64x64, 2 = 128x128, 4 = 256x32; 0 = automatic) */
@@ -181,7 +197,7 @@ int quber_op_conv2d(const float* dev_x, int32_t batch, int32_t h, int32_t w, int
                     int32_t cout, int32_t ksize, int32_t stride, int32_t pad, int32_t dil, const float* dev_scale,
                     const float* dev_shift, const float* dev_residual, int32_t relu, float* dev_packed_scratch,
                     float* dev_y, void* stream);
-/* the same for a 3x3 / stride 1 / pad = dilation convolution through the Winograd F(m x m, 3x3) path, m = 2 or 4
+/* the same for a 3x3 / stride 1 / pad = dilation convolution through the Winograd F(m x m, 3x3) path, m = 2, 4 or 6
  * (cin >= 128 and a multiple of 32, cout >= 128): with P = (m+2)^2, dev_u_scratch holds P*cout*cin floats (transformed
  * weights), dev_ws at least P * batch * dil^2 * ceil(ceil(h/dil)/m) * ceil(ceil(w/dil)/m) * (cin + cout) floats */
 int quber_op_conv3x3_winograd(const float* dev_x, int32_t batch, int32_t h, int32_t w, int32_t cin,

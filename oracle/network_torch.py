@@ -50,6 +50,8 @@ class ArchCfg:
     fusion_target: List[str] = field(default_factory=lambda: ["feat", "pred"])
     fusion_add: bool = False                 # MODEL.BACKBONE.FUSION_STRATEGY "add"
     streams: int = 2                         # 2: RGBDFusionBackbone; 1: plain ResNet (rgb-only / depth-only configs)
+    repeat_fusion: bool = False              # re-evaluate the head-fusion stack once per key, as model.py:760-762 does
+                                             # (same values; only the CPU-baseline timing uses it)
     pixel_mean: List[float] = field(default_factory=lambda: [103.53, 116.28, 123.675, 127.5, 127.5, 127.5])
     pixel_std: List[float] = field(default_factory=lambda: [1.0] * 6)
 
@@ -310,7 +312,9 @@ class InsEmbedHead(nn.Module):
                 x = getattr(self, f"fusion_layers_{i}")(yp)
                 if taps is not None:
                     taps[f"z{i}"] = x
-            for k in keys:
+            for j, k in enumerate(keys):
+                if i > 0 and j > 0 and cfg.repeat_fusion:
+                    x = getattr(self, f"fusion_layers_{i}")(yp)
                 feat[k] = getattr(self, f"{k}_pred_head")(x)
                 out[k] = getattr(self, f"{k}_predictor")(feat[k])
         if taps is not None:

@@ -19,6 +19,7 @@ class QuberConfig(C.Structure):
         ("eee_mask_on", C.c_int32), ("eee_boundary_on", C.c_int32), ("hierarchical", C.c_int32),
         ("fusion_feat", C.c_int32), ("fusion_pred", C.c_int32), ("n_levels", C.c_int32),
         ("level_heads", (C.c_int32 * 5) * 5), ("fusion_add", C.c_int32), ("streams", C.c_int32),
+        ("compute_dtype", C.c_int32),
     ]
 
 
@@ -43,6 +44,11 @@ SIGNATURES = {
     "quber_explicit_error_maps": (C.c_int, [_P, _P, _I, _P, _I, _I, _P, _P]),
     "quber_forward": (C.c_int, [_P, _P, _P, _P, _I, _P, _P]),
     "quber_forward_profiled": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, C.POINTER(C.c_double * 3), C.POINTER(_I * 3)]),
+    "quber_profile_begin": (C.c_int, [_P]),
+    "quber_profile_end": (C.c_int, [_P, _P]),
+    "quber_profile_num_stages": (C.c_int, [_P]),
+    "quber_profile_stage": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                      C.POINTER(C.c_double), C.POINTER(_I)]),
     "quber_postprocess": (C.c_int, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "quber_extract_masks": (C.c_int, [_P, _P, _P, _I, _I, _P, _P]),
     "quber_contingency_workspace_bytes": (C.c_int64, [_I]),
@@ -79,15 +85,17 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    # QUBER_WINOGRAD = auto (default) | f4 | f2 | off : the largest Winograd tile the wide 3x3 layers may use.  auto adds
-    # F(6x6,3x3) on large launches (about a decimal digit of rounding error per layer), F(4x4,3x3) is within ~4x of the
-    # direct kernel's error, "f2" keeps the direct kernel's accuracy at ~0.8x the throughput,
+    # QUBER_WINOGRAD = auto (default) | f6 | f4 | f2 | off : the Winograd tiles the wide 3x3 layers may use.  Each layer's
+    # algorithm is fixed when the plan is built, from its geometry only (never from the batch).  auto = F(4x4,3x3), or
+    # F(2x2) where its tiles fit the map better: both measure the direct kernel's error against float64 at tap level
+    # (profiles/r02a_parity_report.txt).  "f6" opts into F(6x6,3x3) where it multiplies >= 10 % less still: 2.5x the
+    # tap-level error (still 5x inside the 1e-4 bar), +4.5 % throughput at batch 16.  "f2" = 0.8x the throughput,
     # "off" runs every layer as a plain implicit GEMM.
     mode = os.environ.get("QUBER_WINOGRAD", "auto").lower()
-    if mode not in ("auto", "f4", "f2", "off"):
-        raise QuberError(f"QUBER_WINOGRAD={mode!r}: expected auto, f4, f2 or off")
+    if mode not in ("auto", "f6", "f4", "f2", "off"):
+        raise QuberError(f"QUBER_WINOGRAD={mode!r}: expected auto, f6, f4, f2 or off")
     lib.quber_set_tuning(6, 1 if mode == "off" else 0)
-    lib.quber_set_tuning(9, {"f2": 2, "f4": 4}.get(mode, 0))
+    lib.quber_set_tuning(9, {"f2": 2, "f4": 4, "f6": 6}.get(mode, 0))
     _lib = lib
     return lib
 

@@ -115,11 +115,19 @@ def param_specs(depth=50, backbone_fusion_layers=2, head_fusion_layers=3, error_
     return s
 
 
-def init_state_dict(seed=0, **kw):
+LOUD_PRED_SIGMA = 0.25
+
+
+def init_state_dict(seed=0, loud_heads=False, center_bias=0.0, **kw):
     """Seeded float32 numpy state_dict.  Convs: He-normal (fan_out) for the encoder as c2_msra_fill
     (resnet.py:64-66), Xavier-uniform for the heads as c2_xavier_fill (model.py:405-406), predictors
     N(0, 0.001) (model.py:418-419).  Norm statistics are random but benign so that folding is exercised;
-    the last BN of every bottleneck is damped to keep the residual trunk O(1) without training."""
+    the last BN of every bottleneck is damped to keep the residual trunk O(1) without training.
+
+    loud_heads: the faithful N(0, 0.001) predictors give logits of ~3e-3 (a 1e-4 check on them proves little, and
+    no centre ever reaches the 0.3 threshold: K = 0).  The "loud" set draws the final 1x1 predictors from
+    N(0, LOUD_PRED_SIGMA) instead, so every head output is O(1) and sensitive to the features, and shifts the centre
+    head by `center_bias` (see calibrate_center_bias) so that post-processing sees K ~ N instances per frame."""
     rng = np.random.default_rng(seed)
     out = OrderedDict()
     for name, (shape, kind) in param_specs(**kw).items():
@@ -143,13 +151,33 @@ def init_state_dict(seed=0, **kw):
         elif kind in ("gn_b", "bias"):
             v = rng.normal(0, 0.05, shape)
         elif kind == "pred_w":
-            v = rng.normal(0, 0.001, shape)
+            v = rng.normal(0, LOUD_PRED_SIGMA if loud_heads else 0.001, shape)
         elif kind == "pred_b":
             v = np.zeros(shape)
+            if loud_heads and "center_predictor" in name:
+                v = v + center_bias
         else:
             raise AssertionError(kind)
         out[name] = np.ascontiguousarray(v, dtype=np.float32)
     return out
+
+
+def calibrate_center_bias(center, target=20, threshold=0.3, nms_kernel=7):
+    """center: float tensor [B,1,H,W] or [B,H,W] of centre-head outputs computed with center_bias = 0.
+    Returns the bias that makes `target` local maxima per frame (on average) exceed `threshold` after the
+    7x7 max-pool NMS of post_processing.py:9-41 (a constant shift does not move the maxima)."""
+    import torch
+    import torch.nn.functional as F
+    c = torch.as_tensor(center).float()
+    if c.dim() == 3:
+        c = c[:, None]
+    pooled = F.max_pool2d(c, nms_kernel, 1, nms_kernel // 2)
+    cuts = []
+    for b in range(c.shape[0]):
+        peaks = torch.sort(c[b][c[b] == pooled[b]], descending=True).values
+        k = min(target, peaks.numel() - 1)
+        cuts.append(float(0.5 * (peaks[k - 1] + peaks[k])) if k >= 1 else float(peaks[0]) - 1.0)
+    return float(threshold - np.median(cuts))
 
 
 def num_parameters(specs=None):

@@ -47,10 +47,24 @@ struct ConvP {
     int skip_rows;       // kmode 0 only: blocks skip the filter rows that are padding for all their output rows
     long in_gs, out_gs, res_gs, w_gs;
     int ss_gs;
+    const char* tag;     // stage-profile tag of the launch (null = "conv_gemm")
 };
 
 void set_error(const std::string& msg);
 int fail(const std::string& msg);
+
+// Stage profiler (benchmark use only).  Between quber_profile_begin and quber_profile_end every launcher brackets its
+// kernels with a HIP-event pair recorded on the launch stream, tagged with a stage name and the ALGORITHMIC bytes
+// (what the stage must read + write once) and FLOPs of the bracket; outside such a window a ProfScope costs one
+// thread-local load.  Scopes do not nest: they sit at the leaves (one kernel, or a kernel plus its tiny helpers).
+struct ProfScope {
+    int rec;
+    hipStream_t st;
+    ProfScope(const char* tag, double bytes, double flops, hipStream_t s);
+    ~ProfScope();
+    ProfScope(const ProfScope&) = delete;
+    ProfScope& operator=(const ProfScope&) = delete;
+};
 
 // GroupNorm (+ ReLU) folded into the Winograd input transform: sums of the input tensor, affine parameters
 struct WinoNorm {

@@ -504,8 +504,14 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
     p.nfull = p.mtiles * p.ntiles;
     p.tail_shift = 0;
     const dim3 block(WM * WN * 64);
+    // stage profile: algorithmic traffic = the input tensor, the weights and the output (+ residual) once each
+    const double out_bytes = 4.0 * G * (double)p.M * p.Cout;
+    const double conv_bytes = 4.0 * G * ((double)p.B * p.H * p.W * p.Cin + (double)p.Cout * p.K) + out_bytes * (p.res ? 2.0 : 1.0);
+    const double conv_flops = 2.0 * G * (double)p.M * p.K * p.Cout;
+    const char* tag = p.tag ? p.tag : "conv_gemm";
     auto reduce = [&](int parts) {
         const long MN = (long)p.ws_rows * p.Cout;
+        ProfScope prof("splitk_reduce", 4.0 * G * (double)MN * (parts + 1.0), 0.0, st);
         const int V = p.vec_out ? 4 : 1;
         long chunk = (MN + 2047) / 2048;                       // at most 2048 blocks ...
         if (chunk < 256L * V * 4) chunk = 256L * V * 4;        // ... of at least 4 elements-vectors per thread
@@ -539,8 +545,11 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
                 p.ws_row0 = (int)row0;
                 p.ws_rows = p.M - (int)row0;
                 // every piece owns at least one K-slice: (2^shift - 1) * kchunk < nk because nk >= 8 * 2^shift
-                hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 2>), dim3((unsigned)(nfull + (rem << shift)), 1, G), block, 0,
-                                   st, p);
+                {
+                    ProfScope prof(tag, conv_bytes, conv_flops, st);
+                    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 2>), dim3((unsigned)(nfull + (rem << shift)), 1, G), block, 0,
+                                       st, p);
+                }
                 reduce(1 << shift);
                 QB_CHECK(hipGetLastError());
                 return gn_separate();
@@ -549,13 +558,16 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
     }
     const bool skip = BM != 256 && p.skip_rows && p.kmode == 0 && p.kh > 1 && p.Cin % BK == 0 && p.K == p.Kpad && p.ohw > 0;
     if (S > 1) {
-        if (skip) hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 4>), dim3(p.mtiles * p.ntiles, S, G), block, 0, st, p);
-        else hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 1>), dim3(p.mtiles * p.ntiles, S, G), block, 0, st, p);
+        {
+            ProfScope prof(tag, conv_bytes, conv_flops, st);
+            if (skip) hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 4>), dim3(p.mtiles * p.ntiles, S, G), block, 0, st, p);
+            else hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 1>), dim3(p.mtiles * p.ntiles, S, G), block, 0, st, p);
+        }
         reduce(S);
-    } else if (skip) {
-        hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 3>), dim3(p.mtiles * p.ntiles, 1, G), block, 0, st, p);
     } else {
-        hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 0>), dim3(p.mtiles * p.ntiles, 1, G), block, 0, st, p);
+        ProfScope prof(tag, conv_bytes, conv_flops, st);
+        if (skip) hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 3>), dim3(p.mtiles * p.ntiles, 1, G), block, 0, st, p);
+        else hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 0>), dim3(p.mtiles * p.ntiles, 1, G), block, 0, st, p);
     }
     QB_CHECK(hipGetLastError());
     return gn_separate();

@@ -55,6 +55,7 @@ __global__ void preprocess_kernel(const uint8_t* __restrict__ rgb, const uint8_t
 int launch_preprocess(const uint8_t* rgb, const uint8_t* depth, const float* offs, float* x, int B, int Bcap,
                       int H, int W, const float* mean6, const float* std6, int streams, hipStream_t st) {
     const long total = (long)B * H * W;
+    ProfScope prof("preprocess", (double)total * (3.0 * streams + 12.0 + 32.0 * streams), 0.0, st);
     hipLaunchKernelGGL(preprocess_kernel, dim3(cap_grid(total, 256)), dim3(256), 0, st, rgb, depth, offs, x, B,
                        (long)Bcap * H * W * 8, streams, H * W, mean6[0], mean6[1], mean6[2], mean6[3], mean6[4], mean6[5],
                        std6[0], std6[1], std6[2], std6[3], std6[4], std6[5]);
@@ -94,6 +95,7 @@ __global__ void maxpool_kernel(const float* __restrict__ in, float* __restrict__
 
 int launch_maxpool3x3s2(const View& in, const View& out, int B, int G, hipStream_t st) {
     const long total = (long)B * out.H * out.W * (in.C / 4);
+    ProfScope prof("maxpool", 4.0 * G * B * in.C * ((double)in.H * in.W + (double)out.H * out.W), 0.0, st);
     hipLaunchKernelGGL(maxpool_kernel, dim3(cap_grid(total, 256), G), dim3(256), 0, st, in.p, out.p, B, in.H, in.W,
                        in.C / 4, in.cs, out.H, out.W, out.cs, in.gs, out.gs);
     QB_CHECK(hipGetLastError());
@@ -170,6 +172,7 @@ int launch_zero(void* p, size_t bytes, hipStream_t st) {
     if (((uintptr_t)p & 3) || (bytes & 3)) return fail("zero fill: 4-byte granularity");
     if (!bytes) return 0;
     const size_t words = bytes / 4;
+    ProfScope prof("zero", (double)bytes, 0.0, st);
     hipLaunchKernelGGL(zero_kernel, dim3(cap_grid((long)words, 256)), dim3(256), 0, st, (unsigned*)p, words);
     QB_CHECK(hipGetLastError());
     return 0;
@@ -184,6 +187,7 @@ int launch_gn_stats(const View& in, int B, int G, int groups, double* stats, hip
     }
     const int ppb = gn_pixels_per_block(HW, in.C, B, G);
     const int chunks = (HW + ppb - 1) / ppb;
+    ProfScope prof("gn_stats", 4.0 * G * B * (double)HW * in.C, 0.0, st);
     hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks, B, G), dim3(256), 0, st, in.p, HW, in.C, in.cs, in.gs,
                        (long)HW * in.cs, groups, ppb, stats, B);
     QB_CHECK(hipGetLastError());
@@ -247,6 +251,7 @@ int launch_gn_apply(const View& in, const View& out, int B, int G, int groups, c
                     const float* gamma, const float* beta, int param_gs, float eps, int relu, hipStream_t st) {
     const int HW = in.H * in.W;
     const int ppb = gn_pixels_per_block(HW, in.C, B, G);
+    ProfScope prof("gn_apply", 8.0 * G * B * (double)HW * in.C, 0.0, st);
     hipLaunchKernelGGL(gn_apply_kernel, dim3((HW + ppb - 1) / ppb, B, G), dim3(256), 0, st, in.p, out.p, B, HW, in.C,
                        in.cs, out.cs, in.gs, out.gs, groups, stats, gamma, beta, param_gs, relu, ppb,
                        (double)HW * (in.C / groups), eps);
@@ -296,6 +301,7 @@ __global__ void bilinear_kernel(const float* __restrict__ in, float* __restrict_
 
 int launch_bilinear(const View& in, const View& out, int B, hipStream_t st) {
     const long total = (long)B * out.H * out.W * (in.C / 4);
+    ProfScope prof("bilinear", 4.0 * B * in.C * ((double)in.H * in.W + (double)out.H * out.W), 0.0, st);
     hipLaunchKernelGGL(bilinear_kernel, dim3(cap_grid(total, 256)), dim3(256), 0, st, in.p, out.p, B, in.H, in.W,
                        in.C / 4, in.cs, out.H, out.W, out.cs, (float)in.H / (float)out.H, (float)in.W / (float)out.W);
     QB_CHECK(hipGetLastError());
@@ -329,6 +335,7 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ 
 
 int launch_avgpool(const View& in, const View& out, int B, hipStream_t st) {
     if (in.C % 4 || in.cs % 4 || ((uintptr_t)in.p & 15)) return fail("avgpool: channels must come in aligned groups of 4");
+    ProfScope prof("avgpool", 4.0 * B * in.C * ((double)in.H * in.W + 1.0), 0.0, st);
     hipLaunchKernelGGL(avgpool_kernel, dim3((in.C + 63) / 64, B), dim3(256), 0, st, in.p, out.p, in.H * in.W, in.C,
                        in.cs, out.cs);
     QB_CHECK(hipGetLastError());
@@ -381,6 +388,7 @@ int launch_predictor(const View& in, const float* w, const float* bias, int cout
                      float* softmax_dst, int softmax_cs, int act, int B, hipStream_t st) {
     if (in.C != 32 || cout > 4) return fail("predictor: expects 32 input channels and <= 4 outputs");
     const long total = (long)B * in.H * in.W;
+    ProfScope prof("predictor", 4.0 * total * (32.0 + cout * (softmax_dst ? 2.0 : 1.0)), 2.0 * total * 32.0 * cout, st);
     hipLaunchKernelGGL(predictor_kernel<32>, dim3(cap_grid(total, 256)), dim3(256), 0, st, in.p, in.cs, w, bias, cout,
                        q, q_ch0, q_nch, softmax_dst, softmax_cs, act, B, in.H * in.W);
     QB_CHECK(hipGetLastError());
@@ -411,6 +419,7 @@ __global__ void add_channels_kernel(const float* __restrict__ a, const float* __
 
 int launch_add_channels(const View& a, const View& b, const View& out, int B, hipStream_t st) {
     const long pixels = (long)B * a.H * a.W;
+    ProfScope prof("add_channels", 12.0 * pixels * a.C, 0.0, st);
     hipLaunchKernelGGL(add_channels_kernel, dim3(cap_grid(pixels * (a.C / 4), 256)), dim3(256), 0, st, a.p, b.p, out.p,
                        pixels, a.C / 4, a.cs, b.cs, out.cs);
     QB_CHECK(hipGetLastError());
@@ -419,6 +428,7 @@ int launch_add_channels(const View& a, const View& b, const View& out, int B, hi
 
 int launch_copy_channels(const View& in, const View& out, int B, hipStream_t st) {
     const long pixels = (long)B * in.H * in.W;
+    ProfScope prof("copy_channels", 8.0 * pixels * in.C, 0.0, st);
     hipLaunchKernelGGL(copy_channels_kernel, dim3(cap_grid(pixels * (in.C / 4), 256)), dim3(256), 0, st, in.p, out.p,
                        pixels, in.C / 4, in.cs, out.cs);
     QB_CHECK(hipGetLastError());
@@ -472,6 +482,7 @@ int launch_upsample_logits(const float* q, float* out, int B, int nch, int h, in
     if (OH > h * scale || OW > w * scale) return fail("upsample: frame larger than the scaled head map");
     if ((long)OH * OW >= (1L << 31)) return fail("upsample: frame too large");
     const int planes = B * nch;
+    ProfScope prof("upsample_logits", 4.0 * planes * ((double)h * w + (double)OH * OW), 0.0, st);
     if (OW % 4 == 0 && ((uintptr_t)out & 15) == 0) {
         const unsigned n = (unsigned)(OW / 4) * OH;
         hipLaunchKernelGGL(upsample_logits_kernel<4>, dim3((n + 255) / 256, planes), dim3(256), 0, st, q, out, h, w, nch,

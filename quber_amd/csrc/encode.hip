@@ -176,6 +176,8 @@ int launch_encode(const uint8_t* masks, int B, int N, int H, int W, const float*
         return launch_zero(out, sizeof(float) * 3 * HW * B, st);
     }
     if (int rc = launch_zero(stats, sizeof(MaskStat) * (size_t)B * N, st)) return rc;
+    {
+    ProfScope prof("encode_reduce", (double)B * HW * (N + 1.0), 0.0, st);      // every mask byte once + the 1 B/px index map
     if (W % ENC_PIX == 0 && ((uintptr_t)masks & 15) == 0) {
         const int blocks = (int)((HW / ENC_PIX + 255) / 256);
         hipLaunchKernelGGL(encode_reduce_kernel, dim3(blocks, B), dim3(256), sizeof(unsigned) * 3 * N, st, masks, N, H,
@@ -184,7 +186,9 @@ int launch_encode(const uint8_t* masks, int B, int N, int H, int W, const float*
         hipLaunchKernelGGL(encode_reduce_generic_kernel, dim3((int)((HW + 255) / 256), B), dim3(256),
                            sizeof(unsigned) * 3 * N, st, masks, N, H, W, stats, last);
     }
+    }
     QB_CHECK(hipGetLastError());
+    ProfScope prof("encode_paint", (double)B * HW * 13.0, 0.0, st);            // index map in, three f32 planes out
     const size_t sm2 = (size_t)N * (2 * sizeof(double) + 2 * sizeof(int));
     hipLaunchKernelGGL(encode_paint_kernel, dim3((int)((HW + 255) / 256), B), dim3(256), sm2, st, stats, last, gauss, N,
                        H, W, 3 * sigma + 1, out);

@@ -34,6 +34,45 @@ int fail(const std::string& m) {
     return -1;
 }
 
+// ---- stage profiler (common.h: ProfScope) ----
+struct ProfRec { int tag; hipEvent_t e0, e1; double bytes, flops; };
+struct StageSum { std::string name; double ms = 0.0, bytes = 0.0, flops = 0.0; int launches = 0; };
+struct Profiler {
+    std::vector<std::string> tags;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> pool;
+    size_t used = 0;
+    std::vector<StageSum> sums;
+    hipEvent_t get() {
+        if (used == pool.size()) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            pool.push_back(e);
+        }
+        return pool[used++];
+    }
+    ~Profiler() {
+        for (hipEvent_t e : pool) (void)hipEventDestroy(e);
+    }
+};
+static thread_local Profiler* g_prof = nullptr;
+
+ProfScope::ProfScope(const char* tag, double bytes, double flops, hipStream_t s) : rec(-1), st(s) {
+    Profiler* p = g_prof;
+    if (!p) return;
+    int ti = -1;
+    for (size_t i = 0; i < p->tags.size(); ++i)
+        if (p->tags[i] == tag) { ti = (int)i; break; }
+    if (ti < 0) { ti = (int)p->tags.size(); p->tags.emplace_back(tag); }
+    ProfRec r{ti, p->get(), p->get(), bytes, flops};
+    if (!r.e0 || !r.e1 || hipEventRecord(r.e0, s) != hipSuccess) return;
+    rec = (int)p->recs.size();
+    p->recs.push_back(r);
+}
+ProfScope::~ProfScope() {
+    if (rec >= 0 && g_prof) (void)hipEventRecord(g_prof->recs[rec].e1, st);
+}
+
 }  // namespace quber
 
 using namespace quber;
@@ -77,6 +116,7 @@ struct quber_ctx {
     double wino_flops = 0.0;      // algorithmic FLOPs (batch 1) of the layers that take the Winograd path
     double wino_saved = 0.0;      // ... and the part of them the path does not execute
     std::vector<hipEvent_t> prof_events;
+    std::unique_ptr<quber::Profiler> prof;
     bool finalized = false;
     int device = 0;
 };
@@ -95,7 +135,7 @@ struct DeferredNorm {
     const double* stats = nullptr;
     const float *gamma = nullptr, *beta = nullptr;
     int C = 0, G = 0;
-    std::function<bool(int)> absorbed;     // set by the consumer: does it absorb the normalisation at this batch size?
+    bool absorbed = false;                 // set by the consumer at plan time: it normalises while it loads
 };
 struct LastConv { std::shared_ptr<GnFuse> fuse; const float* out = nullptr; int G = 0, C = 0; };
 
@@ -216,65 +256,52 @@ struct Builder {
         p.w_gs = (long)Cout * Kpad; p.ss_gs = Cout;
         p.ohw = OH * OW;
         quber_ctx* ctx = c;
-        // Winograd F(m x m,3x3) alternatives for the wide plain 3x3 layers; chosen per launch (batch) in the lambda below.
+        // Winograd F(m x m,3x3) alternatives for the wide plain 3x3 layers.  The algorithm of a layer is fixed HERE, at plan
+        // time, from the layer's geometry alone (frame size, channels, dilation) - never from the batch of a launch - so
+        // that a frame's logits do not change class of arithmetic with the batch it arrives in (split-K, a pure
+        // re-association of the same fp32 sum, is the only per-launch choice left).
         // Ragged frames and a dilated layer's short phases are padded to whole tiles: a variant qualifies only while it
-        // still executes <= g_wino_max_ratio % of the direct multiplies.  `wq` is the best of m = 4 / 2; `wq6` the 6x6
-        // variant where it executes >= 10 % fewer multiplies still - it costs about half a decimal digit of accuracy and
-        // its 64 small GEMMs only pay on large launches (>= 35 000 output pixels: profiles/r01l_winograd.md).
-        WinoP wq{}, wq6{};
-        bool wino = winograd_eligible(k, stride, pad, dil, Cin, Cout) && cin_real == Cin && !res && prelu.empty();
-        int wm = 0;
-        bool has6 = false;
+        // still executes <= g_wino_max_ratio % of the direct multiplies.  `wq` is the best of m = 4 / 2 (F(4x4) measures the
+        // direct kernel's error against float64, profiles/r02a_parity_report.txt).  `wq6`, the 6x6 variant, is OPT-IN
+        // (quber_set_tuning key 9 = 6 / QUBER_WINOGRAD=f6): 2.5x the error at tap level, +4.5 % throughput at batch 16.
+        WinoP wq{};
+        bool wino = winograd_eligible(k, stride, pad, dil, Cin, Cout) && cin_real == Cin && !res && prelu.empty() && g_winograd != 1;
         if (wino) {
             const double lim = (double)g_wino_max_ratio / 100.0;
             const double r6 = winograd_m6_channels_ok(Cin, Cout) ? winograd_mac_ratio(in.H, in.W, dil, 6) : 1e9;
             const double r4 = winograd_mac_ratio(in.H, in.W, dil, 4), r2 = winograd_mac_ratio(in.H, in.W, dil, 2);
             double best = lim;
+            int wm = 0;
             if (r2 <= best && g_wino_variant != 4 && g_wino_variant != 6) { best = r2; wm = 2; }
             if (r4 <= best && g_wino_variant != 2) { best = r4; wm = 4; }
             if (r2 <= lim && wm == 0) { best = r2; wm = 2; }                     // a forced larger variant does not fit: smaller tiles
-            has6 = (g_wino_variant == 0 || g_wino_variant == 6) && r6 <= 0.9 * best;
-            wino = wm != 0;
+            const bool has6 = wm != 0 && g_wino_variant == 6 && r6 <= 0.9 * best;
+            // Maps of a handful of tiles stay on the direct kernel, and so do the 64-channel layers unless the 6x6 variant
+            // was opted into (below 128 channels only it outweighs its transforms).
+            wino = wm != 0 && (g_winograd == 2 || (Cin < 128 ? has6 : (long)in.H * in.W >= 1024));
             if (wino) {
+                const int m = has6 ? 6 : wm;
                 c->wino_flops += 2.0 * OH * OW * (double)cin_real * k * k * Cout * G;
                 c->wino_saved += 2.0 * OH * OW * (double)cin_real * k * k * Cout * G * (1.0 - (has6 ? r6 : best));
+                const int P = (m + 2) * (m + 2);
+                std::vector<float> u((size_t)G * P * Cout * Cin);
+                for (int g = 0; g < G; ++g) winograd_weights_host(w[g], Cout, Cin, m, &u[(size_t)g * P * Cout * Cin]);
+                wq.in = in; wq.out = out; wq.u = upload(u);
+                wq.scale = p.scale; wq.shift = p.shift; wq.ss_gs = Cout; wq.relu = relu; wq.dil = dil; wq.m = m;
+                const size_t need = winograd_ws_floats(Bmax, in.H, in.W, Cin, Cout, G, dil, m);
+                if (need > c->wino_floats) c->wino_floats = need;
             }
         }
-        auto prepare = [&](WinoP& q, int m) {
-            const int P = (m + 2) * (m + 2);
-            std::vector<float> u((size_t)G * P * Cout * Cin);
-            for (int g = 0; g < G; ++g) winograd_weights_host(w[g], Cout, Cin, m, &u[(size_t)g * P * Cout * Cin]);
-            q.in = in; q.out = out; q.u = upload(u);
-            q.scale = p.scale; q.shift = p.shift; q.ss_gs = Cout; q.relu = relu; q.dil = dil; q.m = m;
-            const size_t need = winograd_ws_floats(Bmax, in.H, in.W, Cin, Cout, G, dil, m);
-            if (need > c->wino_floats) c->wino_floats = need;
-        };
-        if (wino) prepare(wq, wm);
-        if (wino && has6) prepare(wq6, 6);
-        // does this launch take the Winograd path?  (frames of a handful of tiles stay on the direct kernel)
-        const int pH = in.H, pW = in.W;
-        // (64-channel layers: only the 6x6 variant on very large launches pays - 1.25x at 16 frames, < 1 at one)
-        const bool narrow = Cin < 128;
-        auto use_wino = [ctx, wino, pH, pW, narrow, has6, G](int B) {
-            if (!wino || !ctx->wino_ws || g_winograd == 1) return false;
-            if (g_winograd == 2) return true;
-            const long px = (long)B * pH * pW;
-            return narrow ? has6 && px * G >= 300000 : px / 4 >= 256;
-        };
         std::shared_ptr<DeferredNorm> norm;
         if (wino && pending_norm && pending_norm->out.p == in.p && pending_norm->C == Cin && pending_norm->G == G) {
             norm = pending_norm;
-            norm->absorbed = use_wino;
+            norm->absorbed = true;
         }
         pending_norm.reset();
         auto fuse = std::make_shared<GnFuse>();
         last_conv = {fuse, out.p, G, Cout};
-        c->ops.push_back({[p, G, ctx, fuse, this_wq = wq, wq6, has6, use_wino, norm](int B, hipStream_t st) mutable {
-            // Winograd F(m x m,3x3) wins on every eligible layer (>= 128 channels in and out) at every batch size
-            // (profiles/r01l_winograd.md)
-            if (use_wino(B)) {
-                const bool six = has6 && (g_wino_variant == 6 || (long)B * G * p.H * p.W >= 35000);
-                WinoP& wq = six ? wq6 : this_wq;
+        c->ops.push_back({[p, G, ctx, fuse, wq, wino, norm](int B, hipStream_t st) mutable {
+            if (wino) {
                 wq.ws = ctx->wino_ws; wq.ws_floats = ctx->wino_floats;
                 wq.splitk_ws = ctx->splitk_ws; wq.splitk_floats = ctx->splitk_floats;
                 wq.gn_sum = fuse->sums; wq.gn_groups = fuse->groups;
@@ -283,10 +310,6 @@ struct Builder {
                     wq.norm = WinoNorm{norm->stats, norm->gamma, norm->beta, 32, 0, norm->C, 1, 0.0, 1e-5f};
                 }
                 return launch_conv_winograd(wq, B, G, st);
-            }
-            if (norm) {                          // direct path: the skipped normalisation pass runs here instead
-                int rc = launch_gn_apply(norm->in, norm->out, B, G, 32, norm->stats, norm->gamma, norm->beta, norm->C, 1e-5f, 1, st);
-                if (rc) return rc;
             }
             p.B = B;
             p.M = B * p.OH * p.OW;
@@ -369,7 +392,7 @@ struct Builder {
                 int rc = launch_gn_stats(in, B, G, 32, stats, st, false);
                 if (rc) return rc;
             }
-            if (dn && dn->absorbed && dn->absorbed(B)) return 0;      // the consumer normalises while it loads
+            if (dn && dn->absorbed) return 0;      // the consumer normalises while it loads
             return launch_gn_apply(in, out, B, G, 32, stats, dg, db, C, 1e-5f, 1, st);
         }, OP_NORM, names[0], 0.0, fused ? 1 : 2});
     }
@@ -840,6 +863,7 @@ int check_cfg(const quber_config& c) {
     if (c.res5_dilation == 1) return fail("res5_dilation 1 (output stride 32) is not supported by this build");
     if (c.error_classes < 2 || c.error_classes > 4) return fail("error_classes must be 2..4");
     if (c.streams != 1 && c.streams != 2) return fail("streams must be 1 or 2");
+    if (c.compute_dtype != 0) return fail("compute_dtype: only 0 (fp32) is built");
     if (c.with_network && c.hierarchical) {
         if (c.n_levels < 1 || c.n_levels > 5) return fail("n_levels must be 1..5");
         int seen[5] = {0, 0, 0, 0, 0};
@@ -930,6 +954,7 @@ int quber_create(const quber_config* cfg, quber_ctx** out) {
 
 void quber_destroy(quber_ctx* c) {
     if (!c) return;
+    if (c->prof && quber::g_prof == c->prof.get()) quber::g_prof = nullptr;
     for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);   // nothing useful to do with a failure while tearing down
     for (void* p : c->allocs) (void)hipFree(p);
     delete c;
@@ -979,8 +1004,9 @@ int quber_finalize_weights(quber_ctx* c) {
 double quber_forward_flops(quber_ctx* c) { return c ? c->flops : 0.0; }
 double quber_forward_flops_executed(quber_ctx* c) {
     if (!c) return 0.0;
-    // Winograd F(2x2,3x3) layers multiply 16 instead of 36 times per 2x2 output tile and channel pair
-    return g_winograd == 1 ? c->flops : c->flops - c->wino_saved;
+    // a layer planned as Winograd F(m x m,3x3) multiplies (m+2)^2 times per m x m output tile and channel pair (padded tiles
+    // included) instead of 9 m^2
+    return c->flops - c->wino_saved;
 }
 void quber_set_tuning(int32_t key, int32_t value) {
     if (key == 2) {   // stand-alone conv op: allocate (value != 0) or drop the split-K workspace
@@ -994,12 +1020,47 @@ void quber_set_tuning(int32_t key, int32_t value) {
     if (key == 4) g_force_tile = value;    // force the tile shape: 1 = 64x64, 2 = 128x128, 4 = 256x32 (0 = automatic)
     if (key == 11) g_op_skip_rows = value;    // stand-alone conv op: tap-major K order with padded filter rows skipped (dilated 3x3)
     if (key == 10) g_wino_min_cout = value;   // smallest output width eligible for the Winograd path (default 32)
-    if (key == 9) g_wino_variant = value;     // Winograd output tile edge for the eligible layers: 0 = automatic, 2, 4
+    if (key == 9) g_wino_variant = value;     // Winograd output tile edge for the eligible layers: 0 = automatic (4 or 2), 2, 4, 6 (opt-in)
     if (key == 8) g_wino_max_ratio = value;   // Winograd only while executed / direct multiplies <= value % (default 67)
     if (key == 7) g_wino_min_cin = value;  // smallest input width eligible for the Winograd path (default 256)
     if (key == 6) g_winograd = value;      // Winograd F(2x2,3x3) for the eligible 3x3 layers: 0 = where it pays, 1 = never, 2 = always
     if (key == 5) g_tail_split = value;    // split the ragged last round of large convolution launches (default 1)
     if (key == 3) g_force_split = value;   // force the number of K partitions of every convolution with a workspace (0 = automatic)
+}
+
+int quber_profile_begin(quber_ctx* c) {
+    if (!c) return fail("null context");
+    if (!c->prof) c->prof.reset(new quber::Profiler());
+    c->prof->recs.clear();
+    c->prof->sums.clear();
+    c->prof->used = 0;
+    quber::g_prof = c->prof.get();
+    return 0;
+}
+
+int quber_profile_end(quber_ctx* c, void* stream) {
+    if (!c || !c->prof || quber::g_prof != c->prof.get()) return fail("quber_profile_end without quber_profile_begin");
+    quber::g_prof = nullptr;
+    QB_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    quber::Profiler& p = *c->prof;
+    p.sums.assign(p.tags.size(), quber::StageSum());
+    for (size_t i = 0; i < p.tags.size(); ++i) p.sums[i].name = p.tags[i];
+    for (const quber::ProfRec& r : p.recs) {
+        float ms = 0.f;
+        QB_CHECK(hipEventElapsedTime(&ms, r.e0, r.e1));
+        quber::StageSum& s = p.sums[r.tag];
+        s.ms += ms; s.bytes += r.bytes; s.flops += r.flops; s.launches += 1;
+    }
+    return 0;
+}
+
+int quber_profile_num_stages(quber_ctx* c) { return (c && c->prof) ? (int)c->prof->sums.size() : 0; }
+
+int quber_profile_stage(quber_ctx* c, int i, const char** name, double* ms, double* bytes, double* flops, int32_t* launches) {
+    if (!c || !c->prof || i < 0 || i >= (int)c->prof->sums.size()) return fail("stage index out of range");
+    const quber::StageSum& s = c->prof->sums[i];
+    *name = s.name.c_str(); *ms = s.ms; *bytes = s.bytes; *flops = s.flops; *launches = s.launches;
+    return 0;
 }
 
 int quber_num_ops(quber_ctx* c) { return c ? (int)c->ops.size() : 0; }

@@ -400,19 +400,38 @@ int launch_postprocess(const float* logits, int nch, int B, int H, int W, const 
 
     const int r = (c.nms_kernel - 1) / 2;
     const int P = NT + 2 * r;
-    hipLaunchKernelGGL(nms_kernel, dim3((W + NT - 1) / NT, (H + NT - 1) / NT, B), dim3(256), sizeof(float) * P * P, st,
-                       logits, nch, H, W, c.threshold, r, cand);
-    hipLaunchKernelGGL(select_kernel, dim3(B), dim3(1024), 0, st, cand, (int)HW, W, c.top_k, c.cap, centers, ncenters);
+    const double px = (double)B * HW;
+    {   // a8: centre plane in, candidate map out
+        ProfScope prof("post_nms", 8.0 * px, 0.0, st);
+        hipLaunchKernelGGL(nms_kernel, dim3((W + NT - 1) / NT, (H + NT - 1) / NT, B), dim3(256), sizeof(float) * P * P, st,
+                           logits, nch, H, W, c.threshold, r, cand);
+    }
+    {   // a8: k-th largest candidate + ordered compaction (one block per frame; reads the candidate map)
+        ProfScope prof("post_select", 4.0 * px, 0.0, st);
+        hipLaunchKernelGGL(select_kernel, dim3(B), dim3(1024), 0, st, cand, (int)HW, W, c.top_k, c.cap, centers, ncenters);
+    }
     if (int rc = launch_zero(area, (size_t)B * 256 * 4, st)) return rc;
     const int pblocks = (int)((HW + 255) / 256);
-    hipLaunchKernelGGL(group_kernel, dim3(pblocks, B), dim3(256), 0, st, logits, nch, H, W, c.cap, centers, ncenters,
-                       idmap, area);
-    hipLaunchKernelGGL(relabel_kernel, dim3(B), dim3(256), 0, st, area, ncenters, c.min_area, c.stuff_area,
-                       c.label_divisor, c.cap, lut, count, labels, stats);
-    hipLaunchKernelGGL(paint_stats_kernel, dim3((int)((HW + PS_PIX - 1) / PS_PIX), B), dim3(256), 0, st, logits, nch, H, W, c.cap,
-                       c.label_divisor, idmap, lut, pan, stats);
-    hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(256), 0, st, logits, nch, H, W, c.cap, count, stats, scores,
-                       boxes);
+    {   // a9: fg + 2 offset planes in, id map out
+        ProfScope prof("post_group", 13.0 * px, 0.0, st);
+        hipLaunchKernelGGL(group_kernel, dim3(pblocks, B), dim3(256), 0, st, logits, nch, H, W, c.cap, centers, ncenters,
+                           idmap, area);
+    }
+    {
+        ProfScope prof("post_relabel", 2048.0 * B, 0.0, st);
+        hipLaunchKernelGGL(relabel_kernel, dim3(B), dim3(256), 0, st, area, ncenters, c.min_area, c.stuff_area,
+                           c.label_divisor, c.cap, lut, count, labels, stats);
+    }
+    {   // a10 / a11: id map + fg plane in, label map out, per-instance sums
+        ProfScope prof("post_paint_stats", 9.0 * px, 0.0, st);
+        hipLaunchKernelGGL(paint_stats_kernel, dim3((int)((HW + PS_PIX - 1) / PS_PIX), B), dim3(256), 0, st, logits, nch, H, W, c.cap,
+                           c.label_divisor, idmap, lut, pan, stats);
+    }
+    {
+        ProfScope prof("post_finalize", 64.0 * B * c.cap, 0.0, st);
+        hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(256), 0, st, logits, nch, H, W, c.cap, count, stats, scores,
+                           boxes);
+    }
     QB_CHECK(hipGetLastError());
     return 0;
 }
@@ -421,6 +440,7 @@ int launch_extract_masks(const float* pan, const float* labels, int B, int H, in
                          uint8_t* out, hipStream_t st) {
     const long HW = (long)H * W;
     if (max_inst < 1 || max_inst > cap) return fail("extract_masks: max_inst out of range");
+    ProfScope prof("extract_masks", (double)B * HW * (4.0 + max_inst), 0.0, st);   // the label map once (L2 serves the re-reads), every mask byte once
     if (HW % 16 == 0 && (((uintptr_t)pan | (uintptr_t)out) & 15) == 0)
         hipLaunchKernelGGL(extract_masks_kernel, dim3((int)((HW / 16 + 255) / 256), max_inst, B), dim3(256), 0, st, pan,
                            labels, (int)HW, cap, max_inst, out);

@@ -410,8 +410,11 @@ static int run_winograd(const WinoP& q, int B, int G, hipStream_t st) {
         np.cpg = Cin / np.groups;
         np.n = (double)H * W * np.cpg;
     }
-    hipLaunchKernelGGL((wino_input_kernel<O, V>), grid(Cin / V), dim3(256), 0, st, in.p, B, H, W, Cin / V, in.cs, in.gs, TH, TW,
-                       d, v, (long)P * tiles * Cin, np);
+    {   // activations in once, V = P / m^2 times their size out
+        ProfScope prof("wino_input", 4.0 * G * Cin * ((double)B * H * W + (double)P * tiles), 0.0, st);
+        hipLaunchKernelGGL((wino_input_kernel<O, V>), grid(Cin / V), dim3(256), 0, st, in.p, B, H, W, Cin / V, in.cs, in.gs, TH, TW,
+                           d, v, (long)P * tiles * Cin, np);
+    }
     QB_CHECK(hipGetLastError());
     ConvP p{};
     p.in = v; p.w = q.u; p.out = m;
@@ -422,6 +425,7 @@ static int run_winograd(const WinoP& q, int B, int G, hipStream_t st) {
     p.M = (int)tiles; p.ohw = (int)tiles;
     p.in_gs = tiles * Cin; p.out_gs = tiles * Cout; p.w_gs = (long)Cout * Cin;
     p.ws = q.splitk_ws; p.ws_floats = q.splitk_floats;
+    p.tag = "wino_gemm";
     int rc = launch_conv(p, G * P, st);
     if (rc) return rc;
     // GroupNorm sums in the output transform when a block's tiles meet at most two images and vectors stay inside a group
@@ -430,9 +434,12 @@ static int run_winograd(const WinoP& q, int B, int G, hipStream_t st) {
                          wino_tiles(H, W, d, O) >= (long)per_iter * OUT_ITERS;
     dim3 og = grid(CVo);
     og.x = (og.x + OUT_ITERS - 1) / OUT_ITERS;
-    hipLaunchKernelGGL((wino_output_kernel<O, V>), og, dim3(256), 0, st, m, (long)P * tiles * Cout, B, H, W, CVo, TH, TW, d,
-                       q.scale, q.shift, q.ss_gs, q.relu, out.p, out.cs, out.gs, gn_here ? q.gn_sum : nullptr, q.gn_groups,
-                       q.gn_groups ? Cout / q.gn_groups : 1);
+    {   // M in once, the layer's output out once
+        ProfScope prof("wino_output", 4.0 * G * Cout * ((double)P * tiles + (double)B * H * W), 0.0, st);
+        hipLaunchKernelGGL((wino_output_kernel<O, V>), og, dim3(256), 0, st, m, (long)P * tiles * Cout, B, H, W, CVo, TH, TW, d,
+                           q.scale, q.shift, q.ss_gs, q.relu, out.p, out.cs, out.gs, gn_here ? q.gn_sum : nullptr, q.gn_groups,
+                           q.gn_groups ? Cout / q.gn_groups : 1);
+    }
     QB_CHECK(hipGetLastError());
     if (q.gn_sum && !gn_here) return launch_gn_stats(out, B, G, q.gn_groups, q.gn_sum, st, false);
     return 0;

@@ -197,6 +197,20 @@ class Engine:
                                                    _stream(), C.byref(ms), C.byref(cnt)))
         return out, {k: (ms[i], cnt[i]) for i, k in enumerate(("conv", "norm", "other"))}
 
+    def profile_begin(self):
+        """Start a stage profile: every call on this engine until profile_end() brackets its kernels with HIP events."""
+        _lib.check(self.lib.quber_profile_begin(self.h))
+
+    def profile_end(self):
+        """-> {stage: dict(ms, bytes, flops, launches)}; synchronises the current stream."""
+        _lib.check(self.lib.quber_profile_end(self.h, _stream()))
+        out = {}
+        name, ms, by, fl, ln = C.c_char_p(), C.c_double(), C.c_double(), C.c_double(), C.c_int32()
+        for i in range(self.lib.quber_profile_num_stages(self.h)):
+            _lib.check(self.lib.quber_profile_stage(self.h, i, C.byref(name), C.byref(ms), C.byref(by), C.byref(fl), C.byref(ln)))
+            out[name.value.decode()] = {"ms": ms.value, "bytes": by.value, "flops": fl.value, "launches": ln.value}
+        return out
+
     def alloc_post(self, B):
         d, cap = self.device, self.cap
         return {

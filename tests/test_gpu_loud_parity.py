@@ -1,0 +1,172 @@
+"""GPU: parity that bites, on the plan that is benchmarked.
+
+The reference's predictor init N(0, 0.001) (model.py:418-419) gives logits of ~3e-3 and K = 0 instances, so a 1e-4 check
+on those logits proves little and post-processing runs on an empty scene.  These tests use the "loud" weight set
+(arch.init_state_dict(loud_heads=True): predictors N(0, 0.25), centre bias calibrated for ~N peaks per frame): logits
+are O(1), every head output depends on the features, and K ~ N instances reach grouping / merge / extraction.
+
+Bars (BASELINE.json north_star: float within 1e-4, label maps bit-exact):
+  * seven intermediate taps: max |d| <= 1e-4 * max(1, max |ref|)   (measured 2e-6 .. 8e-6, profiles/r02a_parity_report.txt)
+  * head outputs in head units: |d| <= 1e-4 on fg / centre / error logits; the offset planes carry the common-stride
+    factor 4 (model.py:695-700), so their bar is 4e-4 px.  (The fp32 oracle itself is 7e-5 from a float64 evaluation.)
+  * post-processing of the HIP logits: label map, labels, boxes, masks bit-exact against the oracle's post-processing
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import encode_np, postproc_ref
+from oracle.network_torch import ArchCfg, MaskRefinerNet
+from quber_amd import arch, engine, synth
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+STRIDE = 4
+
+
+def _oracle(sd, **kw):
+    kw = dict(kw)
+    if "hierarchy" in kw:
+        kw["hierarchy"] = [list(l) for l in kw["hierarchy"]]
+    if "fusion_target" in kw:
+        kw["fusion_target"] = list(kw["fusion_target"])
+    net = MaskRefinerNet(ArchCfg(**kw)).eval()
+    missing, unexpected = net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing)
+    return net
+
+
+def _scene(seed, b, h, w, n, single=False):
+    batch = synth.make_batch(seed, b, h, w, n)
+    offs = np.stack([encode_np.encode_initial_masks(m) for m in batch["masks"]])
+    parts = [torch.from_numpy(batch["rgb"])] + ([] if single else [torch.from_numpy(batch["depth"])])
+    return batch, offs, torch.cat(parts, -1).permute(0, 3, 1, 2)
+
+
+def loud_state_dict(seed, image, offs, n, **kw):
+    """Loud predictors with the centre bias calibrated (on the oracle, first two frames) so that ~n peaks pass 0.3."""
+    sd0 = arch.init_state_dict(seed=seed, loud_heads=True, **kw)
+    with torch.no_grad():
+        out = _oracle(sd0, **kw)(image[:2], torch.from_numpy(offs[:2]))
+    return arch.init_state_dict(seed=seed, loud_heads=True, center_bias=arch.calibrate_center_bias(out["center"], n), **kw)
+
+
+def _check_heads(logits, ref, planes):
+    """logits [B,P,H,W] from the HIP path against the oracle's head dict, in head units."""
+    o = 0
+    for key in planes:
+        c = ref[key].shape[1]
+        d = float((logits[:, o:o + c] - ref[key]).abs().max())
+        bar = TOL * STRIDE if key == "offset" else TOL
+        assert d < bar, f"{key}: max |d| = {d:.2e} (bar {bar:.0e})"
+        o += c
+    assert o == logits.shape[1]
+
+
+def _rel(got, ref):
+    return float((got - ref).abs().max() / max(1.0, float(ref.abs().max())))
+
+
+@pytest.mark.parametrize("h,w,b,n", [(480, 640, 16, 20), (720, 1280, 1, 30)])
+def test_benchmarked_plan_taps_heads_and_instances(h, w, b, n):
+    """BASELINE.json configs[1] (batch 16, 640x480, N = 20) and configs[2] (1280x720, N = 30) on the default plan."""
+    batch, offs, image = _scene(7, b, h, w, n)
+    sd = loud_state_dict(0, image, offs, n)
+    net = _oracle(sd)
+    taps = {}
+    with torch.no_grad():
+        ref = net(image, torch.from_numpy(offs), taps)
+    eng = engine.Engine(engine.make_config(h, w, max_batch=b, max_instances=n), "cuda:0")
+    eng.load_state_dict(sd)
+    masks = torch.from_numpy(batch["masks"]).cuda()
+    bgr, dep = torch.from_numpy(batch["rgb"]).cuda(), torch.from_numpy(batch["depth"]).cuda()
+    enc = eng.encode(masks)
+    np.testing.assert_array_equal(enc.cpu().numpy().view(np.uint32), offs.view(np.uint32))        # a1 bit-exact
+    lg = eng.forward(bgr, dep, enc)
+    post = eng.postprocess(lg)
+    mx = int(post["count"].max().item())
+    pm = eng.extract_masks(post, max(mx, 1)).cpu().numpy()
+    lgc = lg.cpu()
+    for name in ("res2", "res3", "res5", "y", "feat_eee_boundary", "z1", "feat_center"):
+        got = eng.debug_tensor(name, b).cpu().permute(0, 3, 1, 2)
+        assert _rel(got, taps[name]) < TOL, name
+    _check_heads(lgc, ref, ("foreground", "center", "offset", "eee_boundary"))
+    # a8-a11 on the HIP logits: bit-exact against the oracle's post-processing of the same logits, with K ~ N instances
+    ks, same = [], []
+    for i in range(b):
+        o = postproc_ref.postprocess(lgc[i, 0:1], lgc[i, 1:2], lgc[i, 2:4])
+        k = len(o["labels"])
+        ks.append(k)
+        np.testing.assert_array_equal(post["panoptic"][i].cpu().numpy(), o["panoptic"].numpy())
+        assert int(post["count"][i]) == k
+        np.testing.assert_array_equal(post["labels"][i, :k].cpu().numpy(), o["labels"].numpy())
+        if k:
+            np.testing.assert_array_equal(post["boxes"][i, :k].cpu().numpy(), o["boxes"].numpy())
+            np.testing.assert_array_equal(pm[i, :k].astype(bool), o["masks"].numpy())
+            np.testing.assert_allclose(post["scores"][i, :k].cpu().numpy(), o["scores"].numpy(), rtol=2e-5, atol=1e-6)
+        # end to end (HIP logits -> HIP labels) against (oracle logits -> oracle labels): threshold-straddling pixels may flip
+        e = postproc_ref.postprocess(ref["foreground"][i], ref["center"][i], ref["offset"][i])
+        same.append(float((post["panoptic"][i].cpu() == e["panoptic"]).float().mean()))
+    assert np.mean(ks) >= 15, ks
+    assert min(same) > 0.9999, same
+    if b > 1:
+        # the same frame alone: the per-layer algorithm is fixed at plan time, so only the split-K re-association differs
+        lg1 = eng.forward(bgr[:1], dep[:1], enc[:1]).cpu()
+        assert float((lg1[0] - lgc[0]).abs().max()) < 5e-5
+        p1 = eng.postprocess(lg1.cuda())["panoptic"][0].cpu()
+        assert float((p1 == post["panoptic"][0].cpu()).float().mean()) > 0.99999
+    eng.close()
+
+
+VARIANTS = {
+    "default": dict(),
+    # run_eval.py's default config: ...-hf-m-b-f-c-o-l3-e2-b8.yaml (5 levels, 2 error classes, mask + boundary)
+    "m-b-f-c-o-e2": dict(eee_mask_on=True, error_classes=2, fusion_target=("pred", "feat"),
+                         hierarchy=(("eee_mask",), ("eee_boundary",), ("foreground",), ("center",), ("offset",))),
+    "m-b-fco-feat": dict(eee_mask_on=True, fusion_target=("feat",),
+                         hierarchy=(("eee_mask",), ("eee_boundary",), ("foreground", "center", "offset"))),
+    "bfco-single-level": dict(hierarchy=(("eee_boundary", "foreground", "center", "offset"),)),
+    "noeee-flat": dict(hierarchical=False, eee_boundary_on=False, error_classes=2),
+    "mb-fco-e33-pred": dict(eee_mask_on=True, error_classes=3, fusion_target=("pred",),
+                            hierarchy=(("eee_mask", "eee_boundary"), ("foreground", "center", "offset"))),
+    "l0-backbone-fusion": dict(backbone_fusion_layers=0),
+    "single-stream": dict(streams=1),
+    "add-fusion-l3": dict(fusion_add=True, backbone_fusion_layers=3),    # Base-Mask-Refiner.yaml's own defaults
+    "r101": dict(depth=101),
+}
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_variant_taps_and_heads_loud(name):
+    """Every architecture variant: all intermediate taps the plan exposes and every head output, loud predictors."""
+    kw = VARIANTS[name]
+    h, w, b, n = 128, 160, 2, 4
+    single = kw.get("streams", 2) == 1
+    batch, offs, image = _scene(5, b, h, w, n, single)
+    sd = loud_state_dict(4, image, offs, n, **kw)
+    net = _oracle(sd, **kw)
+    taps = {}
+    with torch.no_grad():
+        ref = net(image, torch.from_numpy(offs), taps)
+    qc = engine.set_arch(engine.make_config(h, w, max_batch=b), **kw)
+    eng = engine.Engine(qc, "cuda:0")
+    eng.load_state_dict(sd)
+    lg = eng.forward(torch.from_numpy(batch["rgb"]).cuda(), None if single else torch.from_numpy(batch["depth"]).cuda(),
+                     torch.from_numpy(offs).cuda()).cpu()
+    checked = 0
+    for tname, tref in taps.items():
+        if tref.dim() != 4:
+            continue
+        try:
+            got = eng.debug_tensor(tname, b).cpu().permute(0, 3, 1, 2)
+        except Exception:
+            continue                                   # a tap the oracle records but the plan keeps inside a fused buffer
+        assert got.shape == tref.shape, tname
+        assert _rel(got, tref) < TOL, tname
+        checked += 1
+    assert checked >= 5, checked
+    planes = ["foreground", "center", "offset"] + (["eee_boundary"] if "eee_boundary" in ref else []) + \
+             (["eee_mask"] if "eee_mask" in ref else [])
+    _check_heads(lg, ref, planes)
+    eng.close()
