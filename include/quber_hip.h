@@ -26,7 +26,7 @@ typedef struct quber_ctx quber_ctx;
 typedef struct quber_config {
     int32_t height, width;           /* frame size; multiples of 16 */
     int32_t max_batch;               /* frames per call the workspace is sized for */
-    int32_t max_instances;           /* initial masks per frame (<= 254) */
+    int32_t max_instances;           /* initial masks per frame a call may carry (any number; > 254 are encoded in chunks) */
     int32_t resnet_depth;            /* MODEL.RESNETS.DEPTH: 50 | 101 | 152 */
     int32_t res5_dilation;           /* MODEL.RESNETS.RES5_DILATION (2) */
     int32_t backbone_fusion_layers;  /* MODEL.BACKBONE.NUM_FUSION_LAYERS (2) */
@@ -60,6 +60,11 @@ typedef struct quber_config {
                                         (build_resnet_deeplab_fusion_backbone: rgb-only or depth-only, pixel_mean[0..2]) */
     int32_t compute_dtype;           /* arithmetic of the convolutions: 0 = exact fp32 MFMA (default; the 1e-4 parity bar),
                                         1 = bf16 operands, fp32 accumulation (BASELINE.json configs[4] stand-in; own tolerance) */
+    int32_t encode_legacy_f32;       /* a1 offset arithmetic (predictor.py:345-346, `np.float64 scalar - float32 array`):
+                                        0 = numpy >= 2 promotion (float64, rounded once; what the reference computes when run
+                                        under this image's numpy 2.2, pinned by tests/golden/encode_*.npz);
+                                        1 = numpy < 2 value-based casting (all float32; the reference's pinned numpy==1.23.1,
+                                        INSTALL.md:14) - differs by 1 ulp on about a third of the mask pixels */
 } quber_config;
 
 /* logit planes produced by quber_forward: [fg, centre, off_y, off_x, eee_boundary x classes (if on), eee_mask x classes (if on)] */

@@ -9,7 +9,11 @@ Arithmetic that matters for bit-exactness:
   * centroid = float64 mean of the integer pixel indices (np.mean of int64),
   * integer centre = Python round() (half to even) of that float64,
   * heat-map = max(existing f32, f32(float64 Gaussian)),
-  * offsets = f32((centroid - coord) / extent) evaluated in float64,
+  * offsets = f32((centroid - coord) / extent): `np.float64 scalar - float32 array`.  Under numpy >= 2 (NEP 50; this
+    image, and what the golden fixtures pin) that is float64 arithmetic rounded once; under the reference's own pinned
+    numpy==1.23.1 (INSTALL.md:14) value-based casting keeps it in float32 throughout.  ``legacy_promotion=True`` restates
+    the latter with explicit casts - **parity unpinned** for that mode (numpy 1.x cannot be run here); it differs from
+    the pinned mode by 1 ulp on about a third of the mask pixels (max 6e-8),
   * later masks overwrite earlier ones in the offset planes; empty masks are skipped.
 """
 import numpy as np
@@ -22,7 +26,7 @@ def gaussian_template(sigma=10):
     return np.exp(-((ax[None, :] - c) ** 2 + (ax[:, None] - c) ** 2) / (2 * sigma ** 2))
 
 
-def encode_initial_masks(masks, height=None, width=None, sigma=10):
+def encode_initial_masks(masks, height=None, width=None, sigma=10, legacy_promotion=False):
     """masks: iterable of [H,W] arrays (non-zero = inside). Returns float32 [3,H,W]."""
     masks = list(masks)
     if height is None:
@@ -44,6 +48,10 @@ def encode_initial_masks(masks, height=None, width=None, sigma=10):
         if wx1 > wx0 and wy1 > wy0:
             win = g[wy0 - y0:wy1 - y0, wx0 - x0:wx1 - x0]
             heat[wy0:wy1, wx0:wx1] = np.maximum(heat[wy0:wy1, wx0:wx1], win)
-        off[0, ys, xs] = (cy - ys.astype(np.float32)) / height
-        off[1, ys, xs] = (cx - xs.astype(np.float32)) / width
+        if legacy_promotion:
+            off[0, ys, xs] = (np.float32(cy) - ys.astype(np.float32)) / np.float32(height)
+            off[1, ys, xs] = (np.float32(cx) - xs.astype(np.float32)) / np.float32(width)
+        else:
+            off[0, ys, xs] = (cy - ys.astype(np.float32)) / height
+            off[1, ys, xs] = (cx - xs.astype(np.float32)) / width
     return np.stack([heat, off[0], off[1]]).astype(np.float32)

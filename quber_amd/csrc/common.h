@@ -143,13 +143,13 @@ int launch_mask_overlap(const uint8_t* masks, const uint8_t* fg, int B, int K, l
 int launch_contingency(const int* pred, const int* gt, long n, int cap, void* ws, hipStream_t st);
 size_t contingency_ws_bytes(int cap);
 
-int launch_encode(const uint8_t* masks, int B, int N, int H, int W, const float* gauss, int sigma,
+int launch_encode(const uint8_t* masks, int B, int N, int H, int W, const float* gauss, int sigma, int legacy_f32,
                   void* ws, float* out, hipStream_t st);
 size_t encode_ws_bytes(int B, int N, int H, int W);
 
-int launch_errmaps(const uint8_t* init, int N, const uint8_t* gt, int Ng, int B, int H, int W, int d,
+int launch_errmaps(const uint8_t* init, int N, const uint8_t* gt, int Ng, int B, int Nmax, int H, int W, int d,
                    uint8_t* ws, uint8_t* out, hipStream_t st);
-size_t errmaps_ws_bytes(int B, int H, int W);
+size_t errmaps_ws_bytes(int B, int Nmax, int H, int W);
 
 struct PostCfg {
     float threshold;

@@ -18,8 +18,8 @@ struct MaskStat {
 
 constexpr int ENC_PIX = 16;  // pixels per lane per mask row
 
-__global__ __launch_bounds__(256) void encode_reduce_kernel(const uint8_t* __restrict__ masks, int N, int H, int W,
-                                                            MaskStat* __restrict__ stats,
+__global__ __launch_bounds__(256) void encode_reduce_kernel(const uint8_t* __restrict__ masks, int N, long frame_stride,
+                                                            int H, int W, MaskStat* __restrict__ stats,
                                                             uint8_t* __restrict__ last) {
     extern __shared__ unsigned int sm[];  // [N][3]
     const int b = blockIdx.y;
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void encode_reduce_kernel(const uint8_t* __res
     uint8_t lastv[ENC_PIX];
 #pragma unroll
     for (int j = 0; j < ENC_PIX; ++j) lastv[j] = 0;
-    const uint8_t* src = masks + (long)b * N * HW + p;
+    const uint8_t* src = masks + (long)b * frame_stride + p;
     for (int n = 0; n < N; ++n) {
         unsigned cnt = 0, sx = 0;
         if (active) {
@@ -76,8 +76,8 @@ __global__ __launch_bounds__(256) void encode_reduce_kernel(const uint8_t* __res
 }
 
 // Fallback for frame widths that are not a multiple of 16 (rows are then not 16-byte aligned): one pixel per lane.
-__global__ __launch_bounds__(256) void encode_reduce_generic_kernel(const uint8_t* __restrict__ masks, int N, int H, int W,
-                                                                    MaskStat* __restrict__ stats,
+__global__ __launch_bounds__(256) void encode_reduce_generic_kernel(const uint8_t* __restrict__ masks, int N, long frame_stride,
+                                                                    int H, int W, MaskStat* __restrict__ stats,
                                                                     uint8_t* __restrict__ last) {
     extern __shared__ unsigned int sm[];  // [N][3]
     const int b = blockIdx.y;
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void encode_reduce_generic_kernel(const uint8_
     const int y = active ? (int)(p / W) : 0;
     const int x = active ? (int)(p - (long)y * W) : 0;
     unsigned lastv = 0;
-    const uint8_t* src = masks + (long)b * N * HW + p;
+    const uint8_t* src = masks + (long)b * frame_stride + p;
     for (int n = 0; n < N; ++n) {
         const bool on = active && src[(long)n * HW] != 0;
         if (on) lastv = n + 1;
@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256) void encode_reduce_generic_kernel(const uint8_
 __global__ __launch_bounds__(256) void encode_paint_kernel(const MaskStat* __restrict__ stats,
                                                            const uint8_t* __restrict__ last,
                                                            const float* __restrict__ gauss, int N, int H, int W,
-                                                           int radius, float* __restrict__ out) {
+                                                           int radius, int legacy_f32, int accumulate,
+                                                           float* __restrict__ out) {
     extern __shared__ double smd[];  // [N] cy, [N] cx, then int [N] iy, [N] ix
     double* cy = smd;
     double* cx = smd + N;
@@ -152,47 +153,69 @@ __global__ __launch_bounds__(256) void encode_paint_kernel(const MaskStat* __res
     float oy = 0.f, ox = 0.f;
     const int l = last[(long)b * HW + p];
     if (l) {
-        oy = (float)((cy[l - 1] - (double)y) / (double)H);
-        ox = (float)((cx[l - 1] - (double)x) / (double)W);
+        if (legacy_f32) {
+            // numpy < 2 value-based casting (the reference pins numpy==1.23.1, INSTALL.md:14): the float64 centroid scalar
+            // does not upcast the float32 coordinate array, so predictor.py:345-346 evaluates entirely in float32
+            oy = ((float)cy[l - 1] - (float)y) / (float)H;
+            ox = ((float)cx[l - 1] - (float)x) / (float)W;
+        } else {
+            // numpy >= 2 (NEP 50): float64 scalar - float32 array -> float64, rounded once on the store
+            oy = (float)((cy[l - 1] - (double)y) / (double)H);
+            ox = (float)((cx[l - 1] - (double)x) / (double)W);
+        }
     }
     float* o = out + (long)b * 3 * HW + p;
+    if (accumulate) {          // a further chunk of > 254 masks: max-paste on the earlier heat-map, overwrite only covered pixels
+        o[0] = fmaxf(o[0], heat);
+        if (l) { o[HW] = oy; o[2 * HW] = ox; }
+        return;
+    }
     o[0] = heat;
     o[HW] = oy;
     o[2 * HW] = ox;
 }
 
+constexpr int ENC_CHUNK = 254;     // masks per pass: the last-covering-mask map is one byte per pixel (0 = none)
+
 size_t encode_ws_bytes(int B, int N, int H, int W) {
+    if (N > ENC_CHUNK) N = ENC_CHUNK;
     return (size_t)B * N * sizeof(MaskStat) + (size_t)B * H * W + 16;
 }
 
-int launch_encode(const uint8_t* masks, int B, int N, int H, int W, const float* gauss, int sigma, void* ws,
+// Any number of masks, like the reference's Python loop (predictor.py:310): more than 254 are encoded in chunks, each
+// later chunk max-pasting its Gaussians and overwriting the offsets of the pixels it covers ("later masks win").
+int launch_encode(const uint8_t* masks, int B, int N, int H, int W, const float* gauss, int sigma, int legacy_f32, void* ws,
                   float* out, hipStream_t st) {
-    if (N < 0 || N > 254) return fail("encode: at most 254 initial masks per frame");
+    if (N < 0) return fail("encode: negative mask count");
     const long HW = (long)H * W;
-    // workspace: [last-index map B*H*W bytes][MaskStat B*N]  (the map first keeps its 16-byte alignment)
+    // workspace: [last-index map B*H*W bytes][MaskStat B*min(N, 254)]  (the map first keeps its 16-byte alignment)
     uint8_t* last = reinterpret_cast<uint8_t*>(ws);
     MaskStat* stats = reinterpret_cast<MaskStat*>(last + (((size_t)B * HW + 15) & ~(size_t)15));
     if (N == 0) {
         return launch_zero(out, sizeof(float) * 3 * HW * B, st);
     }
-    if (int rc = launch_zero(stats, sizeof(MaskStat) * (size_t)B * N, st)) return rc;
-    {
-    ProfScope prof("encode_reduce", (double)B * HW * (N + 1.0), 0.0, st);      // every mask byte once + the 1 B/px index map
-    if (W % ENC_PIX == 0 && ((uintptr_t)masks & 15) == 0) {
-        const int blocks = (int)((HW / ENC_PIX + 255) / 256);
-        hipLaunchKernelGGL(encode_reduce_kernel, dim3(blocks, B), dim3(256), sizeof(unsigned) * 3 * N, st, masks, N, H,
-                           W, stats, last);
-    } else {
-        hipLaunchKernelGGL(encode_reduce_generic_kernel, dim3((int)((HW + 255) / 256), B), dim3(256),
-                           sizeof(unsigned) * 3 * N, st, masks, N, H, W, stats, last);
+    for (int c0 = 0; c0 < N; c0 += ENC_CHUNK) {
+        const int n = N - c0 < ENC_CHUNK ? N - c0 : ENC_CHUNK;
+        const uint8_t* m = masks + (long)c0 * HW;
+        if (int rc = launch_zero(stats, sizeof(MaskStat) * (size_t)B * n, st)) return rc;
+        {
+            ProfScope prof("encode_reduce", (double)B * HW * (n + 1.0), 0.0, st);      // every mask byte once + the 1 B/px index map
+            if (W % ENC_PIX == 0 && ((uintptr_t)m & 15) == 0 && (HW & 15) == 0) {
+                const int blocks = (int)((HW / ENC_PIX + 255) / 256);
+                hipLaunchKernelGGL(encode_reduce_kernel, dim3(blocks, B), dim3(256), sizeof(unsigned) * 3 * n, st, m, n,
+                                   (long)N * HW, H, W, stats, last);
+            } else {
+                hipLaunchKernelGGL(encode_reduce_generic_kernel, dim3((int)((HW + 255) / 256), B), dim3(256),
+                                   sizeof(unsigned) * 3 * n, st, m, n, (long)N * HW, H, W, stats, last);
+            }
+        }
+        QB_CHECK(hipGetLastError());
+        ProfScope prof("encode_paint", (double)B * HW * 13.0, 0.0, st);                // index map in, three f32 planes out
+        const size_t sm2 = (size_t)n * (2 * sizeof(double) + 2 * sizeof(int));
+        hipLaunchKernelGGL(encode_paint_kernel, dim3((int)((HW + 255) / 256), B), dim3(256), sm2, st, stats, last, gauss, n,
+                           H, W, 3 * sigma + 1, legacy_f32, c0 > 0 ? 1 : 0, out);
+        QB_CHECK(hipGetLastError());
     }
-    }
-    QB_CHECK(hipGetLastError());
-    ProfScope prof("encode_paint", (double)B * HW * 13.0, 0.0, st);            // index map in, three f32 planes out
-    const size_t sm2 = (size_t)N * (2 * sizeof(double) + 2 * sizeof(int));
-    hipLaunchKernelGGL(encode_paint_kernel, dim3((int)((HW + 255) / 256), B), dim3(256), sm2, st, stats, last, gauss, N,
-                       H, W, 3 * sigma + 1, out);
-    QB_CHECK(hipGetLastError());
     return 0;
 }
 

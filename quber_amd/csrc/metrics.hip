@@ -59,14 +59,17 @@ __global__ __launch_bounds__(256) void contingency_kernel(const int* __restrict_
                                                           unsigned long long* __restrict__ table /*[cap][cap]*/) {
     extern __shared__ unsigned priv[];
     const int np_ = counts[0], ng = counts[1];
-    if (np_ > cap || ng > cap) return;
+    // counts[2]: label_presence_kernel met a value outside 0..65535 - the LUT cannot index it, the host raises
+    if (np_ > cap || ng > cap || counts[2]) return;
     const bool use_lds = (long)np_ * ng <= 4096;
     if (use_lds) {
         for (int i = threadIdx.x; i < np_ * ng; i += 256) priv[i] = 0;
         __syncthreads();
     }
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const int pj = lut[pred[i]], gi = lut[LAB_MAX + gt[i]];
+        const int pv = pred[i], gv = gt[i];
+        if ((unsigned)pv >= LAB_MAX || (unsigned)gv >= LAB_MAX) continue;     // unreachable once counts[2] is honoured
+        const int pj = lut[pv], gi = lut[LAB_MAX + gv];
         if (use_lds) atomicAdd(&priv[gi * np_ + pj], 1u);
         else atomicAdd(&table[(long)gi * cap + pj], 1ull);
     }

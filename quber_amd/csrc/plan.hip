@@ -857,7 +857,7 @@ int check_cfg(const quber_config& c) {
         return c.max_batch >= 1 ? 0 : fail("max_batch must be >= 1");
     }
     if (c.max_batch < 1) return fail("max_batch must be >= 1");
-    if (c.max_instances < 1 || c.max_instances > 254) return fail("max_instances must be in 1..254");
+    if (c.max_instances < 1) return fail("max_instances must be >= 1");
     if (c.resnet_depth != 50 && c.resnet_depth != 101 && c.resnet_depth != 152) return fail("resnet_depth must be 50, 101 or 152");
     if (c.res5_dilation != 1 && c.res5_dilation != 2 && c.res5_dilation != 4) return fail("res5_dilation must be 1, 2 or 4");
     if (c.res5_dilation == 1) return fail("res5_dilation 1 (output stride 32) is not supported by this build");
@@ -934,7 +934,7 @@ int quber_create(const quber_config* cfg, quber_ctx** out) {
     Builder b(c, false);
     c->gauss = b.upload(g);
     c->enc_ws = b.dalloc_bytes(encode_ws_bytes(B, cfg->max_instances, H, W));
-    c->err_ws = (uint8_t*)b.dalloc_bytes(errmaps_ws_bytes(B, H, W));
+    c->err_ws = (uint8_t*)b.dalloc_bytes(errmaps_ws_bytes(B, cfg->max_instances > 0 ? cfg->max_instances : 1, H, W));
     c->post_ws = b.dalloc_bytes(postprocess_ws_bytes(B, H, W, cfg->top_k));
     if (!b.err.empty()) {
         std::string e = b.err;
@@ -1083,7 +1083,8 @@ int quber_encode_initial_masks(quber_ctx* c, const uint8_t* masks, int32_t batch
     if (check_batch(c, batch)) return -1;
     if (n > c->cfg.max_instances) return fail("more initial masks than max_instances");
     if (!masks && n > 0) return fail("null masks");
-    return launch_encode(masks, batch, n, c->cfg.height, c->cfg.width, c->gauss, c->cfg.gaussian_sigma, c->enc_ws, out,
+    return launch_encode(masks, batch, n, c->cfg.height, c->cfg.width, c->gauss, c->cfg.gaussian_sigma,
+                         c->cfg.encode_legacy_f32, c->enc_ws, out,
                          (hipStream_t)stream);
 }
 
@@ -1094,7 +1095,8 @@ int quber_explicit_error_maps(quber_ctx* c, const uint8_t* init, int32_t n_init,
     // util.py:80-83: dilation = max(1, int(round(ratio * diag)))   (Python round = half to even)
     int d = (int)rint((double)c->cfg.boundary_ratio * sqrt((double)H * H + (double)W * W));
     if (d < 1) d = 1;
-    return launch_errmaps(init, n_init, gt, n_gt, batch, H, W, d, c->err_ws, out, (hipStream_t)stream);
+    return launch_errmaps(init, n_init, gt, n_gt, batch, c->cfg.max_instances > 0 ? c->cfg.max_instances : 1, H, W, d, c->err_ws,
+                          out, (hipStream_t)stream);
 }
 
 int quber_forward(quber_ctx* c, const uint8_t* bgr, const uint8_t* depth, const float* offs, int32_t batch,

@@ -20,9 +20,20 @@ CAP = 256
 def contingency(prediction, gt, device="cuda:0"):
     """-> (labels_pred, labels_gt, table[n_gt, n_pred]) with np.unique ordering; integer label maps of equal shape."""
     lib = _lib.load()
+    prediction, gt = np.asarray(prediction), np.asarray(gt)
+    assert prediction.shape == gt.shape
+    remap = None
+    lo = min(int(prediction.min()), int(gt.min())) if prediction.size else 0
+    hi = max(int(prediction.max()), int(gt.max())) if prediction.size else 0
+    if lo < 0 or hi > 65535:
+        # the reference's np.unique accepts any integers (e.g. the -1 void label of panoptic_seg, or label * 1000 ids); the
+        # kernel's LUT covers 0..65535, so such maps are renumbered densely first (order-preserving, mapped back below)
+        vals = np.unique(np.concatenate([np.unique(prediction), np.unique(gt)]))
+        if vals.size > 65536:
+            raise ValueError("more than 65536 distinct labels")
+        prediction, gt, remap = np.searchsorted(vals, prediction), np.searchsorted(vals, gt), vals
     p = torch.as_tensor(np.ascontiguousarray(prediction)).to(device=device, dtype=torch.int32).contiguous()
     g = torch.as_tensor(np.ascontiguousarray(gt)).to(device=device, dtype=torch.int32).contiguous()
-    assert p.shape == g.shape
     nbytes = lib.quber_contingency_workspace_bytes(CAP)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
     _lib.check(lib.quber_label_contingency(C.c_void_p(p.data_ptr()), C.c_void_p(g.data_ptr()), p.numel(), CAP,
@@ -36,7 +47,10 @@ def contingency(prediction, gt, device="cuda:0"):
         raise ValueError("label values must lie in 0..65535")
     if n_pred > CAP or n_gt > CAP:
         raise ValueError(f"more than {CAP} distinct labels in a map")
-    return labels[0, :n_pred].astype(np.int64), labels[1, :n_gt].astype(np.int64), table[:n_gt, :n_pred].astype(np.int64)
+    lp, lg = labels[0, :n_pred].astype(np.int64), labels[1, :n_gt].astype(np.int64)
+    if remap is not None:
+        lp, lg = remap[lp].astype(np.int64), remap[lg].astype(np.int64)
+    return lp, lg, table[:n_gt, :n_pred].astype(np.int64)
 
 
 def _degenerate(p, r, f, num_pred, num_gt, pct):

@@ -51,7 +51,9 @@ class RefinerModel:
         key = (h, w)
         eng = self._engines.get(key)
         if eng is None or eng.qcfg.max_batch < batch or eng.qcfg.max_instances < n_masks:
+            # grow, never shrink: alternating workloads must not trigger repeated multi-GB rebuilds
             if eng is not None:
+                batch, n_masks = max(batch, eng.qcfg.max_batch), max(n_masks, eng.qcfg.max_instances)
                 eng.close()
             qc = qengine.make_config(h, w, max_batch=max(batch, 1), max_instances=max(64, n_masks), cfg=self.cfg)
             eng = qengine.Engine(qc, self.device)

@@ -59,6 +59,39 @@ def test_encode_vs_oracle(h, w, n, b):
         np.testing.assert_array_equal(got[i].view(np.uint32), exp.view(np.uint32))
 
 
+def test_encode_legacy_float32_arithmetic():
+    """quber_config.encode_legacy_f32: the offset planes as numpy < 2 (the reference's pinned 1.23.1) evaluates them.
+    Parity unpinned for this mode (numpy 1.x cannot run here): checked against the oracle's explicit-cast restatement."""
+    h, w, n = 480, 640, 20
+    sc = synth.make_scene(3, h, w, n)
+    qc = engine.make_config(h, w, max_batch=1, max_instances=n, with_network=False)
+    qc.encode_legacy_f32 = 1
+    e = engine.Engine(qc, "cuda:0")
+    got = e.encode(dev(sc["masks"][None])).cpu().numpy()[0]
+    legacy = encode_np.encode_initial_masks(sc["masks"], legacy_promotion=True)
+    np.testing.assert_array_equal(got.view(np.uint32), legacy.view(np.uint32))
+    pinned = encode_np.encode_initial_masks(sc["masks"])
+    d = np.abs(legacy - pinned)
+    assert 0 < d.max() < 1e-7 and np.array_equal(legacy[0], pinned[0])     # 1-ulp differences, heat-map identical
+    e.close()
+
+
+def test_encode_more_than_254_masks():
+    """The reference's loop takes any number of masks (predictor.py:310); the kernel's index map is one byte per pixel, so
+    N > 254 runs in chunks of 254 - later chunks max-paste the heat-map and overwrite only the pixels they cover."""
+    h, w, n = 96, 128, 300
+    rng = np.random.default_rng(1)
+    masks = np.zeros((1, n, h, w), np.uint8)
+    for i in range(n):
+        y, x = int(rng.integers(0, h - 12)), int(rng.integers(0, w - 12))
+        masks[0, i, y:y + int(rng.integers(3, 12)), x:x + int(rng.integers(3, 12))] = 1
+    masks[0, 270] = 0
+    e = engine.Engine(engine.make_config(h, w, max_batch=1, max_instances=n, with_network=False), "cuda:0")
+    got = e.encode(dev(masks)).cpu().numpy()[0]
+    np.testing.assert_array_equal(got.view(np.uint32), encode_np.encode_initial_masks(masks[0]).view(np.uint32))
+    e.close()
+
+
 def test_encode_zero_masks_and_errors():
     e = eng_for(96, 128)
     out = e.encode(torch.zeros((2, 0, 96, 128), dtype=torch.uint8, device="cuda"))
@@ -81,12 +114,44 @@ def test_error_maps_vs_oracle(h, w, n):
     assert (got.sum(1) == 1).all()
 
 
+@pytest.mark.parametrize("value", [1, 2, 37, 128, 255])
+def test_error_maps_mask_value_and_wraparound(value):
+    """The reference sums the masks / bands in uint8 and tests > 0 (util.py:62-68, 92-99): with mask value v the sum of n
+    overlapping masks is n*v mod 256, e.g. two masks of value 128 cancel.  Heavily overlapping masks, batch of 2."""
+    h, w, n = 96, 128, 9
+    rng = np.random.default_rng(value)
+    def stack():
+        m = np.zeros((n, h, w), np.uint8)
+        for i in range(n):
+            y, x = int(rng.integers(0, 30)), int(rng.integers(0, 40))
+            m[i, y:y + int(rng.integers(20, 60)), x:x + int(rng.integers(20, 80))] = value
+        return m
+    init, gt = np.stack([stack(), stack()]), np.stack([stack(), stack()])
+    e = eng_for(h, w)
+    got = e.error_maps(dev(init), dev(gt)).cpu().numpy()
+    for b in range(2):
+        np.testing.assert_array_equal(got[b], errmaps_np.explicit_error_maps(init[b], gt[b]))
+
+
+def test_error_maps_grey_level_masks():
+    """Masks with several distinct non-zero values are grey-level images to cv2.erode (a minimum filter): the byte-wise
+    kernels take over from the bit-plane path (chosen on the device from the values pass 1 saw)."""
+    h, w, n = 75, 101, 5
+    rng = np.random.default_rng(5)
+    gt, init = synth.make_masks(rng, n, h, w)
+    init = init.astype(np.uint8) * rng.integers(1, 256, (n, h, w)).astype(np.uint8)
+    gt = gt.astype(np.uint8) * 255
+    e = eng_for(h, w)
+    got = e.error_maps(dev(init[None]), dev(gt[None])).cpu().numpy()[0]
+    np.testing.assert_array_equal(got, errmaps_np.explicit_error_maps(init, gt))
+
+
 def test_error_maps_uint8_wrap_semantics():
     z = np.load(golden("fgunion")[0])
     masks = np.zeros((256, 96, 128), np.uint8)
     masks[:, :8, :16] = z["masks"]
     e = eng_for(96, 128)
-    # n_init = 254 is the ABI limit for the encoder only; error maps take any N
+    # error maps take any N with n_init + n_gt <= 2 x max_instances
     got = e.error_maps(dev(masks[None]), dev(masks[None, :1])).cpu().numpy()[0]
     exp = errmaps_np.explicit_error_maps(masks, masks[:1])
     np.testing.assert_array_equal(got, exp)
@@ -211,8 +276,34 @@ def test_contingency_many_labels_and_errors():
     exp = np.zeros((len(lg), len(lp)), np.int64)
     np.add.at(exp, (np.searchsorted(lg, g.ravel()), np.searchsorted(lp, p.ravel())), 1)
     np.testing.assert_array_equal(table, exp)
-    with pytest.raises(ValueError):
-        contingency(np.full((8, 8), 70000, np.int32), np.zeros((8, 8), np.int32))
+    # labels outside the kernel's 0..65535 LUT (the -1 void label of panoptic_seg, label * 1000 ids) are renumbered by the
+    # wrapper, like the reference's np.unique accepts them (evaluation.py:77-80)
+    pan = np.where(p % 3 == 0, -1, p * 1000).astype(np.int64)
+    lp2, lg2, table2 = contingency(pan, g)
+    np.testing.assert_array_equal(lp2, np.unique(pan))
+    exp2 = np.zeros((len(lg2), len(lp2)), np.int64)
+    np.add.at(exp2, (np.searchsorted(lg2, g.ravel()), np.searchsorted(lp2, pan.ravel())), 1)
+    np.testing.assert_array_equal(table2, exp2)
+
+
+def test_contingency_kernel_ignores_out_of_range_labels():
+    """The raw C entry point on labels its LUT cannot index: it must flag them and touch nothing out of bounds
+    (contingency_kernel used to index the LUT with them)."""
+    import ctypes as C
+    from quber_amd import _lib
+    lib = _lib.load()
+    cap = 16
+    bad = torch.tensor([[-1, 3, 70000, 5] * 64] * 64, dtype=torch.int32, device="cuda")
+    gt = torch.zeros_like(bad)
+    ws = torch.empty(lib.quber_contingency_workspace_bytes(cap), dtype=torch.uint8, device="cuda")
+    _lib.check(lib.quber_label_contingency(C.c_void_p(bad.data_ptr()), C.c_void_p(gt.data_ptr()), bad.numel(), cap,
+                                           C.c_void_p(ws.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    o = 2 * 65536 * 4
+    host = ws[o:o + cap * cap * 8 + 2 * cap * 4 + 16].cpu().numpy()
+    counts = host[cap * cap * 8 + 2 * cap * 4:].view(np.int32)
+    assert counts[2] == 1                                            # out-of-range flag
+    assert not host[:cap * cap * 8].view(np.uint64).any()            # and no counting happened
 
 
 # --------------------------------------------------------------------------------------------- adapter pre-processing
