@@ -180,6 +180,7 @@ double quber_forward_flops(quber_ctx* ctx);
 double quber_forward_flops_executed(quber_ctx* ctx);
 /* test-harness knobs: key 2 = give the stand-alone quber_op_conv2d a split-K workspace (value != 0) or drop it (0);
  * key 3 = force the number of K partitions of convolutions that have a workspace (0 = automatic);
+ * key 12 = stand-alone conv op only: bf16 operands with fp32 accumulation (what quber_config.compute_dtype 1 runs);
  * key 11 = stand-alone conv op only: dilated 3x3 layers in tap-major K order with the zero-padding filter rows skipped;
  * key 10 = smallest output width routed to the Winograd path (default 32);
  * key 9 = Winograd output tile edge of the eligible layers (acts at plan time): 0 = automatic (default: F(4x4), or F(2x2)

@@ -48,6 +48,7 @@ struct ConvP {
     long in_gs, out_gs, res_gs, w_gs;
     int ss_gs;
     const char* tag;     // stage-profile tag of the launch (null = "conv_gemm")
+    int bf16;            // operands rounded to bf16 on the way into LDS, fp32 accumulation (quber_config.compute_dtype 1)
 };
 
 void set_error(const std::string& msg);

@@ -28,6 +28,14 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int BK = 32;
 constexpr int PITCH = 36;
+// DT = 1 (quber_config.compute_dtype 1, BASELINE.json configs[4] stand-in): the same implicit GEMM with bf16 operands and
+// fp32 accumulation on v_mfma_f32_32x32x16_bf16 (16x the fp32 matrix rate).  Activations and weights stay fp32 in HBM
+// and are rounded to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) as the K-slice is written to LDS; the LDS image is
+// [row][k] bf16 with an 80-byte pitch, which makes the 16-byte fragment reads of a wave conflict-free; the accumulators,
+// and with them the whole epilogue, are those of the fp32 kernel.
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+constexpr int PITCH_H = 40;   // bf16 elements per LDS row
 
 // Main-loop variants that were measured and rejected (profiles/r01c_conv_variants.md): double-buffered LDS with one
 // barrier per K-slice, a per-block s_setprio stagger, and 256x128 / 128x256 tiles (8 waves, or 4 waves of 128x64) were
@@ -42,7 +50,7 @@ constexpr int PITCH = 36;
 // out short pieces while the last whole tiles drain.
 // The K range is derived without a division (host-computed kchunk): a 64-bit division here costs hipcc ~50 VGPRs over
 // the whole kernel and a wave per SIMD; as written all instantiations allocate the same registers.
-template <int BM, int BN, int WM, int WN, int MODE>
+template <int BM, int BN, int WM, int WN, int MODE, int DT = 0>
 __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
     constexpr int NTH = WM * WN * 64;
     constexpr int RPP = NTH / 8;      // tile rows covered by one pass of the loader
@@ -54,11 +62,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
     static_assert(BM % RPP == 0 && BN % RPP == 0, "loader geometry");
     constexpr int SW = WN * 32;        // columns staged per epilogue pass
     constexpr int SP = SW + 4;         // staging pitch (floats)
-    constexpr int KSLICE_FLOATS = NBUF * (BM + BN) * PITCH;
+    constexpr int KSLICE_FLOATS = DT ? NBUF * (BM + BN) * PITCH_H / 2 : NBUF * (BM + BN) * PITCH;
     constexpr int SMEM_FLOATS = KSLICE_FLOATS > BM * SP ? KSLICE_FLOATS : BM * SP;
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     float* const As = smem;
     float* const Bs = smem + NBUF * BM * PITCH;
+    __bf16* const Ah = reinterpret_cast<__bf16*>(smem);
+    __bf16* const Bh = Ah + NBUF * BM * PITCH_H;
 
     const int t = threadIdx.x;
     const int g = blockIdx.z;
@@ -201,6 +211,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
         }
     };
     auto lstore = [&](int buf) __attribute__((always_inline)) {
+        if constexpr (DT == 1) {
+#pragma unroll
+            for (int i = 0; i < AL; ++i) {
+                const f32x4 v = aok[i] ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<bf16x4*>(&Ah[buf * BM * PITCH_H + (lrow + RPP * i) * PITCH_H + kq]) =
+                    bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+            }
+#pragma unroll
+            for (int i = 0; i < BL; ++i)
+                *reinterpret_cast<bf16x4*>(&Bh[buf * BN * PITCH_H + (lrow + RPP * i) * PITCH_H + kq]) =
+                    bf16x4{(__bf16)rb[i].x, (__bf16)rb[i].y, (__bf16)rb[i].z, (__bf16)rb[i].w};
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < AL; ++i)
             *reinterpret_cast<f32x4*>(&As[buf * BM * PITCH + (lrow + RPP * i) * PITCH + kq]) =
@@ -222,6 +245,20 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    // bf16: MFMA step ks of a slice multiplies k = 16 ks + 8 h + (0..7): one 16-byte fragment read per operand tile
+    auto mma_h = [&](int buf, int ks) __attribute__((always_inline)) {
+        const __bf16* ap = &Ah[buf * BM * PITCH_H + (wm * TM * 32 + r) * PITCH_H + 8 * h + ks * 16];
+        const __bf16* bp = &Bh[buf * BN * PITCH_H + (wn * 32 + r) * PITCH_H + 8 * h + ks * 16];
+        bf16x8 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(ap + i * 32 * PITCH_H);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(bp + j * WN * 32 * PITCH_H);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    };
     auto mma = [&](int buf, int ks) __attribute__((always_inline)) {
         const float* ap = &As[buf * BM * PITCH + (wm * TM * 32 + r) * PITCH + 4 * h];
         const float* bp = &Bs[buf * BN * PITCH + (wn * 32 + r) * PITCH + 4 * h];
@@ -245,8 +282,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) gload(kt + 1);
+        if constexpr (DT == 1) {
 #pragma unroll
-        for (int ks = 0; ks < BK / 8; ++ks) mma(0, ks);
+            for (int ks = 0; ks < BK / 16; ++ks) mma_h(0, ks);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < BK / 8; ++ks) mma(0, ks);
+        }
         __syncthreads();
         if (kt + 1 < nk) {
             lstore(0);
@@ -527,7 +569,7 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
     // together fill about one more (short) round; taken when the model prices it below the launch chosen so far.
     constexpr int BPC = (BM == 64) ? 7 : 3;
     const long slots = 256L * BPC, tiles = (long)p.mtiles * p.ntiles, blocks_all = tiles * G;
-    if (p.ws && g_tail_split && g_force_split == 0 && BM == 128 && blocks_all > slots && nk >= 32) {
+    if (p.ws && !p.bf16 && g_tail_split && g_force_split == 0 && BM == 128 && blocks_all > slots && nk >= 32) {
         const long nfull = (blocks_all / slots) * slots / G / p.ntiles * p.ntiles;    // per group, whole tile rows
         const long rem = tiles - nfull;
         int shift = 0;
@@ -555,6 +597,16 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
                 return gn_separate();
             }
         }
+    }
+    if (p.bf16) {
+        {
+            ProfScope prof(tag, conv_bytes, conv_flops, st);
+            if (S > 1) hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 1, 1>), dim3(p.mtiles * p.ntiles, S, G), block, 0, st, p);
+            else hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 0, 1>), dim3(p.mtiles * p.ntiles, 1, G), block, 0, st, p);
+        }
+        if (S > 1) reduce(S);
+        QB_CHECK(hipGetLastError());
+        return gn_separate();
     }
     const bool skip = BM != 256 && p.skip_rows && p.kmode == 0 && p.kh > 1 && p.Cin % BK == 0 && p.K == p.Kpad && p.ohw > 0;
     if (S > 1) {

@@ -252,6 +252,7 @@ struct Builder {
         p.relu = relu;
         p.kmode = kmode;
         p.skip_rows = skip_rows;
+        p.bf16 = c->cfg.compute_dtype == 1;
         p.in_gs = in.gs; p.out_gs = out.gs; p.res_gs = res ? res->gs : 0;
         p.w_gs = (long)Cout * Kpad; p.ss_gs = Cout;
         p.ohw = OH * OW;
@@ -265,7 +266,9 @@ struct Builder {
         // direct kernel's error against float64, profiles/r02a_parity_report.txt).  `wq6`, the 6x6 variant, is OPT-IN
         // (quber_set_tuning key 9 = 6 / QUBER_WINOGRAD=f6): 2.5x the error at tap level, +4.5 % throughput at batch 16.
         WinoP wq{};
-        bool wino = winograd_eligible(k, stride, pad, dil, Cin, Cout) && cin_real == Cin && !res && prelu.empty() && g_winograd != 1;
+        // (the bf16 mode keeps every layer on the direct kernel: the Winograd transforms amplify the operands' rounding error)
+        bool wino = winograd_eligible(k, stride, pad, dil, Cin, Cout) && cin_real == Cin && !res && prelu.empty() && g_winograd != 1 &&
+                    c->cfg.compute_dtype == 0;
         if (wino) {
             const double lim = (double)g_wino_max_ratio / 100.0;
             const double r6 = winograd_m6_channels_ok(Cin, Cout) ? winograd_mac_ratio(in.H, in.W, dil, 6) : 1e9;
@@ -863,7 +866,7 @@ int check_cfg(const quber_config& c) {
     if (c.res5_dilation == 1) return fail("res5_dilation 1 (output stride 32) is not supported by this build");
     if (c.error_classes < 2 || c.error_classes > 4) return fail("error_classes must be 2..4");
     if (c.streams != 1 && c.streams != 2) return fail("streams must be 1 or 2");
-    if (c.compute_dtype != 0) return fail("compute_dtype: only 0 (fp32) is built");
+    if (c.compute_dtype != 0 && c.compute_dtype != 1) return fail("compute_dtype must be 0 (fp32) or 1 (bf16 operands, fp32 accumulation)");
     if (c.with_network && c.hierarchical) {
         if (c.n_levels < 1 || c.n_levels > 5) return fail("n_levels must be 1..5");
         int seen[5] = {0, 0, 0, 0, 0};
@@ -888,6 +891,7 @@ int check_cfg(const quber_config& c) {
 
 static float* g_op_ws = nullptr;
 static int g_op_skip_rows = 0;
+static int g_op_bf16 = 0;
 static const size_t g_op_ws_floats = (size_t)256 << 20;   // 1 GiB, test harness only
 
 extern "C" {
@@ -1018,6 +1022,7 @@ void quber_set_tuning(int32_t key, int32_t value) {
         }
     }
     if (key == 4) g_force_tile = value;    // force the tile shape: 1 = 64x64, 2 = 128x128, 4 = 256x32 (0 = automatic)
+    if (key == 12) g_op_bf16 = value;         // stand-alone conv op: bf16 operands, fp32 accumulation
     if (key == 11) g_op_skip_rows = value;    // stand-alone conv op: tap-major K order with padded filter rows skipped (dilated 3x3)
     if (key == 10) g_wino_min_cout = value;   // smallest output width eligible for the Winograd path (default 32)
     if (key == 9) g_wino_variant = value;     // Winograd output tile edge for the eligible layers: 0 = automatic (4 or 2), 2, 4, 6 (opt-in)
@@ -1250,6 +1255,7 @@ int quber_op_conv2d(const float* x, int32_t B, int32_t h, int32_t w, int32_t cin
     p.kh = k; p.kw = k; p.stride = stride; p.pad = pad; p.dil = dil; p.relu = relu;
     p.kmode = kmode;
     p.skip_rows = skip_rows;
+    p.bf16 = g_op_bf16;
     p.M = B * p.OH * p.OW;
     p.ohw = p.OH * p.OW;
     p.w_gs = 0; p.ss_gs = 0;

@@ -327,7 +327,7 @@ def test_normalize_depth_full_frame_vs_oracle():
 
 
 # --------------------------------------------------------------------------------------------- kernel-level ops
-def _conv_case(B, H, W, Cin, Cout, k, stride, dil, affine, residual, relu, seed=0):
+def _conv_case(B, H, W, Cin, Cout, k, stride, dil, affine, residual, relu, seed=0, bf16=False):
     lib = _lib.load()
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(B, Cin, H, W, generator=g)
@@ -335,7 +335,10 @@ def _conv_case(B, H, W, Cin, Cout, k, stride, dil, affine, residual, relu, seed=
     pad = dil * (k // 2)
     sc = torch.rand(Cout, generator=g) + 0.5 if affine else None
     sh = torch.randn(Cout, generator=g) if affine else None
-    ref = torch.nn.functional.conv2d(x.double(), wt.double(), None, stride, pad, dil)
+    # bf16 mode: the kernel rounds both operands to bf16 (nearest-even) and accumulates in fp32, so the reference is the
+    # float64 convolution of the rounded operands
+    xr, wr = (x.bfloat16().double(), wt.bfloat16().double()) if bf16 else (x.double(), wt.double())
+    ref = torch.nn.functional.conv2d(xr, wr, None, stride, pad, dil)
     if affine:
         ref = ref * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
     res = torch.randn(ref.shape, generator=g) if residual else None
@@ -351,8 +354,12 @@ def _conv_case(B, H, W, Cin, Cout, k, stride, dil, affine, residual, relu, seed=
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
     scd, shd = (sc.cuda(), sh.cuda()) if affine else (None, None)
     resd = res.permute(0, 2, 3, 1).contiguous().cuda() if residual else None
-    _lib.check(lib.quber_op_conv2d(p(xd), B, H, W, Cin, p(wd), Cout, k, stride, pad, dil, p(scd), p(shd), p(resd),
-                                   int(relu), p(packed), p(y), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    lib.quber_set_tuning(12, int(bf16))
+    try:
+        _lib.check(lib.quber_op_conv2d(p(xd), B, H, W, Cin, p(wd), Cout, k, stride, pad, dil, p(scd), p(shd), p(resd),
+                                       int(relu), p(packed), p(y), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    finally:
+        lib.quber_set_tuning(12, 0)
     got = y.cpu().permute(0, 3, 1, 2).double()
     err = (got - ref).abs().max().item()
     scale = max(1.0, ref.abs().max().item())
@@ -373,6 +380,29 @@ def _conv_case(B, H, W, Cin, Cout, k, stride, dil, affine, residual, relu, seed=
 ])
 def test_conv_igemm_vs_torch(case):
     assert _conv_case(*case) < 2e-6
+
+
+@pytest.mark.parametrize("case", [
+    (2, 24, 32, 8, 32, 3, 2, 1, True, False, True),        # stem conv1 (K = 72, tail), 256x32 tile
+    (2, 24, 32, 32, 64, 3, 1, 1, True, False, True),       # 64x64 tiles
+    (2, 16, 20, 64, 256, 1, 1, 1, True, True, True),       # bottleneck conv3 + residual
+    (1, 30, 40, 256, 128, 1, 2, 1, True, False, True),     # strided 1x1
+    (1, 15, 20, 128, 128, 3, 1, 4, True, False, True),     # dilated 3x3
+    (3, 33, 47, 164, 128, 1, 1, 1, True, False, True),     # K = 164 (tail of 4), ragged M
+    (2, 64, 80, 128, 130, 3, 1, 1, False, False, False),   # 128x128 tiles, ragged N
+    (4, 60, 80, 512, 256, 3, 1, 1, True, False, True),     # K = 4608
+])
+def test_conv_igemm_bf16_vs_rounded_operands(case):
+    """compute_dtype 1 (BASELINE.json configs[4] stand-in): v_mfma_f32_32x32x16_bf16 with fp32 accumulation equals the
+    float64 convolution of the bf16-rounded operands to fp32-accumulation accuracy - i.e. the only error of the mode is
+    the operand rounding itself."""
+    assert _conv_case(*case, bf16=True) < 3e-6
+    lib = _lib.load()
+    lib.quber_set_tuning(2, 1)
+    try:
+        assert _conv_case(*case, bf16=True) < 3e-6          # with the split-K workspace
+    finally:
+        lib.quber_set_tuning(2, 0)
 
 
 @pytest.mark.parametrize("case", [
