@@ -49,9 +49,9 @@ def parse():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--instances", type=int, default=20)
-    ap.add_argument("--dtype", default="f32", choices=("f32", "bf16"),
-                    help="arithmetic of the convolutions: f32 (headline; exact fp32 MFMA) or bf16 operands with fp32 "
-                         "accumulation (BASELINE.json configs[4] stand-in; its own tolerance, see DESIGN.md)")
+    ap.add_argument("--dtype", default="f32", choices=("f32", "f16", "bf16"),
+                    help="arithmetic of the convolutions: f32 (headline; exact fp32 MFMA), or f16 / bf16 operands with fp32 "
+                         "accumulation (BASELINE.json configs[4] stand-in; their own tolerance, see DESIGN.md)")
     ap.add_argument("--heads", default="loud", choices=("loud", "faithful"),
                     help="loud: O(1) predictors + calibrated centre bias so post-processing sees K ~ N instances per frame; "
                          "faithful: the reference's N(0, 0.001) predictor init (K = 0)")
@@ -252,7 +252,7 @@ def main():
 
     def make_engine(sd):
         qc = engine.make_config(H, W, max_batch=B, max_instances=max(N, 1))
-        qc.compute_dtype = 1 if a.dtype == "bf16" else 0
+        qc.compute_dtype = {"f32": 0, "bf16": 1, "f16": 2}[a.dtype]
         e = engine.Engine(qc, dev)
         for kv in filter(None, a.tuning.split(",")):      # before the plan is built: some knobs act at plan time
             k, v = kv.split("=")
@@ -446,7 +446,7 @@ def report(a, eng, world, elapsed, ranks, center_bias, sd, host, t, gpu_step):
     gemm_n = sum(stages[k]["launches"] for k in CONV_GEMM if k in stages)
     executed = sum(stages[k]["flops"] for k in CONV_GEMM if k in stages)       # what the matrix pipe multiplies (2*M*K*N per launch)
     algorithmic = eng.forward_flops() * B                                        # 2 x MAC of the direct convolutions
-    peak = BF16_MFMA_PEAK_TFLOPS if a.dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS
+    peak = FP32_MFMA_PEAK_TFLOPS if a.dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
     hbm = {}
     for k in HBM_STAGES:
         if k in stages and stages[k]["ms"] > 0:
@@ -469,7 +469,7 @@ def report(a, eng, world, elapsed, ranks, center_bias, sd, host, t, gpu_step):
     ms_per_step = elapsed / a.steps * 1e3
     ex_tf = executed / (fam_ms * 1e-3) / 1e12 if fam_ms else 0.0
     line = {
-        "metric": "refined masks/sec on 640x480 RGB-D (N=20 inst)",
+        "metric": f"refined masks/sec on {W}x{H} RGB-D (N={N} inst)",
         "value": world * B * N * a.steps / elapsed,
         "unit": "refined masks/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,

@@ -59,7 +59,8 @@ typedef struct quber_config {
     int32_t streams;                 /* 2: rgb + depth streams (build_resnet_deeplab_rgbd_fusion_backbone); 1: single stream
                                         (build_resnet_deeplab_fusion_backbone: rgb-only or depth-only, pixel_mean[0..2]) */
     int32_t compute_dtype;           /* arithmetic of the convolutions: 0 = exact fp32 MFMA (default; the 1e-4 parity bar),
-                                        1 = bf16 operands, fp32 accumulation (BASELINE.json configs[4] stand-in; own tolerance) */
+                                        2 = fp16 operands, fp32 accumulation (BASELINE.json configs[4] "fp16 MFMA path" stand-in;
+                                        own tolerance, tests/test_gpu_loud_parity.py), 1 = bf16 operands likewise (8x coarser) */
     int32_t encode_legacy_f32;       /* a1 offset arithmetic (predictor.py:345-346, `np.float64 scalar - float32 array`):
                                         0 = numpy >= 2 promotion (float64, rounded once; what the reference computes when run
                                         under this image's numpy 2.2, pinned by tests/golden/encode_*.npz);
@@ -155,6 +156,19 @@ int64_t quber_contingency_workspace_bytes(int32_t cap);
 int quber_label_contingency(const int32_t* dev_pred, const int32_t* dev_gt, int64_t n_pixels, int32_t cap,
                             void* dev_workspace, void* stream);
 
+/* evaluation support - the boundary half of multilabel_metrics: for every (ground-truth object i, predicted object j) the
+ * true-positive counts of eval/evaluation.py:21-54 `boundary_overlap` and the per-object boundary sizes of :165-175.
+ * seg2bmap (eval/utilities.py:672-697: cv2.findContours RETR_EXTERNAL + drawContours) and the disk dilation are restated
+ * from their published algorithms (no OpenCV / skimage in the build image; parity unpinned).
+ *   dev_pred, dev_gt i32 [h][w] label maps; dev_labels i32 [n_pred + n_gt]: the object labels, predicted ones first
+ *   bound_pix: disk radius = ceil(0.003 * hypot(h, w)) in the reference (evaluation.py:33-34)
+ *   -> dev_out u32: boundary size [n_pred + n_gt] | precision_tps [n_gt][n_pred] | recall_tps [n_gt][n_pred]
+ *   dev_workspace: quber_boundary_workspace_bytes(h, w, n_pred + n_gt) bytes; h * ceil(w / 64) * 8 must fit 160 KiB of LDS */
+int64_t quber_boundary_workspace_bytes(int32_t h, int32_t w, int32_t n_masks);
+int quber_boundary_overlap(const int32_t* dev_pred, const int32_t* dev_gt, int32_t h, int32_t w, const int32_t* dev_labels,
+                           int32_t n_pred, int32_t n_gt, int32_t bound_pix, void* dev_workspace, uint32_t* dev_out,
+                           void* stream);
+
 /* post-filter of eval/refiner_model.py:273-277 on LMFFNet logits (foreground_segmentation/predictor.py:85,98):
  *   dev_fg_logits f32 [B][n_classes][HW] -> dev_fg_mask u8 [B][HW] = (argmax == fg_class)
  *   dev_masks u8 [B][n_masks][HW] (may be NULL with n_masks = 0)
@@ -170,6 +184,14 @@ int quber_foreground_filter(const float* dev_fg_logits, int32_t n_classes, int32
 int quber_normalize_depth(const void* dev_depth, int32_t is_float32, int64_t n_pixels, double min_val, double max_val,
                           uint8_t* dev_out3, uint8_t* dev_zero, void* stream);
 
+/* adapter pre-processing - cv2.resize of an interleaved uint8 image (eval/refiner_model.py:229 `cv2.resize(rgb, (w, h))`,
+ * :232 / :254 INTER_NEAREST on masks / depth, :246).  linear = 1: cv2.INTER_LINEAR's 8-bit path (11-bit fixed-point
+ * weights; the area filter at exactly half scale), linear = 0: cv2.INTER_NEAREST.  OpenCV is absent from the build image:
+ * restated from its published algorithm, parity unpinned.
+ *   dev_src u8 [src_h][src_w][channels] (channels 1..4) -> dev_dst u8 [dst_h][dst_w][channels] */
+int quber_resize_u8(const uint8_t* dev_src, int32_t src_h, int32_t src_w, int32_t channels, uint8_t* dev_dst,
+                    int32_t dst_h, int32_t dst_w, int32_t linear, void* stream);
+
 /* ---- introspection / kernel-level entry points used by the parity tests and the benchmark ---- */
 /* device pointer + NHWC geometry of a named intermediate of the last quber_forward ("res2", "res3", "res5", "y", ...) */
 int quber_debug_tensor(quber_ctx* ctx, const char* name, float** dev_ptr, int32_t* dims4, int32_t* channel_stride);
@@ -180,7 +202,7 @@ double quber_forward_flops(quber_ctx* ctx);
 double quber_forward_flops_executed(quber_ctx* ctx);
 /* test-harness knobs: key 2 = give the stand-alone quber_op_conv2d a split-K workspace (value != 0) or drop it (0);
  * key 3 = force the number of K partitions of convolutions that have a workspace (0 = automatic);
- * key 12 = stand-alone conv op only: bf16 operands with fp32 accumulation (what quber_config.compute_dtype 1 runs);
+ * key 12 = stand-alone conv op only: 1 = bf16 / 2 = fp16 operands with fp32 accumulation (quber_config.compute_dtype);
  * key 11 = stand-alone conv op only: dilated 3x3 layers in tap-major K order with the zero-padding filter rows skipped;
  * key 10 = smallest output width routed to the Winograd path (default 32);
  * key 9 = Winograd output tile edge of the eligible layers (acts at plan time): 0 = automatic (default: F(4x4), or F(2x2)

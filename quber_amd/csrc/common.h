@@ -48,7 +48,7 @@ struct ConvP {
     long in_gs, out_gs, res_gs, w_gs;
     int ss_gs;
     const char* tag;     // stage-profile tag of the launch (null = "conv_gemm")
-    int bf16;            // operands rounded to bf16 on the way into LDS, fp32 accumulation (quber_config.compute_dtype 1)
+    int bf16;            // 16-bit operands, fp32 accumulation (quber_config.compute_dtype): 0 = exact fp32, 1 = bf16, 2 = fp16
 };
 
 void set_error(const std::string& msg);
@@ -126,6 +126,8 @@ int launch_upsample_logits(const float* q, float* out, int B, int nch, int h, in
 int launch_normalize_depth(const void* depth, int is_float, long n, double lo, double hi, uint8_t* out3, uint8_t* zero,
                            hipStream_t st);
 
+int launch_resize_u8(const uint8_t* src, int sh, int sw, int ch, uint8_t* dst, int dh, int dw, int linear, hipStream_t st);
+
 // LMFFNet foreground network + post-filter (lmff.hip)
 int launch_lmff_preprocess(const uint8_t* bgr, const uint8_t* depth, long pixels, float* x, hipStream_t st);
 int launch_dwconv3x3(const View& in, const View& out, int B, int dil, const float* w9, const float* scale,
@@ -141,6 +143,9 @@ int launch_argmax_fg(const float* logits, int B, long HW, int nc, int cls, uint8
 int launch_mask_overlap(const uint8_t* masks, const uint8_t* fg, int B, int K, long HW, unsigned long long* counts,
                         hipStream_t st);
 
+int launch_boundary_overlap(const int* pred, const int* gt, int H, int W, const int* labels, int n_pred, int n_gt, int radius,
+                            void* ws, unsigned* out, hipStream_t st);
+size_t boundary_ws_bytes(int H, int W, int n_masks);
 int launch_contingency(const int* pred, const int* gt, long n, int cap, void* ws, hipStream_t st);
 size_t contingency_ws_bytes(int cap);
 

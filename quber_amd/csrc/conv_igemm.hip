@@ -28,14 +28,14 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int BK = 32;
 constexpr int PITCH = 36;
-// DT = 1 (quber_config.compute_dtype 1, BASELINE.json configs[4] stand-in): the same implicit GEMM with bf16 operands and
-// fp32 accumulation on v_mfma_f32_32x32x16_bf16 (16x the fp32 matrix rate).  Activations and weights stay fp32 in HBM
-// and are rounded to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) as the K-slice is written to LDS; the LDS image is
-// [row][k] bf16 with an 80-byte pitch, which makes the 16-byte fragment reads of a wave conflict-free; the accumulators,
-// and with them the whole epilogue, are those of the fp32 kernel.
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
-constexpr int PITCH_H = 40;   // bf16 elements per LDS row
+// DT = 1 / 2 (quber_config.compute_dtype: BASELINE.json configs[4] stand-in): the same implicit GEMM with bf16 / fp16
+// operands and fp32 accumulation on v_mfma_f32_32x32x16_{bf16,f16} (16x the fp32 matrix rate).  Activations and weights
+// stay fp32 in HBM and are rounded to the 16-bit type (round-to-nearest-even) as the K-slice is written to LDS; the LDS
+// image is [row][k] with an 80-byte pitch, which makes the 16-byte fragment reads of a wave conflict-free; the
+// accumulators, and with them the whole epilogue, are those of the fp32 kernel.
+template <int DT> struct Half16 { using T = __bf16; };
+template <> struct Half16<2> { using T = _Float16; };
+constexpr int PITCH_H = 40;   // 16-bit elements per LDS row
 
 // Main-loop variants that were measured and rejected (profiles/r01c_conv_variants.md): double-buffered LDS with one
 // barrier per K-slice, a per-block s_setprio stagger, and 256x128 / 128x256 tiles (8 waves, or 4 waves of 128x64) were
@@ -67,8 +67,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     float* const As = smem;
     float* const Bs = smem + NBUF * BM * PITCH;
-    __bf16* const Ah = reinterpret_cast<__bf16*>(smem);
-    __bf16* const Bh = Ah + NBUF * BM * PITCH_H;
+    using H16 = typename Half16<DT>::T;
+    using h16x8 = __attribute__((ext_vector_type(8))) H16;
+    using h16x4 = __attribute__((ext_vector_type(4))) H16;
+    H16* const Ah = reinterpret_cast<H16*>(smem);
+    H16* const Bh = Ah + NBUF * BM * PITCH_H;
 
     const int t = threadIdx.x;
     const int g = blockIdx.z;
@@ -211,17 +214,17 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
         }
     };
     auto lstore = [&](int buf) __attribute__((always_inline)) {
-        if constexpr (DT == 1) {
+        if constexpr (DT != 0) {
 #pragma unroll
             for (int i = 0; i < AL; ++i) {
                 const f32x4 v = aok[i] ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-                *reinterpret_cast<bf16x4*>(&Ah[buf * BM * PITCH_H + (lrow + RPP * i) * PITCH_H + kq]) =
-                    bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+                *reinterpret_cast<h16x4*>(&Ah[buf * BM * PITCH_H + (lrow + RPP * i) * PITCH_H + kq]) =
+                    h16x4{(H16)v.x, (H16)v.y, (H16)v.z, (H16)v.w};
             }
 #pragma unroll
             for (int i = 0; i < BL; ++i)
-                *reinterpret_cast<bf16x4*>(&Bh[buf * BN * PITCH_H + (lrow + RPP * i) * PITCH_H + kq]) =
-                    bf16x4{(__bf16)rb[i].x, (__bf16)rb[i].y, (__bf16)rb[i].z, (__bf16)rb[i].w};
+                *reinterpret_cast<h16x4*>(&Bh[buf * BN * PITCH_H + (lrow + RPP * i) * PITCH_H + kq]) =
+                    h16x4{(H16)rb[i].x, (H16)rb[i].y, (H16)rb[i].z, (H16)rb[i].w};
             return;
         }
 #pragma unroll
@@ -245,19 +248,22 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // bf16: MFMA step ks of a slice multiplies k = 16 ks + 8 h + (0..7): one 16-byte fragment read per operand tile
+    // 16-bit operands: MFMA step ks of a slice multiplies k = 16 ks + 8 h + (0..7): one 16-byte fragment read per operand tile
     auto mma_h = [&](int buf, int ks) __attribute__((always_inline)) {
-        const __bf16* ap = &Ah[buf * BM * PITCH_H + (wm * TM * 32 + r) * PITCH_H + 8 * h + ks * 16];
-        const __bf16* bp = &Bh[buf * BN * PITCH_H + (wn * 32 + r) * PITCH_H + 8 * h + ks * 16];
-        bf16x8 a[TM], b[TN];
+        const H16* ap = &Ah[buf * BM * PITCH_H + (wm * TM * 32 + r) * PITCH_H + 8 * h + ks * 16];
+        const H16* bp = &Bh[buf * BN * PITCH_H + (wn * 32 + r) * PITCH_H + 8 * h + ks * 16];
+        h16x8 a[TM], b[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(ap + i * 32 * PITCH_H);
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const h16x8*>(ap + i * 32 * PITCH_H);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(bp + j * WN * 32 * PITCH_H);
+        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const h16x8*>(bp + j * WN * 32 * PITCH_H);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (DT == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
     };
     auto mma = [&](int buf, int ks) __attribute__((always_inline)) {
         const float* ap = &As[buf * BM * PITCH + (wm * TM * 32 + r) * PITCH + 4 * h];
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) gload(kt + 1);
-        if constexpr (DT == 1) {
+        if constexpr (DT != 0) {
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) mma_h(0, ks);
         } else {
@@ -601,8 +607,14 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
     if (p.bf16) {
         {
             ProfScope prof(tag, conv_bytes, conv_flops, st);
-            if (S > 1) hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 1, 1>), dim3(p.mtiles * p.ntiles, S, G), block, 0, st, p);
-            else hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 0, 1>), dim3(p.mtiles * p.ntiles, 1, G), block, 0, st, p);
+            const dim3 grid(p.mtiles * p.ntiles, S, G);
+            if (p.bf16 == 2) {
+                if (S > 1) hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 1, 2>), grid, block, 0, st, p);
+                else hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 0, 2>), grid, block, 0, st, p);
+            } else {
+                if (S > 1) hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 1, 1>), grid, block, 0, st, p);
+                else hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 0, 1>), grid, block, 0, st, p);
+            }
         }
         if (S > 1) reduce(S);
         QB_CHECK(hipGetLastError());

@@ -252,7 +252,7 @@ struct Builder {
         p.relu = relu;
         p.kmode = kmode;
         p.skip_rows = skip_rows;
-        p.bf16 = c->cfg.compute_dtype == 1;
+        p.bf16 = c->cfg.compute_dtype;
         p.in_gs = in.gs; p.out_gs = out.gs; p.res_gs = res ? res->gs : 0;
         p.w_gs = (long)Cout * Kpad; p.ss_gs = Cout;
         p.ohw = OH * OW;
@@ -866,7 +866,7 @@ int check_cfg(const quber_config& c) {
     if (c.res5_dilation == 1) return fail("res5_dilation 1 (output stride 32) is not supported by this build");
     if (c.error_classes < 2 || c.error_classes > 4) return fail("error_classes must be 2..4");
     if (c.streams != 1 && c.streams != 2) return fail("streams must be 1 or 2");
-    if (c.compute_dtype != 0 && c.compute_dtype != 1) return fail("compute_dtype must be 0 (fp32) or 1 (bf16 operands, fp32 accumulation)");
+    if (c.compute_dtype < 0 || c.compute_dtype > 2) return fail("compute_dtype must be 0 (fp32), 1 (bf16 operands) or 2 (fp16 operands)");
     if (c.with_network && c.hierarchical) {
         if (c.n_levels < 1 || c.n_levels > 5) return fail("n_levels must be 1..5");
         int seen[5] = {0, 0, 0, 0, 0};
@@ -1022,7 +1022,7 @@ void quber_set_tuning(int32_t key, int32_t value) {
         }
     }
     if (key == 4) g_force_tile = value;    // force the tile shape: 1 = 64x64, 2 = 128x128, 4 = 256x32 (0 = automatic)
-    if (key == 12) g_op_bf16 = value;         // stand-alone conv op: bf16 operands, fp32 accumulation
+    if (key == 12) g_op_bf16 = value;         // stand-alone conv op: 1 = bf16, 2 = fp16 operands, fp32 accumulation
     if (key == 11) g_op_skip_rows = value;    // stand-alone conv op: tap-major K order with padded filter rows skipped (dilated 3x3)
     if (key == 10) g_wino_min_cout = value;   // smallest output width eligible for the Winograd path (default 32)
     if (key == 9) g_wino_variant = value;     // Winograd output tile edge for the eligible layers: 0 = automatic (4 or 2), 2, 4, 6 (opt-in)
@@ -1188,6 +1188,16 @@ int quber_label_contingency(const int32_t* pred, const int32_t* gt, int64_t n_pi
     return launch_contingency(pred, gt, n_pixels, cap, workspace, (hipStream_t)stream);
 }
 
+int64_t quber_boundary_workspace_bytes(int32_t h, int32_t w, int32_t n_masks) {
+    return (int64_t)boundary_ws_bytes(h, w, n_masks);
+}
+
+int quber_boundary_overlap(const int32_t* pred, const int32_t* gt, int32_t h, int32_t w, const int32_t* labels, int32_t n_pred,
+                           int32_t n_gt, int32_t bound_pix, void* workspace, uint32_t* out, void* stream) {
+    if (!pred || !gt || !labels || !workspace || !out || h < 1 || w < 1) return fail("bad argument to quber_boundary_overlap");
+    return launch_boundary_overlap(pred, gt, h, w, labels, n_pred, n_gt, bound_pix, workspace, out, (hipStream_t)stream);
+}
+
 int quber_foreground_filter(const float* fg_logits, int32_t n_classes, int32_t fg_class, const uint8_t* masks,
                             int32_t batch, int32_t n_masks, int64_t hw, uint8_t* fg_mask, uint64_t* counts, void* stream) {
     if (!fg_logits || !fg_mask || batch < 1 || hw < 1 || n_classes < 2) return fail("bad argument to quber_foreground_filter");
@@ -1203,6 +1213,12 @@ int quber_normalize_depth(const void* depth, int32_t is_float32, int64_t n_pixel
     if (!depth || !out3 || n_pixels <= 0) return fail("bad argument to quber_normalize_depth");
     if (!(max_val > min_val)) return fail("normalize_depth: max_val must exceed min_val");
     return launch_normalize_depth(depth, is_float32, n_pixels, min_val, max_val, out3, zero, (hipStream_t)stream);
+}
+
+int quber_resize_u8(const uint8_t* src, int32_t src_h, int32_t src_w, int32_t channels, uint8_t* dst, int32_t dst_h,
+                    int32_t dst_w, int32_t linear, void* stream) {
+    if (!src || !dst) return fail("bad argument to quber_resize_u8");
+    return launch_resize_u8(src, src_h, src_w, channels, dst, dst_h, dst_w, linear, (hipStream_t)stream);
 }
 
 int quber_debug_tensor(quber_ctx* c, const char* name, float** ptr, int32_t* dims4, int32_t* cs) {

@@ -81,6 +81,16 @@ def normalize_depth(depth, min_val=250.0, max_val=1500.0):
     return out, zero
 
 
+def resize_u8(img, dh, dw, linear=True):
+    """cv2.resize(img, (dw, dh), interpolation=INTER_LINEAR | INTER_NEAREST) on the device: img u8 [H,W] or [H,W,C] tensor."""
+    lib = _lib.load()
+    assert img.is_cuda and img.dtype == torch.uint8 and img.is_contiguous() and img.dim() in (2, 3)
+    ch = 1 if img.dim() == 2 else img.shape[2]
+    out = torch.empty((dh, dw) + (() if img.dim() == 2 else (ch,)), dtype=torch.uint8, device=img.device)
+    _lib.check(lib.quber_resize_u8(_ptr(img), img.shape[0], img.shape[1], ch, _ptr(out), dh, dw, int(bool(linear)), _stream()))
+    return out
+
+
 class Engine:
     """One context on the current device.  All methods are asynchronous on torch's current stream."""
 

@@ -1,10 +1,12 @@
-"""Drop-in for the overlap part of the reference's ``eval/evaluation.py:multilabel_metrics`` (lines 57-274): Objects
-P / R / F, their object-size-normalised variants, F@.75 detection counts and the IoU measures, with all pairwise
-overlap counts produced by ONE pass of a HIP kernel over the two label maps instead of one numpy pass per pair.
+"""Drop-in for the reference's ``eval/evaluation.py:multilabel_metrics`` (lines 57-274): Objects P / R / F, their
+object-size-normalised variants, F@.75 detection counts, the IoU measures and the Boundary P / R / F.  All pairwise overlap
+counts come from ONE pass of a HIP kernel over the two label maps instead of one numpy pass per pair; the boundary
+true-positive counts of every pair (evaluation.py:21-54) come from three launches on bit planes (csrc/boundary.hip:
+seg2bmap as an outside flood fill + 4-neighbour test, disk dilation as shifted ORs).
 
-The boundary measures need OpenCV contours and skimage disks (evaluation.py:21-54, utilities.py:672-697) and are not
-built: ``compute_boundary_stuff`` must be False and the Boundary entries are None, exactly what the reference returns
-for that flag."""
+The overlap half reproduces the imported reference bit for bit (tests/golden/metrics_*.npz).  The boundary half restates
+cv2.findContours / drawContours / dilate and skimage's disk from their published algorithms (neither library is in the
+image): parity unpinned."""
 import ctypes as C
 
 import numpy as np
@@ -62,10 +64,30 @@ def _degenerate(p, r, f, num_pred, num_gt, pct):
             'obj_detected_075_percentage': pct, 'obj_detected_075_percentage_normalized': pct}
 
 
-def multilabel_metrics(prediction, gt, i=0, N=0, obj_detect_threshold=0.75, compute_boundary_stuff=False, verbose=False,
+def boundary_counts(prediction, gt, labels_pred, labels_gt, bound_th=0.003, device="cuda:0"):
+    """-> (bound_counts_pred [n_pred], bound_counts_gt [n_gt], precision_tps [n_gt, n_pred], recall_tps [n_gt, n_pred]) as
+    float64, for the given object labels (evaluation.py:165-175 and :21-54 for every pair)."""
+    lib = _lib.load()
+    prediction, gt = np.asarray(prediction), np.asarray(gt)
+    h, w = prediction.shape
+    n_pred, n_gt = len(labels_pred), len(labels_gt)
+    bound_pix = int(bound_th if bound_th >= 1 else np.ceil(bound_th * np.linalg.norm(prediction.shape)))
+    p = torch.as_tensor(np.ascontiguousarray(prediction)).to(device=device, dtype=torch.int32).contiguous()
+    g = torch.as_tensor(np.ascontiguousarray(gt)).to(device=device, dtype=torch.int32).contiguous()
+    labels = torch.as_tensor(np.concatenate([labels_pred, labels_gt]).astype(np.int32)).to(device)
+    ws = torch.empty(lib.quber_boundary_workspace_bytes(h, w, n_pred + n_gt), dtype=torch.uint8, device=device)
+    out = torch.empty(n_pred + n_gt + 2 * n_pred * n_gt, dtype=torch.int32, device=device)
+    _lib.check(lib.quber_boundary_overlap(C.c_void_p(p.data_ptr()), C.c_void_p(g.data_ptr()), h, w, C.c_void_p(labels.data_ptr()),
+                                          n_pred, n_gt, bound_pix, C.c_void_p(ws.data_ptr()), C.c_void_p(out.data_ptr()),
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    o = out.cpu().numpy().astype(np.float64)
+    nm = n_pred + n_gt
+    return (o[:n_pred], o[n_pred:nm], o[nm:nm + n_gt * n_pred].reshape(n_gt, n_pred),
+            o[nm + n_gt * n_pred:].reshape(n_gt, n_pred))
+
+
+def multilabel_metrics(prediction, gt, i=0, N=0, obj_detect_threshold=0.75, compute_boundary_stuff=True, verbose=False,
                        device="cuda:0"):
-    if compute_boundary_stuff:
-        raise NotImplementedError("quber_amd: boundary measures need OpenCV / skimage (evaluation.py:21-54); not built")
     lp, lg, table = contingency(prediction, gt, device)
     area_pred, area_gt = table.sum(axis=0), table.sum(axis=1)     # incl. the background row / column
     kp, kg = lp != BACKGROUND_LABEL, lg != BACKGROUND_LABEL
@@ -96,11 +118,22 @@ def multilabel_metrics(prediction, gt, i=0, N=0, obj_detect_threshold=0.75, comp
         f_measure = (2 * precision * recall) / (precision + recall)
         if np.isnan(f_measure):
             f_measure = 0
+        b = dict.fromkeys(("F", "P", "R", "Fo", "Po", "Ro"))
+        if compute_boundary_stuff:                                   # evaluation.py:165-175, 200-206, 232-243
+            bc_pred, bc_gt, ptps, rtps = boundary_counts(prediction, gt, lp[kp], lg[kg], device=device)
+            bP, bR = ptps / bc_pred[None, :], rtps / bc_gt[:, None]
+            bF = (2 * bP * bR) / (bP + bR)
+            bF[np.isnan(bF)] = 0
+            b["P"], b["R"] = np.sum(ptps[idx]) / np.sum(bc_pred), np.sum(rtps[idx]) / np.sum(bc_gt)
+            b["F"] = (2 * b["P"] * b["R"]) / (b["P"] + b["R"])
+            if np.isnan(b["F"]):
+                b["F"] = 0
+            b["Fo"], b["Po"], b["Ro"] = np.sum(bF[idx]) / max(num_pred, num_gt), np.sum(bP[idx]) / num_pred, np.sum(bR[idx]) / num_gt
         out = {'Objects F-measure': f_measure, 'Objects Precision': precision, 'Objects Recall': recall,
-               'Boundary F-measure': None, 'Boundary Precision': None, 'Boundary Recall': None,
+               'Boundary F-measure': b["F"], 'Boundary Precision': b["P"], 'Boundary Recall': b["R"],
                'Objects OSN F-measure': np.sum(F[idx]) / max(num_pred, num_gt),
                'Objects OSN Precision': np.sum(P[idx]) / num_pred, 'Objects OSN Recall': np.sum(R[idx]) / num_gt,
-               'Boundary OSN F-measure': None, 'Boundary OSN Precision': None, 'Boundary OSN Recall': None,
+               'Boundary OSN F-measure': b["Fo"], 'Boundary OSN Precision': b["Po"], 'Boundary OSN Recall': b["Ro"],
                'obj_detected': num_pred, 'obj_detected_075': detected, 'obj_gt': num_gt,
                'obj_detected_075_percentage': detected / num_gt,
                'obj_detected_075_percentage_normalized': detected / max(num_gt, num_pred),

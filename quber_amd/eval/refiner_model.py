@@ -2,23 +2,31 @@
 ``MaskRefiner(config_file, weights_file, dataset).predict(rgb_path, depth_path, initial_masks, fg_mask)
 -> (refined_masks bool [K,H,W] | [], output dict, seconds, fg_mask)``.
 
-Built: file loading, resize to 640x480, ``normalize_depth`` (eval/preprocess_utils.py:12-28; on the device for
-uint16 / float32 depth, bit-exact against the imported reference function), nearest depth resize, the HIP predictor,
-the OCID zero-depth masking (refiner_model.py:279-288).
-The ``dataset == 'armbench'`` branch (refiner_model.py:226-244: RGB only, shortest edge 800 / longest 1333, nearest
-resize of the masks) is built too; any frame size is accepted by the HIP path.
-The LMFFNet foreground post-filter (refiner_model.py:273-277) runs on the HIP path too when ``foreground_filter=True``
-(the reference always applies it; it is opt-in here because the reference's ``rgbd_lmffnet.pth`` is not available and
-seeded weights give a meaningless foreground).
-Not built: ``cv2.inpaint`` TELEA depth in-painting (zero-depth pixels are left at 0 here; frames without
-zero depth are unaffected because the reference only rewrites zero pixels, preprocess_utils.py:63).  cv2 / imageio are absent, so images are read with PIL and resized with PIL's
-bilinear filter, which is not bit-identical to cv2.resize.
+Built, all on the device: ``cv2.resize`` of the BGR image to 640x480 (INTER_LINEAR, OpenCV's 8-bit fixed-point path,
+``quber_resize_u8``), ``normalize_depth`` (eval/preprocess_utils.py:12-28; bit-exact against the imported reference
+function), the nearest depth / mask resizes, the HIP predictor, the LMFFNet foreground post-filter (refiner_model.py:
+273-277) and the OCID zero-depth masking (refiner_model.py:279-288).  The ``dataset == 'armbench'`` branch
+(refiner_model.py:226-244: RGB only, shortest edge 800 / longest 1333, nearest resize of the masks) is built too.
+
+Return semantics follow the reference exactly: the foreground filter decides which masks survive only for
+``dataset == 'OCID'`` (refiner_model.py:279-288 is the only place ``filt_masks`` is returned); every other dataset gets
+the unfiltered refined masks plus the foreground mask.  The reference always constructs ``lmffNet()``; here the filter
+is opt-in (``foreground_filter=True``) because the reference's ``rgbd_lmffnet.pth`` does not ship and seeded weights give
+a meaningless foreground - with it off, ``fg_mask`` is None and the OCID branch masks zero depth on the unfiltered masks.
+
+Not built: ``inpaint_depth`` (eval/preprocess_utils.py:44-64, ``cv2.inpaint`` TELEA - a fast-marching algorithm with no
+source in the reference; it rewrites the pixels whose NORMALISED depth is 0, i.e. holes and everything nearer than
+``min_val``).  Such pixels are left at 0 and a warning is raised once per adapter; frames without them are unaffected.
+cv2 / imageio are absent from the image, so files are read with PIL.
 """
 import time
+import warnings
 
 import numpy as np
+import torch
 from PIL import Image
 
+from .. import engine as qengine
 from ..maskrefiner.predictor import MaskRefinerPredictor
 
 W = 640
@@ -32,12 +40,6 @@ def normalize_depth(depth, min_val=250.0, max_val=1500.0):
     if depth.ndim == 2:
         depth = depth[..., None]
     return np.uint8(np.repeat(depth, 3, -1))
-
-
-def _resize_nearest(img, w, h):
-    ys = (np.arange(h) * (img.shape[0] / h)).astype(np.int64).clip(0, img.shape[0] - 1)
-    xs = (np.arange(w) * (img.shape[1] / w)).astype(np.int64).clip(0, img.shape[1] - 1)
-    return img[ys][:, xs]
 
 
 def resize_shortest_edge_shape(oldh, oldw, short_edge_length=800, max_size=1333):
@@ -56,40 +58,47 @@ class MaskRefiner:
         self.refiner_predictor = MaskRefinerPredictor(config_file, weights_file=weights_file, device=device)
         self.dataset = dataset
         self.lmffnet = None
+        self._warned_inpaint = False
         if foreground_filter:
             from ..foreground.predictor import lmffNet
             self.lmffnet = lmffNet(lmffnet_weights, device=device)
 
+    def _dev(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(self.refiner_predictor.device)
+
+    def _resize(self, img, h, w, linear):
+        """cv2.resize(img, (w, h)) on the device; img: numpy u8 [H,W] / [H,W,C]."""
+        if img.shape[:2] == (h, w):
+            return np.ascontiguousarray(img)
+        return qengine.resize_u8(self._dev(img), h, w, linear).cpu().numpy()
+
     def predict(self, rgb_path, depth_path, initial_masks, fg_mask=None):
         rgb = np.asarray(Image.open(rgb_path).convert("RGB"))[:, :, ::-1]        # BGR like cv2.imread
+        initial_masks = np.asarray(initial_masks)
+        if initial_masks.dtype == np.bool_:
+            initial_masks = np.uint8(initial_masks) * 255
         if self.dataset == "armbench":
             h, w = resize_shortest_edge_shape(rgb.shape[0], rgb.shape[1], 800, 1333)
-            rgb = np.asarray(Image.fromarray(np.ascontiguousarray(rgb)).resize((w, h), Image.BILINEAR))
-            initial_masks = np.asarray(initial_masks)
-            if initial_masks.dtype == np.bool_:
-                initial_masks = np.uint8(initial_masks) * 255
-            initial_masks = np.array([_resize_nearest(m, w, h) for m in initial_masks])
+            rgb = self._resize(rgb, h, w, linear=True)                           # cv2.resize(rgb_img, (w, h))
+            initial_masks = np.array([self._resize(m, h, w, linear=False) for m in initial_masks])   # INTER_NEAREST
             start = time.time()
             output = self.refiner_predictor.predict(np.ascontiguousarray(rgb), None, initial_masks)[0]
             refined = output["instances"].to("cpu").pred_masks.numpy() if "instances" in output else []
             return refined, output, time.time() - start, None
         depth = np.load(depth_path) if "npy" in depth_path else np.asarray(Image.open(depth_path))
-        if rgb.shape[:2] != (H, W):
-            rgb = np.asarray(Image.fromarray(np.ascontiguousarray(rgb)).resize((W, H), Image.BILINEAR))
+        rgb = self._resize(rgb, H, W, linear=True)                               # cv2.resize(rgb_img, (W, H))
         zero_depth = np.where(depth == 0)
         lo, hi = (0.25, 1.5) if "npy" in depth_path else (250.0, 1500.0)
         if depth.ndim == 2 and depth.dtype in (np.uint16, np.float32):
-            import torch
-            from .. import engine as qengine
-            d = torch.from_numpy(np.array(depth)).to(self.refiner_predictor.device)
-            depth = qengine.normalize_depth(d, lo, hi)[0].cpu().numpy()
+            depth = qengine.normalize_depth(self._dev(np.array(depth)), lo, hi)[0].cpu().numpy()
         else:
             depth = normalize_depth(depth, lo, hi)
-        if depth.shape[:2] != (H, W):
-            depth = _resize_nearest(depth, W, H)
-        initial_masks = np.asarray(initial_masks)
-        if initial_masks.dtype == np.bool_:
-            initial_masks = np.uint8(initial_masks) * 255
+        depth = self._resize(depth, H, W, linear=False)                          # cv2.resize(..., INTER_NEAREST)
+        if not self._warned_inpaint and bool((depth[..., 0] == 0).any()):
+            warnings.warn("quber_amd: the depth image has pixels at or below the minimum range (normalised depth 0); the "
+                          "reference in-paints them (cv2.inpaint TELEA, eval/preprocess_utils.py:44-64), this build leaves "
+                          "them at 0")
+            self._warned_inpaint = True
 
         start = time.time()
         output = self.refiner_predictor.predict(np.ascontiguousarray(rgb), depth, initial_masks)[0]
@@ -97,21 +106,21 @@ class MaskRefiner:
             refined = []
         else:
             refined = output["instances"].to("cpu").pred_masks.numpy()
-        fg = None
+        fg, filt = None, refined
         if self.lmffnet is not None:
-            import torch
             from ..foreground.predictor import filter_masks
-            dev = self.refiner_predictor.device
-            b = torch.from_numpy(np.ascontiguousarray(rgb)[None]).to(dev)
-            d = torch.from_numpy(np.ascontiguousarray(depth)[None]).to(dev)
-            m = torch.from_numpy(np.ascontiguousarray(refined, dtype=np.uint8)[None]).to(dev) if len(refined) else None
-            fg_t, counts = self.lmffnet.net.foreground(b, d, m)
+            m = self._dev(np.ascontiguousarray(refined, dtype=np.uint8)[None]) if len(refined) else None
+            fg_t, counts = self.lmffnet.net.foreground(self._dev(rgb[None]), self._dev(depth[None]), m)
             fg = fg_t[0].cpu().numpy().astype(bool)
             if len(refined):
-                refined = np.asarray(filter_masks(refined, counts[0]))
+                filt = np.asarray(filter_masks(refined, counts[0]))              # inter / area > 0.3 (refiner_model.py:274-276)
         elapsed = time.time() - start
-        if self.dataset == "OCID" and len(refined):
-            refined = refined.copy()
-            for m in refined:
+        if self.dataset == "OCID":
+            # refiner_model.py:279-288: only here do the FILTERED masks (minus zero-depth pixels) replace refined_masks
+            out = []
+            for m in filt:
+                m = m.copy()
                 m[zero_depth] = False
+                out.append(m)
+            refined = np.asarray(out)
         return refined, output, elapsed, fg

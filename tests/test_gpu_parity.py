@@ -326,8 +326,21 @@ def test_normalize_depth_full_frame_vs_oracle():
     np.testing.assert_array_equal(out.cpu().numpy(), adapter_np.normalize_depth(f, 0.25, 1.5))
 
 
+@pytest.mark.parametrize("sh,sw,ch,dh,dw", [(720, 1280, 3, 480, 640), (960, 1280, 3, 480, 640), (480, 640, 3, 800, 1067),
+                                            (37, 53, 1, 91, 29), (480, 640, 3, 480, 640)])
+def test_resize_u8_vs_restatement(sh, sw, ch, dh, dw):
+    """quber_resize_u8 (cv2.resize INTER_LINEAR / INTER_NEAREST, uint8) against the numpy restatement, bit-exact."""
+    from oracle import adapter_np
+    rng = np.random.default_rng(sh + dw)
+    img = rng.integers(0, 256, (sh, sw, ch) if ch > 1 else (sh, sw)).astype(np.uint8)
+    lin = engine.resize_u8(dev(img), dh, dw, linear=True).cpu().numpy()
+    np.testing.assert_array_equal(lin, adapter_np.cv2_resize_linear_u8(img, dw, dh))
+    near = engine.resize_u8(dev(img), dh, dw, linear=False).cpu().numpy()
+    np.testing.assert_array_equal(near, adapter_np.cv2_resize_nearest(img, dw, dh))
+
+
 # --------------------------------------------------------------------------------------------- kernel-level ops
-def _conv_case(B, H, W, Cin, Cout, k, stride, dil, affine, residual, relu, seed=0, bf16=False):
+def _conv_case(B, H, W, Cin, Cout, k, stride, dil, affine, residual, relu, seed=0, bf16=0):
     lib = _lib.load()
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(B, Cin, H, W, generator=g)
@@ -337,7 +350,8 @@ def _conv_case(B, H, W, Cin, Cout, k, stride, dil, affine, residual, relu, seed=
     sh = torch.randn(Cout, generator=g) if affine else None
     # bf16 mode: the kernel rounds both operands to bf16 (nearest-even) and accumulates in fp32, so the reference is the
     # float64 convolution of the rounded operands
-    xr, wr = (x.bfloat16().double(), wt.bfloat16().double()) if bf16 else (x.double(), wt.double())
+    half = {0: None, 1: torch.bfloat16, 2: torch.float16}[int(bf16)]
+    xr, wr = (x.to(half).double(), wt.to(half).double()) if half else (x.double(), wt.double())
     ref = torch.nn.functional.conv2d(xr, wr, None, stride, pad, dil)
     if affine:
         ref = ref * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
@@ -392,15 +406,16 @@ def test_conv_igemm_vs_torch(case):
     (2, 64, 80, 128, 130, 3, 1, 1, False, False, False),   # 128x128 tiles, ragged N
     (4, 60, 80, 512, 256, 3, 1, 1, True, False, True),     # K = 4608
 ])
-def test_conv_igemm_bf16_vs_rounded_operands(case):
-    """compute_dtype 1 (BASELINE.json configs[4] stand-in): v_mfma_f32_32x32x16_bf16 with fp32 accumulation equals the
-    float64 convolution of the bf16-rounded operands to fp32-accumulation accuracy - i.e. the only error of the mode is
-    the operand rounding itself."""
-    assert _conv_case(*case, bf16=True) < 3e-6
+@pytest.mark.parametrize("dt", [1, 2], ids=["bf16", "fp16"])
+def test_conv_igemm_16bit_vs_rounded_operands(case, dt):
+    """compute_dtype 1 / 2 (BASELINE.json configs[4] stand-in): v_mfma_f32_32x32x16_{bf16,f16} with fp32 accumulation
+    equals the float64 convolution of the rounded operands to fp32-accumulation accuracy - i.e. the only error of the
+    mode is the operand rounding itself."""
+    assert _conv_case(*case, bf16=dt) < 3e-6
     lib = _lib.load()
     lib.quber_set_tuning(2, 1)
     try:
-        assert _conv_case(*case, bf16=True) < 3e-6          # with the split-K workspace
+        assert _conv_case(*case, bf16=dt) < 3e-6          # with the split-K workspace
     finally:
         lib.quber_set_tuning(2, 0)
 

@@ -127,3 +127,20 @@ def test_munkres_matches_vendored_solver():
     for k in z.files:
         m = z[k]
         assert [list(a) for a in munkres_assign(m.max() - m)] == exp[k], k
+
+
+def test_cv2_resize_restatement_hand_derived():
+    """OpenCV's 8-bit resize, restated (parity unpinned: no cv2 in the image).  Hand-derived cases:
+    * 2 -> 4 columns of [0, 100]: fx = -0.25 (clamped: 0), 0.25, 0.75, 1.25 (clamped: 100)  -> weights 2048/0, 1536/512,
+      512/1536, 2048/0 -> horizontal 0, 51200, 153600, 204800 -> (((2048 * (h >> 4)) >> 16) + 2) >> 2 = 0, 25, 75, 100
+    * exactly half scale in both directions = the 2x2 area filter (a + b + c + d + 2) >> 2
+    * nearest: sx = floor(dx * sw / dw), the last source column / row clamped"""
+    np.testing.assert_array_equal(adapter_np.cv2_resize_linear_u8(np.array([[0, 100]], np.uint8), 4, 1), [[0, 25, 75, 100]])
+    img = np.array([[10, 20, 30, 40], [50, 60, 70, 81]], np.uint8)
+    np.testing.assert_array_equal(adapter_np.cv2_resize_linear_u8(img, 2, 1), [[(10 + 20 + 50 + 60 + 2) >> 2, (30 + 40 + 70 + 81 + 2) >> 2]])
+    np.testing.assert_array_equal(adapter_np.cv2_resize_nearest(np.arange(12).reshape(3, 4), 6, 5)[:, [0, 1, 2, 5]],
+                                  [[0, 0, 1, 3], [0, 0, 1, 3], [4, 4, 5, 7], [4, 4, 5, 7], [8, 8, 9, 11]])
+    same = np.random.default_rng(0).integers(0, 256, (7, 9, 3)).astype(np.uint8)
+    np.testing.assert_array_equal(adapter_np.cv2_resize_linear_u8(same, 9, 7), same)      # identity size: weights 2048 / 0
+    # a constant image stays constant through the fixed-point passes
+    assert (adapter_np.cv2_resize_linear_u8(np.full((5, 6), 203, np.uint8), 11, 13) == 203).all()
