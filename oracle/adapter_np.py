@@ -26,7 +26,7 @@ def cv2_resize_nearest(img, dw, dh):
     ifx, ify = 1.0 / (dw / sw), 1.0 / (dh / sh)
     xs = np.minimum(np.floor(np.arange(dw) * ifx).astype(np.int64), sw - 1)
     ys = np.minimum(np.floor(np.arange(dh) * ify).astype(np.int64), sh - 1)
-    return img[ys][:, xs]
+    return np.ascontiguousarray(img[ys][:, xs])
 
 
 def _lin_coef(dsize, ssize):

@@ -117,6 +117,31 @@ def main():
         gen_metrics()
     if "post" in what:
         gen_post()
+    if "raster" in what or "post" in what:
+        gen_group_raster()
+
+
+def gen_group_raster():
+    """group_raster_*.npz: K = 20 / 199 centres as the reference itself enumerates them - find_instance_center on a centre
+    map with K isolated peaks (raster order) - fed to group_pixels with large random offsets.  The HIP path can only be
+    driven through the centre map, so these are the large-K grouping cases it is checked on."""
+    post = load("ref_post", "maskrefiner/modeling/mask_refiner/post_processing.py")
+    for name, h, w, k, seed, sigma in (("20", 96, 128, 20, 31, 5.0), ("199", 384, 512, 199, 32, 20.0)):
+        rng = np.random.default_rng(seed)
+        c = np.full((h, w), 0.1, np.float32)
+        pts = set()
+        while len(pts) < k:
+            y, x = int(rng.integers(0, h)), int(rng.integers(0, w))
+            if all(max(abs(y - py), abs(x - px)) > 3 for py, px in pts):      # one peak per 7x7 NMS window
+                pts.add((y, x))
+        for i, (y, x) in enumerate(sorted(pts)):
+            c[y, x] = 0.5 + 0.002 * ((i * 37) % k)                             # distinct values, all kept by top-200
+        ct = torch.as_tensor(c).reshape(1, h, w)
+        centers = post.find_instance_center(ct.clone(), threshold=0.3, nms_kernel=7, top_k=200)
+        assert centers.shape[0] == k
+        offsets = torch.as_tensor(rng.normal(0, sigma, (2, h, w)), dtype=torch.float32)
+        out = post.group_pixels(centers, offsets)
+        save("group_raster_" + name, center=c, centers=centers.numpy(), offsets=offsets.numpy(), out=out.numpy().astype(np.int32))
 
 
 def gen_post():

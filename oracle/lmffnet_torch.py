@@ -8,7 +8,10 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from quber_amd.lmff_arch import SEM1_DIL, SEM2_DIL
+# dilation rates of the two SEM-B stacks (foreground_segmentation/lmffnet.py:299, 305); restated here, not imported
+# from the product
+SEM1_DIL = (2, 2, 2)
+SEM2_DIL = (4, 4, 8, 8, 16, 16, 32, 32)
 
 MEAN, STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
 

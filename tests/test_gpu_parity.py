@@ -181,9 +181,12 @@ def test_group_golden(path):
     # fixtures whose centre list is in raster order can be reproduced through a centre map with peaks there
     z = np.load(path)
     h, w = z["offsets"].shape[1:]
-    c = np.full((h, w), 0.1, np.float32)
-    for i, (y, x) in enumerate(z["centers"]):
-        c[y, x] = 0.9
+    if "center" in z.files:                 # group_raster_*: the very centre map the reference's find_instance_center saw
+        c = z["center"]
+    else:
+        c = np.full((h, w), 0.1, np.float32)
+        for i, (y, x) in enumerate(z["centers"]):
+            c[y, x] = 0.9
     _, o, _ = run_post(np.full((h, w), 4.0, np.float32), c, z["offsets"])
     k = int(o["ncenters"])
     np.testing.assert_array_equal(o["centers"][:k], z["centers"])
@@ -263,6 +266,37 @@ def test_multilabel_metrics_golden(path):
     for i, gi in enumerate(lg):
         for j, pj in enumerate(lp):
             assert table[i, j] == np.count_nonzero((z["gt"] == gi) & (z["pred"] == pj))
+
+
+@pytest.mark.parametrize("h,w,n,seed", [(480, 640, 12, 0), (96, 128, 5, 1), (75, 101, 4, 2), (720, 1280, 20, 3)])
+def test_boundary_metrics_vs_oracle(h, w, n, seed):
+    """The boundary half of multilabel_metrics (evaluation.py:21-54, 165-175, 232-243) on the HIP path against the numpy /
+    scipy restatement: every integer count equal, every derived measure equal."""
+    from oracle import metrics_np
+    from quber_amd.eval.evaluation import boundary_counts, multilabel_metrics
+    rng = np.random.default_rng(seed)
+    gtm, initm = synth.make_masks(rng, n, h, w)
+    gt, pred = np.zeros((h, w), np.int64), np.zeros((h, w), np.int64)
+    for i in range(n):
+        gt[gtm[i]] = i + 2
+        pred[initm[i]] = i + 1
+    gt[h // 3:h // 3 + 9, w // 3:w // 3 + 9] = 0                  # a hole with an object nested in it
+    gt[h // 3 + 3:h // 3 + 6, w // 3 + 3:w // 3 + 6] = n + 5
+    pred[:7, :] = 77                                              # an object along the frame
+    lp, lg = np.unique(pred), np.unique(gt)
+    lp, lg = lp[lp != 0], lg[lg != 0]
+    bc_p, bc_g, ptps, rtps = boundary_counts(pred, gt, lp, lg)
+    for j, pj in enumerate(lp):
+        assert bc_p[j] == metrics_np.seg2bmap(pred == pj).sum()
+    for i, gi in enumerate(lg):
+        assert bc_g[i] == metrics_np.seg2bmap(gt == gi).sum()
+        for j, pj in enumerate(lp):
+            assert (ptps[i, j], rtps[i, j]) == metrics_np.boundary_overlap(pred == pj, gt == gi), (gi, pj)
+    got = multilabel_metrics(pred, gt, 0, 1, compute_boundary_stuff=True)
+    exp = metrics_np.multilabel_metrics(pred, gt, compute_boundary_stuff=True)
+    assert set(got) == set(exp)
+    for k, v in exp.items():
+        assert float(got[k]) == float(v), (k, got[k], v)
 
 
 def test_contingency_many_labels_and_errors():

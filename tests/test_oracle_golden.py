@@ -144,3 +144,43 @@ def test_cv2_resize_restatement_hand_derived():
     np.testing.assert_array_equal(adapter_np.cv2_resize_linear_u8(same, 9, 7), same)      # identity size: weights 2048 / 0
     # a constant image stays constant through the fixed-point passes
     assert (adapter_np.cv2_resize_linear_u8(np.full((5, 6), 203, np.uint8), 11, 13) == 203).all()
+
+
+def test_boundary_restatement_hand_derived():
+    """seg2bmap / disk / boundary_overlap (evaluation.py:21-54, utilities.py:672-697) restated without OpenCV / skimage
+    (parity unpinned).  Hand-derived cases for the contour semantics the restatement assumes."""
+    from oracle import metrics_np as M
+    seg = np.zeros((9, 9), np.uint8)
+    seg[2:7, 2:7] = 1
+    exp = seg.copy()
+    exp[3:6, 3:6] = 0
+    np.testing.assert_array_equal(M.seg2bmap(seg), exp)                       # a solid block: its one-pixel rim
+    ring = np.zeros((11, 11), np.uint8)
+    ring[1:10, 1:10] = 1
+    ring[3:8, 3:8] = 0                                                        # a hole ...
+    ring[5, 5] = 1                                                            # ... with an object nested in it
+    b = M.seg2bmap(ring)
+    outer = np.zeros_like(ring)
+    outer[1:10, 1:10] = 1
+    outer[2:9, 2:9] = 0
+    np.testing.assert_array_equal(b, outer)            # RETR_EXTERNAL: neither the hole's border nor the nested object
+    edge = np.zeros((6, 8), np.uint8)
+    edge[0:3, 0:4] = 1                                                        # touches the frame: frame-side pixels are border
+    e = edge.copy()
+    e[1, 1:3] = 0
+    np.testing.assert_array_equal(M.seg2bmap(edge), e)
+    diag = np.zeros((5, 5), np.uint8)
+    diag[1, 1] = diag[2, 2] = 1
+    np.testing.assert_array_equal(M.seg2bmap(diag), diag)
+    corner = np.ones((4, 4), np.uint8)                                         # an inner pixel that only touches the outside
+    corner[0, 0] = 0                                                           # diagonally is not on the 8-connected border
+    c = np.pad(corner, 1)
+    bc = M.seg2bmap(c)
+    assert bc[2, 2] == 0 and bc[1, 2] == 1 and bc[2, 1] == 1
+    assert M.disk(1).sum() == 5 and M.disk(2).sum() == 13 and M.disk(3).sum() == 29 and M.disk(3)[0].tolist() == [0, 0, 0, 1, 0, 0, 0]
+    # two unit squares two pixels apart: every border pixel of one lies inside the other's dilation by disk(3)
+    a, g = np.zeros((12, 16), bool), np.zeros((12, 16), bool)
+    a[4:8, 3:7] = True
+    g[4:8, 5:9] = True
+    assert M.boundary_overlap(a, g, bound_th=3) == (12, 12)
+    assert np.ceil(0.003 * np.linalg.norm((480, 640))) == 3
