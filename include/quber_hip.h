@@ -97,6 +97,16 @@ int quber_weight_spec(quber_ctx* ctx, int index, const char** name, int64_t* num
 int quber_encode_initial_masks(quber_ctx* ctx, const uint8_t* dev_masks, int32_t batch, int32_t n_masks,
                                float* dev_out, void* stream);
 
+/* a1 from a label map: dev_labels i32 [B][H][W] with values 0 (no instance) or 1..n_instances (<= 254), i.e. the n
+ * non-overlapping masks (labels == i + 1); same output as quber_encode_initial_masks on those masks.  Values outside
+ * 0..n_instances count as 0. */
+int quber_encode_label_map(quber_ctx* ctx, const int32_t* dev_labels, int32_t batch, int32_t n_instances, float* dev_out,
+                           void* stream);
+
+/* device bytes the context owns (weights in kernel layout, activations, workspaces).  Everything is allocated by
+ * quber_create / quber_finalize_weights; no hot call allocates. */
+int64_t quber_workspace_bytes(quber_ctx* ctx);
+
 /* a2 - explicit quadruple error maps.  Replaces masks_to_fg_mask / masks_to_boundary
  * (explicit_error_estimation/util.py:62-99) and the TP/TN/FP/FN logic of tools/ours/panoptic2eee.py:110-123.
  *   dev_init u8 [B][N][H][W], dev_gt u8 [B][Ng][H][W]  ->  dev_out u8 [B][2 (region,boundary)][4 (TP,TN,FP,FN)][H][W] */

@@ -41,6 +41,8 @@ SIGNATURES = {
     "quber_num_weights": (C.c_int, [_P]),
     "quber_weight_spec": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64)]),
     "quber_encode_initial_masks": (C.c_int, [_P, _P, _I, _I, _P, _P]),
+    "quber_encode_label_map": (C.c_int, [_P, _P, _I, _I, _P, _P]),
+    "quber_workspace_bytes": (C.c_int64, [_P]),
     "quber_explicit_error_maps": (C.c_int, [_P, _P, _I, _P, _I, _I, _P, _P]),
     "quber_forward": (C.c_int, [_P, _P, _P, _P, _I, _P, _P]),
     "quber_forward_profiled": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, C.POINTER(C.c_double * 3), C.POINTER(_I * 3)]),

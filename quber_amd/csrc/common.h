@@ -151,6 +151,8 @@ size_t contingency_ws_bytes(int cap);
 
 int launch_encode(const uint8_t* masks, int B, int N, int H, int W, const float* gauss, int sigma, int legacy_f32,
                   void* ws, float* out, hipStream_t st);
+int launch_encode_labels(const int* labels, int B, int N, int H, int W, const float* gauss, int sigma, int legacy_f32, void* ws,
+                         float* out, int* bad, hipStream_t st);
 size_t encode_ws_bytes(int B, int N, int H, int W);
 
 int launch_errmaps(const uint8_t* init, int N, const uint8_t* gt, int Ng, int B, int Nmax, int H, int W, int d,

@@ -18,6 +18,11 @@ struct MaskStat {
 
 constexpr int ENC_PIX = 16;  // pixels per lane per mask row
 
+constexpr int ENC_R = 4;     // 16-pixel groups per lane per mask: one wave reduction per 4 KiB of mask bytes
+
+// grid (ceil(HW / (256 * 16 * ENC_R)), B).  A lane owns ENC_R groups of 16 pixels, 1 KiB (one wave load) apart, so every
+// load instruction of a wave is one contiguous KiB; per mask it issues its ENC_R loads back to back, folds them into
+// (count, sum y, sum x) in registers and the wave reduces once.  The last-covering-mask bytes stay in registers throughout.
 __global__ __launch_bounds__(256) void encode_reduce_kernel(const uint8_t* __restrict__ masks, int N, long frame_stride,
                                                             int H, int W, MaskStat* __restrict__ stats,
                                                             uint8_t* __restrict__ last) {
@@ -26,50 +31,63 @@ __global__ __launch_bounds__(256) void encode_reduce_kernel(const uint8_t* __res
     const long HW = (long)H * W;
     for (int i = threadIdx.x; i < N * 3; i += blockDim.x) sm[i] = 0;
     __syncthreads();
-    const long p = ((long)blockIdx.x * blockDim.x + threadIdx.x) * ENC_PIX;
-    const bool active = p < HW;
-    const int y = active ? (int)(p / W) : 0;
-    const int x0 = active ? (int)(p - (long)y * W) : 0;
-    uint8_t lastv[ENC_PIX];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // wave w of block x covers pixels [((x * 4 + w) * ENC_R + r) * 1024 + lane * 16, +16), r = 0..ENC_R-1
+    const long base = ((long)blockIdx.x * 4 + wave) * ENC_R * 1024 + lane * ENC_PIX;
+    int y[ENC_R], x0[ENC_R];
+    bool act[ENC_R];
+    uint4 lastv[ENC_R];
 #pragma unroll
-    for (int j = 0; j < ENC_PIX; ++j) lastv[j] = 0;
-    const uint8_t* src = masks + (long)b * frame_stride + p;
+    for (int r = 0; r < ENC_R; ++r) {
+        const long p = base + (long)r * 1024;
+        act[r] = p < HW;
+        y[r] = act[r] ? (int)(p / W) : 0;
+        x0[r] = act[r] ? (int)(p - (long)y[r] * W) : 0;
+        lastv[r] = make_uint4(0, 0, 0, 0);
+    }
+    const uint8_t* src = masks + (long)b * frame_stride + base;
     for (int n = 0; n < N; ++n) {
-        unsigned cnt = 0, sx = 0;
-        if (active) {
-            const uint4 v = *reinterpret_cast<const uint4*>(src + (long)n * HW);
-            const unsigned wds[4] = {v.x, v.y, v.z, v.w};
+        uint4 v[ENC_R];
 #pragma unroll
-            for (int j = 0; j < ENC_PIX; ++j) {
-                const bool on = ((wds[j >> 2] >> (8 * (j & 3))) & 0xffu) != 0;
-                if (on) {
-                    cnt += 1;
-                    sx += x0 + j;
-                    lastv[j] = (uint8_t)(n + 1);
-                }
+        for (int r = 0; r < ENC_R; ++r)
+            v[r] = act[r] ? *reinterpret_cast<const uint4*>(src + (long)n * HW + (long)r * 1024) : make_uint4(0, 0, 0, 0);
+        unsigned cnt = 0, sx = 0, sy = 0;
+        const unsigned tag = (unsigned)(n + 1);
+#pragma unroll
+        for (int r = 0; r < ENC_R; ++r) {
+            const unsigned wds[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
+            unsigned* lw = &lastv[r].x;
+            unsigned c = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned wd = wds[j];
+                // per byte: 0xff where the mask byte is non-zero
+                const unsigned nz = ((((wd & 0x7f7f7f7fu) + 0x7f7f7f7fu) | wd) & 0x80808080u) >> 7;     // 0x01 per non-zero byte
+                const unsigned full = nz * 0xffu;
+                lw[j] = (lw[j] & ~full) | (full & (tag * 0x01010101u));
+                const unsigned k = __popc(nz);
+                c += k;
+                // sum of the byte positions (0..3) of the set bytes: bits 0, 8, 16, 24 of nz
+                sx += (unsigned)(x0[r] + 4 * j) * k + ((nz >> 8) & 1u) + 2u * ((nz >> 16) & 1u) + 3u * ((nz >> 24) & 1u);
             }
+            cnt += c;
+            sy += c * (unsigned)y[r];
         }
-        unsigned sy = cnt * (unsigned)y;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             cnt += __shfl_down(cnt, o);
             sy += __shfl_down(sy, o);
             sx += __shfl_down(sx, o);
         }
-        if ((threadIdx.x & 63) == 0 && cnt) {
+        if (lane == 0 && cnt) {
             atomicAdd(&sm[n * 3], cnt);
             atomicAdd(&sm[n * 3 + 1], sy);
             atomicAdd(&sm[n * 3 + 2], sx);
         }
     }
-    if (active) {
-        uint4 o;
-        unsigned* ow = &o.x;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            ow[k] = lastv[4 * k] | (lastv[4 * k + 1] << 8) | (lastv[4 * k + 2] << 16) | ((unsigned)lastv[4 * k + 3] << 24);
-        *reinterpret_cast<uint4*>(last + (long)b * HW + p) = o;
-    }
+    for (int r = 0; r < ENC_R; ++r)
+        if (act[r]) *reinterpret_cast<uint4*>(last + (long)b * HW + base + (long)r * 1024) = lastv[r];
     __syncthreads();
     for (int i = threadIdx.x; i < N * 3; i += blockDim.x)
         if (sm[i]) atomicAdd(&(&stats[(long)b * N].cnt)[i], (unsigned long long)sm[i]);
@@ -175,6 +193,48 @@ __global__ __launch_bounds__(256) void encode_paint_kernel(const MaskStat* __res
     o[2 * HW] = ox;
 }
 
+// Label-map input: labels[p] in 1..N names the one mask covering pixel p (0 = none), i.e. N non-overlapping
+// masks m_i = (labels == i + 1).  A lane walks 16 consecutive pixels, folds runs of equal labels in registers and adds each
+// run's (count, sum y, sum x) to the block's LDS table; the index map is the label itself.
+__global__ __launch_bounds__(256) void encode_label_reduce_kernel(const int* __restrict__ labels, int N, int H, int W,
+                                                                  MaskStat* __restrict__ stats, uint8_t* __restrict__ last,
+                                                                  int* __restrict__ bad) {
+    extern __shared__ unsigned int sm[];  // [N][3]
+    const int b = blockIdx.y;
+    const long HW = (long)H * W;
+    for (int i = threadIdx.x; i < N * 3; i += blockDim.x) sm[i] = 0;
+    __syncthreads();
+    const long p0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    int run = 0;
+    unsigned cnt = 0, sy = 0, sx = 0;
+    auto flush = [&]() {
+        if (run > 0 && cnt) {
+            atomicAdd(&sm[(run - 1) * 3], cnt);
+            atomicAdd(&sm[(run - 1) * 3 + 1], sy);
+            atomicAdd(&sm[(run - 1) * 3 + 2], sx);
+        }
+        cnt = sy = sx = 0;
+    };
+    for (int j = 0; j < 16; ++j) {
+        const long p = p0 + j;
+        if (p >= HW) break;
+        int l = labels[(long)b * HW + p];
+        if (l < 0 || l > N) { *bad = 1; l = 0; }
+        last[(long)b * HW + p] = (uint8_t)l;
+        if (l != run) { flush(); run = l; }
+        if (l > 0) {
+            const int y = (int)(p / W);
+            cnt += 1;
+            sy += (unsigned)y;
+            sx += (unsigned)(p - (long)y * W);
+        }
+    }
+    flush();
+    __syncthreads();
+    for (int i = threadIdx.x; i < N * 3; i += blockDim.x)
+        if (sm[i]) atomicAdd(&(&stats[(long)b * N].cnt)[i], (unsigned long long)sm[i]);
+}
+
 constexpr int ENC_CHUNK = 254;     // masks per pass: the last-covering-mask map is one byte per pixel (0 = none)
 
 size_t encode_ws_bytes(int B, int N, int H, int W) {
@@ -201,7 +261,7 @@ int launch_encode(const uint8_t* masks, int B, int N, int H, int W, const float*
         {
             ProfScope prof("encode_reduce", (double)B * HW * (n + 1.0), 0.0, st);      // every mask byte once + the 1 B/px index map
             if (W % ENC_PIX == 0 && ((uintptr_t)m & 15) == 0 && (HW & 15) == 0) {
-                const int blocks = (int)((HW / ENC_PIX + 255) / 256);
+                const int blocks = (int)((HW + 256L * ENC_PIX * ENC_R - 1) / (256L * ENC_PIX * ENC_R));
                 hipLaunchKernelGGL(encode_reduce_kernel, dim3(blocks, B), dim3(256), sizeof(unsigned) * 3 * n, st, m, n,
                                    (long)N * HW, H, W, stats, last);
             } else {
@@ -216,6 +276,29 @@ int launch_encode(const uint8_t* masks, int B, int N, int H, int W, const float*
                            H, W, 3 * sigma + 1, legacy_f32, c0 > 0 ? 1 : 0, out);
         QB_CHECK(hipGetLastError());
     }
+    return 0;
+}
+
+int launch_encode_labels(const int* labels, int B, int N, int H, int W, const float* gauss, int sigma, int legacy_f32, void* ws,
+                         float* out, int* bad, hipStream_t st) {
+    if (N < 0 || N > ENC_CHUNK) return fail("encode (label map): 0..254 instances per frame");
+    const long HW = (long)H * W;
+    uint8_t* last = reinterpret_cast<uint8_t*>(ws);
+    MaskStat* stats = reinterpret_cast<MaskStat*>(last + (((size_t)B * HW + 15) & ~(size_t)15));
+    if (N == 0) return launch_zero(out, sizeof(float) * 3 * HW * B, st);
+    if (int rc = launch_zero(stats, sizeof(MaskStat) * (size_t)B * N, st)) return rc;
+    if (int rc = launch_zero(bad, sizeof(int), st)) return rc;
+    {
+        ProfScope prof("encode_label_reduce", (double)B * HW * 5.0, 0.0, st);
+        hipLaunchKernelGGL(encode_label_reduce_kernel, dim3((int)((HW + 4095) / 4096), B), dim3(256), sizeof(unsigned) * 3 * N, st,
+                           labels, N, H, W, stats, last, bad);
+    }
+    QB_CHECK(hipGetLastError());
+    ProfScope prof("encode_paint", (double)B * HW * 13.0, 0.0, st);
+    const size_t sm2 = (size_t)N * (2 * sizeof(double) + 2 * sizeof(int));
+    hipLaunchKernelGGL(encode_paint_kernel, dim3((int)((HW + 255) / 256), B), dim3(256), sm2, st, stats, last, gauss, N, H, W,
+                       3 * sigma + 1, legacy_f32, 0, out);
+    QB_CHECK(hipGetLastError());
     return 0;
 }
 

@@ -94,6 +94,8 @@ struct quber_ctx {
     std::map<std::string, std::vector<float>> hostw;
     std::vector<std::pair<std::string, int64_t>> specs;
     std::vector<void*> allocs;
+    size_t alloc_bytes = 0;       // device bytes owned by the context (quber_workspace_bytes)
+    int* enc_bad = nullptr;       // out-of-range flag of the label-map encoder
     std::vector<Op> ops;
     std::map<std::string, View> taps;
     float* gauss = nullptr;
@@ -178,6 +180,7 @@ struct Builder {
             return nullptr;
         }
         c->allocs.push_back(p);
+        c->alloc_bytes += bytes ? bytes : 16;
         if (hipMemset(p, 0, bytes ? bytes : 16) != hipSuccess && err.empty()) err = "hipMemset of a new buffer failed";
         return p;
     }
@@ -938,6 +941,7 @@ int quber_create(const quber_config* cfg, quber_ctx** out) {
     Builder b(c, false);
     c->gauss = b.upload(g);
     c->enc_ws = b.dalloc_bytes(encode_ws_bytes(B, cfg->max_instances, H, W));
+    c->enc_bad = (int*)b.dalloc_bytes(16);
     c->err_ws = (uint8_t*)b.dalloc_bytes(errmaps_ws_bytes(B, cfg->max_instances > 0 ? cfg->max_instances : 1, H, W));
     c->post_ws = b.dalloc_bytes(postprocess_ws_bytes(B, H, W, cfg->top_k));
     if (!b.err.empty()) {
@@ -1092,6 +1096,16 @@ int quber_encode_initial_masks(quber_ctx* c, const uint8_t* masks, int32_t batch
                          c->cfg.encode_legacy_f32, c->enc_ws, out,
                          (hipStream_t)stream);
 }
+
+int quber_encode_label_map(quber_ctx* c, const int32_t* labels, int32_t batch, int32_t n, float* out, void* stream) {
+    if (check_batch(c, batch)) return -1;
+    if (n > c->cfg.max_instances) return fail("more instances than max_instances");
+    if (!labels && n > 0) return fail("null label map");
+    return launch_encode_labels(labels, batch, n, c->cfg.height, c->cfg.width, c->gauss, c->cfg.gaussian_sigma,
+                                c->cfg.encode_legacy_f32, c->enc_ws, out, c->enc_bad, (hipStream_t)stream);
+}
+
+int64_t quber_workspace_bytes(quber_ctx* c) { return c ? (int64_t)c->alloc_bytes : 0; }
 
 int quber_explicit_error_maps(quber_ctx* c, const uint8_t* init, int32_t n_init, const uint8_t* gt, int32_t n_gt,
                               int32_t batch, uint8_t* out, void* stream) {

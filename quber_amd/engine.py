@@ -170,6 +170,18 @@ class Engine:
         _lib.check(self.lib.quber_encode_initial_masks(self.h, _ptr(masks), B, N, _ptr(out), _stream()))
         return out
 
+    def encode_label_map(self, labels, n, out=None):
+        """labels i32 [B,H,W] (device; 0 = none, 1..n = instance) -> f32 [B,3,H,W], as encode() on the masks (labels == i + 1)."""
+        B = labels.shape[0]
+        assert labels.dtype == torch.int32 and labels.is_contiguous() and labels.shape[1:] == (self.H, self.W)
+        if out is None:
+            out = torch.empty((B, 3, self.H, self.W), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.quber_encode_label_map(self.h, _ptr(labels), B, n, _ptr(out), _stream()))
+        return out
+
+    def workspace_bytes(self):
+        return self.lib.quber_workspace_bytes(self.h)
+
     def error_maps(self, init_masks, gt_masks, out=None):
         B, N = init_masks.shape[:2]
         Ng = gt_masks.shape[1]

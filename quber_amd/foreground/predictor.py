@@ -84,14 +84,18 @@ class lmffNet:
         return fg[0].cpu().numpy().astype(bool)
 
     def predict(self, rgb_path, depth_path):
-        from ..eval.refiner_model import _resize_nearest, normalize_depth
+        from .. import engine as qengine
+        from ..eval.refiner_model import normalize_depth
         bgr = np.asarray(Image.open(rgb_path).convert("RGB"))[:, :, ::-1]
         if "npy" in depth_path:
             depth = normalize_depth(np.load(depth_path), 0.25, 1.5)
         else:
             depth = normalize_depth(np.asarray(Image.open(depth_path)))
-        if bgr.shape[:2] != (H, W):
-            bgr = np.asarray(Image.fromarray(np.ascontiguousarray(bgr)).resize((W, H), Image.BILINEAR))
-        if depth.shape[:2] != (H, W):
-            depth = _resize_nearest(depth, W, H)
-        return self.predict_arrays(bgr, depth)
+
+        def resize(img, linear):                    # cv2.resize(img, (W, H)[, INTER_NEAREST]) on the device
+            if img.shape[:2] == (H, W):
+                return img
+            t = torch.from_numpy(np.ascontiguousarray(img)).to(self.device)
+            return qengine.resize_u8(t, H, W, linear).cpu().numpy()
+
+        return self.predict_arrays(resize(bgr, True), resize(depth, False))

@@ -106,8 +106,9 @@ def test_benchmarked_plan_taps_heads_and_instances(h, w, b, n):
             np.testing.assert_array_equal(pm[i, :k].astype(bool), o["masks"].numpy())
             np.testing.assert_allclose(post["scores"][i, :k].cpu().numpy(), o["scores"].numpy(), rtol=2e-5, atol=1e-6)
         # end to end (HIP logits -> HIP labels) against (oracle logits -> oracle labels): threshold-straddling pixels may flip
-        e = postproc_ref.postprocess(ref["foreground"][i], ref["center"][i], ref["offset"][i])
-        same.append(float((post["panoptic"][i].cpu() == e["panoptic"]).float().mean()))
+        if i % 4 == 0:                      # (the oracle's grouping takes ~1 s per frame on the host: every fourth frame)
+            e = postproc_ref.postprocess(ref["foreground"][i], ref["center"][i], ref["offset"][i])
+            same.append(float((post["panoptic"][i].cpu() == e["panoptic"]).float().mean()))
     assert np.mean(ks) >= 15, ks
     assert min(same) > 0.9999, same
     if b > 1:
@@ -185,6 +186,22 @@ HALF_TOL = {"fp16": dict(dtype=2, taps=1e-2, heads=5e-2, fg_iou=0.99),
             "bf16": dict(dtype=1, taps=8e-2, heads=5e-1, fg_iou=0.96)}
 
 
+_HALF_REF = {}
+
+
+def _half_reference(h, w, b, n):
+    """scene, weights, oracle taps / heads / label maps at 1024x1024 - computed once for both modes (host time)."""
+    if not _HALF_REF:
+        batch, offs, image = _scene(11, b, h, w, n)
+        sd = loud_state_dict(0, image, offs, n)
+        taps = {}
+        with torch.no_grad():
+            ref = _oracle(sd)(image, torch.from_numpy(offs), taps)
+        pans = [postproc_ref.postprocess(ref["foreground"][i], ref["center"][i], ref["offset"][i])["panoptic"] for i in range(b)]
+        _HALF_REF.update(batch=batch, offs=offs, sd=sd, taps=taps, ref=ref, pans=pans)
+    return _HALF_REF
+
+
 @pytest.mark.parametrize("mode", ["fp16", "bf16"])
 def test_half_precision_mode_config5_1024x1024(mode):
     """BASELINE.json configs[4] stand-in (the R50 refiner with 16-bit operands, fp32 accumulation, at 1024x1024):
@@ -193,11 +210,8 @@ def test_half_precision_mode_config5_1024x1024(mode):
     own logits."""
     tol = HALF_TOL[mode]
     h, w, b, n = 1024, 1024, 2, 20
-    batch, offs, image = _scene(11, b, h, w, n)
-    sd = loud_state_dict(0, image, offs, n)
-    taps = {}
-    with torch.no_grad():
-        ref = _oracle(sd)(image, torch.from_numpy(offs), taps)
+    R = _half_reference(h, w, b, n)
+    batch, offs, sd, taps, ref = R["batch"], R["offs"], R["sd"], R["taps"], R["ref"]
     qc = engine.make_config(h, w, max_batch=b, max_instances=n)
     qc.compute_dtype = tol["dtype"]
     eng = engine.Engine(qc, "cuda:0")
@@ -213,11 +227,10 @@ def test_half_precision_mode_config5_1024x1024(mode):
     errs["heads"] = float((got - exp).abs().max())
     ious, same = [], []
     for i in range(b):
-        e = postproc_ref.postprocess(ref["foreground"][i], ref["center"][i], ref["offset"][i])
         pan = post["panoptic"][i].cpu()
-        a, b_ = pan >= 0, e["panoptic"] >= 0
+        a, b_ = pan >= 0, R["pans"][i] >= 0
         ious.append(float((a & b_).sum()) / float((a | b_).sum()))
-        same.append(float((pan == e["panoptic"]).float().mean()))
+        same.append(float((pan == R["pans"][i]).float().mean()))
         o = postproc_ref.postprocess(lgc[i, 0:1], lgc[i, 1:2], lgc[i, 2:4])
         np.testing.assert_array_equal(pan.numpy(), o["panoptic"].numpy())
     print(f"\n[{mode}] errors {errs}, fg IoU {ious}, label maps equal {same}")

@@ -92,6 +92,23 @@ def test_encode_more_than_254_masks():
     e.close()
 
 
+@pytest.mark.parametrize("h,w,n", [(480, 640, 20), (75, 101, 7), (96, 128, 254)])
+def test_encode_label_map_equals_mask_encoding(h, w, n):
+    """quber_encode_label_map: a label map with values 1..n is the n non-overlapping masks (labels == i + 1)."""
+    rng = np.random.default_rng(n)
+    lab = np.zeros((2, h, w), np.int32)
+    for b in range(2):
+        for i in rng.permutation(n):
+            y, x = int(rng.integers(0, h - 4)), int(rng.integers(0, w - 4))
+            lab[b, y:y + int(rng.integers(2, max(3, h // 4))), x:x + int(rng.integers(2, max(3, w // 4)))] = i + 1
+    e = eng_for(h, w)
+    got = e.encode_label_map(dev(lab), n).cpu().numpy()
+    for b in range(2):
+        masks = np.stack([(lab[b] == i + 1) for i in range(n)]).astype(np.uint8)
+        np.testing.assert_array_equal(got[b].view(np.uint32), encode_np.encode_initial_masks(masks).view(np.uint32))
+    assert e.workspace_bytes() > 0
+
+
 def test_encode_zero_masks_and_errors():
     e = eng_for(96, 128)
     out = e.encode(torch.zeros((2, 0, 96, 128), dtype=torch.uint8, device="cuda"))
