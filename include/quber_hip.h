@@ -59,6 +59,9 @@ typedef struct quber_config {
     int32_t streams;                 /* 2: rgb + depth streams (build_resnet_deeplab_rgbd_fusion_backbone); 1: single stream
                                         (build_resnet_deeplab_fusion_backbone: rgb-only or depth-only, pixel_mean[0..2]) */
     int32_t compute_dtype;           /* arithmetic of the convolutions: 0 = exact fp32 MFMA (default; the 1e-4 parity bar),
+                                        3 = fp32-equivalent on the bf16 matrix pipe: every fp32 operand split into 3 bf16 terms,
+                                        6 exact partial products per multiply, fp32 accumulation (dropped terms < 2^-26; same
+                                        plan, same 1e-4 bar, 6/16 of the matrix time),
                                         2 = fp16 operands, fp32 accumulation (BASELINE.json configs[4] "fp16 MFMA path" stand-in;
                                         own tolerance, tests/test_gpu_loud_parity.py), 1 = bf16 operands likewise (8x coarser) */
     int32_t encode_legacy_f32;       /* a1 offset arithmetic (predictor.py:345-346, `np.float64 scalar - float32 array`):
@@ -212,7 +215,7 @@ double quber_forward_flops(quber_ctx* ctx);
 double quber_forward_flops_executed(quber_ctx* ctx);
 /* test-harness knobs: key 2 = give the stand-alone quber_op_conv2d a split-K workspace (value != 0) or drop it (0);
  * key 3 = force the number of K partitions of convolutions that have a workspace (0 = automatic);
- * key 12 = stand-alone conv op only: 1 = bf16 / 2 = fp16 operands with fp32 accumulation (quber_config.compute_dtype);
+ * key 12 = stand-alone conv ops only: quber_config.compute_dtype of the launch (1 = bf16 / 2 = fp16 operands, 3 = bf16x3);
  * key 11 = stand-alone conv op only: dilated 3x3 layers in tap-major K order with the zero-padding filter rows skipped;
  * key 10 = smallest output width routed to the Winograd path (default 32);
  * key 9 = Winograd output tile edge of the eligible layers (acts at plan time): 0 = automatic (default: F(4x4), or F(2x2)

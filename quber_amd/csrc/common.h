@@ -48,7 +48,7 @@ struct ConvP {
     long in_gs, out_gs, res_gs, w_gs;
     int ss_gs;
     const char* tag;     // stage-profile tag of the launch (null = "conv_gemm")
-    int bf16;            // 16-bit operands, fp32 accumulation (quber_config.compute_dtype): 0 = exact fp32, 1 = bf16, 2 = fp16
+    int bf16;            // quber_config.compute_dtype: 0 = fp32 MFMA, 1 = bf16 / 2 = fp16 operands, 3 = fp32 operands split into 3 bf16 terms
 };
 
 void set_error(const std::string& msg);
@@ -86,6 +86,7 @@ struct WinoP {
     int ss_gs, relu;
     int dil;                 // dilation (= padding)
     int m;                   // output tile edge: 2 = F(2x2,3x3), 4 = F(4x4,3x3)
+    int dtype;               // arithmetic of the P GEMMs (ConvP::bf16): 0 = fp32 MFMA, 3 = fp32 operands as 3 bf16 terms
     double* gn_sum;          // GroupNorm sums of the output to accumulate ([G][B][gn_groups][2]) or null
     int gn_groups;
     WinoNorm norm;           // normalisation of the INPUT applied on load (stats == null: none)

@@ -33,9 +33,17 @@ constexpr int PITCH = 36;
 // stay fp32 in HBM and are rounded to the 16-bit type (round-to-nearest-even) as the K-slice is written to LDS; the LDS
 // image is [row][k] with an 80-byte pitch, which makes the 16-byte fragment reads of a wave conflict-free; the
 // accumulators, and with them the whole epilogue, are those of the fp32 kernel.
+// DT = 3 (compute_dtype 3, "bf16x3"): fp32-equivalent arithmetic on the bf16 matrix pipe.  Every fp32 operand is split as
+// it enters LDS into three bf16 terms, x = x1 + x2 + x3 with x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)
+// (round-to-nearest: |x2| <= 2^-9 |x|, |x3| <= 2^-18 |x|, and the three terms carry all 24 significand bits), and a
+// product a b is evaluated as the six partial products a1 b1 + a1 b2 + a2 b1 + a2 b2 + a1 b3 + a3 b1 - each exact in
+// fp32 - accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The dropped terms (a2 b3, a3 b2, a3 b3) are below 2^-26 |a b|,
+// a quarter of an fp32 ulp, so the result differs from the exact-fp32 MFMA chain only by accumulation order.  Six bf16
+// MFMAs take 6/16 of the time of the fp32 MFMAs they replace.
 template <int DT> struct Half16 { using T = __bf16; };
 template <> struct Half16<2> { using T = _Float16; };
 constexpr int PITCH_H = 40;   // 16-bit elements per LDS row
+constexpr int NPL(int dt) { return dt == 3 ? 3 : 1; }     // bf16 planes per operand
 
 // Main-loop variants that were measured and rejected (profiles/r01c_conv_variants.md): double-buffered LDS with one
 // barrier per K-slice, a per-block s_setprio stagger, and 256x128 / 128x256 tiles (8 waves, or 4 waves of 128x64) were
@@ -62,7 +70,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
     static_assert(BM % RPP == 0 && BN % RPP == 0, "loader geometry");
     constexpr int SW = WN * 32;        // columns staged per epilogue pass
     constexpr int SP = SW + 4;         // staging pitch (floats)
-    constexpr int KSLICE_FLOATS = DT ? NBUF * (BM + BN) * PITCH_H / 2 : NBUF * (BM + BN) * PITCH;
+    constexpr int KSLICE_FLOATS = DT ? NPL(DT) * NBUF * (BM + BN) * PITCH_H / 2 : NBUF * (BM + BN) * PITCH;
     constexpr int SMEM_FLOATS = KSLICE_FLOATS > BM * SP ? KSLICE_FLOATS : BM * SP;
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     float* const As = smem;
@@ -70,8 +78,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
     using H16 = typename Half16<DT>::T;
     using h16x8 = __attribute__((ext_vector_type(8))) H16;
     using h16x4 = __attribute__((ext_vector_type(4))) H16;
-    H16* const Ah = reinterpret_cast<H16*>(smem);
-    H16* const Bh = Ah + NBUF * BM * PITCH_H;
+    H16* const Ah = reinterpret_cast<H16*>(smem);                    // DT = 3: planes [3][BM][PITCH_H], then [3][BN][PITCH_H]
+    H16* const Bh = Ah + NPL(DT) * NBUF * BM * PITCH_H;
 
     const int t = threadIdx.x;
     const int g = blockIdx.z;
@@ -214,6 +222,29 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
         }
     };
     auto lstore = [&](int buf) __attribute__((always_inline)) {
+        if constexpr (DT == 3) {
+            auto split = [&](const f32x4 v, H16* dst, int plane_stride) __attribute__((always_inline)) {
+                h16x4 p1, p2, p3;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = v[e];
+                    const H16 x1 = (H16)x;
+                    const float r1 = x - (float)x1;
+                    const H16 x2 = (H16)r1;
+                    const float r2 = r1 - (float)x2;
+                    p1[e] = x1; p2[e] = x2; p3[e] = (H16)r2;
+                }
+                *reinterpret_cast<h16x4*>(dst) = p1;
+                *reinterpret_cast<h16x4*>(dst + plane_stride) = p2;
+                *reinterpret_cast<h16x4*>(dst + 2 * plane_stride) = p3;
+            };
+#pragma unroll
+            for (int i = 0; i < AL; ++i)
+                split(aok[i] ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f}, &Ah[(lrow + RPP * i) * PITCH_H + kq], BM * PITCH_H);
+#pragma unroll
+            for (int i = 0; i < BL; ++i) split(rb[i], &Bh[(lrow + RPP * i) * PITCH_H + kq], BN * PITCH_H);
+            return;
+        }
         if constexpr (DT != 0) {
 #pragma unroll
             for (int i = 0; i < AL; ++i) {
@@ -265,6 +296,32 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
                 else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
             }
     };
+    // bf16x3: three fragments per operand tile, six MFMAs per output tile and k-step, smallest partial products first
+    auto mma_x3 = [&](int ks) __attribute__((always_inline)) {
+        const H16* ap = &Ah[(wm * TM * 32 + r) * PITCH_H + 8 * h + ks * 16];
+        const H16* bp = &Bh[(wn * 32 + r) * PITCH_H + 8 * h + ks * 16];
+        h16x8 a[3][TM], b[3][TN];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[q][i] = *reinterpret_cast<const h16x8*>(ap + q * BM * PITCH_H + i * 32 * PITCH_H);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[q][j] = *reinterpret_cast<const h16x8*>(bp + q * BN * PITCH_H + j * WN * 32 * PITCH_H);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f32x16 c = acc[i][j];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], c, 0, 0, 0);
+                acc[i][j] = c;
+            }
+    };
     auto mma = [&](int buf, int ks) __attribute__((always_inline)) {
         const float* ap = &As[buf * BM * PITCH + (wm * TM * 32 + r) * PITCH + 4 * h];
         const float* bp = &Bs[buf * BN * PITCH + (wn * 32 + r) * PITCH + 4 * h];
@@ -288,7 +345,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) gload(kt + 1);
-        if constexpr (DT != 0) {
+        if constexpr (DT == 3) {
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) mma_x3(ks);
+        } else if constexpr (DT != 0) {
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) mma_h(0, ks);
         } else {
@@ -608,7 +668,10 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
         {
             ProfScope prof(tag, conv_bytes, conv_flops, st);
             const dim3 grid(p.mtiles * p.ntiles, S, G);
-            if (p.bf16 == 2) {
+            if (p.bf16 == 3) {
+                if (S > 1) hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 1, 3>), grid, block, 0, st, p);
+                else hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 0, 3>), grid, block, 0, st, p);
+            } else if (p.bf16 == 2) {
                 if (S > 1) hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 1, 2>), grid, block, 0, st, p);
                 else hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 0, 2>), grid, block, 0, st, p);
             } else {

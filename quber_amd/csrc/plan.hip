@@ -269,9 +269,10 @@ struct Builder {
         // direct kernel's error against float64, profiles/r02a_parity_report.txt).  `wq6`, the 6x6 variant, is OPT-IN
         // (quber_set_tuning key 9 = 6 / QUBER_WINOGRAD=f6): 2.5x the error at tap level, +4.5 % throughput at batch 16.
         WinoP wq{};
-        // (the bf16 mode keeps every layer on the direct kernel: the Winograd transforms amplify the operands' rounding error)
+        // (the 16-bit operand modes keep every layer on the direct kernel: the Winograd transforms amplify the operands'
+        // rounding error; the bf16x3 mode is fp32-equivalent and takes the same plan as the exact fp32 MFMA mode)
         bool wino = winograd_eligible(k, stride, pad, dil, Cin, Cout) && cin_real == Cin && !res && prelu.empty() && g_winograd != 1 &&
-                    c->cfg.compute_dtype == 0;
+                    (c->cfg.compute_dtype == 0 || c->cfg.compute_dtype == 3);
         if (wino) {
             const double lim = (double)g_wino_max_ratio / 100.0;
             const double r6 = winograd_m6_channels_ok(Cin, Cout) ? winograd_mac_ratio(in.H, in.W, dil, 6) : 1e9;
@@ -294,6 +295,7 @@ struct Builder {
                 for (int g = 0; g < G; ++g) winograd_weights_host(w[g], Cout, Cin, m, &u[(size_t)g * P * Cout * Cin]);
                 wq.in = in; wq.out = out; wq.u = upload(u);
                 wq.scale = p.scale; wq.shift = p.shift; wq.ss_gs = Cout; wq.relu = relu; wq.dil = dil; wq.m = m;
+                wq.dtype = c->cfg.compute_dtype;
                 const size_t need = winograd_ws_floats(Bmax, in.H, in.W, Cin, Cout, G, dil, m);
                 if (need > c->wino_floats) c->wino_floats = need;
             }
@@ -869,7 +871,8 @@ int check_cfg(const quber_config& c) {
     if (c.res5_dilation == 1) return fail("res5_dilation 1 (output stride 32) is not supported by this build");
     if (c.error_classes < 2 || c.error_classes > 4) return fail("error_classes must be 2..4");
     if (c.streams != 1 && c.streams != 2) return fail("streams must be 1 or 2");
-    if (c.compute_dtype < 0 || c.compute_dtype > 2) return fail("compute_dtype must be 0 (fp32), 1 (bf16 operands) or 2 (fp16 operands)");
+    if (c.compute_dtype < 0 || c.compute_dtype > 3)
+        return fail("compute_dtype must be 0 (fp32 MFMA), 1 (bf16 operands), 2 (fp16 operands) or 3 (fp32 operands as 3 bf16 terms)");
     if (c.with_network && c.hierarchical) {
         if (c.n_levels < 1 || c.n_levels > 5) return fail("n_levels must be 1..5");
         int seen[5] = {0, 0, 0, 0, 0};
@@ -1026,7 +1029,7 @@ void quber_set_tuning(int32_t key, int32_t value) {
         }
     }
     if (key == 4) g_force_tile = value;    // force the tile shape: 1 = 64x64, 2 = 128x128, 4 = 256x32 (0 = automatic)
-    if (key == 12) g_op_bf16 = value;         // stand-alone conv op: 1 = bf16, 2 = fp16 operands, fp32 accumulation
+    if (key == 12) g_op_bf16 = value;         // stand-alone conv ops: 1 = bf16, 2 = fp16 operands, 3 = fp32 as 3 bf16 terms; fp32 accumulation
     if (key == 11) g_op_skip_rows = value;    // stand-alone conv op: tap-major K order with padded filter rows skipped (dilated 3x3)
     if (key == 10) g_wino_min_cout = value;   // smallest output width eligible for the Winograd path (default 32)
     if (key == 9) g_wino_variant = value;     // Winograd output tile edge for the eligible layers: 0 = automatic (4 or 2), 2, 4, 6 (opt-in)
@@ -1309,6 +1312,7 @@ int quber_op_conv3x3_winograd(const float* x, int32_t B, int32_t h, int32_t w, i
     WinoP q{};
     q.in = mkview(x, B, h, w, cin); q.out = mkview(y, B, h, w, cout);
     q.u = u; q.scale = scale; q.shift = shift; q.ss_gs = 0; q.relu = relu; q.dil = dil; q.m = m;
+    q.dtype = g_op_bf16;
     q.ws = ws; q.ws_floats = (size_t)ws_floats;
     q.splitk_ws = g_op_ws; q.splitk_floats = g_op_ws ? g_op_ws_floats : 0;
     return launch_conv_winograd(q, B, 1, st);

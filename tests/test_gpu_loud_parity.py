@@ -68,16 +68,32 @@ def _rel(got, ref):
     return float((got - ref).abs().max() / max(1.0, float(ref.abs().max())))
 
 
-@pytest.mark.parametrize("h,w,b,n", [(480, 640, 16, 20), (720, 1280, 1, 30)])
-def test_benchmarked_plan_taps_heads_and_instances(h, w, b, n):
-    """BASELINE.json configs[1] (batch 16, 640x480, N = 20) and configs[2] (1280x720, N = 30) on the default plan."""
-    batch, offs, image = _scene(7, b, h, w, n)
-    sd = loud_state_dict(0, image, offs, n)
-    net = _oracle(sd)
-    taps = {}
-    with torch.no_grad():
-        ref = net(image, torch.from_numpy(offs), taps)
-    eng = engine.Engine(engine.make_config(h, w, max_batch=b, max_instances=n), "cuda:0")
+_PLAN_REF = {}
+
+
+def _plan_reference(h, w, b, n):
+    """scene, calibrated loud weights and the oracle's taps / heads for a configuration - computed once per size (host time)."""
+    key = (h, w, b, n)
+    if key not in _PLAN_REF:
+        batch, offs, image = _scene(7, b, h, w, n)
+        sd = loud_state_dict(0, image, offs, n)
+        taps = {}
+        with torch.no_grad():
+            ref = _oracle(sd)(image, torch.from_numpy(offs), taps)
+        _PLAN_REF.clear()                                    # one configuration at a time: the taps are large
+        _PLAN_REF[key] = (batch, offs, sd, taps, ref, {})
+    return _PLAN_REF[key]
+
+
+@pytest.mark.parametrize("h,w,b,n,dtype", [(480, 640, 16, 20, 0), (480, 640, 16, 20, 3), (720, 1280, 1, 30, 0), (720, 1280, 1, 30, 3)],
+                         ids=["b16-640x480-f32", "b16-640x480-bf16x3", "b1-1280x720-f32", "b1-1280x720-bf16x3"])
+def test_benchmarked_plan_taps_heads_and_instances(h, w, b, n, dtype):
+    """BASELINE.json configs[1] (batch 16, 640x480, N = 20) and configs[2] (1280x720, N = 30) on the default plan, in the
+    exact fp32 MFMA mode (compute_dtype 0) and in the fp32-equivalent bf16x3 mode (compute_dtype 3) - the SAME bars."""
+    batch, offs, sd, taps, ref, e2e = _plan_reference(h, w, b, n)
+    qc = engine.make_config(h, w, max_batch=b, max_instances=n)
+    qc.compute_dtype = dtype
+    eng = engine.Engine(qc, "cuda:0")
     eng.load_state_dict(sd)
     masks = torch.from_numpy(batch["masks"]).cuda()
     bgr, dep = torch.from_numpy(batch["rgb"]).cuda(), torch.from_numpy(batch["depth"]).cuda()
@@ -107,8 +123,9 @@ def test_benchmarked_plan_taps_heads_and_instances(h, w, b, n):
             np.testing.assert_allclose(post["scores"][i, :k].cpu().numpy(), o["scores"].numpy(), rtol=2e-5, atol=1e-6)
         # end to end (HIP logits -> HIP labels) against (oracle logits -> oracle labels): threshold-straddling pixels may flip
         if i % 4 == 0:                      # (the oracle's grouping takes ~1 s per frame on the host: every fourth frame)
-            e = postproc_ref.postprocess(ref["foreground"][i], ref["center"][i], ref["offset"][i])
-            same.append(float((post["panoptic"][i].cpu() == e["panoptic"]).float().mean()))
+            if i not in e2e:
+                e2e[i] = postproc_ref.postprocess(ref["foreground"][i], ref["center"][i], ref["offset"][i])["panoptic"]
+            same.append(float((post["panoptic"][i].cpu() == e2e[i]).float().mean()))
     assert np.mean(ks) >= 15, ks
     assert min(same) > 0.9999, same
     if b > 1:

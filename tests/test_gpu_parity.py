@@ -285,7 +285,7 @@ def test_multilabel_metrics_golden(path):
             assert table[i, j] == np.count_nonzero((z["gt"] == gi) & (z["pred"] == pj))
 
 
-@pytest.mark.parametrize("h,w,n,seed", [(480, 640, 12, 0), (96, 128, 5, 1), (75, 101, 4, 2), (720, 1280, 20, 3)])
+@pytest.mark.parametrize("h,w,n,seed", [(480, 640, 12, 0), (96, 128, 5, 1), (75, 101, 4, 2), (720, 1280, 6, 3)])
 def test_boundary_metrics_vs_oracle(h, w, n, seed):
     """The boundary half of multilabel_metrics (evaluation.py:21-54, 165-175, 232-243) on the HIP path against the numpy /
     scipy restatement: every integer count equal, every derived measure equal."""
@@ -401,7 +401,7 @@ def _conv_case(B, H, W, Cin, Cout, k, stride, dil, affine, residual, relu, seed=
     sh = torch.randn(Cout, generator=g) if affine else None
     # bf16 mode: the kernel rounds both operands to bf16 (nearest-even) and accumulates in fp32, so the reference is the
     # float64 convolution of the rounded operands
-    half = {0: None, 1: torch.bfloat16, 2: torch.float16}[int(bf16)]
+    half = {0: None, 1: torch.bfloat16, 2: torch.float16, 3: None}[int(bf16)]     # 3 = bf16x3: fp32-equivalent
     xr, wr = (x.to(half).double(), wt.to(half).double()) if half else (x.double(), wt.double())
     ref = torch.nn.functional.conv2d(xr, wr, None, stride, pad, dil)
     if affine:
@@ -467,6 +467,30 @@ def test_conv_igemm_16bit_vs_rounded_operands(case, dt):
     lib.quber_set_tuning(2, 1)
     try:
         assert _conv_case(*case, bf16=dt) < 3e-6          # with the split-K workspace
+    finally:
+        lib.quber_set_tuning(2, 0)
+
+
+@pytest.mark.parametrize("case", [
+    (2, 24, 32, 8, 32, 3, 2, 1, True, False, True),
+    (2, 24, 32, 32, 64, 3, 1, 1, True, False, True),
+    (2, 16, 20, 64, 256, 1, 1, 1, True, True, True),
+    (1, 30, 40, 256, 128, 1, 2, 1, True, False, True),
+    (1, 15, 20, 128, 128, 3, 1, 4, True, False, True),
+    (3, 33, 47, 164, 128, 1, 1, 1, True, False, True),
+    (2, 64, 80, 128, 130, 3, 1, 1, False, False, False),
+    (4, 60, 80, 512, 256, 3, 1, 1, True, False, True),      # K = 4608
+    (1, 30, 40, 2048, 256, 1, 1, 1, True, False, True),     # K = 2048
+])
+def test_conv_igemm_bf16x3_meets_the_fp32_bar(case):
+    """compute_dtype 3: fp32 operands split into three bf16 terms, six exact partial products per multiply, fp32
+    accumulation.  Held to the SAME bar against the float64 convolution of the UNROUNDED fp32 operands as the exact fp32
+    MFMA kernel (test_conv_igemm_vs_torch: 2e-6)."""
+    assert _conv_case(*case, bf16=3) < 2e-6
+    lib = _lib.load()
+    lib.quber_set_tuning(2, 1)
+    try:
+        assert _conv_case(*case, bf16=3) < 2e-6
     finally:
         lib.quber_set_tuning(2, 0)
 
