@@ -48,8 +48,7 @@ struct ConvP {
     long in_gs, out_gs, res_gs, w_gs;
     int ss_gs;
     const char* tag;     // stage-profile tag of the launch (null = "conv_gemm")
-    int bf16;            // quber_config.compute_dtype: 0 = fp32 MFMA, 1 = bf16 / 2 = fp16 operands, 3 = fp32 operands split into 3 bf16
-                         // terms on the fly; 4 = the same with `w` already split: bf16 planes [G][3][Cout][Kpad], w_gs = Cout * Kpad
+    int bf16;            // quber_config.compute_dtype: 0 = fp32 MFMA, 1 = bf16 / 2 = fp16 operands, 3 = fp32 operands split into 3 bf16 terms
 };
 
 void set_error(const std::string& msg);

@@ -43,9 +43,7 @@ constexpr int PITCH = 36;
 template <int DT> struct Half16 { using T = __bf16; };
 template <> struct Half16<2> { using T = _Float16; };
 constexpr int PITCH_H = 40;   // 16-bit elements per LDS row
-// DT = 4: the same with the WEIGHTS split once at plan time into three bf16 planes [3][Cout][Kpad] in HBM (what the network
-// plan runs); DT = 3 splits both operands on the fly (stand-alone conv op: weights arrive as fp32).
-constexpr int NPL(int dt) { return dt >= 3 ? 3 : 1; }     // bf16 planes per operand
+constexpr int NPL(int dt) { return dt == 3 ? 3 : 1; }     // bf16 planes per operand
 
 // Main-loop variants that were measured and rejected (profiles/r01c_conv_variants.md): double-buffered LDS with one
 // barrier per K-slice, a per-block s_setprio stagger, and 256x128 / 128x256 tiles (8 waves, or 4 waves of 128x64) were
@@ -167,13 +165,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
         }
     }
     const float* wrow[BL];
-    const unsigned short* wrow16[BL];     // DT = 4: rows of the first bf16 plane; planes are p.w_gs elements apart
 #pragma unroll
     for (int i = 0; i < BL; ++i) {
         const int n = n0 + lrow + RPP * i;
         wrow[i] = wt + (long)(n < p.Cout ? n : 0) * p.Kpad + kq;   // columns >= Cout are never stored
-        wrow16[i] = reinterpret_cast<const unsigned short*>(p.w) + (long)g * 3 * p.w_gs + (long)k_begin * BK +
-                    (long)(n < p.Cout ? n : 0) * p.Kpad + kq;
     }
     int kc, kx, ky;
     if (p.kmode) {
@@ -194,7 +189,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
     }
 
     f32x4 ra[AL], rb[BL];
-    uint2 rbh[DT == 4 ? 3 : 1][BL];
     bool aok[AL];
     auto gload = [&](int kt) __attribute__((always_inline)) {
         const bool kok = p.kmode || ky < p.kh;
@@ -206,15 +200,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
             aok[i] = ok;
             ra[i] = *reinterpret_cast<const f32x4*>(ok ? rowp[i] + off : in);
         }
-        if constexpr (DT == 4) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
-#pragma unroll
-                for (int i = 0; i < BL; ++i) rbh[q][i] = *reinterpret_cast<const uint2*>(wrow16[i] + (long)q * p.w_gs + kt * BK);
-        } else {
-#pragma unroll
-            for (int i = 0; i < BL; ++i) rb[i] = *reinterpret_cast<const f32x4*>(wrow[i] + kt * BK);
-        }
+        for (int i = 0; i < BL; ++i) rb[i] = *reinterpret_cast<const f32x4*>(wrow[i] + kt * BK);
         // advance to the next K-slice
         if (p.kmode) {
             // slice-major K order (k = (c/32, tap, c%32)): the taps of one 32-channel slice are consecutive K-slices,
@@ -235,7 +222,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
         }
     };
     auto lstore = [&](int buf) __attribute__((always_inline)) {
-        if constexpr (DT >= 3) {
+        if constexpr (DT == 3) {
             auto split = [&](const f32x4 v, H16* dst, int plane_stride) __attribute__((always_inline)) {
                 h16x4 p1, p2, p3;
 #pragma unroll
@@ -254,16 +241,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
 #pragma unroll
             for (int i = 0; i < AL; ++i)
                 split(aok[i] ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f}, &Ah[(lrow + RPP * i) * PITCH_H + kq], BM * PITCH_H);
-            if constexpr (DT == 4) {
 #pragma unroll
-                for (int q = 0; q < 3; ++q)
-#pragma unroll
-                    for (int i = 0; i < BL; ++i)
-                        *reinterpret_cast<uint2*>(&Bh[q * BN * PITCH_H + (lrow + RPP * i) * PITCH_H + kq]) = rbh[q][i];
-            } else {
-#pragma unroll
-                for (int i = 0; i < BL; ++i) split(rb[i], &Bh[(lrow + RPP * i) * PITCH_H + kq], BN * PITCH_H);
-            }
+            for (int i = 0; i < BL; ++i) split(rb[i], &Bh[(lrow + RPP * i) * PITCH_H + kq], BN * PITCH_H);
             return;
         }
         if constexpr (DT != 0) {
@@ -366,7 +345,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) gload(kt + 1);
-        if constexpr (DT >= 3) {
+        if constexpr (DT == 3) {
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) mma_x3(ks);
         } else if constexpr (DT != 0) {
@@ -689,10 +668,7 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
         {
             ProfScope prof(tag, conv_bytes, conv_flops, st);
             const dim3 grid(p.mtiles * p.ntiles, S, G);
-            if (p.bf16 == 4) {
-                if (S > 1) hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 1, 4>), grid, block, 0, st, p);
-                else hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 0, 4>), grid, block, 0, st, p);
-            } else if (p.bf16 == 3) {
+            if (p.bf16 == 3) {
                 if (S > 1) hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 1, 3>), grid, block, 0, st, p);
                 else hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 0, 3>), grid, block, 0, st, p);
             } else if (p.bf16 == 2) {

@@ -184,35 +184,6 @@ struct Builder {
         if (hipMemset(p, 0, bytes ? bytes : 16) != hipSuccess && err.empty()) err = "hipMemset of a new buffer failed";
         return p;
     }
-    // fp32 -> three bf16 planes [3][n] (x = x1 + x2 + x3, round-to-nearest-even like the device's v_cvt_pk_bf16_f32)
-    static std::vector<uint16_t> split_bf16x3(const float* v, size_t n) {
-        auto rne = [](float x) { uint32_t u; memcpy(&u, &x, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
-        auto up = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
-        std::vector<uint16_t> out(3 * n);
-        for (size_t i = 0; i < n; ++i) {
-            const float x = v[i];
-            const uint16_t a = rne(x);
-            const float r1 = x - up(a);
-            const uint16_t b = rne(r1);
-            const float r2 = r1 - up(b);
-            out[i] = a; out[n + i] = b; out[2 * n + i] = rne(r2);
-        }
-        return out;
-    }
-    // weights of group-major layout [G][per_group] -> [G][3][per_group] bf16 planes, uploaded
-    const float* upload_split(const std::vector<float>& v, int G) {
-        const size_t per = v.size() / G;
-        std::vector<uint16_t> all;
-        all.reserve(3 * v.size());
-        for (int g = 0; g < G; ++g) {
-            std::vector<uint16_t> s = split_bf16x3(v.data() + (size_t)g * per, per);
-            all.insert(all.end(), s.begin(), s.end());
-        }
-        void* d = dalloc_bytes(all.size() * sizeof(uint16_t));
-        if (d && hipMemcpy(d, all.data(), all.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess && err.empty())
-            err = "upload of split weights failed";
-        return reinterpret_cast<const float*>(d);
-    }
     float* upload(const std::vector<float>& v) {
         float* d = (float*)dalloc_bytes(v.size() * sizeof(float));
         if (d && hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess && err.empty())
@@ -270,8 +241,7 @@ struct Builder {
                     }
             }
         ConvP p{};
-        const bool x3 = c->cfg.compute_dtype == 3;       // fp32-equivalent bf16x3: weights split into bf16 planes once, here
-        p.in = in.p; p.w = x3 ? upload_split(packed, G) : upload(packed);
+        p.in = in.p; p.w = upload(packed);
         p.scale = affine ? upload(scale) : nullptr;
         p.shift = affine ? upload(shift) : nullptr;
         p.prelu = prelu.empty() ? nullptr : upload(prelu);
@@ -285,7 +255,7 @@ struct Builder {
         p.relu = relu;
         p.kmode = kmode;
         p.skip_rows = skip_rows;
-        p.bf16 = x3 ? 4 : c->cfg.compute_dtype;
+        p.bf16 = c->cfg.compute_dtype;
         p.in_gs = in.gs; p.out_gs = out.gs; p.res_gs = res ? res->gs : 0;
         p.w_gs = (long)Cout * Kpad; p.ss_gs = Cout;
         p.ohw = OH * OW;
@@ -323,9 +293,9 @@ struct Builder {
                 const int P = (m + 2) * (m + 2);
                 std::vector<float> u((size_t)G * P * Cout * Cin);
                 for (int g = 0; g < G; ++g) winograd_weights_host(w[g], Cout, Cin, m, &u[(size_t)g * P * Cout * Cin]);
-                wq.in = in; wq.out = out; wq.u = x3 ? upload_split(u, G * P) : upload(u);
+                wq.in = in; wq.out = out; wq.u = upload(u);
                 wq.scale = p.scale; wq.shift = p.shift; wq.ss_gs = Cout; wq.relu = relu; wq.dil = dil; wq.m = m;
-                wq.dtype = x3 ? 4 : 0;
+                wq.dtype = c->cfg.compute_dtype;
                 const size_t need = winograd_ws_floats(Bmax, in.H, in.W, Cin, Cout, G, dil, m);
                 if (need > c->wino_floats) c->wino_floats = need;
             }

@@ -426,7 +426,7 @@ static int run_winograd(const WinoP& q, int B, int G, hipStream_t st) {
     p.in_gs = tiles * Cin; p.out_gs = tiles * Cout; p.w_gs = (long)Cout * Cin;
     p.ws = q.splitk_ws; p.ws_floats = q.splitk_floats;
     p.tag = "wino_gemm";
-    p.bf16 = q.dtype >= 3 ? q.dtype : 0;      // 3: split both operands on the fly; 4: `u` holds bf16 planes [G * P][3][Cout][Cin]
+    p.bf16 = q.dtype == 3 ? 3 : 0;
     int rc = launch_conv(p, G * P, st);
     if (rc) return rc;
     // GroupNorm sums in the output transform when a block's tiles meet at most two images and vectors stay inside a group

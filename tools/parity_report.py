@@ -28,7 +28,6 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--instances", type=int, default=20)
     ap.add_argument("--modes", default="auto,off,f2,f4,f6")
-    ap.add_argument("--compute-dtype", type=int, default=0, help="quber_config.compute_dtype: 0 fp32 MFMA, 3 bf16x3, 2 fp16, 1 bf16")
     ap.add_argument("--fp64", action="store_true", help="also run the oracle in float64 on frame 0 (its own fp32 error)")
     a = ap.parse_args()
     B, H, W, N = a.batch, a.height, a.width, a.instances
@@ -66,9 +65,7 @@ def main():
         k6, k9 = MODES[mode]
         lib.quber_set_tuning(6, k6)
         lib.quber_set_tuning(9, k9)
-        qc = engine.make_config(H, W, max_batch=B, max_instances=N)
-        qc.compute_dtype = a.compute_dtype
-        eng = engine.Engine(qc, "cuda:0")
+        eng = engine.Engine(engine.make_config(H, W, max_batch=B, max_instances=N), "cuda:0")
         eng.load_state_dict(sd)
         lg = eng.forward(bgr, dep, off)
         post = eng.postprocess(lg)
@@ -85,7 +82,7 @@ def main():
             o = postproc_ref.postprocess(ref["foreground"][i], ref["center"][i], ref["offset"][i])
             same.append(float((post["panoptic"][i].cpu() == o["panoptic"]).float().mean()))
             ks.append(len(o["labels"]))
-        print(f"| {mode} (compute_dtype {a.compute_dtype}) | executed/algorithmic {eng.forward_flops_executed() / eng.forward_flops():.3f} | taps rel: "
+        print(f"| {mode} | executed/algorithmic {eng.forward_flops_executed() / eng.forward_flops():.3f} | taps rel: "
               + ", ".join(f"{k} {v:.1e}" for k, v in row.items())
               + " | logits abs: " + ", ".join(f"{k} {float(v):.1e}" for k, v in planes.items())
               + f" | label maps equal {np.mean(same):.6f} (min {np.min(same):.6f}), K mean {np.mean(ks):.1f} |", flush=True)
