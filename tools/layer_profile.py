@@ -18,15 +18,17 @@ sys.path.insert(0, ROOT)
 def run(a):
     import torch
     from quber_amd import arch, engine, synth
-    eng = engine.Engine(engine.make_config(a.height, a.width, max_batch=a.batch), "cuda:0")
-    eng.load_state_dict(arch.init_state_dict(seed=0))
+    qc = engine.make_config(a.height, a.width, max_batch=a.batch)
+    qc.compute_dtype = a.compute_dtype
+    eng = engine.Engine(qc, "cuda:0")
+    eng.load_state_dict(arch.init_state_dict(seed=0, loud_heads=True))
     b = synth.make_batch(7, a.batch, a.height, a.width, 20)
     masks, bgr, depth = (torch.from_numpy(b[k]).cuda() for k in ("masks", "rgb", "depth"))
     offs = eng.encode(masks)
     for _ in range(a.iters):
         eng.forward(bgr, depth, offs)
     torch.cuda.synchronize()
-    json.dump({"batch": a.batch, "iters": a.iters, "plan": eng.plan()}, open(a.plan, "w"))
+    json.dump({"batch": a.batch, "iters": a.iters, "compute_dtype": a.compute_dtype, "plan": eng.plan()}, open(a.plan, "w"))
 
 
 def report(a):
@@ -72,5 +74,6 @@ if __name__ == "__main__":
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--compute-dtype", type=int, default=0, help="quber_config.compute_dtype (0 fp32 MFMA, 3 bf16x3, 2 fp16)")
     a = ap.parse_args()
     run(a) if a.mode == "run" else report(a)

@@ -5,7 +5,11 @@ half the bytes of 16-byte-per-lane reads (128-B requests tallied at 64 B)."""
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import source_digest  # noqa: E402  (bench.py reports the file only while the kernel sources still match)
 
 
 FAMILY = ("conv_igemm", "wino_input", "wino_output", "splitk_reduce")
@@ -33,6 +37,7 @@ def main(plan_json, fetch_csv, write_csv, out_json):
     fam = {k: {"fetch_bytes": f[k] * 1024 * 2, "write_bytes": w[k] * 1024} for k in FAMILY}
     tot = sum(v["fetch_bytes"] + v["write_bytes"] for v in fam.values())
     out = {"batch": meta["batch"], "launches": len(convs), "bytes_per_launch": tot / len(convs),
+           "source_digest": source_digest(), "dtype": {0: "f32", 1: "bf16", 2: "f16", 3: "f32-bf16x3"}[meta.get("compute_dtype", 0)],
            "fetch_bytes_total": sum(v["fetch_bytes"] for v in fam.values()),
            "write_bytes_total": sum(v["write_bytes"] for v in fam.values()),
            "note": "HBM-side bytes of one forward's convolution ops (GEMM launches, Winograd input / output transforms, "
