@@ -664,6 +664,10 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
             }
         }
     }
+    // bf16x3 pays where the matrix pipe is the limit.  The HBM-bound short-K launches on 64x64 tiles (bottleneck conv3 +
+    // residual) and the 32-column head layers on 256x32 tiles lose occupancy to its three LDS planes and gain nothing
+    // (profiles/r02j_conv_layers_dtype{0,3}.md): they keep the exact fp32 MFMA kernel, which is at least as accurate.
+    if (p.bf16 == 3 && (BM == 256 || (BM == 64 && nk <= 8))) p.bf16 = 0;
     if (p.bf16) {
         {
             ProfScope prof(tag, conv_bytes, conv_flops, st);

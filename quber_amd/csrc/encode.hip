@@ -46,11 +46,20 @@ __global__ __launch_bounds__(256) void encode_reduce_kernel(const uint8_t* __res
         lastv[r] = make_uint4(0, 0, 0, 0);
     }
     const uint8_t* src = masks + (long)b * frame_stride + base;
+    // the next mask's ENC_R loads are issued before this mask's reduction: 8 KiB per wave in flight
+    uint4 nxt[ENC_R];
+#pragma unroll
+    for (int r = 0; r < ENC_R; ++r)
+        nxt[r] = act[r] ? *reinterpret_cast<const uint4*>(src + (long)r * 1024) : make_uint4(0, 0, 0, 0);
     for (int n = 0; n < N; ++n) {
         uint4 v[ENC_R];
 #pragma unroll
-        for (int r = 0; r < ENC_R; ++r)
-            v[r] = act[r] ? *reinterpret_cast<const uint4*>(src + (long)n * HW + (long)r * 1024) : make_uint4(0, 0, 0, 0);
+        for (int r = 0; r < ENC_R; ++r) v[r] = nxt[r];
+        if (n + 1 < N) {
+#pragma unroll
+            for (int r = 0; r < ENC_R; ++r)
+                nxt[r] = act[r] ? *reinterpret_cast<const uint4*>(src + (long)(n + 1) * HW + (long)r * 1024) : make_uint4(0, 0, 0, 0);
+        }
         unsigned cnt = 0, sx = 0, sy = 0;
         const unsigned tag = (unsigned)(n + 1);
 #pragma unroll
