@@ -20,15 +20,17 @@ LAYERS = [
     ("aspp 3x3 d18 2048>256 @30x40", 16, 30, 40, 2048, 256, 3, 1, 18),
     ("stem.conv3 3x3 32>64 @240x320 x2", 32, 240, 320, 32, 64, 3, 1, 1),
 ]
-CONFIGS = [("f32 auto", 0, 0), ("x3 auto", 3, 0), ("x3 64x64", 3, 1), ("x3 128x128", 3, 2), ("f16 auto", 2, 0)]
+# name, key 12 (arithmetic), key 4 (forced tile), key 13 (warp-specialised bf16x3 kernel)
+CONFIGS = [("f32 auto", 0, 0, 1), ("x3 plain loop", 3, 0, 0), ("x3 warp-specialised", 3, 0, 1), ("x3 ws 128x128 forced", 3, 2, 1),
+           ("f16 auto", 2, 0, 1)]
 
 
 def main():
     lib = _lib.load()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
-    lib.quber_set_tuning(2, 1)
-    print("| layer | " + " | ".join(f"{n} TF/s" for n, _, _ in CONFIGS) + " |")
+    lib.quber_set_tuning(2, 0)          # no split-K workspace: every launch computes whole tiles
+    print("| layer | " + " | ".join(f"{c[0]} TF/s" for c in CONFIGS) + " |")
     print("|---|" + "---|" * len(CONFIGS))
     for (name, B, H, W, Cin, Cout, k, s, d) in LAYERS:
         x = torch.randn(B, H, W, Cin, device="cuda")
@@ -39,9 +41,10 @@ def main():
         packed = torch.empty(Cout * ((k * k * Cin + 31) // 32 * 32), device="cuda")
         flops = 2.0 * B * H * W * Cin * k * k * Cout
         res = []
-        for (_, dt, tile) in CONFIGS:
+        for (_, dt, tile, ws) in CONFIGS:
             lib.quber_set_tuning(12, dt)
             lib.quber_set_tuning(4, tile)
+            lib.quber_set_tuning(13, ws)
             ts = []
             for rd in range(4):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -57,6 +60,7 @@ def main():
         print(f"| {name} | " + " | ".join("%.1f" % r for r in res) + " |", flush=True)
     lib.quber_set_tuning(12, 0)
     lib.quber_set_tuning(4, 0)
+    lib.quber_set_tuning(13, 1)
     lib.quber_set_tuning(2, 0)
 
 
