@@ -17,6 +17,8 @@
 // B[kk = h][col r].  The order of k inside a K-slice is free as long as A and B agree, so each lane
 // fetches 4 consecutive k with one ds_read_b128 and feeds them to 4 successive MFMAs:
 // MFMA step s of group ks multiplies k = ks*8 + 4*h + s.
+#include <type_traits>
+
 #include "common.h"
 
 namespace quber {
@@ -477,7 +479,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
 // profiles/r02j_conv_mfma_busy_dtype3.md): per K-slice a wave does 48 MFMAs (1536 cycles) and then, between two barriers, ~270
 // vector instructions of operand splitting plus 24 LDS stores.  Here the two kinds of work run in different waves of a
 // 512-thread block, one of each per SIMD, so the matrix pipe and the vector pipe work at the same time:
-//   waves 4-7 (producers): global loads two K-slices ahead (two register sets), split fp32 -> 3 bf16 planes, LDS stores
+//   waves 4-7 (producers): global loads three K-slices ahead (three register sets), split fp32 -> 3 bf16 planes, LDS stores
 //   waves 0-3 (consumers): fragment reads + the six MFMAs per output tile and k-step, nothing else
 // over a double-buffered LDS image (2 x 61 KB: one block per CU) with ONE barrier per K-slice.  Loader state, K orders,
 // operand layout, MFMA order and the epilogue are those of conv_igemm_f32<128,128,2,2,0,3>; results are bit-identical to it.
@@ -556,20 +558,27 @@ __global__ __launch_bounds__(512) void conv_igemm_x3ws(const ConvP p) {
             ky = tap / p.kw;
             kx = tap - ky * p.kw;
         }
-        f32x4 ra[2][AL], rb[2][BL];
-        bool aok[2][AL];
+        f32x4 ra[3][AL], rb[3][BL];       // three register sets: loads run three K-slices ahead of the multiplies
+        bool aok[3][AL];
         auto gload = [&](int kt, f32x4 (&a)[AL], f32x4 (&b)[BL], bool (&ok)[AL]) __attribute__((always_inline)) {
             const bool kok = p.kmode || ky < p.kh;
             const int dy = ky * p.dil, dx = kx * p.dil;
             const long off = ((long)dy * p.W + dx) * p.in_cs + kc;
+            // The loads are inline asm on purpose: three register sets must be in flight at once, and hipcc, left to allocate
+            // the destinations of ordinary loads, gives every set the same registers and waits vmcnt(0) before re-issuing
+            // (cdna_hip_programming.md 5.7: asm loads are invisible to its wait bookkeeping; `wait_set` below counts them).
 #pragma unroll
             for (int i = 0; i < AL; ++i) {
                 const bool o = kok && (unsigned)(iy0[i] + dy) < (unsigned)p.H && (unsigned)(ix0[i] + dx) < (unsigned)p.W;
                 ok[i] = o;
-                a[i] = *reinterpret_cast<const f32x4*>(o ? rowp[i] + off : in);
+                const float* src = o ? rowp[i] + off : in;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a[i]) : "v"(src) : "memory");
             }
 #pragma unroll
-            for (int i = 0; i < BL; ++i) b[i] = *reinterpret_cast<const f32x4*>(wrow[i] + kt * BK);
+            for (int i = 0; i < BL; ++i) {
+                const float* src = wrow[i] + kt * BK;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(b[i]) : "v"(src) : "memory");
+            }
             if (p.kmode) {
                 if (++kx == p.kw) {
                     kx = 0;
@@ -601,6 +610,17 @@ __global__ __launch_bounds__(512) void conv_igemm_x3ws(const ConvP p) {
             *reinterpret_cast<h16x4*>(dst + plane_stride) = p2;
             *reinterpret_cast<h16x4*>(dst + 2 * plane_stride) = p3;
         };
+        // wait until at most `newer` loads issued after this set's are outstanding; naming the set "+v" keeps every use below
+        auto wait_set = [&](auto NEWER, f32x4 (&a)[AL], f32x4 (&b)[BL]) __attribute__((always_inline)) {
+            static_assert(AL == 4 && BL == 4, "operand list of the wait statement");
+            constexpr int newer = decltype(NEWER)::value;
+            if constexpr (newer == 16)
+                asm volatile("s_waitcnt vmcnt(16)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) :: "memory");
+            else if constexpr (newer == 8)
+                asm volatile("s_waitcnt vmcnt(8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) :: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) :: "memory");
+        };
         auto lstore = [&](int buf, const f32x4 (&a)[AL], const f32x4 (&b)[BL], const bool (&ok)[AL]) __attribute__((always_inline)) {
             H16* Ah = lds + buf * BUF;
             H16* Bh = Ah + 3 * PLANE_A;
@@ -610,20 +630,44 @@ __global__ __launch_bounds__(512) void conv_igemm_x3ws(const ConvP p) {
 #pragma unroll
             for (int i = 0; i < BL; ++i) split(b[i], &Bh[(lrow + RPP * i) * PITCH_H + kq], PLANE_B);
         };
-        gload(0, ra[0], rb[0], aok[0]);
-        if (nk > 1) gload(1, ra[1], rb[1], aok[1]);
-        lstore(0, ra[0], rb[0], aok[0]);
-        __syncthreads();                                   // buffer 0 = slice 0
-        for (int kt = 0; kt < nk; kt += 2) {
-            // consumers multiply slice kt from buffer 0; slice kt+1 goes from register set 1 to buffer 1
-            if (kt + 2 < nk) gload(kt + 2, ra[0], rb[0], aok[0]);
-            if (kt + 1 < nk) lstore(1, ra[1], rb[1], aok[1]);
-            __syncthreads();
+        // Slice s lives in register set s % 3 from its loads (issued while slice s - 3 is being multiplied) until it is split
+        // into LDS buffer s & 1 (while slice s - 1 is being multiplied): two whole iterations of latency hiding.  The
+        // sched_barrier keeps the loads of an iteration ahead of its split: left alone, the scheduler sinks them below it
+        // (one iteration of hiding, and with the 6x cheaper multiplies the HBM / L2-miss latency shows).
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        using N0 = std::integral_constant<int, 0>;
+        using N8 = std::integral_constant<int, 8>;
+        using N16 = std::integral_constant<int, 16>;
+        // One loop issues every load (no peeled prologue: with the first loads outside the loop the allocator copies their
+        // destination registers into the loop's assignment BEFORE the data has landed - tools/check_asm_loads.py audits the .s).
+        // Iteration kt (from -3): request slice kt + 3; split slice kt + 1 (requested two iterations ago) into buffer
+        // (kt + 1) & 1; from kt = -1 on, one barrier per iteration (the consumers' 1 + nk).
+        auto step = [&](auto LS, auto SS, int buf, int kt) __attribute__((always_inline)) {
+            constexpr int ls = decltype(LS)::value, ss = decltype(SS)::value;
+            if (kt + 3 < nk) gload(kt + 3, ra[ls], rb[ls], aok[ls]);
+            if (kt + 1 >= 0 && kt + 1 < nk) {
+                // loads issued after slice kt + 1's: slices kt + 2 and kt + 3, where they exist
+                if (kt + 3 < nk) wait_set(N16{}, ra[ss], rb[ss]);
+                else if (kt + 2 < nk) wait_set(N8{}, ra[ss], rb[ss]);
+                else wait_set(N0{}, ra[ss], rb[ss]);
+                lstore(buf, ra[ss], rb[ss], aok[ss]);
+            }
+            if (kt >= -1) __syncthreads();                 // slice kt + 1 is in `buf`; the consumers have multiplied slice kt
+        };
+        for (int kt = -3; kt < nk; kt += 6) {
+            step(I0{}, I1{}, 0, kt);
             if (kt + 1 >= nk) break;
-            // consumers multiply slice kt+1 from buffer 1; slice kt+2 goes from register set 0 to buffer 0
-            if (kt + 3 < nk) gload(kt + 3, ra[1], rb[1], aok[1]);
-            if (kt + 2 < nk) lstore(0, ra[0], rb[0], aok[0]);
-            __syncthreads();
+            step(I1{}, I2{}, 1, kt + 1);
+            if (kt + 2 >= nk) break;
+            step(I2{}, I0{}, 0, kt + 2);
+            if (kt + 3 >= nk) break;
+            step(I0{}, I1{}, 1, kt + 3);
+            if (kt + 4 >= nk) break;
+            step(I1{}, I2{}, 0, kt + 4);
+            if (kt + 5 >= nk) break;
+            step(I2{}, I0{}, 1, kt + 5);
         }
     } else {
         auto mma_x3 = [&](int buf, int ks) __attribute__((always_inline)) {
@@ -655,7 +699,7 @@ __global__ __launch_bounds__(512) void conv_igemm_x3ws(const ConvP p) {
         for (int kt = 0; kt < nk; kt += 2) {
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) mma_x3(0, ks);
-            __syncthreads();
+            __syncthreads();                               // (one barrier per K-slice, matching the producers' `step`)
             if (kt + 1 >= nk) break;
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) mma_x3(1, ks);
