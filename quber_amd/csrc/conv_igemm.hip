@@ -610,16 +610,28 @@ __global__ __launch_bounds__(512) void conv_igemm_x3ws(const ConvP p) {
             *reinterpret_cast<h16x4*>(dst + plane_stride) = p2;
             *reinterpret_cast<h16x4*>(dst + 2 * plane_stride) = p3;
         };
-        // wait until at most `newer` loads issued after this set's are outstanding; naming the set "+v" keeps every use below
-        auto wait_set = [&](auto NEWER, f32x4 (&a)[AL], f32x4 (&b)[BL]) __attribute__((always_inline)) {
+        // Wait until at most `newer_sets` x 8 loads issued after this set's are outstanding.  ONE statement, with the choice of
+        // the count inside it: three alternative wait statements merge through a phi, and the allocator then copies the
+        // load destinations into the phi's registers BEFORE the wait of two of the three (seen in the .s, wrong results).
+        // Naming the set "+v" keeps every use of it below the wait.
+        auto wait_set = [&](int newer_sets, f32x4 (&a)[AL], f32x4 (&b)[BL]) __attribute__((always_inline)) {
             static_assert(AL == 4 && BL == 4, "operand list of the wait statement");
-            constexpr int newer = decltype(NEWER)::value;
-            if constexpr (newer == 16)
-                asm volatile("s_waitcnt vmcnt(16)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) :: "memory");
-            else if constexpr (newer == 8)
-                asm volatile("s_waitcnt vmcnt(8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) :: "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) :: "memory");
+            asm volatile(
+                "s_cmp_lt_i32 %8, 2\n\t"
+                "s_cbranch_scc1 1f\n\t"
+                "s_waitcnt vmcnt(16)\n\t"
+                "s_branch 3f\n"
+                "1:\n\t"
+                "s_cmp_lt_i32 %8, 1\n\t"
+                "s_cbranch_scc1 2f\n\t"
+                "s_waitcnt vmcnt(8)\n\t"
+                "s_branch 3f\n"
+                "2:\n\t"
+                "s_waitcnt vmcnt(0)\n"
+                "3:\n"
+                : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
+                : "s"(__builtin_amdgcn_readfirstlane(newer_sets))
+                : "memory", "scc");
         };
         auto lstore = [&](int buf, const f32x4 (&a)[AL], const f32x4 (&b)[BL], const bool (&ok)[AL]) __attribute__((always_inline)) {
             H16* Ah = lds + buf * BUF;
@@ -637,9 +649,6 @@ __global__ __launch_bounds__(512) void conv_igemm_x3ws(const ConvP p) {
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>;
-        using N0 = std::integral_constant<int, 0>;
-        using N8 = std::integral_constant<int, 8>;
-        using N16 = std::integral_constant<int, 16>;
         // One loop issues every load (no peeled prologue: with the first loads outside the loop the allocator copies their
         // destination registers into the loop's assignment BEFORE the data has landed - tools/check_asm_loads.py audits the .s).
         // Iteration kt (from -3): request slice kt + 3; split slice kt + 1 (requested two iterations ago) into buffer
@@ -649,9 +658,7 @@ __global__ __launch_bounds__(512) void conv_igemm_x3ws(const ConvP p) {
             if (kt + 3 < nk) gload(kt + 3, ra[ls], rb[ls], aok[ls]);
             if (kt + 1 >= 0 && kt + 1 < nk) {
                 // loads issued after slice kt + 1's: slices kt + 2 and kt + 3, where they exist
-                if (kt + 3 < nk) wait_set(N16{}, ra[ss], rb[ss]);
-                else if (kt + 2 < nk) wait_set(N8{}, ra[ss], rb[ss]);
-                else wait_set(N0{}, ra[ss], rb[ss]);
+                wait_set((kt + 3 < nk ? 1 : 0) + (kt + 2 < nk ? 1 : 0), ra[ss], rb[ss]);
                 lstore(buf, ra[ss], rb[ss], aok[ss]);
             }
             if (kt >= -1) __syncthreads();                 // slice kt + 1 is in `buf`; the consumers have multiplied slice kt
