@@ -215,8 +215,6 @@ double quber_forward_flops(quber_ctx* ctx);
 double quber_forward_flops_executed(quber_ctx* ctx);
 /* test-harness knobs: key 2 = give the stand-alone quber_op_conv2d a split-K workspace (value != 0) or drop it (0);
  * key 3 = force the number of K partitions of convolutions that have a workspace (0 = automatic);
- * key 13 = bf16x3 mode: warp-specialised kernel (producer / consumer waves, double-buffered LDS) for the 128x128-tile launches
- *          without K split (1, default) or the plain loop everywhere (0);
  * key 12 = stand-alone conv ops only: quber_config.compute_dtype of the launch (1 = bf16 / 2 = fp16 operands, 3 = bf16x3);
  * key 11 = stand-alone conv op only: dilated 3x3 layers in tap-major K order with the zero-padding filter rows skipped;
  * key 10 = smallest output width routed to the Winograd path (default 32);

@@ -106,7 +106,7 @@ bool winograd_m6_channels_ok(int Cin, int Cout);
 size_t winograd_ws_floats(int B, int H, int W, int Cin, int Cout, int G, int dil, int m);
 double winograd_mac_ratio(int H, int W, int dil, int m);
 extern int g_winograd, g_wino_min_cin, g_wino_max_ratio, g_wino_variant, g_wino_min_cout;
-extern int g_force_split, g_force_tile, g_tail_split, g_x3_ws;
+extern int g_force_split, g_force_tile, g_tail_split;
 int launch_preprocess(const uint8_t* rgb, const uint8_t* depth, const float* offs, float* x, int B, int Bcap,
                       int H, int W, const float* mean6, const float* std6, int streams, hipStream_t st);
 int launch_maxpool3x3s2(const View& in, const View& out, int B, int G, hipStream_t st);

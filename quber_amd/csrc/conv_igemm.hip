@@ -17,8 +17,6 @@
 // B[kk = h][col r].  The order of k inside a K-slice is free as long as A and B agree, so each lane
 // fetches 4 consecutive k with one ds_read_b128 and feeds them to 4 successive MFMAs:
 // MFMA step s of group ks multiplies k = ks*8 + 4*h + s.
-#include <type_traits>
-
 #include "common.h"
 
 namespace quber {
@@ -474,351 +472,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
     }
 }
 
-// ---- bf16x3, warp-specialised (compute_dtype 3, 128x128 tiles, no K split) -------------------------------------------------
-// Once the multiplies are 2.7x cheaper the loop above is bound by everything BUT the matrix pipe (MFMA busy 0.32,
-// profiles/r02j_conv_mfma_busy_dtype3.md): per K-slice a wave does 48 MFMAs (1536 cycles) and then, between two barriers, ~270
-// vector instructions of operand splitting plus 24 LDS stores.  Here the two kinds of work run in different waves of a
-// 512-thread block, one of each per SIMD, so the matrix pipe and the vector pipe work at the same time:
-//   waves 4-7 (producers): global loads three K-slices ahead (three register sets), split fp32 -> 3 bf16 planes, LDS stores
-//   waves 0-3 (consumers): fragment reads + the six MFMAs per output tile and k-step, nothing else
-// over a double-buffered LDS image (2 x 61 KB: one block per CU) with ONE barrier per K-slice.  Loader state, K orders,
-// operand layout, MFMA order and the epilogue are those of conv_igemm_f32<128,128,2,2,0,3>; results are bit-identical to it.
-__global__ __launch_bounds__(512) void conv_igemm_x3ws(const ConvP p) {
-    constexpr int BM = 128, BN = 128, TM = 2, TN = 2, WN = 2, NTH = 512, NPR = 256, RPP = NPR / 8, AL = BM / RPP, BL = BN / RPP;
-    constexpr int SW = WN * 32, SP = SW + 4;
-    constexpr int PLANE_A = BM * PITCH_H, PLANE_B = BN * PITCH_H, BUF = 3 * (PLANE_A + PLANE_B);   // 16-bit elements
-    using H16 = __bf16;
-    using h16x8 = __attribute__((ext_vector_type(8))) H16;
-    using h16x4 = __attribute__((ext_vector_type(4))) H16;
-    static_assert(2 * BUF * 2 >= BM * SP * 4, "the epilogue staging fits the operand buffers");
-    __shared__ __attribute__((aligned(16))) H16 lds[2 * BUF];
-    float* const smem = reinterpret_cast<float*>(lds);
-
-    const int t = threadIdx.x;
-    const int g = blockIdx.z;
-    const bool producer = t >= 256;
-    int tile;
-    {
-        const int bid = blockIdx.x, nblk = gridDim.x;
-        const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int nt = tile % p.ntiles, mt = tile / p.ntiles;
-    const int m0 = mt * BM, n0 = nt * BN;
-    const int nk = p.Kpad / BK;
-    const int wave = (t >> 6) & 3, lane = t & 63;
-    const int wm = wave / WN, wn = wave % WN;
-    const int r = lane & 31, h = lane >> 5;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    if (producer) {
-        const float* __restrict__ in = p.in + (long)g * p.in_gs;
-        const float* __restrict__ wt = p.w + (long)g * p.w_gs;
-        const int tp = t - 256;
-        const int kq = (tp & 7) * 4, lrow = tp >> 3;
-        int iy0[AL], ix0[AL];
-        const float* rowp[AL];
-#pragma unroll
-        for (int i = 0; i < AL; ++i) {
-            const int m = m0 + lrow + RPP * i;
-            if (m < p.M) {
-                const int ohw = p.OH * p.OW;
-                const int b = m / ohw;
-                const int rem = m - b * ohw;
-                const int oy = rem / p.OW;
-                const int ox = rem - oy * p.OW;
-                iy0[i] = oy * p.stride - p.pad;
-                ix0[i] = ox * p.stride - p.pad;
-                rowp[i] = in + ((long)b * p.H * p.W + (long)iy0[i] * p.W + ix0[i]) * p.in_cs;
-            } else {
-                iy0[i] = -(1 << 28);
-                ix0[i] = 0;
-                rowp[i] = in;
-            }
-        }
-        const float* wrow[BL];
-#pragma unroll
-        for (int i = 0; i < BL; ++i) {
-            const int n = n0 + lrow + RPP * i;
-            wrow[i] = wt + (long)(n < p.Cout ? n : 0) * p.Kpad + kq;
-        }
-        int kc, kx = 0, ky = 0;
-        if (p.kmode) {
-            kc = kq;
-        } else {
-            const int tap = kq / p.Cin;
-            kc = kq - tap * p.Cin;
-            ky = tap / p.kw;
-            kx = tap - ky * p.kw;
-        }
-        f32x4 ra[3][AL], rb[3][BL];       // three register sets: loads run three K-slices ahead of the multiplies
-        bool aok[3][AL];
-        auto gload = [&](int kt, f32x4 (&a)[AL], f32x4 (&b)[BL], bool (&ok)[AL]) __attribute__((always_inline)) {
-            const bool kok = p.kmode || ky < p.kh;
-            const int dy = ky * p.dil, dx = kx * p.dil;
-            const long off = ((long)dy * p.W + dx) * p.in_cs + kc;
-            // The loads are inline asm on purpose: three register sets must be in flight at once, and hipcc, left to allocate
-            // the destinations of ordinary loads, gives every set the same registers and waits vmcnt(0) before re-issuing
-            // (cdna_hip_programming.md 5.7: asm loads are invisible to its wait bookkeeping; `wait_set` below counts them).
-#pragma unroll
-            for (int i = 0; i < AL; ++i) {
-                const bool o = kok && (unsigned)(iy0[i] + dy) < (unsigned)p.H && (unsigned)(ix0[i] + dx) < (unsigned)p.W;
-                ok[i] = o;
-                const float* src = o ? rowp[i] + off : in;
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a[i]) : "v"(src) : "memory");
-            }
-#pragma unroll
-            for (int i = 0; i < BL; ++i) {
-                const float* src = wrow[i] + kt * BK;
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(b[i]) : "v"(src) : "memory");
-            }
-            if (p.kmode) {
-                if (++kx == p.kw) {
-                    kx = 0;
-                    if (++ky == p.kh) { ky = 0; kc += BK; }
-                }
-            } else {
-                kc += BK;
-#pragma unroll
-                for (int it = 0; it < BK / 8; ++it) {
-                    if (kc >= p.Cin) {
-                        kc -= p.Cin;
-                        if (++kx == p.kw) { kx = 0; ++ky; }
-                    }
-                }
-            }
-        };
-        auto split = [&](const f32x4 v, H16* dst, int plane_stride) __attribute__((always_inline)) {
-            h16x4 p1, p2, p3;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float x = v[e];
-                const H16 x1 = (H16)x;
-                const float r1 = x - (float)x1;
-                const H16 x2 = (H16)r1;
-                const float r2 = r1 - (float)x2;
-                p1[e] = x1; p2[e] = x2; p3[e] = (H16)r2;
-            }
-            *reinterpret_cast<h16x4*>(dst) = p1;
-            *reinterpret_cast<h16x4*>(dst + plane_stride) = p2;
-            *reinterpret_cast<h16x4*>(dst + 2 * plane_stride) = p3;
-        };
-        // Wait until at most `newer_sets` x 8 loads issued after this set's are outstanding.  ONE statement, with the choice of
-        // the count inside it: three alternative wait statements merge through a phi, and the allocator then copies the
-        // load destinations into the phi's registers BEFORE the wait of two of the three (seen in the .s, wrong results).
-        // Naming the set "+v" keeps every use of it below the wait.
-        auto wait_set = [&](int newer_sets, f32x4 (&a)[AL], f32x4 (&b)[BL]) __attribute__((always_inline)) {
-            static_assert(AL == 4 && BL == 4, "operand list of the wait statement");
-            asm volatile(
-                "s_cmp_lt_i32 %8, 2\n\t"
-                "s_cbranch_scc1 1f\n\t"
-                "s_waitcnt vmcnt(16)\n\t"
-                "s_branch 3f\n"
-                "1:\n\t"
-                "s_cmp_lt_i32 %8, 1\n\t"
-                "s_cbranch_scc1 2f\n\t"
-                "s_waitcnt vmcnt(8)\n\t"
-                "s_branch 3f\n"
-                "2:\n\t"
-                "s_waitcnt vmcnt(0)\n"
-                "3:\n"
-                : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
-                : "s"(__builtin_amdgcn_readfirstlane(newer_sets))
-                : "memory", "scc");
-        };
-        auto lstore = [&](int buf, const f32x4 (&a)[AL], const f32x4 (&b)[BL], const bool (&ok)[AL]) __attribute__((always_inline)) {
-            H16* Ah = lds + buf * BUF;
-            H16* Bh = Ah + 3 * PLANE_A;
-#pragma unroll
-            for (int i = 0; i < AL; ++i)
-                split(ok[i] ? a[i] : f32x4{0.f, 0.f, 0.f, 0.f}, &Ah[(lrow + RPP * i) * PITCH_H + kq], PLANE_A);
-#pragma unroll
-            for (int i = 0; i < BL; ++i) split(b[i], &Bh[(lrow + RPP * i) * PITCH_H + kq], PLANE_B);
-        };
-        // Slice s lives in register set s % 3 from its loads (issued while slice s - 3 is being multiplied) until it is split
-        // into LDS buffer s & 1 (while slice s - 1 is being multiplied): two whole iterations of latency hiding.  The
-        // sched_barrier keeps the loads of an iteration ahead of its split: left alone, the scheduler sinks them below it
-        // (one iteration of hiding, and with the 6x cheaper multiplies the HBM / L2-miss latency shows).
-        using I0 = std::integral_constant<int, 0>;
-        using I1 = std::integral_constant<int, 1>;
-        using I2 = std::integral_constant<int, 2>;
-        // One loop issues every load (no peeled prologue: with the first loads outside the loop the allocator copies their
-        // destination registers into the loop's assignment BEFORE the data has landed - tools/check_asm_loads.py audits the .s).
-        // Iteration kt (from -3): request slice kt + 3; split slice kt + 1 (requested two iterations ago) into buffer
-        // (kt + 1) & 1; from kt = -1 on, one barrier per iteration (the consumers' 1 + nk).
-        auto step = [&](auto LS, auto SS, int buf, int kt) __attribute__((always_inline)) {
-            constexpr int ls = decltype(LS)::value, ss = decltype(SS)::value;
-            if (kt + 3 < nk) gload(kt + 3, ra[ls], rb[ls], aok[ls]);
-            if (kt + 1 >= 0 && kt + 1 < nk) {
-                // loads issued after slice kt + 1's: slices kt + 2 and kt + 3, where they exist
-                wait_set((kt + 3 < nk ? 1 : 0) + (kt + 2 < nk ? 1 : 0), ra[ss], rb[ss]);
-                lstore(buf, ra[ss], rb[ss], aok[ss]);
-            }
-            if (kt >= -1) __syncthreads();                 // slice kt + 1 is in `buf`; the consumers have multiplied slice kt
-        };
-        for (int kt = -3; kt < nk; kt += 6) {
-            step(I0{}, I1{}, 0, kt);
-            if (kt + 1 >= nk) break;
-            step(I1{}, I2{}, 1, kt + 1);
-            if (kt + 2 >= nk) break;
-            step(I2{}, I0{}, 0, kt + 2);
-            if (kt + 3 >= nk) break;
-            step(I0{}, I1{}, 1, kt + 3);
-            if (kt + 4 >= nk) break;
-            step(I1{}, I2{}, 0, kt + 4);
-            if (kt + 5 >= nk) break;
-            step(I2{}, I0{}, 1, kt + 5);
-        }
-    } else {
-        auto mma_x3 = [&](int buf, int ks) __attribute__((always_inline)) {
-            const H16* ap = lds + buf * BUF + (wm * TM * 32 + r) * PITCH_H + 8 * h + ks * 16;
-            const H16* bp = lds + buf * BUF + 3 * PLANE_A + (wn * 32 + r) * PITCH_H + 8 * h + ks * 16;
-            h16x8 a[3][TM], b[3][TN];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[q][i] = *reinterpret_cast<const h16x8*>(ap + q * PLANE_A + i * 32 * PITCH_H);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b[q][j] = *reinterpret_cast<const h16x8*>(bp + q * PLANE_B + j * WN * 32 * PITCH_H);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    f32x16 c = acc[i][j];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], c, 0, 0, 0);
-                    acc[i][j] = c;
-                }
-        };
-        __syncthreads();                                   // buffer 0 = slice 0
-        for (int kt = 0; kt < nk; kt += 2) {
-#pragma unroll
-            for (int ks = 0; ks < BK / 16; ++ks) mma_x3(0, ks);
-            __syncthreads();                               // (one barrier per K-slice, matching the producers' `step`)
-            if (kt + 1 >= nk) break;
-#pragma unroll
-            for (int ks = 0; ks < BK / 16; ++ks) mma_x3(1, ks);
-            __syncthreads();
-        }
-    }
-
-    // ---- epilogue (as conv_igemm_f32, all 512 threads store; only the consumer waves hold accumulators) ----
-    float* __restrict__ out = p.out + (long)g * p.out_gs;
-    const int out_cs = p.out_cs;
-    const float* __restrict__ res = p.res ? p.res + (long)g * p.res_gs : nullptr;
-    const float* __restrict__ scale = p.scale ? p.scale + g * p.ss_gs : nullptr;
-    const float* __restrict__ shift = p.shift ? p.shift + g * p.ss_gs : nullptr;
-    const bool relu = p.relu;
-    const float* __restrict__ prelu = p.prelu ? p.prelu + g * p.ss_gs : nullptr;
-    __shared__ double gacc[2 * 32 * 2];
-    const bool gn = p.gn_sum != nullptr;
-    int b0 = 0, m_next = 0;
-    if (gn) {
-        if (t < 128) gacc[t] = 0.0;
-        b0 = m0 / p.ohw;
-        m_next = (b0 + 1) * p.ohw;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        if (!producer) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    smem[row * SP + wn * 32 + r] = acc[i][j][e];
-                }
-        }
-        __syncthreads();
-        const int nb = n0 + j * SW;
-        if (p.vec_out) {
-            constexpr int CPR = SW / 4;
-            static_assert(NTH % CPR == 0, "a thread keeps its channel column across the rows of a pass");
-            double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
-#pragma unroll
-            for (int c = t; c < BM * CPR; c += NTH) {
-                const int row = c / CPR, q = (c - row * CPR) * 4;
-                const int m = m0 + row, n = nb + q;
-                if (m < p.M && n < p.Cout) {
-                    float4 v = *reinterpret_cast<const float4*>(&smem[row * SP + q]);
-                    if (scale) {
-                        const float4 sc = *reinterpret_cast<const float4*>(scale + n);
-                        const float4 sh = *reinterpret_cast<const float4*>(shift + n);
-                        v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
-                        v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
-                    }
-                    if (res) {
-                        const float4 rv = *reinterpret_cast<const float4*>(res + (long)m * p.res_cs + n);
-                        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-                    }
-                    if (relu) {
-                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                    }
-                    if (prelu) {
-                        const float4 sl = *reinterpret_cast<const float4*>(prelu + n);
-                        v.x = v.x > 0.f ? v.x : v.x * sl.x; v.y = v.y > 0.f ? v.y : v.y * sl.y;
-                        v.z = v.z > 0.f ? v.z : v.z * sl.z; v.w = v.w > 0.f ? v.w : v.w * sl.w;
-                    }
-                    *reinterpret_cast<float4*>(out + (long)m * out_cs + n) = v;
-                    if (gn) {
-                        const double a = (double)v.x + (double)v.y + (double)v.z + (double)v.w;
-                        const double b = (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
-                        if (m < m_next) { s0 += a; q0 += b; } else { s1 += a; q1 += b; }
-                    }
-                }
-            }
-            if (gn) {
-                const int n = nb + (t % CPR) * 4;
-                if (n < p.Cout) {
-                    const int grp = n / p.gn_cpg;
-                    atomicAdd(&gacc[grp * 2], s0);
-                    atomicAdd(&gacc[grp * 2 + 1], q0);
-                    if (s1 != 0.0 || q1 != 0.0) {
-                        atomicAdd(&gacc[64 + grp * 2], s1);
-                        atomicAdd(&gacc[64 + grp * 2 + 1], q1);
-                    }
-                }
-            }
-        } else {
-            for (int c = t; c < BM * SW; c += NTH) {
-                const int row = c / SW, q = c - row * SW;
-                const int m = m0 + row, n = nb + q;
-                if (m < p.M && n < p.Cout) {
-                    float v = smem[row * SP + q];
-                    if (scale) v = fmaf(v, scale[n], shift[n]);
-                    if (res) v += res[(long)m * p.res_cs + n];
-                    if (relu) v = fmaxf(v, 0.f);
-                    if (prelu) v = v > 0.f ? v : v * prelu[n];
-                    out[(long)m * out_cs + n] = v;
-                }
-            }
-        }
-        if (j + 1 < TN) __syncthreads();
-    }
-    if (gn) {
-        __syncthreads();
-        if (t < 128) {
-            const double v = gacc[t];
-            const int b = b0 + (t >> 6);
-            if (v != 0.0 && b < p.B)
-                atomicAdd(&p.gn_sum[(((long)g * p.B + b) * p.gn_groups) * 2 + (t & 63)], v);
-        }
-    }
-}
-
 // sums the split-K partial tiles in a fixed order (deterministic) and applies the fused epilogue; block x owns the
 // contiguous element range [x*chunk, (x+1)*chunk) so that, with GroupNorm sums requested, it meets at most two images
 template <int V>
@@ -885,7 +538,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvP p, int S
 int g_winograd = 0;       // key 6: Winograd path for the eligible 3x3 layers: 0 = where it pays, 1 = never, 2 = always
 int g_force_tile = 0;     // test-harness knobs (quber_set_tuning keys 4 / 3): force the tile shape / the number of K partitions
 int g_force_split = 0;
-int g_x3_ws = 1;           // key 13: bf16x3 launches on 128x128 tiles without K split take the warp-specialised kernel (1) or the plain loop (0)
 int g_tail_split = 1;      // key 5: split the ragged last round of large launches when the model favours it (1), never (0), whenever feasible (2)
 
 // ---- work distribution -------------------------------------------------------------------------------------------
@@ -1016,16 +668,6 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
     // residual) and the 32-column head layers on 256x32 tiles lose occupancy to its three LDS planes and gain nothing
     // (profiles/r02j_conv_layers_dtype{0,3}.md): they keep the exact fp32 MFMA kernel, which is at least as accurate.
     if (p.bf16 == 3 && (BM == 256 || (BM == 64 && nk <= 8))) p.bf16 = 0;
-    if constexpr (BM == 128 && BN == 128) {
-        if (p.bf16 == 3 && S == 1 && g_x3_ws) {
-            {
-                ProfScope prof(tag, conv_bytes, conv_flops, st);
-                hipLaunchKernelGGL(conv_igemm_x3ws, dim3(p.mtiles * p.ntiles, 1, G), dim3(512), 0, st, p);
-            }
-            QB_CHECK(hipGetLastError());
-            return gn_separate();
-        }
-    }
     if (p.bf16) {
         {
             ProfScope prof(tag, conv_bytes, conv_flops, st);

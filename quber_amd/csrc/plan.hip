@@ -1029,7 +1029,6 @@ void quber_set_tuning(int32_t key, int32_t value) {
         }
     }
     if (key == 4) g_force_tile = value;    // force the tile shape: 1 = 64x64, 2 = 128x128, 4 = 256x32 (0 = automatic)
-    if (key == 13) g_x3_ws = value;           // bf16x3: warp-specialised kernel for 128x128-tile launches without K split (default 1)
     if (key == 12) g_op_bf16 = value;         // stand-alone conv ops: 1 = bf16, 2 = fp16 operands, 3 = fp32 as 3 bf16 terms; fp32 accumulation
     if (key == 11) g_op_skip_rows = value;    // stand-alone conv op: tap-major K order with padded filter rows skipped (dilated 3x3)
     if (key == 10) g_wino_min_cout = value;   // smallest output width eligible for the Winograd path (default 32)

@@ -481,7 +481,7 @@ def test_conv_igemm_16bit_vs_rounded_operands(case, dt):
     (2, 64, 80, 128, 130, 3, 1, 1, False, False, False),
     (4, 60, 80, 512, 256, 3, 1, 1, True, False, True),      # K = 4608
     (1, 30, 40, 2048, 256, 1, 1, 1, True, False, True),     # K = 2048
-    # >= 384 tiles of 128x128 without K split: the warp-specialised kernel (producer / consumer waves, double-buffered LDS)
+    # >= 384 tiles of 128x128 without K split
     (8, 120, 160, 64, 128, 3, 1, 1, True, True, True),      # 1200 tiles, 18 K-slices (even), residual
     (6, 120, 160, 96, 256, 1, 1, 1, True, False, True),     # 3 K-slices (odd), tap-major K order
     (5, 100, 131, 128, 200, 3, 1, 2, True, False, True),    # ragged M and N, dilated, 36 K-slices
@@ -498,11 +498,6 @@ def test_conv_igemm_bf16x3_meets_the_fp32_bar(case):
         assert _conv_case(*case, bf16=3) < 2e-6
     finally:
         lib.quber_set_tuning(2, 0)
-    lib.quber_set_tuning(13, 0)                       # the plain (not warp-specialised) loop
-    try:
-        assert _conv_case(*case, bf16=3) < 2e-6
-    finally:
-        lib.quber_set_tuning(13, 1)
 
 
 @pytest.mark.parametrize("case", [

@@ -20,9 +20,8 @@ LAYERS = [
     ("aspp 3x3 d18 2048>256 @30x40", 16, 30, 40, 2048, 256, 3, 1, 18),
     ("stem.conv3 3x3 32>64 @240x320 x2", 32, 240, 320, 32, 64, 3, 1, 1),
 ]
-# name, key 12 (arithmetic), key 4 (forced tile), key 13 (warp-specialised bf16x3 kernel)
-CONFIGS = [("f32 auto", 0, 0, 1), ("x3 plain loop", 3, 0, 0), ("x3 warp-specialised", 3, 0, 1), ("x3 ws 128x128 forced", 3, 2, 1),
-           ("f16 auto", 2, 0, 1)]
+# name, key 12 (arithmetic), key 4 (forced tile)
+CONFIGS = [("f32 auto", 0, 0), ("x3 auto", 3, 0), ("x3 64x64", 3, 1), ("x3 128x128", 3, 2), ("f16 auto", 2, 0)]
 
 
 def main():
@@ -41,10 +40,9 @@ def main():
         packed = torch.empty(Cout * ((k * k * Cin + 31) // 32 * 32), device="cuda")
         flops = 2.0 * B * H * W * Cin * k * k * Cout
         res = []
-        for (_, dt, tile, ws) in CONFIGS:
+        for (_, dt, tile) in CONFIGS:
             lib.quber_set_tuning(12, dt)
             lib.quber_set_tuning(4, tile)
-            lib.quber_set_tuning(13, ws)
             ts = []
             for rd in range(4):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -60,7 +58,6 @@ def main():
         print(f"| {name} | " + " | ".join("%.1f" % r for r in res) + " |", flush=True)
     lib.quber_set_tuning(12, 0)
     lib.quber_set_tuning(4, 0)
-    lib.quber_set_tuning(13, 1)
     lib.quber_set_tuning(2, 0)
 
 
