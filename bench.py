@@ -339,13 +339,17 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]     # per-step device times (spread only)
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    marks[0].record()
+    for i in range(a.steps):
         step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]
     rank_info = {"rank": rank, "world_size": dist.get_world_size() if dist is not None else 1, "device": str(dev),
                  "device_name": torch.cuda.get_device_name(dev), "backend": dist.get_backend() if dist is not None else None}
     ranks = [rank_info]
@@ -361,7 +365,7 @@ def main():
         host_io = host_io_run(a, eng, host, offsets, logits, post, max_inst, dev)
 
     if rank == 0:
-        line = report(a, eng, world, elapsed, ranks, center_bias, sd, host,
+        line = report(a, eng, world, elapsed, ranks, center_bias, sd, host, step_ms,
                       dict(masks=masks, gt_masks=gt_masks, bgr=bgr, depth=depth, offsets=offsets, logits=logits, post=post,
                            out_masks=out_masks, max_inst=max_inst), gpu_step)
         if host_io is not None:
@@ -476,7 +480,7 @@ def host_io_run(a, eng, host, offsets, logits, post, max_inst, dev):
                     "double-buffered copy streams; single GPU"}
 
 
-def report(a, eng, world, elapsed, ranks, center_bias, sd, host, t, gpu_step):
+def report(a, eng, world, elapsed, ranks, center_bias, sd, host, step_ms, t, gpu_step):
     import torch
     B, H, W, N = a.batch, a.height, a.width, a.instances
     # ---- stage profile: HIP events around every kernel of one step (+ the explicit error maps, a2), median of 3 ----
@@ -525,6 +529,7 @@ def report(a, eng, world, elapsed, ranks, center_bias, sd, host, t, gpu_step):
         "value": world * B * N * a.steps / elapsed,
         "unit": "refined masks/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+        "step_ms_min_median_max_rank0": [float(np.min(step_ms)), float(np.median(step_ms)), float(np.max(step_ms))],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": f"batch={B} {W}x{H} RGB-D, {N} initial instances/frame, ResNet-50 RGB-D refiner "
