@@ -205,6 +205,14 @@ int quber_normalize_depth(const void* dev_depth, int32_t is_float32, int64_t n_p
 int quber_resize_u8(const uint8_t* dev_src, int32_t src_h, int32_t src_w, int32_t channels, uint8_t* dev_dst,
                     int32_t dst_h, int32_t dst_w, int32_t linear, void* stream);
 
+/* adapter pre-processing - cv2.inpaint(img, mask, radius, cv2.INPAINT_TELEA) of one 8-bit channel (inpaint_depth,
+ * eval/preprocess_utils.py:44-64).  The ONE entry point that takes HOST pointers and runs on the host, like the OpenCV call
+ * it replaces (the fast-marching method is sequential; it runs once per frame outside the refiner's timed region).
+ * Restated from Telea's published algorithm in the form OpenCV implements it; parity unpinned, own tolerance.
+ *   host_img u8 [h][w], host_mask u8 [h][w] (non-zero = to be filled)  ->  host_out u8 [h][w] */
+int quber_inpaint_telea_u8(const uint8_t* host_img, const uint8_t* host_mask, int32_t h, int32_t w, int32_t radius,
+                           uint8_t* host_out);
+
 /* ---- introspection / kernel-level entry points used by the parity tests and the benchmark ---- */
 /* device pointer + NHWC geometry of a named intermediate of the last quber_forward ("res2", "res3", "res5", "y", ...) */
 int quber_debug_tensor(quber_ctx* ctx, const char* name, float** dev_ptr, int32_t* dims4, int32_t* channel_stride);

@@ -1232,6 +1232,11 @@ int quber_normalize_depth(const void* depth, int32_t is_float32, int64_t n_pixel
     return launch_normalize_depth(depth, is_float32, n_pixels, min_val, max_val, out3, zero, (hipStream_t)stream);
 }
 
+int quber_inpaint_telea_u8(const uint8_t* host_img, const uint8_t* host_mask, int32_t h, int32_t w, int32_t radius,
+                           uint8_t* host_out) {
+    return inpaint_telea_u8_host(host_img, host_mask, h, w, radius, host_out);
+}
+
 int quber_resize_u8(const uint8_t* src, int32_t src_h, int32_t src_w, int32_t channels, uint8_t* dst, int32_t dst_h,
                     int32_t dst_w, int32_t linear, void* stream) {
     if (!src || !dst) return fail("bad argument to quber_resize_u8");

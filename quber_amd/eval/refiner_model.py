@@ -14,13 +14,13 @@ the unfiltered refined masks plus the foreground mask.  The reference always con
 is opt-in (``foreground_filter=True``) because the reference's ``rgbd_lmffnet.pth`` does not ship and seeded weights give
 a meaningless foreground - with it off, ``fg_mask`` is None and the OCID branch masks zero depth on the unfiltered masks.
 
-Not built: ``inpaint_depth`` (eval/preprocess_utils.py:44-64, ``cv2.inpaint`` TELEA - a fast-marching algorithm with no
-source in the reference; it rewrites the pixels whose NORMALISED depth is 0, i.e. holes and everything nearer than
-``min_val``).  Such pixels are left at 0 and a warning is raised once per adapter; frames without them are unaffected.
+``inpaint_depth`` (eval/preprocess_utils.py:44-64: the pixels whose NORMALISED depth is 0 - holes and everything nearer than
+``min_val`` - are filled with ``cv2.inpaint(..., 3, cv2.INPAINT_TELEA)``) runs on the host, as in the reference:
+``quber_inpaint_telea_u8`` restates Telea's fast-marching method in the form OpenCV implements it (csrc/inpaint.hip; parity
+unpinned, own tolerance - OpenCV is not in the image).  ``MaskRefiner(inpaint=False)`` skips it.
 cv2 / imageio are absent from the image, so files are read with PIL.
 """
 import time
-import warnings
 
 import numpy as np
 import torch
@@ -42,6 +42,37 @@ def normalize_depth(depth, min_val=250.0, max_val=1500.0):
     return np.uint8(np.repeat(depth, 3, -1))
 
 
+def inpaint_depth(depth, kernel_size=3):
+    """eval/preprocess_utils.py:44-64 with factor = 1: mask = pixels whose three channels are 0, dilated by a 3x3 square;
+    TELEA in-painting with radius 3; only the zero pixels of the input are replaced."""
+    import ctypes as C
+    from .. import _lib
+    lib = _lib.load()
+    depth = np.ascontiguousarray(depth, dtype=np.uint8)
+    h, w = depth.shape[:2]
+    mask = np.all(depth == 0, axis=2)
+    if not mask.any():
+        return depth
+    r = kernel_size // 2
+    pad = np.pad(mask, r)
+    dil = np.zeros_like(mask)
+    for dy in range(kernel_size):
+        for dx in range(kernel_size):
+            dil |= pad[dy:dy + h, dx:dx + w]
+    m8 = np.ascontiguousarray(dil, dtype=np.uint8)
+    filled = np.empty_like(depth)
+    same = bool((depth[..., 0] == depth[..., 1]).all() and (depth[..., 0] == depth[..., 2]).all())
+    for c in range(1 if same else depth.shape[2]):      # normalize_depth replicates one channel: in-paint it once
+        src = np.ascontiguousarray(depth[..., c])
+        dst = np.empty_like(src)
+        _lib.check(lib.quber_inpaint_telea_u8(C.c_void_p(src.ctypes.data), C.c_void_p(m8.ctypes.data), h, w, kernel_size,
+                                              C.c_void_p(dst.ctypes.data)))
+        filled[..., c] = dst
+    if same:
+        filled[..., 1] = filled[..., 2] = filled[..., 0]
+    return np.where(depth == 0, filled, depth)
+
+
 def resize_shortest_edge_shape(oldh, oldw, short_edge_length=800, max_size=1333):
     """[d2] ResizeShortestEdge.get_output_shape, used by the armbench branch (refiner_model.py:228)."""
     scale = short_edge_length * 1.0 / min(oldh, oldw)
@@ -54,11 +85,11 @@ def resize_shortest_edge_shape(oldh, oldw, short_edge_length=800, max_size=1333)
 
 class MaskRefiner:
     def __init__(self, config_file=None, weights_file=None, dataset="OSD", device="cuda:0", foreground_filter=False,
-                 lmffnet_weights="./foreground_segmentation/rgbd_lmffnet.pth"):
+                 lmffnet_weights="./foreground_segmentation/rgbd_lmffnet.pth", inpaint=True):
         self.refiner_predictor = MaskRefinerPredictor(config_file, weights_file=weights_file, device=device)
         self.dataset = dataset
         self.lmffnet = None
-        self._warned_inpaint = False
+        self.inpaint = inpaint
         if foreground_filter:
             from ..foreground.predictor import lmffNet
             self.lmffnet = lmffNet(lmffnet_weights, device=device)
@@ -94,11 +125,8 @@ class MaskRefiner:
         else:
             depth = normalize_depth(depth, lo, hi)
         depth = self._resize(depth, H, W, linear=False)                          # cv2.resize(..., INTER_NEAREST)
-        if not self._warned_inpaint and bool((depth[..., 0] == 0).any()):
-            warnings.warn("quber_amd: the depth image has pixels at or below the minimum range (normalised depth 0); the "
-                          "reference in-paints them (cv2.inpaint TELEA, eval/preprocess_utils.py:44-64), this build leaves "
-                          "them at 0")
-            self._warned_inpaint = True
+        if self.inpaint:
+            depth = inpaint_depth(depth)                                         # refiner_model.py:255
 
         start = time.time()
         output = self.refiner_predictor.predict(np.ascontiguousarray(rgb), depth, initial_masks)[0]

@@ -184,3 +184,49 @@ def test_boundary_restatement_hand_derived():
     g[4:8, 5:9] = True
     assert M.boundary_overlap(a, g, bound_th=3) == (12, 12)
     assert np.ceil(0.003 * np.linalg.norm((480, 640))) == 3
+
+
+def test_inpaint_telea_restatement():
+    """cv2.inpaint(..., 3, INPAINT_TELEA) restated (parity unpinned: no OpenCV in the image).  The library's host function and
+    the independent numpy restatement agree exactly; hand-derivable properties: pixels outside the mask are untouched, a
+    constant image is reproduced exactly in holes away from the frame, a smooth depth-like image to a few grey levels."""
+    import ctypes as C
+    from oracle import inpaint_np
+    from quber_amd import _lib
+    from quber_amd.eval.refiner_model import inpaint_depth
+    lib = _lib.load()
+
+    def run(img, mask, r=3):
+        out = np.empty_like(img)
+        assert lib.quber_inpaint_telea_u8(C.c_void_p(img.ctypes.data), C.c_void_p(mask.ctypes.data), img.shape[0], img.shape[1],
+                                          r, C.c_void_p(out.ctypes.data)) == 0
+        return out
+
+    h, w = 48, 64
+    yy, xx = np.mgrid[0:h, 0:w]
+    mask = np.zeros((h, w), np.uint8)
+    mask[10:18, 20:33] = 1
+    mask[30:33, 5:40] = 1
+    mask[40:48, 60:64] = 1                                         # touches the frame
+    rng = np.random.default_rng(0)
+    for name, img in (("const", np.full((h, w), 117, np.uint8)), ("ramp", (2 * xx + yy).astype(np.uint8)),
+                      ("noise", rng.integers(0, 256, (h, w)).astype(np.uint8))):
+        src = img.copy()
+        src[mask != 0] = 0
+        got = run(src, mask)
+        np.testing.assert_array_equal(got, inpaint_np.inpaint_telea_u8(src, mask), err_msg=name)
+        np.testing.assert_array_equal(got[mask == 0], src[mask == 0])
+        if name == "const":
+            np.testing.assert_array_equal(got, img)
+        if name == "ramp":                                             # slope 2 / px; holes away from the frame
+            e = np.abs(got.astype(int) - img.astype(int))
+            assert e[10:18, 20:33].max() <= 6 and e[30:33, 5:40].max() <= 4
+    # inpaint_depth (eval/preprocess_utils.py:44-64): only zero pixels change, all three channels alike
+    d = np.clip(60 + yy * 2 + 10 * np.sin(xx / 9.0), 1, 255).astype(np.uint8)
+    d3 = np.repeat(d[:, :, None], 3, 2)
+    d3[12:20, 30:41] = 0
+    d3[0:3, 0:4] = 0
+    out = inpaint_depth(d3)
+    np.testing.assert_array_equal(out, inpaint_np.inpaint_depth(d3))
+    assert (out[d3 != 0] == d3[d3 != 0]).all() and (out[12:20, 30:41] > 0).all()
+    assert np.abs(out[12:20, 30:41, 0].astype(int) - d[12:20, 30:41]).max() <= 8
