@@ -102,6 +102,9 @@ def load():
         raise QuberError(f"QUBER_WINOGRAD={mode!r}: expected auto, f6, f4, f2 or off")
     lib.quber_set_tuning(6, 1 if mode == "off" else 0)
     lib.quber_set_tuning(9, {"f2": 2, "f4": 4, "f6": 6}.get(mode, 0))
+    # QUBER_PERSIST = 0 | 1: persistent convolution launches (csrc/conv_persist.hip, tuning key 13)
+    if "QUBER_PERSIST" in os.environ:
+        lib.quber_set_tuning(13, int(os.environ["QUBER_PERSIST"]))
     _lib = lib
     return lib
 

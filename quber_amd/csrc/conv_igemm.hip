@@ -631,6 +631,21 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
         else
             hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(blocks, G), dim3(256), 0, st, p, parts, G, chunk);
     };
+    const bool skip = BM != 256 && p.skip_rows && p.kmode == 0 && p.kh > 1 && p.Cin % BK == 0 && p.K == p.Kpad && p.ohw > 0;
+    // Persistent launch (conv_persist.hip): one block per resident slot walks whole tiles and an equal share of the
+    // K-slices of the remainder
+    if (g_persist && (BM == 128 || g_persist == 2) && !skip && p.ws && conv_persistent_ok(p)) {
+        if (p.bf16 == 3 && (BM == 256 || (BM == 64 && nk <= 8))) p.bf16 = 0;
+        const int bpc = BM == 64 ? (p.bf16 == 3 ? 5 : 7) : (p.bf16 == 3 ? 2 : 3);
+        if (p.ws_floats >= conv_persistent_ws_floats(BM, BN, bpc)) {
+            {
+                ProfScope prof(tag, conv_bytes, conv_flops, st);
+                const int rc = launch_conv_persistent<BM, BN, WM, WN>(p, G, bpc, st);
+                if (rc) return rc;
+            }
+            return gn_separate();
+        }
+    }
     // Split tail: with more than one round of tiles, cut the tiles of the ragged last round into 2^shift K-pieces that
     // together fill about one more (short) round; taken when the model prices it below the launch chosen so far.
     constexpr int BPC = (BM == 64) ? 7 : 3;
@@ -687,7 +702,6 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
         QB_CHECK(hipGetLastError());
         return gn_separate();
     }
-    const bool skip = BM != 256 && p.skip_rows && p.kmode == 0 && p.kh > 1 && p.Cin % BK == 0 && p.K == p.Kpad && p.ohw > 0;
     if (S > 1) {
         {
             ProfScope prof(tag, conv_bytes, conv_flops, st);

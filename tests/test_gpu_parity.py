@@ -500,6 +500,59 @@ def test_conv_igemm_bf16x3_meets_the_fp32_bar(case):
         lib.quber_set_tuning(2, 0)
 
 
+PERSISTENT_CASES = [
+    # B, H, W, Cin, Cout, k, stride, dil, affine, residual, relu
+    (2, 24, 32, 8, 32, 3, 2, 1, True, False, True),         # 256x32 tiles, K = 72 (tail), a handful of tiles: stream-K only
+    (2, 24, 32, 32, 64, 3, 1, 1, True, False, True),        # 64x64 tiles
+    (2, 16, 20, 64, 256, 1, 1, 1, True, True, True),        # bottleneck conv3 + residual
+    (1, 30, 40, 256, 128, 1, 2, 1, True, False, True),      # strided 1x1
+    (1, 15, 20, 128, 128, 3, 1, 4, True, False, True),      # dilated 3x3, slice-major K order
+    (3, 33, 47, 164, 128, 1, 1, 1, True, False, True),      # K = 164 (tail of 4), ragged M
+    (2, 64, 80, 128, 132, 3, 1, 1, False, False, False),    # ragged N (132 = 128 + 4)
+    (1, 1, 1, 2048, 256, 1, 1, 1, True, False, True),       # M = 1
+    (4, 60, 80, 512, 256, 3, 1, 1, True, False, True),      # K = 4608, 300 tiles: every tile shared between blocks
+    (1, 30, 40, 2048, 256, 1, 1, 1, True, False, True),     # 20 tiles, K = 2048
+    (8, 120, 160, 64, 128, 3, 1, 1, True, True, True),      # 1200 tiles = 1 round + 432: whole tiles, then shares, residual
+    (6, 120, 160, 96, 256, 1, 1, 1, True, False, True),     # 3 K-slices, tap-major K order, 1800 tiles
+    (5, 100, 131, 128, 200, 3, 1, 2, True, False, True),    # ragged M and N, dilated
+    (12, 120, 160, 32, 128, 1, 1, 1, False, False, False),  # a single K-slice per tile
+    (9, 120, 160, 32, 256, 1, 1, 1, False, False, False),   # 2700 tiles
+    (2, 60, 80, 256, 64, 3, 1, 1, True, True, True),        # 64x64 tiles with residual
+    (1, 120, 160, 128, 32, 3, 1, 1, True, False, True),     # 256x32 tiles, 75 tiles
+    (16, 30, 40, 1024, 2048, 1, 1, 1, True, True, True),    # res5 shortcut-like: 2400 tiles of 32 slices
+]
+
+
+@pytest.mark.parametrize("dt", [0, 3], ids=["f32", "bf16x3"])
+@pytest.mark.parametrize("case", PERSISTENT_CASES)
+def test_conv_persistent_vs_torch(case, dt):
+    """Persistent launch (conv_persist.hip, tuning key 13): whole tiles round-robin per XCD, then equal shares of the
+    K-slices of the remainder, partial tiles summed by the fix-up kernel - held to the bar of the one-tile-per-block kernel."""
+    lib = _lib.load()
+    lib.quber_set_tuning(2, 1)
+    lib.quber_set_tuning(13, 2)
+    try:
+        assert _conv_case(*case, bf16=dt) < 2e-6
+    finally:
+        lib.quber_set_tuning(13, 0)
+        lib.quber_set_tuning(2, 0)
+
+
+@pytest.mark.parametrize("case,m", [((2, 30, 40, 256, 256, 1, True, True), 4), ((1, 31, 45, 512, 512, 1, True, False), 4),
+                                    ((2, 30, 40, 512, 512, 2, True, True), 2), ((1, 30, 40, 2048, 256, 6, True, True), 4),
+                                    ((3, 12, 16, 256, 128, 1, False, False), 6)])
+def test_conv3x3_winograd_persistent_gemm(case, m):
+    """the grouped Winograd GEMM (36 / 16 / 64 groups) through the persistent launch"""
+    lib = _lib.load()
+    lib.quber_set_tuning(2, 1)
+    lib.quber_set_tuning(13, 2)
+    try:
+        test_conv3x3_winograd_vs_float64(case, m)
+    finally:
+        lib.quber_set_tuning(13, 0)
+        lib.quber_set_tuning(2, 0)
+
+
 @pytest.mark.parametrize("case", [
     # split-K (needs the op workspace) and launches around the one-round boundary
     (4, 120, 160, 64, 128, 3, 1, 1, True, True, True),      # 600 tiles of 128x128 (below one round): K split in two
