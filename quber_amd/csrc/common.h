@@ -48,7 +48,7 @@ struct ConvP {
     long in_gs, out_gs, res_gs, w_gs;
     int ss_gs;
     const char* tag;     // stage-profile tag of the launch (null = "conv_gemm")
-    int pk_T, pk_tpg, pk_min, pk_in_bytes, pk_stagger, pk_debug;   // persistent launch (conv_persist.hip): tiles over all groups, tiles per group, shortest K share
+    int pk_T, pk_tpg, pk_min, pk_in_bytes, pk_debug;   // persistent launch (conv_persist.hip): tiles over all groups, tiles per group, shortest K share
     int bf16;            // quber_config.compute_dtype: 0 = fp32 MFMA, 1 = bf16 / 2 = fp16 operands, 3 = fp32 operands split into 3 bf16 terms
 };
 
@@ -107,7 +107,7 @@ bool winograd_m6_channels_ok(int Cin, int Cout);
 size_t winograd_ws_floats(int B, int H, int W, int Cin, int Cout, int G, int dil, int m);
 double winograd_mac_ratio(int H, int W, int dil, int m);
 extern int g_winograd, g_wino_min_cin, g_wino_max_ratio, g_wino_variant, g_wino_min_cout;
-extern int g_force_split, g_force_tile, g_tail_split, g_persist, g_persist_min_nk, g_persist_stagger, g_persist_debug;
+extern int g_force_split, g_force_tile, g_tail_split, g_persist, g_persist_min_nk, g_persist_debug;
 // persistent launch of the implicit GEMM (conv_persist.hip); p.mtiles / ntiles / vec_out filled in by the caller
 template <int BM, int BN, int WM, int WN> int launch_conv_persistent(ConvP p, int G, int bpc, hipStream_t st);
 size_t conv_persistent_ws_floats(int BM, int BN, int bpc);

@@ -72,8 +72,6 @@ __device__ unsigned long long g_pk_span[2048 * 4];      // per block: kernel ent
 #else
 #define PK_STAMP(i) do {} while (0)
 #endif
-__device__ unsigned g_pk_tickets[8 * 256];      // per CU: blocks of persistent launches seen so far (start stagger)
-
 // resident blocks per CU the kernel is built for (= waves per SIMD: a block is one wave on each SIMD)
 constexpr int pk_occupancy(int BM, int DT) { return BM == 64 ? (DT == 3 ? 5 : 7) : (DT == 3 ? 2 : 3); }
 
@@ -128,7 +126,9 @@ __device__ __forceinline__ void buf_store4(f32x4 v, __amdgpu_buffer_rsrc_t r, un
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN, int DT, bool RES>
+// EPI: what the fused epilogue carries besides the affine and the ReLU - 0 nothing, 1 the residual add, 2 the GroupNorm sums
+// of the stored values (fp64 sum and sum of squares per (image, norm group), as conv_igemm_f32)
+template <int BM, int BN, int WM, int WN, int DT, int EPI>
 __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(pk_occupancy(BM, DT))))
 void conv_igemm_pk(const ConvP p) {
     constexpr int NTH = WM * WN * 64;
@@ -139,6 +139,8 @@ void conv_igemm_pk(const ConvP p) {
     constexpr int BL = BN / RPP;
     static_assert(BM % RPP == 0 && BN % RPP == 0, "loader geometry");
     static_assert(DT == 0 || DT == 3, "16-bit operand modes keep the one-tile-per-block kernel");
+    constexpr bool RES = EPI == 1, GN = EPI == 2;
+    __shared__ double gacc[GN ? 2 * 32 * 2 : 1];       // [image b0 / b0 + 1][norm group][sum, sum of squares] of the tile being stored
     constexpr int SMEM_FLOATS = DT ? NPL(DT) * (BM + BN) * PITCH_H / 2 : (BM + BN) * PITCH;
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     float* const As = smem;
@@ -150,6 +152,9 @@ void conv_igemm_pk(const ConvP p) {
     H16* const Bh = Ah + NPL(DT) * BM * PITCH_H;
 
     const int t = threadIdx.x;
+    if constexpr (GN) {
+        if (t < 128) gacc[t] = 0.0;       // published by the barriers of the first K-slice
+    }
 #ifdef PK_STAMPS
     if (t == 0 && blockIdx.x < 2048) {
         g_pk_span[blockIdx.x * 4] = __builtin_amdgcn_s_memrealtime();
@@ -159,24 +164,6 @@ void conv_igemm_pk(const ConvP p) {
     const int nkt = p.Kpad / BK;
     const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
     const PkPlan pl = pk_plan(p.pk_T, gridDim.x, xcd, nkt, p.pk_min);
-
-    // Stagger the blocks that share a CU.  They would otherwise run in lockstep - same number of K-slices, same shared
-    // matrix pipe - and every block of the chip would store its tile in the same microseconds: 768 x 64 KB = 50 MB per
-    // tile round, which the memory system takes 8-9 us to absorb while all matrix pipes wait (tools/ksweep.py).  Each
-    // block draws a ticket from its CU's counter (never reset: consecutive launches keep counting) and starts
-    // (ticket mod blocks per CU) * pk_stagger cycles late.
-    if (p.pk_stagger > 0) {
-        __shared__ int ticket;
-        if (t == 0) {
-            const unsigned hw = __builtin_amdgcn_s_getreg(63492);       // HW_ID: CU_ID [11:8], SH_ID [12], SE_ID [15:13]
-            const unsigned xcc = __builtin_amdgcn_s_getreg(63508) & 7u; // XCC_ID
-            ticket = (int)(atomicAdd(&g_pk_tickets[xcc * 256 + ((hw >> 8) & 255u)], 1u) % (unsigned)pk_occupancy(BM, DT));
-        }
-        __syncthreads();
-        const long wait = (long)ticket * p.pk_stagger;
-        const long t0 = (long)__builtin_amdgcn_s_memtime();
-        while ((long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-    }
 
     // ---- segment cursor (block-uniform) ----
     int round = 0, u = 0, u_end = 0;
@@ -381,6 +368,8 @@ void conv_igemm_pk(const ConvP p) {
     // from the MFMA layout, or staging through LDS, costs 5-7 us per tile: make STAMPS=1, tools/pk_stamps.py.)
     int c_m0 = 0, c_n0 = 0, c_g = 0, c_slot = 0;
     bool c_raw = false;
+    int fin_b0 = 0, fin_g = 0;     // GroupNorm sums of the tile stored last: its first image, its group ...
+    bool fin_gn = false;           // ... and whether there are any (not for a partial tile)
 #ifdef PK_STAMPS
     const bool stamp_on = t == 0 && blockIdx.x < STAMP_BLOCKS;
     int stamp_tile = -1;
@@ -397,11 +386,20 @@ void conv_igemm_pk(const ConvP p) {
             rs_res = make_rsrc(p.res + (long)c_g * p.res_gs + res_org, c_raw ? 0 : (int)(((long)p.M * p.res_cs - res_org) * 4));
         const unsigned res_cs4 = p.res_cs * 4;
         const bool affine = p.scale != nullptr && !c_raw;
-        const bool relu = p.relu && !c_raw;
+        const float lo = (p.relu && !c_raw) ? 0.f : -__builtin_inff();     // ReLU as max(y, lo)
         const float* __restrict__ scale = uniform_ptr(p.scale + c_g * p.ss_gs + c_n0);
         const float* __restrict__ shift = uniform_ptr(p.shift + c_g * p.ss_gs + c_n0);
         const bool q0 = lane & 1, q1 = lane & 2;
         const unsigned lrow = (r & 3) + 4 * h, lcol4 = (r >> 2) * 4;
+        const bool gn = GN && !c_raw;
+        int rows0 = BM, rows = BM;             // tile rows of image b0 (the rest belong to b0 + 1); valid rows
+        if constexpr (GN) {
+            fin_b0 = c_m0 / p.ohw;
+            fin_g = c_g;
+            fin_gn = gn;
+            rows0 = (fin_b0 + 1) * p.ohw - c_m0;
+            rows = p.M - c_m0;
+        }
         PK_STAMP(5);
         // vmcnt counts loads and stores in issue order: a load issued after a tile's stores cannot be waited for without
         // waiting for those stores to reach memory (2-3 us).  So the affine parameters of all column blocks are fetched
@@ -420,36 +418,56 @@ void conv_igemm_pk(const ConvP p) {
             }
         }
         PK_STAMP(6);
-        f32x4 rv[4];
-        auto res_off = [&](int tt) __attribute__((always_inline)) -> unsigned {
-            const int j = tt / TM, i = tt % TM;
-            return nok[j] ? ((wm * TM + i) * 32 + lrow) * res_cs4 + ((j * WN + wn) * 32 + lcol4) * 4 : OOB;
+        // ... and the residual one row group ahead of its use, issued before the stores of the group in hand
+        auto res_off = [&](int s) __attribute__((always_inline)) -> unsigned {
+            const int tt = s >> 2, g4 = s & 3, j = tt / TM, i = tt % TM;
+            return nok[j] ? ((wm * TM + i) * 32 + lrow + g4 * 8) * res_cs4 + ((j * WN + wn) * 32 + lcol4) * 4 : OOB;
         };
-        if constexpr (RES) {
-            const unsigned vr = res_off(0);
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) rv[g4] = buf_load4(rs_res, vr + g4 * 8 * res_cs4);
-        }
+        f32x4 rv_next = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (RES) rv_next = buf_load4(rs_res, res_off(0));
+        double s0 = 0.0, q0s = 0.0, s1 = 0.0, q1s = 0.0;
 #pragma unroll
         for (int tt = 0; tt < TM * TN; ++tt) {
             const int j = tt / TM, i = tt % TM;
             const unsigned vo = nok[j] ? ((wm * TM + i) * 32 + lrow) * out_cs4 + ((j * WN + wn) * 32 + lcol4) * 4 : OOB;
-            const unsigned vr = RES && tt + 1 < TM * TN ? res_off(tt + 1) : 0u;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 rv = rv_next;
+                if constexpr (RES) {
+                    if (tt * 4 + g4 + 1 < TM * TN * 4) rv_next = buf_load4(rs_res, res_off(tt * 4 + g4 + 1));
+                }
                 float a0 = acc[i][j][4 * g4], a1 = acc[i][j][4 * g4 + 1], a2 = acc[i][j][4 * g4 + 2], a3 = acc[i][j][4 * g4 + 3];
                 quad_transpose(a0, a1, a2, a3, q0, q1);
                 f32x4 v = {a0, a1, a2, a3};
 #pragma unroll
                 for (int x = 0; x < 4; ++x) {
                     float y = fmaf(v[x], sc[j][x], sh[j][x]);
-                    if constexpr (RES) y += rv[g4][x];
-                    v[x] = relu ? fmaxf(y, 0.f) : y;
-                }
-                if constexpr (RES) {     // the next tile's residual, same rows, into the registers just consumed
-                    if (tt + 1 < TM * TN) rv[g4] = buf_load4(rs_res, vr + g4 * 8 * res_cs4);
+                    if constexpr (RES) y += rv[x];
+                    v[x] = fmaxf(y, lo);
                 }
                 buf_store4(v, rs_out, vo + g4 * 8 * out_cs4);
+                if constexpr (GN) {
+                    const int row = (wm * TM + i) * 32 + (int)lrow + g4 * 8;
+                    if (gn && nok[j] && row < rows) {
+                        const double a = (double)v[0] + (double)v[1] + (double)v[2] + (double)v[3];
+                        const double b = (double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2] + (double)v[3] * v[3];
+                        if (row < rows0) { s0 += a; q0s += b; } else { s1 += a; q1s += b; }
+                    }
+                }
+            }
+            if constexpr (GN) {
+                if (i == TM - 1) {               // this lane's 4 channels of column block j are done: one norm group
+                    if (gn && nok[j]) {
+                        const int grp = (c_n0 + (j * WN + wn) * 32 + (int)lcol4) / p.gn_cpg;
+                        atomicAdd(&gacc[grp * 2], s0);
+                        atomicAdd(&gacc[grp * 2 + 1], q0s);
+                        if (s1 != 0.0 || q1s != 0.0) {
+                            atomicAdd(&gacc[64 + grp * 2], s1);
+                            atomicAdd(&gacc[64 + grp * 2 + 1], q1s);
+                        }
+                    }
+                    s0 = q0s = s1 = q1s = 0.0;
+                }
             }
             PK_STAMP(7 + tt);
         }
@@ -483,7 +501,19 @@ void conv_igemm_pk(const ConvP p) {
             if (t == 0 && blockIdx.x < 2048) g_pk_span[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
             if (t == 0 && blockIdx.x < 2048 && !cur) g_pk_span[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
-            if (!more) break;
+            if (!more) {
+                if constexpr (GN) {
+                    if (fin_gn) {
+                        __syncthreads();
+                        if (t < 128) {
+                            const double v = gacc[t];
+                            const int b = fin_b0 + (t >> 6);
+                            if (v != 0.0 && b < p.B) atomicAdd(&p.gn_sum[(((long)fin_g * p.B + b) * p.gn_groups) * 2 + (t & 63)], v);
+                        }
+                    }
+                }
+                break;
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -502,6 +532,17 @@ void conv_igemm_pk(const ConvP p) {
             ++kt;
         }
         __syncthreads();                   // the next slice is in LDS
+        if constexpr (GN) {
+            if (last && fin_gn) {          // every wave has added its sums: out to the layer's accumulators, LDS cleared for the next tile
+                if (t < 128) {
+                    const double v = gacc[t];
+                    gacc[t] = 0.0;
+                    const int b = fin_b0 + (t >> 6);
+                    if (v != 0.0 && b < p.B) atomicAdd(&p.gn_sum[(((long)fin_g * p.B + b) * p.gn_groups) * 2 + (t & 63)], v);
+                }
+                fin_gn = false;
+            }
+        }
         if (kt == 0) PK_STAMP(0);
         if (kt == 1) PK_STAMP(4);
     }
@@ -591,9 +632,8 @@ __global__ __launch_bounds__(256) void pk_fixup_kernel(const ConvP p, int P) {
 }  // namespace
 
 int g_persist_min_nk = 32; // key 14: shortest K (in 32-wide slices) whose remainder tiles are shared between blocks
-int g_persist_stagger = 4100;   // key 15: start delay per wave slot, in shader cycles per K-slice of the tile (at most 8 slices)
 int g_persist_debug = 0;  // key 16 (diagnostics): 1 = zero-length output descriptor, every store of the epilogue is dropped by the range check
-int g_persist = 0;        // key 13: persistent launches: 0 = never, 1 = wherever eligible
+int g_persist = 1;        // key 13: persistent launches: 0 = never, 1 = 128x128 tiles (default), 2 = every tile shape
 
 // Eligibility beyond conv_persistent_ok() is decided by the caller (conv_igemm.hip: run<>): no skipped filter rows, a
 // workspace of 2 * P tiles.  p.mtiles / p.ntiles / p.vec_out are filled in.  Returns 0 on success.
@@ -614,14 +654,16 @@ int launch_conv_persistent(ConvP p, int G, int bpc, hipStream_t st) {
     }
     const dim3 block(WM * WN * 64);
     p.pk_in_bytes = (int)((long)p.B * p.H * p.W * p.in_cs * 4);
-    p.pk_stagger = (nk < 8 ? nk : 8) * g_persist_stagger;
     p.pk_debug = g_persist_debug;
+    const int epi = p.gn_sum ? 2 : p.res ? 1 : 0;       // host: never both (conv_persistent_ok)
     if (p.bf16 == 3) {
-        if (p.res) hipLaunchKernelGGL((conv_igemm_pk<BM, BN, WM, WN, 3, true>), dim3(P), block, 0, st, p);
-        else hipLaunchKernelGGL((conv_igemm_pk<BM, BN, WM, WN, 3, false>), dim3(P), block, 0, st, p);
+        if (epi == 2) hipLaunchKernelGGL((conv_igemm_pk<BM, BN, WM, WN, 3, 2>), dim3(P), block, 0, st, p);
+        else if (epi == 1) hipLaunchKernelGGL((conv_igemm_pk<BM, BN, WM, WN, 3, 1>), dim3(P), block, 0, st, p);
+        else hipLaunchKernelGGL((conv_igemm_pk<BM, BN, WM, WN, 3, 0>), dim3(P), block, 0, st, p);
     } else {
-        if (p.res) hipLaunchKernelGGL((conv_igemm_pk<BM, BN, WM, WN, 0, true>), dim3(P), block, 0, st, p);
-        else hipLaunchKernelGGL((conv_igemm_pk<BM, BN, WM, WN, 0, false>), dim3(P), block, 0, st, p);
+        if (epi == 2) hipLaunchKernelGGL((conv_igemm_pk<BM, BN, WM, WN, 0, 2>), dim3(P), block, 0, st, p);
+        else if (epi == 1) hipLaunchKernelGGL((conv_igemm_pk<BM, BN, WM, WN, 0, 1>), dim3(P), block, 0, st, p);
+        else hipLaunchKernelGGL((conv_igemm_pk<BM, BN, WM, WN, 0, 0>), dim3(P), block, 0, st, p);
     }
     // any tile shared between blocks?
     int max_rem = 0;
@@ -649,11 +691,11 @@ int pk_read_stamps(unsigned long long* dst, int n) {
 
 size_t conv_persistent_ws_floats(int BM, int BN, int bpc) { return (size_t)2 * 256 * bpc * BM * BN; }
 
-// what the persistent kernel covers: fp32 / bf16x3 arithmetic, affine + residual + ReLU epilogues with 16-byte-aligned
-// channel counts, every view below 2 GiB (32-bit buffer offsets)
+// what the persistent kernel covers: fp32 / bf16x3 arithmetic, affine + ReLU epilogues with either a residual or GroupNorm
+// sums, 16-byte-aligned channel counts, every view below 2 GiB (32-bit buffer offsets)
 bool conv_persistent_ok(const ConvP& p) {
     const long lim = (long)1 << 31;
-    return (p.bf16 == 0 || p.bf16 == 3) && p.vec_out && !p.prelu && !p.gn_sum &&
+    return (p.bf16 == 0 || p.bf16 == 3) && p.vec_out && !p.prelu && !(p.gn_sum && p.res) &&
            (long)p.B * p.H * p.W * p.in_cs * 4 < lim && (long)p.M * p.out_cs * 4 < lim &&
            (!p.res || (long)p.M * p.res_cs * 4 < lim) && (long)p.Cout * p.Kpad * 4 < lim;
 }

@@ -1030,7 +1030,6 @@ void quber_set_tuning(int32_t key, int32_t value) {
     }
     if (key == 4) g_force_tile = value;    // force the tile shape: 1 = 64x64, 2 = 128x128, 4 = 256x32 (0 = automatic)
     if (key == 16) g_persist_debug = value;   // diagnostics of the persistent kernel (1 = drop the epilogue's stores)
-    if (key == 15) g_persist_stagger = value; // persistent launches: start delay per wave slot (shader cycles per K-slice, 0 = none)
     if (key == 14) g_persist_min_nk = value;  // persistent launches: shortest K (slices) whose remainder is shared between blocks
     if (key == 13) g_persist = value;         // persistent convolution launches (conv_persist.hip): 0 = never, 1 = wherever eligible
     if (key == 12) g_op_bf16 = value;         // stand-alone conv ops: 1 = bf16, 2 = fp16 operands, 3 = fp32 as 3 bf16 terms; fp32 accumulation

@@ -534,7 +534,7 @@ def test_conv_persistent_vs_torch(case, dt):
     try:
         assert _conv_case(*case, bf16=dt) < 2e-6
     finally:
-        lib.quber_set_tuning(13, 0)
+        lib.quber_set_tuning(13, 1)
         lib.quber_set_tuning(2, 0)
 
 
@@ -549,7 +549,7 @@ def test_conv3x3_winograd_persistent_gemm(case, m):
     try:
         test_conv3x3_winograd_vs_float64(case, m)
     finally:
-        lib.quber_set_tuning(13, 0)
+        lib.quber_set_tuning(13, 1)
         lib.quber_set_tuning(2, 0)
 
 
@@ -563,11 +563,14 @@ def test_conv3x3_winograd_persistent_gemm(case, m):
     (1, 120, 160, 128, 32, 3, 1, 1, True, False, True),     # 256x32 tiles, 75 blocks: split-K
 ])
 def test_conv_split_paths_vs_torch(case):
+    """the one-tile-per-block kernel's split-K / split-tail launches (persistent launches off: tuning key 13)"""
     lib = _lib.load()
     lib.quber_set_tuning(2, 1)
+    lib.quber_set_tuning(13, 0)
     try:
         assert _conv_case(*case) < 2e-6
     finally:
+        lib.quber_set_tuning(13, 1)
         lib.quber_set_tuning(2, 0)
 
 
@@ -629,6 +632,7 @@ def test_conv_split_tail_equals_whole(case):
     packed = torch.empty(Cout * ((k * k * Cin + 31) // 32 * 32), device="cuda")
     outs = []
     lib.quber_set_tuning(2, 1)
+    lib.quber_set_tuning(13, 0)           # the one-tile-per-block kernel
     try:
         for tail in (0, 2):               # never / whenever feasible
             lib.quber_set_tuning(5, tail)
@@ -638,6 +642,7 @@ def test_conv_split_tail_equals_whole(case):
             outs.append(y)
     finally:
         lib.quber_set_tuning(5, 1)
+        lib.quber_set_tuning(13, 1)
         lib.quber_set_tuning(2, 0)
     whole, tail = outs
     assert torch.isfinite(tail).all()

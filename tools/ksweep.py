@@ -55,4 +55,4 @@ for name, col in (("tile-per-block", 1), ("persistent", 2)):
     t = np.array([r[col] for r in rows]) * 1e3 / (tiles / 768)
     b, a = np.polyfit(nk, t, 1)
     print(f"{name}: per tile-round {a:.2f} us + {b:.3f} us per K-slice (pure MFMA at 2.4 GHz: {3 * 4096 / 2400:.3f} us per slice of 3 resident blocks)")
-lib.quber_set_tuning(4, 0); lib.quber_set_tuning(13, 0); lib.quber_set_tuning(2, 0); lib.quber_set_tuning(5, 1)
+lib.quber_set_tuning(4, 0); lib.quber_set_tuning(13, 1); lib.quber_set_tuning(2, 0); lib.quber_set_tuning(5, 1)

@@ -17,7 +17,9 @@ sys.path.insert(0, ROOT)
 
 def run(a):
     import torch
-    from quber_amd import arch, engine, synth
+    from quber_amd import _lib, arch, engine, synth
+    for kv in (a.tuning.split(",") if a.tuning else []):
+        _lib.load().quber_set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))
     qc = engine.make_config(a.height, a.width, max_batch=a.batch)
     qc.compute_dtype = a.compute_dtype
     eng = engine.Engine(qc, "cuda:0")
@@ -52,11 +54,11 @@ def report(a):
             ms += dur(allk[k - 1])
             path = "winograd"
         nxt = k + 1
-        while nxt < len(allk) and any(t in allk[nxt]["Kernel_Name"] for t in ("splitk_reduce", "wino_output")):
+        while nxt < len(allk) and any(t in allk[nxt]["Kernel_Name"] for t in ("splitk_reduce", "pk_fixup", "wino_output")):
             ms += dur(allk[nxt])
             nxt += 1
         fl = c[2] * B
-        tile = r["Kernel_Name"].split("<")[1].split(">")[0].replace(" ", "")
+        tile = ("persistent " if "conv_igemm_pk" in r["Kernel_Name"] else "") + r["Kernel_Name"].split("<")[1].split(">")[0].replace(" ", "")
         out.append("| %d | %s | %s %s | %.1f | %.3f | %.1f |" % (i, c[0].replace("backbone.", "b.").replace("ins_embed_head.", "h."),
                                                                path, tile, fl / 1e9, ms, fl / ms / 1e9))
         tot_t += ms
@@ -74,6 +76,7 @@ if __name__ == "__main__":
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--tuning", default="", help="quber_set_tuning knobs, e.g. 13=1")
     ap.add_argument("--compute-dtype", type=int, default=0, help="quber_config.compute_dtype (0 fp32 MFMA, 3 bf16x3, 2 fp16)")
     a = ap.parse_args()
     run(a) if a.mode == "run" else report(a)

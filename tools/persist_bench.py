@@ -76,7 +76,7 @@ def main():
                       "%.1f (diff %.1e)" % (flops / (np.median(ts[1]) * 1e-3) / 1e12, diff)]
         print(f"| {name} | " + " | ".join(cells) + " |", flush=True)
     lib.quber_set_tuning(12, 0)
-    lib.quber_set_tuning(13, 0)
+    lib.quber_set_tuning(13, 1)
     lib.quber_set_tuning(2, 0)
 
 
