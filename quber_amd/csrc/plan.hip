@@ -1029,6 +1029,7 @@ void quber_set_tuning(int32_t key, int32_t value) {
         }
     }
     if (key == 4) g_force_tile = value;    // force the tile shape: 1 = 64x64, 2 = 128x128, 4 = 256x32 (0 = automatic)
+    if (key == 17) g_wino_pairs = value;      // F(4x4) Winograd transforms on channel pairs instead of quads
     if (key == 16) g_persist_debug = value;   // diagnostics of the persistent kernel (1 = drop the epilogue's stores)
     if (key == 14) g_persist_min_nk = value;  // persistent launches: shortest K (slices) whose remainder is shared between blocks
     if (key == 13) g_persist = value;         // persistent convolution launches (conv_persist.hip): 0 = never, 1 = wherever eligible

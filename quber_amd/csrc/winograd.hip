@@ -27,6 +27,7 @@ int g_wino_min_cin = 64;      // key 7 (test harness): smallest input width rout
 int g_wino_max_ratio = 67;    // key 8: executed / direct multiplies (%) up to which a (dilated) layer takes this path
 int g_wino_variant = 0;       // key 9: output tile edge m for the eligible layers: 0 = automatic, 2, 4
 int g_wino_min_cout = 32;     // key 10: smallest output width routed to this path
+int g_wino_pairs = 0;         // key 17: F(4x4) transforms on channel pairs (8-byte accesses, half the registers per thread) instead of quads
 
 namespace {
 
@@ -131,8 +132,13 @@ __device__ inline TileAt locate(long tile, int TH, int TW, int d) {
 // the normalisation (same arithmetic as gn_apply_kernel) is applied to the in-range pixels as they are loaded, which
 // saves the separate read + write pass over the activations.
 // CV = C / V channel groups; a block holds 256 / CV tiles (CV <= 256) or a tile needs CV / 256 blocks (grid.y).
+// waves per SIMD the transforms are compiled for (F(4x4): the input transform needs 4 registers fewer than hipcc takes
+// unasked to fit a third wave; the output transform's 36 loads in flight fill the register file of a single wave)
+constexpr int wino_in_waves(int O, int V) { return O == 4 ? (V == 4 ? 3 : 5) : O == 2 ? 4 : 2; }
+constexpr int wino_out_waves(int O, int V) { return O == 4 ? (V == 4 ? 2 : 3) : O == 2 ? 4 : 1; }
+
 template <int O, int V>
-__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ in, int B, int H, int W, int CV, int in_cs,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(wino_in_waves(O, V)))) void wino_input_kernel(const float* __restrict__ in, int B, int H, int W, int CV, int in_cs,
                                                          long in_gs, int TH, int TW, int d, float* __restrict__ v, long v_gs,
                                                          const WinoNorm np) {
     constexpr int T = O + 2;
@@ -143,7 +149,12 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
     const int tpb = 256 / CV;
     const int cv = tpb ? threadIdx.x % CV : blockIdx.y * 256 + threadIdx.x;
     const long tiles = (long)B * d * d * TH * TW;
-    const long tile = tpb ? (long)blockIdx.x * tpb + threadIdx.x / CV : blockIdx.x;
+    // XCD-aware order: blocks b and b + 8 share an XCD (and its L2).  Every input pixel is read by up to (T/O)^2 = 2.25
+    // tiles (the 2-pixel halo); with consecutive blocks on consecutive tiles the neighbours sit on other XCDs and every
+    // halo read misses L2 (rocprofv3: 1.9x the input fetched from HBM).  Each XCD gets one contiguous run of tiles instead.
+    const int nblk = gridDim.x, xcd = blockIdx.x & 7, bq = nblk >> 3, br = nblk & 7;
+    const int vb = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + (blockIdx.x >> 3);
+    const long tile = tpb ? (long)vb * tpb + threadIdx.x / CV : vb;
     if (tile >= tiles || cv >= CV || (tpb && (int)(threadIdx.x / CV) >= tpb)) return;
     const TileAt ta = locate(tile, TH, TW, d);
     const int c = cv * V;
@@ -200,7 +211,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 // (fp64, LDS per block, one global atomic per (image, group) per block - as the direct kernel's epilogue does).
 constexpr int OUT_ITERS = 4;
 template <int O, int V>
-__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ m, long m_gs, int B, int OH, int OW, int CV,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(wino_out_waves(O, V)))) void wino_output_kernel(const float* __restrict__ m, long m_gs, int B, int OH, int OW, int CV,
                                                           int TH, int TW, int d, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int ss_gs, int relu,
                                                           float* __restrict__ out, int out_cs, long out_gs,
@@ -388,10 +399,9 @@ double winograd_mac_ratio(int H, int W, int dil, int m) {
     return (double)((m + 2) * (m + 2)) * wino_tiles(H, W, dil, m) / (9.0 * H * W);
 }
 
-template <int O>
+template <int O, int V>     // V: channels per thread in the transforms
 static int run_winograd(const WinoP& q, int B, int G, hipStream_t st) {
     constexpr int P = (O + 2) * (O + 2);
-    constexpr int V = O == 6 ? 2 : 4;                // channels per thread in the transforms
     const View& in = q.in;
     const View& out = q.out;
     const int H = in.H, W = in.W, Cin = in.C, Cout = out.C, d = q.dil;
@@ -454,7 +464,8 @@ int launch_conv_winograd(const WinoP& q, int B, int G, hipStream_t st) {
     if (q.m == 6 && !winograd_m6_channels_ok(in.C, out.C)) return fail("winograd: channel counts unsupported by the 6x6 variant");
     if (in.cs % 4 || out.cs % 4 || ((uintptr_t)in.p & 15) || ((uintptr_t)out.p & 15) || (in.gs & 3) || (out.gs & 3))
         return fail("winograd: operands must be 16-byte aligned");
-    return q.m == 6 ? run_winograd<6>(q, B, G, st) : q.m == 4 ? run_winograd<4>(q, B, G, st) : run_winograd<2>(q, B, G, st);
+    if (q.m == 4 && g_wino_pairs && winograd_m6_channels_ok(in.C, out.C)) return run_winograd<4, 2>(q, B, G, st);
+    return q.m == 6 ? run_winograd<6, 2>(q, B, G, st) : q.m == 4 ? run_winograd<4, 4>(q, B, G, st) : run_winograd<2, 4>(q, B, G, st);
 }
 
 }  // namespace quber
