@@ -222,6 +222,14 @@ double quber_forward_flops(quber_ctx* ctx);
  * (m+2)^2 / (9 m^2) of its algorithmic FLOPs, padded tiles included (transform additions not counted) */
 double quber_forward_flops_executed(quber_ctx* ctx);
 /* test-harness knobs: key 2 = give the stand-alone quber_op_conv2d a split-K workspace (value != 0) or drop it (0);
+ * key 18 = (acts at plan time) the projection block of every ResNet stage runs conv3 and its shortcut as ONE 1x1 GEMM over
+ *          the concatenated inputs (1, default; reference: detectron2 BottleneckBlock as built by
+ *          maskrefiner/modeling/backbone/resnet.py:37-63) or as two convolutions (0);
+ * key 17 = Winograd F(4x4) transforms on channel pairs instead of quads (measured: input transform 6 % slower; default 0);
+ * key 16 = diagnostics of the persistent convolution kernel (1 = its output stores are dropped by the range check);
+ * key 14 = persistent launches: shortest K, in 32-wide slices, whose remainder tiles are shared between blocks (default 32);
+ * key 13 = persistent convolution launches (csrc/conv_persist.hip): 0 = never (one tile per block everywhere),
+ *          1 = the 128x128-tile launches (default), 2 = every tile shape;
  * key 3 = force the number of K partitions of convolutions that have a workspace (0 = automatic);
  * key 12 = stand-alone conv ops only: quber_config.compute_dtype of the launch (1 = bf16 / 2 = fp16 operands, 3 = bf16x3);
  * key 11 = stand-alone conv op only: dilated 3x3 layers in tap-major K order with the zero-padding filter rows skipped;
@@ -246,6 +254,12 @@ int quber_op_conv2d(const float* dev_x, int32_t batch, int32_t h, int32_t w, int
                     int32_t cout, int32_t ksize, int32_t stride, int32_t pad, int32_t dil, const float* dev_scale,
                     const float* dev_shift, const float* dev_residual, int32_t relu, float* dev_packed_scratch,
                     float* dev_y, void* stream);
+/* one 1x1 GEMM over two inputs: out = relu?(y . w[:, :mid] + x[::stride, ::stride] . w[:, mid:] + shift), NHWC;
+ * y [batch][oh][ow][mid], x [batch][h2][w2][cin], w [cout][mid + cin], `dev_ones` = cout ones (the kernel's affine scale).
+ * Needs the op workspace (key 2) and fp32 / bf16x3 arithmetic (key 12 = 0 / 3). */
+int quber_op_conv1x1_dual(const float* dev_y, const float* dev_x, int32_t batch, int32_t oh, int32_t ow, int32_t mid,
+                          int32_t h2, int32_t w2, int32_t cin, int32_t stride, const float* dev_w, const float* dev_shift,
+                          const float* dev_ones, int32_t cout, int32_t relu, float* dev_out, void* stream);
 /* the same for a 3x3 / stride 1 / pad = dilation convolution through the Winograd F(m x m, 3x3) path, m = 2, 4 or 6
  * (cin >= 128 and a multiple of 32, cout >= 128): with P = (m+2)^2, dev_u_scratch holds P*cout*cin floats (transformed
  * weights), dev_ws at least P * batch * dil^2 * ceil(ceil(h/dil)/m) * ceil(ceil(w/dil)/m) * (cin + cout) floats */

@@ -49,6 +49,10 @@ struct ConvP {
     int ss_gs;
     const char* tag;     // stage-profile tag of the launch (null = "conv_gemm")
     int pk_T, pk_tpg, pk_min, pk_in_bytes, pk_debug;   // persistent launch (conv_persist.hip): tiles over all groups, tiles per group, shortest K share
+    // second input of a dual 1x1 launch (launch_conv_dual: K = K1 channels of `in`, then the channels of `in2` at stride2), or null
+    const float* in2;
+    int in2_cs, H2, W2, stride2, K1, pk_in2_bytes;
+    long in2_gs;
     int bf16;            // quber_config.compute_dtype: 0 = fp32 MFMA, 1 = bf16 / 2 = fp16 operands, 3 = fp32 operands split into 3 bf16 terms
 };
 
@@ -112,6 +116,7 @@ extern int g_force_split, g_force_tile, g_tail_split, g_persist, g_persist_min_n
 template <int BM, int BN, int WM, int WN> int launch_conv_persistent(ConvP p, int G, int bpc, hipStream_t st);
 size_t conv_persistent_ws_floats(int BM, int BN, int bpc);
 bool conv_persistent_ok(const ConvP& p);
+int launch_conv_dual(ConvP p, int G, hipStream_t st);   // 0 done, 1 not covered (run the two convolutions), -1 error
 #ifdef PK_STAMPS
 int pk_read_stamps(unsigned long long* dst, int n);
 int pk_read_span(unsigned long long* dst, int n);

@@ -140,6 +140,10 @@ void conv_igemm_pk(const ConvP p) {
     static_assert(BM % RPP == 0 && BN % RPP == 0, "loader geometry");
     static_assert(DT == 0 || DT == 3, "16-bit operand modes keep the one-tile-per-block kernel");
     constexpr bool RES = EPI == 1, GN = EPI == 2;
+    // EPI 3: a 1x1 convolution whose K runs over TWO inputs - p.K1 channels of `in` (stride 1), then the channels of `in2`
+    // sampled with stride p.stride2: a bottleneck's conv3 and its projection shortcut as one GEMM (BN scales folded into
+    // the packed weights, shifts added), which keeps the shortcut's output out of HBM altogether
+    constexpr bool DUAL = EPI == 3;
     __shared__ double gacc[GN ? 2 * 32 * 2 : 1];       // [image b0 / b0 + 1][norm group][sum, sum of squares] of the tile being stored
     constexpr int SMEM_FLOATS = DT ? NPL(DT) * (BM + BN) * PITCH_H / 2 : (BM + BN) * PITCH;
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
@@ -195,8 +199,9 @@ void conv_igemm_pk(const ConvP p) {
     unsigned rowoff[AL];                // byte offset of the row's window origin (may be "negative": wraps, fixed by + off)
     unsigned wrow[BL];                  // byte offset of the weight row at this thread's k column
     __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in, 0);
-    __amdgpu_buffer_rsrc_t rs_w = rs_in;
+    __amdgpu_buffer_rsrc_t rs_w = rs_in, rs_in2 = rs_in;
     int kc = 0, kx = 0, ky = 0, ks = 0;
+    int n_k0 = 0;                      // first K-slice of that segment
     int n_m0 = 0, n_n0 = 0, n_g = 0;   // tile origin / group of that segment
     auto setup = [&]() __attribute__((always_inline)) {
         const int g = s_gt / p.pk_tpg;
@@ -206,10 +211,27 @@ void conv_igemm_pk(const ConvP p) {
         n_m0 = mt * BM; n_n0 = nt * BN; n_g = g;
         rs_in = make_rsrc(p.in + (long)g * p.in_gs, p.pk_in_bytes);
         rs_w = make_rsrc(p.w + (long)g * p.w_gs + (long)s_k0 * BK, (p.Cout * p.Kpad - s_k0 * BK) * 4);
+        n_k0 = s_k0;
         const int ohw = p.OH * p.OW;
+        if constexpr (DUAL) rs_in2 = make_rsrc(p.in2 + (long)g * p.in2_gs, p.pk_in2_bytes);
 #pragma unroll
         for (int i = 0; i < AL; ++i) {
             const int m = n_m0 + lrow + RPP * i;
+            if constexpr (DUAL) {        // rowoff: pixel m of `in`; iy0 (reused): the strided pixel of `in2`; OOB for the rows past M
+                if (m < p.M) {
+                    const int b = m / ohw;
+                    const int rem = m - b * ohw;
+                    const int oy = rem / p.OW;
+                    const int ox = rem - oy * p.OW;
+                    rowoff[i] = (unsigned)(m * p.in_cs) * 4u;
+                    iy0[i] = (int)((unsigned)(((b * p.H2 + oy * p.stride2) * p.W2 + ox * p.stride2) * p.in2_cs) * 4u);
+                } else {
+                    rowoff[i] = OOB;
+                    iy0[i] = (int)OOB;
+                }
+                ix0[i] = 0;
+                continue;
+            }
             if (m < p.M) {
                 const int b = m / ohw;
                 const int rem = m - b * ohw;
@@ -247,6 +269,19 @@ void conv_igemm_pk(const ConvP p) {
 
     f32x4 ra[AL], rb[BL];
     auto gload = [&]() __attribute__((always_inline)) {
+        if constexpr (DUAL) {
+            const int kg = n_k0 + ks, nk1 = p.K1 / BK;
+            const bool second = kg >= nk1;                                    // block-uniform
+            const unsigned off = (unsigned)((second ? kg - nk1 : kg) * BK + kq) * 4u;
+#pragma unroll
+            for (int i = 0; i < AL; ++i)
+                ra[i] = second ? buf_load4(rs_in2, (unsigned)iy0[i] + off) : buf_load4(rs_in, rowoff[i] + off);
+            const unsigned woff = (unsigned)(ks * BK) * 4u;
+#pragma unroll
+            for (int i = 0; i < BL; ++i) rb[i] = buf_load4(rs_w, wrow[i] + woff);
+            ++ks;
+            return;
+        }
         const bool kok = p.kmode || ky < p.kh;
         const int dy = ky * p.dil, dx = kx * p.dil;
         const unsigned off = (unsigned)((dy * p.W + dx) * p.in_cs + kc) * 4u;
@@ -655,13 +690,15 @@ int launch_conv_persistent(ConvP p, int G, int bpc, hipStream_t st) {
     const dim3 block(WM * WN * 64);
     p.pk_in_bytes = (int)((long)p.B * p.H * p.W * p.in_cs * 4);
     p.pk_debug = g_persist_debug;
-    const int epi = p.gn_sum ? 2 : p.res ? 1 : 0;       // host: never both (conv_persistent_ok)
+    const int epi = p.in2 ? 3 : p.gn_sum ? 2 : p.res ? 1 : 0;       // host: never two of them (conv_persistent_ok)
     if (p.bf16 == 3) {
-        if (epi == 2) hipLaunchKernelGGL((conv_igemm_pk<BM, BN, WM, WN, 3, 2>), dim3(P), block, 0, st, p);
+        if (epi == 3) hipLaunchKernelGGL((conv_igemm_pk<BM, BN, WM, WN, 3, 3>), dim3(P), block, 0, st, p);
+        else if (epi == 2) hipLaunchKernelGGL((conv_igemm_pk<BM, BN, WM, WN, 3, 2>), dim3(P), block, 0, st, p);
         else if (epi == 1) hipLaunchKernelGGL((conv_igemm_pk<BM, BN, WM, WN, 3, 1>), dim3(P), block, 0, st, p);
         else hipLaunchKernelGGL((conv_igemm_pk<BM, BN, WM, WN, 3, 0>), dim3(P), block, 0, st, p);
     } else {
-        if (epi == 2) hipLaunchKernelGGL((conv_igemm_pk<BM, BN, WM, WN, 0, 2>), dim3(P), block, 0, st, p);
+        if (epi == 3) hipLaunchKernelGGL((conv_igemm_pk<BM, BN, WM, WN, 0, 3>), dim3(P), block, 0, st, p);
+        else if (epi == 2) hipLaunchKernelGGL((conv_igemm_pk<BM, BN, WM, WN, 0, 2>), dim3(P), block, 0, st, p);
         else if (epi == 1) hipLaunchKernelGGL((conv_igemm_pk<BM, BN, WM, WN, 0, 1>), dim3(P), block, 0, st, p);
         else hipLaunchKernelGGL((conv_igemm_pk<BM, BN, WM, WN, 0, 0>), dim3(P), block, 0, st, p);
     }
@@ -695,9 +732,36 @@ size_t conv_persistent_ws_floats(int BM, int BN, int bpc) { return (size_t)2 * 2
 // sums, 16-byte-aligned channel counts, every view below 2 GiB (32-bit buffer offsets)
 bool conv_persistent_ok(const ConvP& p) {
     const long lim = (long)1 << 31;
-    return (p.bf16 == 0 || p.bf16 == 3) && p.vec_out && !p.prelu && !(p.gn_sum && p.res) &&
+    return (p.bf16 == 0 || p.bf16 == 3) && p.vec_out && !p.prelu && !(p.gn_sum && p.res) && !(p.in2 && (p.res || p.gn_sum)) &&
            (long)p.B * p.H * p.W * p.in_cs * 4 < lim && (long)p.M * p.out_cs * 4 < lim &&
            (!p.res || (long)p.M * p.res_cs * 4 < lim) && (long)p.Cout * p.Kpad * 4 < lim;
+}
+
+// conv3 + projection shortcut of a bottleneck as one 1x1 GEMM over two inputs (kernel: EPI 3).  Returns 1 when the
+// launch is not covered (the caller then runs the two convolutions separately), 0 on success, -1 on a launch error.
+int launch_conv_dual(ConvP p, int G, hipStream_t st) {
+    if (!g_persist || !p.in2 || !p.ws) return 1;
+    if (p.kh != 1 || p.kw != 1 || p.pad != 0 || p.stride != 1 || p.kmode || p.K1 % BK || p.K1 <= 0 || p.K1 >= p.Kpad || p.K != p.Kpad ||
+        p.Kpad % BK || p.in_cs % 4 || p.in2_cs % 4 || ((uintptr_t)p.in & 15) || ((uintptr_t)p.in2 & 15) || (p.in_gs & 3) || (p.in2_gs & 3))
+        return 1;
+    p.vec_out = (p.Cout % 4 == 0) && (p.out_cs % 4 == 0) && (((uintptr_t)p.out & 15) == 0) && (p.out_gs % 4 == 0) &&
+                (!p.scale || ((((uintptr_t)p.scale & 15) == 0) && (p.ss_gs % 4 == 0)));
+    const long in2_bytes = (long)p.B * p.H2 * p.W2 * p.in2_cs * 4;
+    if (!conv_persistent_ok(p) || in2_bytes >= ((long)1 << 31)) return 1;
+    p.pk_in2_bytes = (int)in2_bytes;
+    if (p.bf16 == 3 && p.Kpad / BK <= 8) p.bf16 = 0;       // as the separate launches: short K gains nothing from bf16x3
+    const long tiles128 = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * G;
+    const bool big = tiles128 >= 192 && p.Cout > 64;
+    const int bpc = big ? (p.bf16 == 3 ? 2 : 3) : (p.bf16 == 3 ? 5 : 7);
+    const int BMs = big ? 128 : 64;
+    if (p.ws_floats < conv_persistent_ws_floats(BMs, BMs, bpc)) return 1;
+    p.mtiles = (p.M + BMs - 1) / BMs;
+    p.ntiles = (p.Cout + BMs - 1) / BMs;
+    const double out_bytes = 4.0 * G * (double)p.M * p.Cout;
+    const double bytes = 4.0 * G * ((double)p.M * p.Kpad + (double)p.Cout * p.Kpad) + out_bytes;
+    ProfScope prof(p.tag ? p.tag : "conv_gemm", bytes, 2.0 * G * (double)p.M * p.Kpad * p.Cout, st);
+    const int rc = big ? launch_conv_persistent<128, 128, 2, 2>(p, G, bpc, st) : launch_conv_persistent<64, 64, 2, 2>(p, G, bpc, st);
+    return rc ? -1 : 0;
 }
 
 template int launch_conv_persistent<64, 64, 2, 2>(ConvP, int, int, hipStream_t);

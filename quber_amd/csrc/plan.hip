@@ -141,6 +141,8 @@ struct DeferredNorm {
 };
 struct LastConv { std::shared_ptr<GnFuse> fuse; const float* out = nullptr; int G = 0, C = 0; };
 
+static int g_fuse_shortcut = 1;   // key 18 (plan time): conv3 + projection shortcut of a bottleneck as one dual-input GEMM
+
 struct Builder {
     quber_ctx* c;
     bool dry;
@@ -365,6 +367,65 @@ struct Builder {
         emit_conv(names[0], w, in, cin_real, out, k, stride, pad, dil, af != AF_NONE, scale, shift, {}, res, relu);
     }
 
+    // Projection block of a stage: the two ops emitted last - `shortcut` (1x1, stride s, FrozenBN) and `conv3` (1x1, FrozenBN,
+    // + shortcut output, ReLU) - become ONE op that computes relu(bn3(conv3(y)) + bn_s(shortcut(x))) as a single 1x1 GEMM
+    // over the concatenated channels of y and x (launch_conv_dual: BN scales folded into the packed weights, shifts
+    // added), so that the shortcut's output never exists in HBM.  Launches the dual kernel does not cover (16-bit operand
+    // modes, views past 2 GiB) run the two original ops.
+    void fuse_shortcut(const std::vector<std::string>& n3, const std::vector<std::string>& ns, const View& y, int mid,
+                       const View& x, int cin, int stride, const View& out) {
+        if (dry || !g_fuse_shortcut || c->ops.size() < 2) return;
+        const int G = (int)n3.size(), Cout = out.C, Kd = mid + cin;
+        if (mid % 32 || cin % 32 || y.C != mid || x.C != cin) return;
+        std::vector<float> packed((size_t)G * Cout * Kd), ones((size_t)G * Cout, 1.f), shift((size_t)G * Cout);
+        for (int g = 0; g < G; ++g) {
+            const float* w3 = hw(n3[g] + ".weight", (int64_t)Cout * mid);
+            const float* wsh = hw(ns[g] + ".weight", (int64_t)Cout * cin);
+            const float* bn[2][4];
+            for (int q = 0; q < 2; ++q) {
+                const std::string& n = q ? ns[g] : n3[g];
+                bn[q][0] = hw(n + ".norm.weight", Cout); bn[q][1] = hw(n + ".norm.bias", Cout);
+                bn[q][2] = hw(n + ".norm.running_mean", Cout); bn[q][3] = hw(n + ".norm.running_var", Cout);
+            }
+            if (!w3 || !wsh) return;
+            for (int q = 0; q < 2; ++q)
+                for (int e = 0; e < 4; ++e)
+                    if (!bn[q][e]) return;
+            for (int o = 0; o < Cout; ++o) {
+                // the same per-channel affine as conv() derives for the separate launches
+                const float s3 = bn[0][0][o] * (1.0f / sqrtf(bn[0][3][o] + 1e-5f)), h3 = bn[0][1][o] - bn[0][2][o] * s3;
+                const float ss = bn[1][0][o] * (1.0f / sqrtf(bn[1][3][o] + 1e-5f)), hs = bn[1][1][o] - bn[1][2][o] * ss;
+                float* dst = &packed[((size_t)g * Cout + o) * Kd];
+                for (int ci = 0; ci < mid; ++ci) dst[ci] = s3 * w3[(size_t)o * mid + ci];
+                for (int ci = 0; ci < cin; ++ci) dst[mid + ci] = ss * wsh[(size_t)o * cin + ci];
+                shift[(size_t)g * Cout + o] = h3 + hs;
+            }
+        }
+        ConvP p{};
+        p.in = y.p; p.in2 = x.p; p.w = upload(packed); p.scale = upload(ones); p.shift = upload(shift); p.out = out.p;
+        p.H = y.H; p.W = y.W; p.Cin = mid; p.in_cs = y.cs; p.in_gs = y.gs;
+        p.H2 = x.H; p.W2 = x.W; p.in2_cs = x.cs; p.in2_gs = x.gs; p.stride2 = stride; p.K1 = mid;
+        p.OH = out.H; p.OW = out.W; p.Cout = Cout; p.out_cs = out.cs; p.out_gs = out.gs;
+        p.K = Kd; p.Kpad = Kd; p.kh = 1; p.kw = 1; p.stride = 1; p.pad = 0; p.dil = 1; p.relu = 1;
+        p.bf16 = c->cfg.compute_dtype;
+        p.w_gs = (long)Cout * Kd; p.ss_gs = Cout; p.ohw = out.H * out.W;
+        Op op3 = c->ops.back();
+        c->ops.pop_back();
+        Op ops = c->ops.back();
+        c->ops.pop_back();
+        quber_ctx* ctx = c;
+        c->ops.push_back({[p, G, ctx, op3, ops](int B, hipStream_t st) mutable {
+            p.B = B;
+            p.M = B * p.OH * p.OW;
+            p.ws = ctx->splitk_ws;
+            p.ws_floats = ctx->splitk_floats;
+            const int rc = launch_conv_dual(p, G, st);
+            if (rc != 1) return rc;
+            const int r1 = ops.run(B, st);
+            return r1 ? r1 : op3.run(B, st);
+        }, OP_CONV, op3.name + " + shortcut", op3.flops + ops.flops, 1});
+    }
+
     // GroupNorm(32) + ReLU from `in` into `out` (possibly a concat slice); names = norm key prefixes per group
     void gn_relu(const std::vector<std::string>& names, const View& in, const View& out, bool single_consumer = false) {
         const int G = (int)names.size(), C = in.C;
@@ -480,6 +541,7 @@ struct Builder {
                     resv = sc;
                 }
                 conv(two(tail + "conv3", true), t2, mid, out, 1, 1, 0, 1, AF_FROZEN_BN, &resv, true);
+                if (cin != cout) fuse_shortcut(two(tail + "conv3", true), two(tail + "shortcut", true), t2, mid, x, cin, stride, out);
                 x = out;
                 cin = cout;
             }
@@ -1029,6 +1091,7 @@ void quber_set_tuning(int32_t key, int32_t value) {
         }
     }
     if (key == 4) g_force_tile = value;    // force the tile shape: 1 = 64x64, 2 = 128x128, 4 = 256x32 (0 = automatic)
+    if (key == 18) g_fuse_shortcut = value;   // acts at plan time: 0 = keep the projection shortcut a convolution of its own
     if (key == 17) g_wino_pairs = value;      // F(4x4) Winograd transforms on channel pairs instead of quads
     if (key == 16) g_persist_debug = value;   // diagnostics of the persistent kernel (1 = drop the epilogue's stores)
     if (key == 14) g_persist_min_nk = value;  // persistent launches: shortest K (slices) whose remainder is shared between blocks
@@ -1310,6 +1373,25 @@ int quber_op_conv2d(const float* x, int32_t B, int32_t h, int32_t w, int32_t cin
     p.ws = g_op_ws;
     p.ws_floats = g_op_ws ? g_op_ws_floats : 0;
     return launch_conv(p, 1, st);
+}
+
+// y: [B][oh][ow][mid], x: [B][h2][w2][cin] (sampled at `stride`), w: [cout][mid + cin] (BN scales already folded in),
+// out = relu?(y . w[:, :mid] + x[::stride, ::stride] . w[:, mid:] + shift)
+int quber_op_conv1x1_dual(const float* y, const float* x, int32_t B, int32_t oh, int32_t ow, int32_t mid, int32_t h2, int32_t w2,
+                          int32_t cin, int32_t stride, const float* w, const float* shift, const float* ones, int32_t cout,
+                          int32_t relu, float* out, void* stream) {
+    ConvP p{};
+    p.in = y; p.in2 = x; p.w = w; p.scale = ones; p.shift = shift; p.out = out;
+    p.B = B; p.H = oh; p.W = ow; p.Cin = mid; p.in_cs = mid;
+    p.H2 = h2; p.W2 = w2; p.in2_cs = cin; p.stride2 = stride; p.K1 = mid;
+    p.OH = oh; p.OW = ow; p.Cout = cout; p.out_cs = cout;
+    p.K = mid + cin; p.Kpad = mid + cin; p.kh = 1; p.kw = 1; p.stride = 1; p.pad = 0; p.dil = 1; p.relu = relu;
+    p.bf16 = g_op_bf16;
+    p.M = B * oh * ow; p.ohw = oh * ow; p.ss_gs = 0;
+    p.ws = g_op_ws; p.ws_floats = g_op_ws ? g_op_ws_floats : 0;
+    const int rc = launch_conv_dual(p, 1, (hipStream_t)stream);
+    if (rc == 1) return fail("conv1x1_dual: launch not covered by the dual kernel (workspace: tuning key 2)");
+    return rc;
 }
 
 static View mkview(const float* p, int B, int h, int w, int c);

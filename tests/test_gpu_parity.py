@@ -538,6 +538,42 @@ def test_conv_persistent_vs_torch(case, dt):
         lib.quber_set_tuning(2, 0)
 
 
+@pytest.mark.parametrize("dt", [0, 3], ids=["f32", "bf16x3"])
+@pytest.mark.parametrize("case", [
+    # B, oh, ow, mid, cin, cout, stride: conv3 + projection shortcut of a bottleneck as one GEMM over both inputs
+    (2, 30, 40, 64, 64, 256, 1),          # res2.0 geometry (stride 1), few tiles: K shared between blocks, 64x64 tiles
+    (16, 60, 80, 128, 256, 512, 2),       # res3.0: strided shortcut input, 128x128 tiles
+    (3, 15, 21, 256, 512, 1024, 2),       # ragged M, odd input size (h2 = 29, w2 = 41)
+    (16, 30, 40, 512, 1024, 2048, 1),     # res5.0: K = 1536, 2400 tiles
+    (1, 1, 1, 64, 64, 256, 1),            # a single pixel
+])
+def test_conv1x1_dual_vs_torch(case, dt):
+    B, oh, ow, mid, cin, cout, stride = case
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    h2, w2 = oh * stride - (stride - 1) * (oh % 2 if False else 0), ow * stride
+    h2, w2 = (oh - 1) * stride + 1, (ow - 1) * stride + 1          # smallest input that yields oh x ow at this stride
+    y = torch.randn(B, oh, ow, mid, generator=g)
+    x = torch.randn(B, h2, w2, cin, generator=g)
+    w = torch.randn(cout, mid + cin, generator=g) / np.sqrt(mid + cin)
+    sh = torch.randn(cout, generator=g)
+    ref = (torch.einsum("bhwc,oc->bhwo", y.double(), w[:, :mid].double()) +
+           torch.einsum("bhwc,oc->bhwo", x[:, ::stride, ::stride].double(), w[:, mid:].double()) + sh.double()).relu()
+    out = torch.full((B, oh, ow, cout), float("nan"), device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    yd, xd, wd, shd, ones = y.cuda(), x.cuda(), w.cuda(), sh.cuda(), torch.ones(cout, device="cuda")
+    lib.quber_set_tuning(2, 1)
+    lib.quber_set_tuning(12, dt)
+    try:
+        _lib.check(lib.quber_op_conv1x1_dual(p(yd), p(xd), B, oh, ow, mid, h2, w2, cin, stride, p(wd), p(shd), p(ones), cout, 1,
+                                             p(out), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    finally:
+        lib.quber_set_tuning(12, 0)
+        lib.quber_set_tuning(2, 0)
+    err = (out.cpu().double() - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+    assert err < 2e-6
+
+
 @pytest.mark.parametrize("case,m", [((2, 30, 40, 256, 256, 1, True, True), 4), ((1, 31, 45, 512, 512, 1, True, False), 4),
                                     ((2, 30, 40, 512, 512, 2, True, True), 2), ((1, 30, 40, 2048, 256, 6, True, True), 4),
                                     ((3, 12, 16, 256, 128, 1, False, False), 6)])
