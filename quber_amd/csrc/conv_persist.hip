@@ -243,7 +243,7 @@ void conv_igemm_pk(const ConvP p) {
             } else {
                 iy0[i] = -(1 << 28);
                 ix0[i] = 0;
-                rowoff[i] = 0;
+                rowoff[i] = OOB;
             }
         }
 #pragma unroll
@@ -267,6 +267,7 @@ void conv_igemm_pk(const ConvP p) {
         }
     };
 
+    const bool one_by_one = p.kh == 1 && p.kw == 1 && p.pad == 0 && p.K == p.Kpad && !p.kmode;
     f32x4 ra[AL], rb[BL];
     auto gload = [&]() __attribute__((always_inline)) {
         if constexpr (DUAL) {
@@ -280,6 +281,17 @@ void conv_igemm_pk(const ConvP p) {
 #pragma unroll
             for (int i = 0; i < BL; ++i) rb[i] = buf_load4(rs_w, wrow[i] + woff);
             ++ks;
+            return;
+        }
+        if (one_by_one) {      // 1x1, no padding, K a multiple of 32: every tap is inside the image, only the rows past M are not
+            const unsigned off = (unsigned)kc * 4u;
+#pragma unroll
+            for (int i = 0; i < AL; ++i) ra[i] = buf_load4(rs_in, rowoff[i] + off);
+            const unsigned woff = (unsigned)(ks * BK) * 4u;
+#pragma unroll
+            for (int i = 0; i < BL; ++i) rb[i] = buf_load4(rs_w, wrow[i] + woff);
+            ++ks;
+            kc += BK;
             return;
         }
         const bool kok = p.kmode || ky < p.kh;
