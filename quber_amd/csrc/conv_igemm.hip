@@ -634,7 +634,11 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
     const bool skip = BM != 256 && p.skip_rows && p.kmode == 0 && p.kh > 1 && p.Cin % BK == 0 && p.K == p.Kpad && p.ohw > 0;
     // Persistent launch (conv_persist.hip): one block per resident slot walks whole tiles and an equal share of the
     // K-slices of the remainder
-    if (g_persist && (BM == 128 || g_persist == 2) && !skip && p.ws && conv_persistent_ok(p)) {
+    // (launches of a few dozen tiles - small batches - keep the one-tile-per-block kernel and its fitted split-K model:
+    // sharing every tile's K between all resident blocks writes more partial tiles than that model's 2-8 partitions)
+    if (g_persist && (BM == 128 || g_persist == 2) && !skip && p.ws && conv_persistent_ok(p) &&
+        (long)p.mtiles * p.ntiles * G >= g_persist_min_tiles &&
+        ((long)p.mtiles * p.ntiles * G >= 256L * (BM == 64 ? 7 : 3) || nk >= g_persist_min_nk)) {      // several tiles per block, or K worth sharing
         if (p.bf16 == 3 && (BM == 256 || (BM == 64 && nk <= 8))) p.bf16 = 0;
         const int bpc = BM == 64 ? (p.bf16 == 3 ? 5 : 7) : (p.bf16 == 3 ? 2 : 3);
         if (p.ws_floats >= conv_persistent_ws_floats(BM, BN, bpc)) {

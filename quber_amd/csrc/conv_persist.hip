@@ -679,6 +679,7 @@ __global__ __launch_bounds__(256) void pk_fixup_kernel(const ConvP p, int P) {
 }  // namespace
 
 int g_persist_min_nk = 32; // key 14: shortest K (in 32-wide slices) whose remainder tiles are shared between blocks
+int g_persist_min_tiles = 256;   // key 15: fewest tiles (all groups) of a launch that goes persistent
 int g_persist_debug = 0;  // key 16 (diagnostics): 1 = zero-length output descriptor, every store of the epilogue is dropped by the range check
 int g_persist = 1;        // key 13: persistent launches: 0 = never, 1 = 128x128 tiles (default), 2 = every tile shape
 
@@ -763,6 +764,7 @@ int launch_conv_dual(ConvP p, int G, hipStream_t st) {
     p.pk_in2_bytes = (int)in2_bytes;
     if (p.bf16 == 3 && p.Kpad / BK <= 8) p.bf16 = 0;       // as the separate launches: short K gains nothing from bf16x3
     const long tiles128 = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * G;
+    if (tiles128 < g_persist_min_tiles) return 1;          // small batches: the two separate launches with their split-K model
     const bool big = tiles128 >= 192 && p.Cout > 64;
     const int bpc = big ? (p.bf16 == 3 ? 2 : 3) : (p.bf16 == 3 ? 5 : 7);
     const int BMs = big ? 128 : 64;

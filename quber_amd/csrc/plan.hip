@@ -1094,6 +1094,7 @@ void quber_set_tuning(int32_t key, int32_t value) {
     if (key == 18) g_fuse_shortcut = value;   // acts at plan time: 0 = keep the projection shortcut a convolution of its own
     if (key == 17) g_wino_pairs = value;      // F(4x4) Winograd transforms on channel pairs instead of quads
     if (key == 16) g_persist_debug = value;   // diagnostics of the persistent kernel (1 = drop the epilogue's stores)
+    if (key == 15) g_persist_min_tiles = value;   // persistent launches: fewest tiles of a launch that goes persistent (default 256)
     if (key == 14) g_persist_min_nk = value;  // persistent launches: shortest K (slices) whose remainder is shared between blocks
     if (key == 13) g_persist = value;         // persistent convolution launches (conv_persist.hip): 0 = never, 1 = wherever eligible
     if (key == 12) g_op_bf16 = value;         // stand-alone conv ops: 1 = bf16, 2 = fp16 operands, 3 = fp32 as 3 bf16 terms; fp32 accumulation

@@ -20,6 +20,7 @@ lib = _lib.load()
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 lib.quber_set_tuning(2, 1)
+lib.quber_set_tuning(15, 0)
 lib.quber_set_tuning(5, 0)
 for kv in (sys.argv[3].split(",") if len(sys.argv) > 3 else []):
     lib.quber_set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))

@@ -39,6 +39,7 @@ def main():
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
     lib.quber_set_tuning(2, 1)
+    lib.quber_set_tuning(15, 0)
     for kv in (sys.argv[2].split(",") if len(sys.argv) > 2 else []):
         lib.quber_set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))
     print("| layer | " + " | ".join(f"dt{d} tile-per-block TF/s | dt{d} persistent TF/s" for d in dts) + " |")

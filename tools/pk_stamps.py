@@ -22,6 +22,7 @@ raw = C.CDLL(_lib.LIB_PATH)
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 lib.quber_set_tuning(2, 1)
+lib.quber_set_tuning(15, 0)
 lib.quber_set_tuning(13, 1)
 lib.quber_set_tuning(4, 2)
 for kv in (sys.argv[4].split(",") if len(sys.argv) > 4 else []):
