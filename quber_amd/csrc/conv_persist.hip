@@ -537,9 +537,8 @@ void conv_igemm_pk(const ConvP p) {
         if (more) lstore();
         if (last) {
             PK_STAMP(2);
-            // the epilogue's ~500 vector instructions get the leftover issue slots beside the other blocks' MFMA waves
-            // (5-6 us per tile, stores or no stores); at raised priority they go first and the MFMA waves, which need
-            // one slot per 64 cycles, lose nothing
+            // (raised priority for the epilogue's ~500 vector instructions beside the other blocks' MFMA waves: measured
+            // neutral - the epilogue's time is its scalar set-up and the stores - and kept only as a diagnostic switch)
             if (p.pk_debug != 2) __builtin_amdgcn_s_setprio(3);
             if (cur) epilogue();
             __builtin_amdgcn_s_setprio(0);
