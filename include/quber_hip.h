@@ -227,6 +227,8 @@ double quber_forward_flops_executed(quber_ctx* ctx);
  *          maskrefiner/modeling/backbone/resnet.py:37-63) or as two convolutions (0);
  * key 17 = Winograd F(4x4) transforms on channel pairs instead of quads (measured: input transform 6 % slower; default 0);
  * key 16 = diagnostics of the persistent convolution kernel (1 = its output stores are dropped by the range check);
+ * key 15 = persistent launches: fewest tiles (all groups) of a launch that goes persistent (default 256; smaller launches -
+ *          small batches - keep the one-tile-per-block kernel and its split-K model);
  * key 14 = persistent launches: shortest K, in 32-wide slices, whose remainder tiles are shared between blocks (default 32);
  * key 13 = persistent convolution launches (csrc/conv_persist.hip): 0 = never (one tile per block everywhere),
  *          1 = the 128x128-tile launches (default), 2 = every tile shape;
