@@ -538,6 +538,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvP p, int S
 int g_winograd = 0;       // key 6: Winograd path for the eligible 3x3 layers: 0 = where it pays, 1 = never, 2 = always
 int g_force_tile = 0;     // test-harness knobs (quber_set_tuning keys 4 / 3): force the tile shape / the number of K partitions
 int g_force_split = 0;
+int g_tile_128x64 = 1;     // key 19: 128x64 tiles for the 33-64 channel layers (0: 64x64 as before)
 int g_tail_split = 1;      // key 5: split the ragged last round of large launches when the model favours it (1), never (0), whenever feasible (2)
 
 // ---- work distribution -------------------------------------------------------------------------------------------
@@ -636,7 +637,7 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
     // K-slices of the remainder
     // (launches of a few dozen tiles - small batches - keep the one-tile-per-block kernel and its fitted split-K model:
     // sharing every tile's K between all resident blocks writes more partial tiles than that model's 2-8 partitions)
-    if (g_persist && (BM == 128 || g_persist == 2) && !skip && p.ws && conv_persistent_ok(p) &&
+    if (g_persist && ((BM == 128 && BN == 128) || (g_persist == 2 && (BM == BN || BM == 256))) && !skip && p.ws && conv_persistent_ok(p) &&
         (long)p.mtiles * p.ntiles * G >= g_persist_min_tiles &&
         ((long)p.mtiles * p.ntiles * G >= 256L * (BM == 64 ? 7 : 3) || nk >= g_persist_min_nk)) {      // several tiles per block, or K worth sharing
         if (p.bf16 == 3 && (BM == 256 || (BM == 64 && nk <= 8))) p.bf16 = 0;
@@ -644,7 +645,8 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
         if (p.ws_floats >= conv_persistent_ws_floats(BM, BN, bpc)) {
             {
                 ProfScope prof(tag, conv_bytes, conv_flops, st);
-                const int rc = launch_conv_persistent<BM, BN, WM, WN>(p, G, bpc, st);
+                int rc = 0;
+                if constexpr (BM == BN || BM == 256) rc = launch_conv_persistent<BM, BN, WM, WN>(p, G, bpc, st);
                 if (rc) return rc;
             }
             return gn_separate();
@@ -734,6 +736,7 @@ int launch_conv(const ConvP& p, int G, hipStream_t st) {
         case 1: return run<64, 64, 2, 2>(p, G, 1, st);
         case 2: return run<128, 128, 2, 2>(p, G, 1, st);
         case 4: return run<256, 32, 4, 1>(p, G, 1, st);
+        case 3: return run<128, 64, 2, 2>(p, G, 1, st);
         default: break;
     }
     // Tile shape (sweep: profiles/r01i_conv_sweep_*.md).  <= 32 output channels: 256x32.  <= 64 channels, and the
@@ -741,6 +744,9 @@ int launch_conv(const ConvP& p, int G, hipStream_t st) {
     // loads in flight.  Otherwise 128x128, split when the model says so; 64x64 again for launches too small for that.
     const int nk = p.Kpad / BK;
     if (p.Cout <= 32) return run<256, 32, 4, 1>(p, G, choose_split(p, G, 256, 32, 3), st);
+    // 33-64 output channels without a residual, at least a round of tiles: 128x64 (each wave 64x32: the weight fragments
+    // are read from LDS half as often as with 64x64 tiles; +3-5 % on stem.conv3 / res2 conv1, conv2 - tools/tile_ab.py)
+    if (g_tile_128x64 && p.Cout <= 64 && p.Cout > 32 && !p.res && (long)((p.M + 127) / 128) * G >= 1024) return run<128, 64, 2, 2>(p, G, 1, st);
     if (p.Cout <= 64 || (p.res && nk <= 8 && p.Cout >= 128)) return run<64, 64, 2, 2>(p, G, choose_split(p, G, 64, 64, 7), st);
     const long tiles128 = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * G;
     const int s128 = choose_split(p, G, 128, 128, 3);

@@ -90,10 +90,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr, int
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long)hi << 32) | lo), 0,
                                              __builtin_amdgcn_readfirstlane(bytes), RSRC_FLAGS);
 }
-__device__ __forceinline__ const float* uniform_ptr(const float* ptr) {
+// A block-uniform pointer into GLOBAL memory: address in SGPRs, and typed as address space 1 so that loads through it
+// are global_load (vmcnt only) - a generic pointer gives flat_load, whose wait (lgkmcnt) also covers the LDS stores
+// just issued for the next tile's first K-slice.
+using gf32x4_ptr = const f32x4 __attribute__((address_space(1)))*;
+__device__ __forceinline__ gf32x4_ptr uniform_gptr(const float* ptr) {
     const unsigned long a = (unsigned long)ptr;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-    return reinterpret_cast<const float*>(((unsigned long)hi << 32) | lo);
+    return (gf32x4_ptr)(((unsigned long)hi << 32) | lo);
 }
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff) {
     using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
@@ -434,8 +438,8 @@ void conv_igemm_pk(const ConvP p) {
         const unsigned res_cs4 = p.res_cs * 4;
         const bool affine = p.scale != nullptr && !c_raw;
         const float lo = (p.relu && !c_raw) ? 0.f : -__builtin_inff();     // ReLU as max(y, lo)
-        const float* __restrict__ scale = uniform_ptr(p.scale + c_g * p.ss_gs + c_n0);
-        const float* __restrict__ shift = uniform_ptr(p.shift + c_g * p.ss_gs + c_n0);
+        const gf32x4_ptr scale = uniform_gptr(p.scale + c_g * p.ss_gs + c_n0);      // 16-byte aligned: c_n0 % 64 == 0, host checks the base
+        const gf32x4_ptr shift = uniform_gptr(p.shift + c_g * p.ss_gs + c_n0);
         const bool q0 = lane & 1, q1 = lane & 2;
         const unsigned lrow = (r & 3) + 4 * h, lcol4 = (r >> 2) * 4;
         const bool gn = GN && !c_raw;
@@ -460,8 +464,8 @@ void conv_igemm_pk(const ConvP p) {
             sc[j] = f32x4{1.f, 1.f, 1.f, 1.f};
             sh[j] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (affine && nok[j]) {
-                sc[j] = *reinterpret_cast<const f32x4*>(scale + col);
-                sh[j] = *reinterpret_cast<const f32x4*>(shift + col);
+                sc[j] = scale[col >> 2];
+                sh[j] = shift[col >> 2];
             }
         }
         PK_STAMP(6);
@@ -537,11 +541,7 @@ void conv_igemm_pk(const ConvP p) {
         if (more) lstore();
         if (last) {
             PK_STAMP(2);
-            // (raised priority for the epilogue's ~500 vector instructions beside the other blocks' MFMA waves: measured
-            // neutral - the epilogue's time is its scalar set-up and the stores - and kept only as a diagnostic switch)
-            if (p.pk_debug != 2) __builtin_amdgcn_s_setprio(3);
             if (cur) epilogue();
-            __builtin_amdgcn_s_setprio(0);
             PK_STAMP(3);
 #ifdef PK_STAMPS
             if (t == 0 && blockIdx.x < 2048) g_pk_span[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();

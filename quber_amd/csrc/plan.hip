@@ -1091,6 +1091,7 @@ void quber_set_tuning(int32_t key, int32_t value) {
         }
     }
     if (key == 4) g_force_tile = value;    // force the tile shape: 1 = 64x64, 2 = 128x128, 4 = 256x32 (0 = automatic)
+    if (key == 19) g_tile_128x64 = value;     // 128x64 tiles for the 33-64 channel convolutions (default 1)
     if (key == 18) g_fuse_shortcut = value;   // acts at plan time: 0 = keep the projection shortcut a convolution of its own
     if (key == 17) g_wino_pairs = value;      // F(4x4) Winograd transforms on channel pairs instead of quads
     if (key == 16) g_persist_debug = value;   // diagnostics of the persistent kernel (1 = drop the epilogue's stores)
