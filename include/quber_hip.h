@@ -222,6 +222,7 @@ double quber_forward_flops(quber_ctx* ctx);
  * (m+2)^2 / (9 m^2) of its algorithmic FLOPs, padded tiles included (transform additions not counted) */
 double quber_forward_flops_executed(quber_ctx* ctx);
 /* test-harness knobs: key 2 = give the stand-alone quber_op_conv2d a split-K workspace (value != 0) or drop it (0);
+ * key 19 = 128x64 tiles for the convolutions with 33-64 output channels and no residual (1, default) or 64x64 (0);
  * key 18 = (acts at plan time) the projection block of every ResNet stage runs conv3 and its shortcut as ONE 1x1 GEMM over
  *          the concatenated inputs (1, default; reference: detectron2 BottleneckBlock as built by
  *          maskrefiner/modeling/backbone/resnet.py:37-63) or as two convolutions (0);
