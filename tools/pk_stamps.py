@@ -81,7 +81,7 @@ print(f"  K loop, all slices (0 -> 1)               {us(t[:, :, 1] - t[:, :, 0])
 print(f"  wait for + store next tile's slice (1->2) {us(t[:, :, 2] - t[:, :, 1]):7.2f}")
 print(f"  epilogue (2 -> 3)                         {us(t[:, :, 3] - t[:, :, 2]):7.2f}")
 for a, b_, name in ((2, 5, "descriptors, addresses (2 -> 5)"), (5, 6, "issue affine-parameter loads (5 -> 6)"), (6, 7, "tile 0: wait, transposition, 4 stores (6 -> 7)"),
-                    (7, 8, "tile 1 (7 -> 8)"), (8, 9, "tile 2 (8 -> 9)"), (9, 10, "tile 3 (9 -> 10)"), (10, 3, "set priority back (10 -> 3)")):
+                    (7, 8, "tile 1 (7 -> 8)"), (8, 9, "tile 2 (8 -> 9)"), (9, 10, "tile 3 (9 -> 10)"), (10, 3, "end of the epilogue (10 -> 3)")):
     print(f"      {name:48s} {us(t[:, :, b_] - t[:, :, a]):7.2f}")
 print(f"  zero accumulators + barrier (3 -> next 0) {us(nxt0 - t[:, :, 3]):7.2f}")
 print(f"  whole tile (0 -> next 0)                  {us(nxt0 - t[:, :, 0]):7.2f}")

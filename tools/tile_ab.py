@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Stand-alone convolution op with the tile shape forced (tuning key 4: 1 = 64x64, 3 = 128x64, 2 = 128x128) on the layers
+with at most 64 output channels and on a residual 1x1; one-tile-per-block kernel (key 13 = 0).  GPU box only."""
 import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
