@@ -326,16 +326,26 @@ def main():
         with torch.cuda.graph(graph):
             gpu_step()
 
+    pending = [None]      # the label-map gather of the previous step: it travels over xGMI while this step computes
+
     def step():
         if graph is not None:
             graph.replay()
         else:
             gpu_step()
         if dist is not None and not a.no_gather:
-            qdist.gather_label_maps(post["panoptic"], counts, dst=0)
+            if pending[0] is not None:
+                pending[0].wait()
+            pending[0] = qdist.gather_label_maps(post["panoptic"], counts, dst=0, async_op=True)
+
+    def drain():
+        if pending[0] is not None:
+            pending[0].wait()
+            pending[0] = None
 
     for _ in range(a.warmup):
         step()
+    drain()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -345,6 +355,7 @@ def main():
     for i in range(a.steps):
         step()
         marks[i + 1].record()
+    drain()                     # the last step's gather belongs to the timed region
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

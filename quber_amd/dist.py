@@ -41,17 +41,37 @@ def broadcast_state_dict(sd, specs, src=0, device="cpu"):
     return out
 
 
-def gather_label_maps(local, counts, dst=0):
+def gather_label_maps(local, counts, dst=0, async_op=False):
     """local: [b_r, H, W] label maps of this rank (b_r may differ by one between ranks); counts: frames per rank.
-    Returns the concatenated [sum(b_r), H, W] tensor on `dst`, None elsewhere."""
+    Returns the concatenated [sum(b_r), H, W] tensor on `dst`, None elsewhere.
+    async_op=True: returns a handle instead, `h.wait()` -> that result.  The collective then runs on the backend's
+    own stream beside whatever the caller enqueues next (the next step's kernels); `local` is copied first, so the
+    caller may overwrite it at once."""
     world, rank = dist.get_world_size(), dist.get_rank()
     bmax = max(counts)
-    pad = local
     if local.shape[0] < bmax:
         pad = torch.cat([local, local.new_full((bmax - local.shape[0],) + tuple(local.shape[1:]), -1)])
+    else:
+        pad = local.clone() if async_op else local
     pad = pad.contiguous().to(_comm_device(pad.device))
     bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-    dist.gather(pad, bufs, dst=dst)
-    if rank != dst:
-        return None
-    return torch.cat([b[:c] for b, c in zip(bufs, counts)])
+    work = dist.gather(pad, bufs, dst=dst, async_op=async_op)
+
+    def finish():
+        if rank != dst:
+            return None
+        return torch.cat([b[:c] for b, c in zip(bufs, counts)])
+
+    if not async_op:
+        return finish()
+    return _PendingGather(work, finish, pad)
+
+
+class _PendingGather:
+    def __init__(self, work, finish, keep):
+        self.work, self.finish, self.keep = work, finish, keep      # `keep`: the send buffer stays alive until the wait
+
+    def wait(self):
+        self.work.wait()
+        self.keep = None
+        return self.finish()

@@ -34,10 +34,17 @@ def _worker(rank, world, port, n_frames, q):
         local = torch.stack([torch.full((4, 6), float(i)) for i in range(s, e)]) if e > s else torch.zeros((0, 4, 6))
         counts = [qdist.shard_range(n_frames, r, world)[1] - qdist.shard_range(n_frames, r, world)[0] for r in range(world)]
         allmaps = qdist.gather_label_maps(local, counts, dst=0)
+        # the asynchronous form bench.py uses (the gather of step i travels while step i + 1 computes): the send buffer is
+        # copied, so overwriting `local` right after the call must not change what arrives
+        mine = local.clone()
+        handle = qdist.gather_label_maps(mine, counts, dst=0, async_op=True)
+        mine.fill_(-7.0)
+        later = handle.wait()
         if rank == 0:
             ok_g = allmaps.shape == (n_frames, 4, 6) and all(float(allmaps[i, 0, 0]) == i for i in range(n_frames))
+            ok_g = ok_g and torch.equal(later, allmaps)
         else:
-            ok_g = allmaps is None
+            ok_g = allmaps is None and later is None
         q.put((rank, ok_w, ok_g, (s, e)))
     finally:
         dist.destroy_process_group()
