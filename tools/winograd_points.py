@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Which interpolation points for Winograd F(m x m, 3x3)?  Toom-Cook matrices for a point set (exact, fractions), then the
+fp32 pipeline simulated in numpy (U = G g G^T in float64 rounded once, V = B^T d B, channel sum and A^T M A in float32)
+against the float64 convolution, 256 channels.  CPU only.  Result (mean max error relative to the output scale): F(4x4) on
+0, +-1, +-2: 3.7e-6; on 0, +-3/4, +-3/2 (what csrc/winograd.hip uses): 1.5e-6; F(6x6) on 0, +-1, +-2, +-1/2: 5.9e-6, and
+none of 20 other symmetric point sets (scalings by 1/2 ... 5/4, other triples) comes below it - F(6x6) stays opt-in."""
+from fractions import Fraction as F
+
+def matrices(points, m, r=3):
+    """Toom-Cook F(m, r) with the given finite points + infinity.  Returns AT (m x n), G (n x r), BT (n x n) as float64."""
+    n = m + r - 1
+    p = [F(x) for x in points]
+    assert len(p) == n - 1
+    # polynomial helpers (coeff lists low->high, Fractions)
+    def mul(a, b):
+        out = [F(0)] * (len(a) + len(b) - 1)
+        for i, x in enumerate(a):
+            for j, y in enumerate(b):
+                out[i + j] += x * y
+        return out
+    AT = [[p[j] ** i for j in range(n - 1)] + [F(1) if i == m - 1 else F(0)] for i in range(m)]
+    G = []
+    for j in range(n - 1):
+        N = F(1)
+        for k in range(n - 1):
+            if k != j: N *= (p[j] - p[k])
+        G.append([p[j] ** k / N for k in range(r)])
+    G.append([F(0)] * (r - 1) + [F(1)])
+    BT = []
+    for j in range(n - 1):
+        poly = [F(1)]
+        for k in range(n - 1):
+            if k != j: poly = mul(poly, [-p[k], F(1)])
+        BT.append(poly + [F(0)] * (n - len(poly)))
+    poly = [F(1)]
+    for k in range(n - 1): poly = mul(poly, [-p[k], F(1)])
+    BT.append(poly)
+    f = lambda M: np.array([[float(x) for x in row] for row in M])
+    return f(AT), f(G), f(BT)
+
+def balance(AT, G, BT):
+    """move row scales between G and BT so that BT rows have max |entry| 1-ish power of two? (keep exactness: use powers of two)"""
+    return AT, G, BT
+
+def error(points, m, C=256, trials=6, seed=0, scale_rows=None):
+    AT, G, BT = matrices(points, m)
+    n = m + 2
+    if scale_rows is not None:           # diagonal rescale D: BT <- D BT, G <- D^-1 G   (exact when D is a power of two)
+        D = np.array(scale_rows, float)
+        BT = BT * D[:, None]; G = G / D[:, None]
+    rng = np.random.default_rng(seed)
+    errs = []
+    for t in range(trials):
+        d = rng.standard_normal((C, n, n))
+        g = rng.standard_normal((C, 3, 3)) / np.sqrt(C * 9)
+        # reference: direct correlation, float64
+        ref = np.zeros((m, m))
+        for y in range(m):
+            for x in range(m):
+                ref[y, x] = np.sum(d[:, y:y + 3, x:x + 3] * g)
+        d32 = d.astype(np.float32); BT32 = BT.astype(np.float32); AT32 = AT.astype(np.float32)
+        U = np.einsum("ij,cjk,lk->cil", G, g, G).astype(np.float32)            # fp64 on the host, rounded once
+        V = np.einsum("ij,cjk->cik", BT32, d32).astype(np.float32)
+        V = np.einsum("cik,lk->cil", V, BT32).astype(np.float32)
+        M = np.zeros((n, n), np.float32)
+        for c in range(C):
+            M = (M + U[c] * V[c]).astype(np.float32)
+        Y = (AT32 @ M).astype(np.float32)
+        Y = (Y @ AT32.T).astype(np.float32)
+        errs.append(np.abs(Y - ref).max() / max(1.0, np.abs(ref).max()))
+    return float(np.mean(errs))
+
+if __name__ == "__main__":
+    print("F(4x4) 0,+-1,+-2      :", error([0, 1, -1, 2, -2], 4))
+    print("F(4x4) 0,+-3/4,+-3/2  :", error([0, F(3,4), F(-3,4), F(3,2), F(-3,2)], 4))
+    base = error([0, 1, -1, 2, -2, F(1,2), F(-1,2)], 6)
+    print("F(6x6) 0,+-1,+-2,+-1/2:", base)
+    cands = {}
+    for s in (F(1,2), F(5,8), F(3,4), F(7,8), F(1), F(5,4)):
+        cands[f"scaled by {s}: 0,+-{s},+-{2*s},+-{s/2}"] = [0, s, -s, 2*s, -2*s, s/2, -s/2]
+    for trip in ((F(1,2), F(1), F(3,2)), (F(1,2), F(3,4), F(3,2)), (F(3,8), F(3,4), F(3,2)), (F(1,4), F(1,2), F(1)), (F(1,2), F(1), F(7,4)),
+                 (F(2,5), F(4,5), F(8,5)), (F(3,8), F(7,8), F(13,8)), (F(1,2), F(7,8), F(3,2)), (F(3,8), F(3,4), F(5,4)), (F(1,3), F(2,3), F(4,3)),
+                 (F(7,16), F(7,8), F(7,4)), (F(5,16), F(5,8), F(5,4)), (F(1,2),F(1),F(5,4)), (F(3,5),F(1),F(8,5))):
+        a, b, c = trip
+        cands[f"0,+-{a},+-{b},+-{c}"] = [0, a, -a, b, -b, c, -c]
+    res = sorted((error(v, 6), k) for k, v in cands.items())
+    for e, k in res: print(f"  {e:.3e} ({e / base:.2f}x)  {k}")
