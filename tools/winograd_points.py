@@ -6,6 +6,8 @@ against the float64 convolution, 256 channels.  CPU only.  Result (mean max erro
 none of 20 other symmetric point sets (scalings by 1/2 ... 5/4, other triples) comes below it - F(6x6) stays opt-in."""
 from fractions import Fraction as F
 
+import numpy as np
+
 def matrices(points, m, r=3):
     """Toom-Cook F(m, r) with the given finite points + infinity.  Returns AT (m x n), G (n x r), BT (n x n) as float64."""
     n = m + r - 1
