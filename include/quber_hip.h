@@ -248,6 +248,16 @@ double quber_forward_flops_executed(quber_ctx* ctx);
  *         favours it (1, default), never (0), whenever feasible (2);
  * key 4 = force the convolution tile shape (1 = 64x64, 2 = 128x128, 4 = 256x32; 0 = automatic) */
 void quber_set_tuning(int32_t key, int32_t value);
+/* Host view of the work distribution of a persistent convolution launch (csrc/conv_persist.hip), for the CPU tests: no GPU.
+ * _segments: the work list of block `block` of a launch of `blocks` blocks over `tiles` tiles of `k_slices` K-slices each
+ *   (min_share = shortest K share of the remainder, 0 = remainder tiles whole): up to cap x (tile, first slice, end slice,
+ *   workspace slot or -1 for a whole tile); returns their number.
+ * _fixup: for remainder tile j of XCD run xcd: its tile index and the workspace slots the fix-up pass sums, in order;
+ *   returns their number, 0 when the tile is computed whole, -1 past the remainder. */
+int32_t quber_debug_persistent_segments(int32_t tiles, int32_t blocks, int32_t k_slices, int32_t min_share, int32_t block,
+                                        int32_t* out4, int32_t cap);
+int32_t quber_debug_persistent_fixup(int32_t tiles, int32_t blocks, int32_t k_slices, int32_t min_share, int32_t xcd, int32_t j,
+                                     int32_t* tile, int32_t* slots, int32_t cap);
 /* the launch plan of quber_forward, in execution order (after the input pre-processing kernel):
  * kind 0 = convolution, 1 = GroupNorm, 2 = other; flops = algorithmic FLOPs at batch 1 */
 int quber_num_ops(quber_ctx* ctx);

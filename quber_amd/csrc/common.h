@@ -117,6 +117,8 @@ extern int g_force_split, g_force_tile, g_tail_split, g_persist, g_persist_min_n
 template <int BM, int BN, int WM, int WN> int launch_conv_persistent(ConvP p, int G, int bpc, hipStream_t st);
 size_t conv_persistent_ws_floats(int BM, int BN, int bpc);
 bool conv_persistent_ok(const ConvP& p);
+int conv_persistent_segments(int T, int P, int nk, int min_slices, int bid, int* out4, int cap);
+int conv_persistent_fixup(int T, int P, int nk, int min_slices, int xcd, int j, int* tile, int* slots, int cap);
 int launch_conv_dual(ConvP p, int G, hipStream_t st);   // 0 done, 1 not covered (run the two convolutions), -1 error
 #ifdef PK_STAMPS
 int pk_read_stamps(unsigned long long* dst, int n);

@@ -740,6 +740,41 @@ int pk_read_stamps(unsigned long long* dst, int n) {
 
 size_t conv_persistent_ws_floats(int BM, int BN, int bpc) { return (size_t)2 * 256 * bpc * BM * BN; }
 
+// Host view of the work list of block `bid` of a persistent launch (the arithmetic conv_igemm_pk runs on the device), for
+// the CPU tests: up to `cap` segments as (tile, first K-slice, end K-slice, workspace slot or -1 for a whole tile).
+int conv_persistent_segments(int T, int P, int nk, int min_slices, int bid, int* out4, int cap) {
+    const int xcd = bid & 7, l = bid >> 3;
+    const PkPlan pl = pk_plan(T, P, xcd, nk, min_slices);
+    int n = 0;
+    for (int round = 0; round < pl.R && n < cap; ++round, ++n) {
+        out4[4 * n] = pl.c0 + round * pl.PX + l; out4[4 * n + 1] = 0; out4[4 * n + 2] = nk; out4[4 * n + 3] = -1;
+    }
+    if (l < pl.PXs) {
+        int u = pk_u0(pl, l);
+        const int u_first = u, u_end = pk_u0(pl, l + 1);
+        while (u < u_end && n < cap) {
+            const int j = u / nk, k0 = u - j * nk, k1 = (nk < k0 + (u_end - u)) ? nk : k0 + (u_end - u);
+            out4[4 * n] = pl.c0 + pl.R * pl.PX + j; out4[4 * n + 1] = k0; out4[4 * n + 2] = k1;
+            out4[4 * n + 3] = (k1 - k0 == nk) ? -1 : 2 * bid + (u == u_first ? 0 : 1);
+            u += k1 - k0;
+            ++n;
+        }
+    }
+    return n;
+}
+// ... and of the fix-up pass: the slots summed, in order, for remainder tile j of XCD run `xcd` (0 = computed whole)
+int conv_persistent_fixup(int T, int P, int nk, int min_slices, int xcd, int j, int* tile, int* slots, int cap) {
+    const PkPlan pl = pk_plan(T, P, xcd, nk, min_slices);
+    if (j >= pl.rem) return -1;
+    *tile = pl.c0 + pl.R * pl.PX + j;
+    const int ua = j * nk;
+    const int bf = pk_owner(pl, ua), bl = pk_owner(pl, ua + nk - 1);
+    if (bf == bl) return 0;
+    int n = 0;
+    for (int b = bf; b <= bl && n < cap; ++b, ++n) slots[n] = 2 * (b * 8 + xcd) + ((b == bf && pk_u0(pl, bf) < ua) ? 1 : 0);
+    return n;
+}
+
 // what the persistent kernel covers: fp32 / bf16x3 arithmetic, affine + ReLU epilogues with either a residual or GroupNorm
 // sums, 16-byte-aligned channel counts, every view below 2 GiB (32-bit buffer offsets)
 bool conv_persistent_ok(const ConvP& p) {

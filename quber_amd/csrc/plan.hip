@@ -1114,6 +1114,15 @@ int quber_pk_read_stamps(unsigned long long* dst, int n) { return quber::pk_read
 int quber_pk_read_span(unsigned long long* dst, int n) { return quber::pk_read_span(dst, n); }
 #endif
 
+int32_t quber_debug_persistent_segments(int32_t tiles, int32_t blocks, int32_t k_slices, int32_t min_share, int32_t block, int32_t* out4,
+                                        int32_t cap) {
+    return quber::conv_persistent_segments(tiles, blocks, k_slices, min_share, block, out4, cap);
+}
+int32_t quber_debug_persistent_fixup(int32_t tiles, int32_t blocks, int32_t k_slices, int32_t min_share, int32_t xcd, int32_t j,
+                                     int32_t* tile, int32_t* slots, int32_t cap) {
+    return quber::conv_persistent_fixup(tiles, blocks, k_slices, min_share, xcd, j, tile, slots, cap);
+}
+
 int quber_profile_begin(quber_ctx* c) {
     if (!c) return fail("null context");
     if (!c->prof) c->prof.reset(new quber::Profiler());
