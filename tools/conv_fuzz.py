@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Randomised cross-check of the convolution launch structures on the stand-alone op: persistent launches for every tile
+shape (tuning keys 13 = 2, 15 = 0) against the one-tile-per-block kernel (13 = 0) on random geometries - ragged M and N,
+strides, dilations, K tails, residuals, both fp32-class arithmetic modes - and the dual-input 1x1 op against a float64
+einsum.  GPU box only.  usage: conv_fuzz.py [cases] [seed]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from quber_amd import _lib  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+lib = _lib.load()
+st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+lib.quber_set_tuning(2, 1)
+lib.quber_set_tuning(15, 0)
+worst, bad = 0.0, 0
+for case in range(N):
+    k = int(rng.choice([1, 1, 3]))
+    Cin = int(rng.choice([4, 8, 32, 36, 64, 96, 128, 164, 256, 512, 1024]))
+    Cout = int(rng.choice([4, 32, 48, 64, 100, 128, 132, 256, 512, 1024]))
+    stride = int(rng.choice([1, 1, 2]))
+    dil = int(rng.choice([1, 1, 2, 6])) if k == 3 and stride == 1 else 1
+    H, W = int(rng.integers(1, 70)), int(rng.integers(1, 90))
+    B = int(rng.integers(1, 24))
+    while B * H * W * max(Cin, Cout) > 3.0e8:
+        B = max(1, B // 2); H = max(1, H // 2)
+    res, relu, dt = bool(rng.integers(2)), int(rng.integers(2)), int(rng.choice([0, 0, 3]))
+    pad = dil * (k // 2)
+    OH, OW = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1, (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    g = torch.Generator(device="cuda").manual_seed(case)
+    x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
+    w = torch.randn(Cout, Cin, k, k, device="cuda", generator=g) / np.sqrt(Cin * k * k)
+    sc, sh = torch.rand(Cout, device="cuda", generator=g) + 0.5, torch.randn(Cout, device="cuda", generator=g)
+    r = torch.randn(B, OH, OW, Cout, device="cuda", generator=g) if res else None
+    packed = torch.empty(Cout * ((k * k * Cin + 31) // 32 * 32), device="cuda")
+    outs = []
+    lib.quber_set_tuning(12, dt)
+    for mode in (0, 2):
+        lib.quber_set_tuning(13, mode)
+        y = torch.full((B, OH, OW, Cout), float("nan"), device="cuda")
+        _lib.check(lib.quber_op_conv2d(p(x), B, H, W, Cin, p(w), Cout, k, stride, pad, dil, p(sc), p(sh), p(r), relu, p(packed), p(y), st))
+        outs.append(y)
+    torch.cuda.synchronize()
+    ok = bool(torch.isfinite(outs[1]).all())
+    err = float((outs[0] - outs[1]).abs().max()) / max(1.0, float(outs[0].abs().max())) if ok else float("inf")
+    worst = max(worst, err)
+    if not ok or err > 4e-6:
+        bad += 1
+        print("MISMATCH", dict(B=B, H=H, W=W, Cin=Cin, Cout=Cout, k=k, stride=stride, dil=dil, res=res, relu=relu, dt=dt), err, flush=True)
+print(f"conv2d: {N} random cases, persistent vs one-tile-per-block: {bad} mismatches, worst relative difference {worst:.2e}")
+
+# dual-input 1x1 against float64
+worst2, bad2 = 0.0, 0
+ones_cache = {}
+for case in range(N // 3):
+    mid, cin = int(rng.choice([32, 64, 128, 256, 512])), int(rng.choice([32, 64, 256, 512, 1024]))
+    cout = int(rng.choice([64, 128, 256, 512, 1024, 2048]))
+    stride = int(rng.choice([1, 2]))
+    oh, ow, B = int(rng.integers(1, 40)), int(rng.integers(1, 50)), int(rng.integers(1, 17))
+    h2, w2 = (oh - 1) * stride + 1 + int(rng.integers(0, stride)), (ow - 1) * stride + 1 + int(rng.integers(0, stride))
+    dt = int(rng.choice([0, 3]))
+    g = torch.Generator(device="cuda").manual_seed(1000 + case)
+    y = torch.randn(B, oh, ow, mid, device="cuda", generator=g)
+    x = torch.randn(B, h2, w2, cin, device="cuda", generator=g)
+    w = torch.randn(cout, mid + cin, device="cuda", generator=g) / np.sqrt(mid + cin)
+    sh = torch.randn(cout, device="cuda", generator=g)
+    ones = torch.ones(cout, device="cuda")
+    out = torch.full((B, oh, ow, cout), float("nan"), device="cuda")
+    lib.quber_set_tuning(12, dt)
+    lib.quber_set_tuning(13, 1)
+    _lib.check(lib.quber_op_conv1x1_dual(p(y), p(x), B, oh, ow, mid, h2, w2, cin, stride, p(w), p(sh), p(ones), cout, 1, p(out), st))
+    ref = (torch.einsum("bhwc,oc->bhwo", y.double(), w[:, :mid].double()) +
+           torch.einsum("bhwc,oc->bhwo", x[:, ::stride, ::stride][:, :oh, :ow].double(), w[:, mid:].double()) + sh.double()).relu()
+    err = float((out.double() - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+    worst2 = max(worst2, err)
+    if not (err < 3e-6):
+        bad2 += 1
+        print("DUAL MISMATCH", dict(B=B, oh=oh, ow=ow, mid=mid, cin=cin, cout=cout, stride=stride, dt=dt), err, flush=True)
+print(f"conv1x1_dual: {N // 3} random cases against float64: {bad2} mismatches, worst relative error {worst2:.2e}")
+lib.quber_set_tuning(12, 0); lib.quber_set_tuning(13, 1); lib.quber_set_tuning(15, 256); lib.quber_set_tuning(2, 0)
+sys.exit(1 if bad or bad2 else 0)
