@@ -730,6 +730,9 @@ int launch_conv(const ConvP& p, int G, hipStream_t st) {
     if (((uintptr_t)p.in & 15) || ((uintptr_t)p.w & 15) || (p.in_gs & 3) || (p.w_gs & 3))
         return fail("conv: operands must be 16-byte aligned");
     if (p.M <= 0 || p.Cout <= 0) return fail("conv: empty problem");
+    // the loader steps its filter-tap position at most BK/8 times per K-slice (found by tools/conv_fuzz.py: Cin = 4 with a 3x3
+    // filter read the wrong taps; the refiner pads its 4-channel input to 8)
+    if (p.kh * p.kw > 1 && p.Cin < 8) return fail("conv: filters larger than 1x1 need at least 8 input channels (pad the input)");
     if (p.kmode && (p.Cin % BK || p.K != p.Kpad)) return fail("conv: slice-major weights need Cin % 32 == 0");
     if ((p.scale == nullptr) != (p.shift == nullptr)) return fail("conv: scale and shift go together");
     switch (g_force_tile) {

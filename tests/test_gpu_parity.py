@@ -500,6 +500,20 @@ def test_conv_igemm_bf16x3_meets_the_fp32_bar(case):
         lib.quber_set_tuning(2, 0)
 
 
+@pytest.mark.gpu
+def test_conv_refuses_narrow_inputs_for_3x3():
+    """fewer than 8 input channels under a 3x3 filter: refused loudly (the loader's tap stepping assumes >= 8 per tap)"""
+    lib = _lib.load()
+    x = torch.randn(1, 8, 8, 4, device="cuda")
+    w = torch.randn(32, 4, 3, 3, device="cuda")
+    y = torch.empty(1, 8, 8, 32, device="cuda")
+    packed = torch.empty(32 * 64, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    rc = lib.quber_op_conv2d(p(x), 1, 8, 8, 4, p(w), 32, 3, 1, 1, 1, C.c_void_p(0), C.c_void_p(0), C.c_void_p(0), 0, p(packed), p(y),
+                             C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc != 0 and b"8 input channels" in lib.quber_last_error()
+
+
 PERSISTENT_CASES = [
     # B, H, W, Cin, Cout, k, stride, dil, affine, residual, relu
     (2, 24, 32, 8, 32, 3, 2, 1, True, False, True),         # 256x32 tiles, K = 72 (tail), a handful of tiles: stream-K only
