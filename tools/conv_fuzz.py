@@ -101,5 +101,41 @@ for case in range(N // 3):
         bad2 += 1
         print("DUAL MISMATCH", dict(B=B, oh=oh, ow=ow, mid=mid, cin=cin, cout=cout, stride=stride, dt=dt), err, flush=True)
 print(f"conv1x1_dual: {N // 3} random cases against float64: {bad2} mismatches, worst relative error {worst2:.2e}")
+
+# Winograd F(m x m, 3x3) op (grouped GEMM through the persistent launch) against the direct kernel on random geometries
+worst3, bad3, n3 = {2: 0.0, 4: 0.0, 6: 0.0}, 0, 0
+lib.quber_set_tuning(12, 0)
+lib.quber_set_tuning(13, 1)
+for case in range(N // 5):
+    Cin = int(rng.choice([64, 128, 256, 512, 1024]))
+    Cout = int(rng.choice([32, 64, 128, 256, 512]))
+    dil = int(rng.choice([1, 1, 1, 2, 3, 6]))
+    H, W, B = int(rng.integers(3, 64)), int(rng.integers(3, 80)), int(rng.integers(1, 9))
+    m = int(rng.choice([2, 4, 6]))
+    P = (m + 2) ** 2
+    tiles = B * dil * dil * ((-(-H // dil) + m - 1) // m) * ((-(-W // dil) + m - 1) // m)
+    if P * tiles * (Cin + Cout) > 4.0e8:
+        continue
+    g = torch.Generator(device="cuda").manual_seed(5000 + case)
+    x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) / np.sqrt(Cin * 9)
+    sc, sh = torch.rand(Cout, device="cuda", generator=g) + 0.5, torch.randn(Cout, device="cuda", generator=g)
+    u = torch.empty(P * Cout * Cin, device="cuda")
+    ws = torch.empty(P * tiles * (Cin + Cout), device="cuda")
+    y = torch.full((B, H, W, Cout), float("nan"), device="cuda")
+    rc = lib.quber_op_conv3x3_winograd(p(x), B, H, W, Cin, p(w), Cout, dil, m, p(sc), p(sh), 1, p(u), p(ws), ws.numel(), p(y), st)
+    if rc != 0:
+        continue            # geometry the path does not take (refused loudly)
+    packed = torch.empty(Cout * 9 * Cin, device="cuda")
+    yd = torch.empty_like(y)
+    _lib.check(lib.quber_op_conv2d(p(x), B, H, W, Cin, p(w), Cout, 3, 1, dil, dil, p(sc), p(sh), p(None), 1, p(packed), p(yd), st))
+    err = float((y - yd).abs().max()) / max(1.0, float(yd.abs().max())) if bool(torch.isfinite(y).all()) else float("inf")
+    n3 += 1
+    worst3[m] = max(worst3[m], err)
+    if not (err < {2: 1e-5, 4: 2e-5, 6: 1e-4}[m]):
+        bad3 += 1
+        print("WINOGRAD MISMATCH", dict(B=B, H=H, W=W, Cin=Cin, Cout=Cout, dil=dil, m=m), err, flush=True)
+print(f"conv3x3_winograd: {n3} random cases against the direct kernel: {bad3} mismatches, worst relative difference "
+      f"F(2x2) {worst3[2]:.1e}, F(4x4) {worst3[4]:.1e}, F(6x6) {worst3[6]:.1e}")
 lib.quber_set_tuning(12, 0); lib.quber_set_tuning(13, 1); lib.quber_set_tuning(15, 256); lib.quber_set_tuning(2, 0)
-sys.exit(1 if bad or bad2 else 0)
+sys.exit(1 if bad or bad2 or bad3 else 0)
