@@ -1,18 +1,20 @@
-// Persistent form of the implicit-GEMM convolution (conv_igemm.hip): the same tiles, loader, LDS image, MFMA mapping and
-// fused epilogue, but the grid is one block per resident slot of the chip and every block walks a fixed list of K-ranges
-// of tiles ("segments") instead of owning one tile:
+// Persistent form of the implicit-GEMM convolution (conv_igemm.hip): the same tiles, LDS image and MFMA mapping, but the
+// grid is one block per resident slot of the chip and every block walks a fixed list of K-ranges of tiles ("segments")
+// instead of owning one tile:
 //   * whole tiles, round-robin inside the block's XCD - the blocks of an XCD are on consecutive tiles at the same K phase,
 //     as in the one-tile-per-block launch, so they share their A rows / weight rows in that XCD's L2;
-//   * then an equal share of the K-slices of the tiles left over when the tile count is not a multiple of the slots
-//     (stream-K on the remainder only): a block finishes someone's tile, computes tiles in between whole, and starts one
-//     more.  Partial tiles go to two workspace slots per block and pk_fixup_kernel sums them in block order
-//     (deterministic) under the fused epilogue.
-// What this buys over one tile per block: no ragged last round (every block gets the same number of K-slices), and the
-// first K-slice of the next segment is fetched while the last slice of the current one is multiplied, so neither the
-// epilogue nor the address set-up of a tile sees global-memory latency - that is what short-K launches (the Winograd
-// GEMMs, K = 128-512; the bottleneck 1x1s) lose most of their time to.
+//   * then, where K is long enough to pay for it (launch_conv_persistent), an equal share of the K-slices of the tiles
+//     left over when the tile count is not a multiple of the slots (stream-K on the remainder only): a block finishes
+//     someone's tile, computes tiles in between whole, and starts one more.  Partial tiles go to two workspace slots per
+//     block and pk_fixup_kernel sums them in block order (deterministic) under the fused epilogue.
+// What this buys over one tile per block: the first K-slice of the next segment is fetched while the last slice of the
+// current one is multiplied and its epilogue needs neither LDS nor barriers, so a tile boundary costs the matrix pipe
+// little - that is what short-K launches (the Winograd GEMMs, K = 128-512; the bottleneck 1x1s) lose most of their time
+// to - and long-K launches end without a ragged last round.  Global memory is addressed through buffer descriptors
+// (hardware range check instead of predicates).  Epilogue variants: affine + ReLU, + residual, + GroupNorm sums, and a
+// 1x1 convolution over TWO inputs (a bottleneck's conv3 and its projection shortcut as one GEMM).
 // Layers with padded filter rows skipped (MODE 3 / 4 of conv_igemm.hip) keep the one-tile-per-block kernel: their K range
-// depends on the tile.
+// depends on the tile; so do the 16-bit operand modes and launches of a few dozen tiles.
 #include "common.h"
 
 namespace quber {
