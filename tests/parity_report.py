@@ -2,7 +2,8 @@
 """Tap-level parity of the HIP network against the oracle at the BENCHMARKED configuration (batch 16, 640x480, N = 20,
 "loud" predictor set so that logits are O(1) and K ~ N instances come out), per convolution-algorithm mode.
 Prints one markdown table per mode: relative error of the seven intermediate taps, absolute error of the logits,
-label-map agreement.  GPU box only; writes nothing.  usage: parity_report.py [--batch 16] [--modes auto,off,f2,f4,f6]"""
+label-map agreement.  GPU box only; writes nothing.  usage: tests/parity_report.py [--batch 16] [--modes auto,off,f2,f4,f6].  Lives under tests/ because it runs the oracle
+(test infrastructure: nothing outside tests/, smoke() and the bench's CPU baseline may)."""
 import argparse
 import os
 import sys

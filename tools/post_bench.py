@@ -10,15 +10,15 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import encode_np  # noqa: E402  (only to build plausible inputs; nothing here is shipped)
 from quber_amd import engine, synth  # noqa: E402
 
 B, H, W, N = 16, 480, 640, 20
 eng = engine.Engine(engine.make_config(H, W, max_batch=B, max_instances=N, with_network=False), "cuda:0")
 batch = synth.make_batch(7, B, H, W, N)
 frames = []
+enc_all = eng.encode(torch.from_numpy(batch["masks"]).cuda()).cpu().numpy()      # the library's own encoder builds the inputs
 for i in range(B):
-    enc = encode_np.encode_initial_masks(batch["masks"][i])
+    enc = enc_all[i]
     lg, ce, of = synth.fake_head_outputs(enc, batch["masks"][i], np.random.default_rng(i), noise=0.4)
     frames.append(np.concatenate([lg, ce, of, np.zeros((4, H, W), np.float32)]))
 logits = torch.from_numpy(np.stack(frames)).cuda()
