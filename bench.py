@@ -34,7 +34,8 @@ HBM_PEAK_GBPS = 8000.0          # same guide, "HBM3E peak BW" (spec; 6.29 TB/s m
 
 # stage tags (quber_profile_stage) of the convolution family and of the HBM-bound stages reported in `hbm_stages`
 CONV_GEMM = ("conv_gemm", "wino_gemm")
-CONV_FAMILY = CONV_GEMM + ("splitk_reduce", "wino_input", "wino_output")
+CONV_GEMM_F32PIPE = ("conv_gemm_f32pipe",)   # launches of the bf16x3 mode that keep the exact fp32 MFMA kernel (short K, narrow tiles)
+CONV_FAMILY = CONV_GEMM + CONV_GEMM_F32PIPE + ("splitk_reduce", "wino_input", "wino_output")
 HBM_STAGES = ("encode_reduce", "encode_paint", "errmaps_pack", "errmaps_erode", "errmaps_quadruple", "preprocess", "wino_input",
               "wino_output", "splitk_reduce", "gn_stats", "gn_apply", "maxpool", "bilinear", "predictor", "upsample_logits",
               "post_nms", "post_select", "post_group", "post_paint_stats", "extract_masks")
@@ -160,21 +161,47 @@ def cpu_baseline(sd, h, w, n, frames, grad_frames, eng=None, batch_eng=None, bat
                      "masks_per_s": n / float(np.median(times))}
     parity = None
     if batch_eng is not None:
-        # frames 0 and B-1 of the benchmarked batch through the oracle vs the batch-B HIP results already on the device
+        # frames 0 and B-1 of the benchmarked batch through the oracle (float32 as the reference computes, and float64 as
+        # the anchor) vs the batch-B HIP results already on the device: the stated tolerance "within 1e-4 (float) /
+        # bit-exact (label maps)" adjudicated as tests/test_gpu_loud_parity.py::test_benchmarked_plan_float64_anchor does
+        from tests import fp64_anchor as fa
         lg_all, pan_all = batch["logits"].cpu(), batch["panoptic"].cpu()
-        dl, eq, iou, ks = [], [], [], []
-        for i in sorted({0, lg_all.shape[0] - 1}):
+        frames = sorted({0, lg_all.shape[0] - 1})
+        anchor, flips, flip_error, iou, ks, dl = fa.AnchorErrors(), [], None, [], [], []
+        image = torch.from_numpy(np.concatenate([batch["host"]["rgb"], batch["host"]["depth"]], -1)).permute(0, 3, 1, 2)
+        offs = np.stack([encode_np.encode_initial_masks(batch["host"]["masks"][i]) for i in range(lg_all.shape[0])])
+        o64 = {i: fa.cat_heads(o)[0] for i, o, _ in fa.oracle64(sd, image, offs, frames=frames, want_taps=())}
+        for i in frames:
             sc = {k: batch["host"][k][i] for k in ("rgb", "depth", "masks")}
             _, out, ref = one(sc, False)
-            exp = torch.cat([out["foreground"], out["center"], out["offset"], out["eee_boundary"]], 1)[0]
-            dl.append(float((lg_all[i] - exp).abs().max()))
-            a, b_ = pan_all[i] >= 0, ref["panoptic"] >= 0
-            union = int((a | b_).sum())
-            eq.append(float((pan_all[i] == ref["panoptic"]).float().mean()))
-            iou.append(float((a & b_).sum()) / union if union else 1.0)
+            exp = fa.cat_heads(out)
+            anchor.add_heads(lg_all[i:i + 1], exp, o64[i][None])
+            dl.append(float((lg_all[i] - exp[0]).abs().max()))
+            try:
+                flips.append(fa.explain_label_flips(lg_all[i], exp[0], o64[i], pan_hip=pan_all[i]))
+            except AssertionError as e:
+                flip_error = flip_error or f"frame {i}: {e}"
+            a_, b_ = pan_all[i] >= 0, ref["panoptic"] >= 0
+            union = int((a_ | b_).sum())
+            iou.append(float((a_ & b_).sum()) / union if union else 1.0)
             ks.append(len(ref["labels"]))
-        parity = {"engine_batch": int(lg_all.shape[0]), "frames_checked": len(dl), "max_abs_dlogit": max(dl),
-                  "label_map_equal_fraction": min(eq), "fg_iou": min(iou), "oracle_instances_per_frame": ks}
+        ok, bad = anchor.verdict()
+        tot = fa.summarize(flips)
+        parity = {"engine_batch": int(lg_all.shape[0]), "frames_checked": len(frames),
+                  "within_stated_tolerance": bool(ok and flip_error is None),
+                  "stated_tolerance": "1e-4 on every head output in head units (what the predictors emit; the offset planes are "
+                                      "multiplied by the common stride 4 afterwards, model.py:700) against the fp32 oracle; max |HIP - "
+                                      "fp64| <= 1.5 x max |oracle_fp32 - fp64| per head; every label pixel that differs from the "
+                                      "oracle's map is a float64 near-tie of the decision that produced it (margins = 1e-4 on "
+                                      "logits, 1.13e-3 px on centre distances), otherwise bit-exact",
+                  "failures": bad + ([flip_error] if flip_error else []),
+                  "per_head": {k: {"max_abs_hip_vs_oracle_fp32": e["hip_vs_oracle32"], "max_abs_hip_vs_fp64": e["hip"],
+                                   "max_abs_oracle_fp32_vs_fp64": e["oracle32"],
+                                   "unit": "px (raw, after x4)" if k == "offset_px_raw" else "head units"}
+                               for k, e in anchor.err.items()},
+                  "max_abs_dlogit_raw": max(dl),
+                  "label_map_equal_fraction": tot["label_map_equal_fraction"], "label_flips": tot,
+                  "fg_iou": min(iou), "oracle_instances_per_frame": ks}
     best = max(res.values(), key=lambda r: r["masks_per_s"])
     return {"value": best["masks_per_s"], "unit": "refined masks/s", "cores": cores, "kind": "port",
             "cpu_model": model, "usable_cpus": usable, "torch": torch.__version__, "variants": res, "parity_vs_hip": parity,
@@ -442,6 +469,7 @@ def host_io_run(a, eng, host, offsets, logits, post, max_inst, dev):
     dev_out = [torch.empty((B, max_inst, H, W), dtype=torch.uint8, device=dev) for _ in range(2)]
     host_out = [torch.empty((B, max_inst, H, W), dtype=torch.uint8).pin_memory() for _ in range(2)]
     host_cnt = [torch.empty((B,), dtype=torch.int32).pin_memory() for _ in range(2)]
+    dev_cnt = [torch.empty((B,), dtype=torch.int32, device=dev) for _ in range(2)]   # per-slot snapshot: post["count"] is rewritten by step i+1
     up, down, main = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.current_stream()
     ev_up = [torch.cuda.Event() for _ in range(2)]
     ev_done = [torch.cuda.Event() for _ in range(2)]
@@ -471,12 +499,13 @@ def host_io_run(a, eng, host, offsets, logits, post, max_inst, dev):
             eng.forward(dev_in[s]["rgb"], dev_in[s]["depth"], offsets, logits)
             eng.postprocess(logits, post)
             eng.extract_masks(post, max_inst, dev_out[s])
+            dev_cnt[s].copy_(post["count"])         # on the main stream, before ev_done: the download reads the snapshot
             ev_free_in[s].record(main)
             ev_done[s].record(main)
             with torch.cuda.stream(down):
                 down.wait_event(ev_done[s])
                 host_out[s].copy_(dev_out[s], non_blocking=True)
-                host_cnt[s].copy_(post["count"], non_blocking=True)
+                host_cnt[s].copy_(dev_cnt[s], non_blocking=True)
                 ev_down[s].record(down)
         torch.cuda.synchronize()
 
@@ -509,11 +538,16 @@ def report(a, eng, world, elapsed, ranks, center_bias, sd, host, step_ms, t, gpu
     gemm_ms = sum(stages[k]["ms"] for k in CONV_GEMM if k in stages)
     gemm_n = sum(stages[k]["launches"] for k in CONV_GEMM if k in stages)
     executed = sum(stages[k]["flops"] for k in CONV_GEMM if k in stages)       # what the matrix pipe multiplies (2*M*K*N per launch)
+    # bf16x3 mode: the launches that stayed on the exact fp32 MFMA kernel are priced on THEIR pipe, apart
+    f32p_ms = sum(stages[k]["ms"] for k in CONV_GEMM_F32PIPE if k in stages)
+    f32p_n = sum(stages[k]["launches"] for k in CONV_GEMM_F32PIPE if k in stages)
+    f32p_flops = sum(stages[k]["flops"] for k in CONV_GEMM_F32PIPE if k in stages)
     algorithmic = eng.forward_flops() * B                                        # 2 x MAC of the direct convolutions
     peak = FP32_MFMA_PEAK_TFLOPS if a.dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
-    nominal = executed           # fp32 multiply-adds the GEMM launches evaluate
+    nominal = executed + f32p_flops   # fp32 multiply-adds the GEMM launches evaluate
     if a.dtype == "f32-bf16x3":
         executed *= 6.0          # six bf16 partial products per fp32 multiply: what the bf16 matrix pipe executes
+    fam_ms_pipe = fam_ms - f32p_ms                                               # the dominant pipe's share of the family time
     hbm = {}
     for k in HBM_STAGES:
         if k in stages and stages[k]["ms"] > 0:
@@ -534,7 +568,7 @@ def report(a, eng, world, elapsed, ranks, center_bias, sd, host, step_ms, t, gpu
             traffic_note = "profiles/conv_hbm_traffic.json unreadable"
     count = t["post"]["count"].cpu().numpy()
     ms_per_step = elapsed / a.steps * 1e3
-    ex_tf = executed / (fam_ms * 1e-3) / 1e12 if fam_ms else 0.0
+    ex_tf = executed / (fam_ms_pipe * 1e-3) / 1e12 if fam_ms_pipe else 0.0
     line = {
         "metric": f"refined masks/sec on {W}x{H} RGB-D (N={N} inst)",
         "value": world * B * N * a.steps / elapsed,
@@ -566,6 +600,11 @@ def report(a, eng, world, elapsed, ranks, center_bias, sd, host, step_ms, t, gpu
                                          "same time; exceeds `achieved` because Winograd F(m x m,3x3) executes (m+2)^2 / 9m^2 of them",
                      "executed_over_algorithmic": nominal / algorithmic if algorithmic else None,
                      "fp32_equivalent_tflops": nominal / (fam_ms * 1e-3) / 1e12 if fam_ms else 0.0,
+                     "fp32_pipe_launches": None if not f32p_n else {
+                         "launches": f32p_n, "ms": f32p_ms, "tflops": f32p_flops / (f32p_ms * 1e-3) / 1e12,
+                         "frac_of_fp32_mfma_peak": f32p_flops / (f32p_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                         "note": "launches of this mode that keep the exact fp32 MFMA kernel (HBM-bound short-K / narrow-tile "
+                                 "layers); excluded from `achieved`, `frac` and gemm_kernel_* above, which price the bf16 pipe only"},
                      "gemm_launches_per_step": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
                      "flops_per_launch": executed / max(gemm_n, 1),
                      "conv_family_ms": {k: stages[k]["ms"] for k in CONV_FAMILY if k in stages},

@@ -191,12 +191,9 @@ int launch_boundary_overlap(const int* pred, const int* gt, int H, int W, const 
     hipLaunchKernelGGL(bnd_pack_kernel, dim3((unsigned)(((long)H * wpr + 3) / 4), nm), dim3(256), 0, st, pred, gt, labels, n_pred, H,
                        W, wpr, seg);
     QB_CHECK(hipGetLastError());
-    static bool attr_set = false;
-    if (!attr_set) {
-        QB_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(bnd_bmap_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     160 * 1024 - 64));
-        attr_set = true;
-    }
+    // the attribute is per device (and this entry point may be called from several threads): set it on every call
+    QB_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(bnd_bmap_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 160 * 1024 - 64));
     hipLaunchKernelGGL(bnd_bmap_kernel, dim3(nm), dim3(1024), plane, st, seg, H, W, wpr, radius, bmap, dil, out);
     QB_CHECK(hipGetLastError());
     hipLaunchKernelGGL(bnd_pair_kernel, dim3(n_pred, n_gt), dim3(256), 0, st, bmap, dil, H * wpr, n_pred, out + nm,

@@ -618,6 +618,9 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
     const double conv_bytes = 4.0 * G * ((double)p.B * p.H * p.W * p.Cin + (double)p.Cout * p.K) + out_bytes * (p.res ? 2.0 : 1.0);
     const double conv_flops = 2.0 * G * (double)p.M * p.K * p.Cout;
     const char* tag = p.tag ? p.tag : "conv_gemm";
+    // a launch of the bf16x3 mode that keeps the exact fp32 MFMA kernel is profiled under its own stage, so that the
+    // bench prices each matrix pipe with the work it actually executed
+    auto exact_fallback = [&]() { p.bf16 = 0; tag = "conv_gemm_f32pipe"; };
     auto reduce = [&](int parts) {
         const long MN = (long)p.ws_rows * p.Cout;
         ProfScope prof("splitk_reduce", 4.0 * G * (double)MN * (parts + 1.0), 0.0, st);
@@ -640,7 +643,7 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
     if (g_persist && ((BM == 128 && BN == 128) || (g_persist == 2 && (BM == BN || BM == 256))) && !skip && p.ws && conv_persistent_ok(p) &&
         (long)p.mtiles * p.ntiles * G >= g_persist_min_tiles &&
         ((long)p.mtiles * p.ntiles * G >= 256L * (BM == 64 ? 7 : 3) || nk >= g_persist_min_nk)) {      // several tiles per block, or K worth sharing
-        if (p.bf16 == 3 && (BM == 256 || (BM == 64 && nk <= 8))) p.bf16 = 0;
+        if (p.bf16 == 3 && (BM == 256 || (BM == 64 && nk <= 8))) exact_fallback();
         const int bpc = BM == 64 ? (p.bf16 == 3 ? 5 : 7) : (p.bf16 == 3 ? 2 : 3);
         if (p.ws_floats >= conv_persistent_ws_floats(BM, BN, bpc)) {
             {
@@ -688,7 +691,7 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
     // bf16x3 pays where the matrix pipe is the limit.  The HBM-bound short-K launches on 64x64 tiles (bottleneck conv3 +
     // residual) and the 32-column head layers on 256x32 tiles lose occupancy to its three LDS planes and gain nothing
     // (profiles/r02j_conv_layers_dtype{0,3}.md): they keep the exact fp32 MFMA kernel, which is at least as accurate.
-    if (p.bf16 == 3 && (BM == 256 || (BM == 64 && nk <= 8))) p.bf16 = 0;
+    if (p.bf16 == 3 && (BM == 256 || (BM == 64 && nk <= 8))) exact_fallback();
     if (p.bf16) {
         {
             ProfScope prof(tag, conv_bytes, conv_flops, st);

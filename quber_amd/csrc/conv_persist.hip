@@ -798,7 +798,11 @@ int launch_conv_dual(ConvP p, int G, hipStream_t st) {
     const long in2_bytes = (long)p.B * p.H2 * p.W2 * p.in2_cs * 4;
     if (!conv_persistent_ok(p) || in2_bytes >= ((long)1 << 31)) return 1;
     p.pk_in2_bytes = (int)in2_bytes;
-    if (p.bf16 == 3 && p.Kpad / BK <= 8) p.bf16 = 0;       // as the separate launches: short K gains nothing from bf16x3
+    const char* tag = p.tag ? p.tag : "conv_gemm";
+    if (p.bf16 == 3 && p.Kpad / BK <= 8) {                 // as the separate launches: short K gains nothing from bf16x3
+        p.bf16 = 0;
+        tag = "conv_gemm_f32pipe";                         // profiled apart: this launch runs on the fp32 matrix pipe
+    }
     const long tiles128 = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * G;
     if (tiles128 < g_persist_min_tiles) return 1;          // small batches: the two separate launches with their split-K model
     const bool big = tiles128 >= 192 && p.Cout > 64;
@@ -809,7 +813,7 @@ int launch_conv_dual(ConvP p, int G, hipStream_t st) {
     p.ntiles = (p.Cout + BMs - 1) / BMs;
     const double out_bytes = 4.0 * G * (double)p.M * p.Cout;
     const double bytes = 4.0 * G * ((double)p.M * p.Kpad + (double)p.Cout * p.Kpad) + out_bytes;
-    ProfScope prof(p.tag ? p.tag : "conv_gemm", bytes, 2.0 * G * (double)p.M * p.Kpad * p.Cout, st);
+    ProfScope prof(tag, bytes, 2.0 * G * (double)p.M * p.Kpad * p.Cout, st);
     const int rc = big ? launch_conv_persistent<128, 128, 2, 2>(p, G, bpc, st) : launch_conv_persistent<64, 64, 2, 2>(p, G, bpc, st);
     return rc ? -1 : 0;
 }

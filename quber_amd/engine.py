@@ -3,6 +3,7 @@ device pointers and the current HIP stream to the C ABI.  torch is plumbing only
 streams); every computation on the hot path happens in the HIP library.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -41,11 +42,19 @@ def set_arch(qc, depth=50, backbone_fusion_layers=2, head_fusion_layers=3, error
     return qc
 
 
+# predictor.py:345-346 subtracts a float32 index array from a float64 scalar.  numpy < 2 (the reference pins 1.23.1,
+# INSTALL.md:14) keeps that in float32 (value-based casting); numpy >= 2 promotes to float64.  The drop-in reproduces what
+# the reference computes UNDER THE NUMPY OF THE CALLING PROCESS - so that swapping the predictor in changes no bit of a1 in
+# either environment; QUBER_ENCODE_LEGACY_F32=0/1 overrides.  (C default: 0, the mode the golden fixtures pin.)
+ENCODE_LEGACY_F32 = int(os.environ.get("QUBER_ENCODE_LEGACY_F32", int(np.lib.NumpyVersion(np.__version__) < "2.0.0")))
+
+
 def make_config(height=480, width=640, max_batch=1, max_instances=64, cfg=None, with_network=True):
     """quber_config from an (optional) validated yaml CfgNode."""
     lib = _lib.load()
     qc = _lib.QuberConfig()
     lib.quber_default_config(C.byref(qc))
+    qc.encode_legacy_f32 = ENCODE_LEGACY_F32
     qc.height, qc.width, qc.max_batch, qc.max_instances = height, width, max_batch, max_instances
     qc.with_network = 1 if with_network else 0
     if cfg is not None:

@@ -4,7 +4,9 @@ and the 30 % overlap post-filter built on it (eval/refiner_model.py:273-277), on
 ``lmffNet(weight_path).predict(rgb_path, depth_path) -> bool [480, 640]`` (class 2 = foreground) keeps the reference's
 signature; ``predict_arrays`` / ``filter_masks`` are the array-level forms the adapter uses.  Without a checkpoint
 (the reference's ``rgbd_lmffnet.pth`` is not in its repository) seeded synthetic weights are used.
-``cv2.inpaint`` depth in-painting (predictor.py:77) is not built: zero-depth pixels stay 0."""
+``predict`` in-paints the normalised, resized depth (``inpaint_depth(depth_img, factor=1)``, predictor.py:77) with the same
+TELEA restatement the refiner adapter uses (quber_amd/eval/refiner_model.py:inpaint_depth; ``lmffNet(inpaint=False)``
+skips it), so the stand-alone foreground mask and the adapter's are computed from the same depth image."""
 import ctypes as C
 import os
 import warnings
@@ -65,7 +67,8 @@ def filter_masks(masks_bool, counts, ratio=0.3):
 
 
 class lmffNet:
-    def __init__(self, weight_path="./foreground_segmentation/rgbd_lmffnet.pth", device="cuda:0", seed=0):
+    def __init__(self, weight_path="./foreground_segmentation/rgbd_lmffnet.pth", device="cuda:0", seed=0, inpaint=True):
+        self.inpaint = inpaint
         if weight_path is not None and os.path.exists(weight_path):
             ck = torch.load(weight_path, map_location="cpu", weights_only=False)
             sd = {k: v.numpy() for k, v in ck["model"].items() if not k.endswith("num_batches_tracked")}
@@ -85,7 +88,7 @@ class lmffNet:
 
     def predict(self, rgb_path, depth_path):
         from .. import engine as qengine
-        from ..eval.refiner_model import normalize_depth
+        from ..eval.refiner_model import inpaint_depth, normalize_depth
         bgr = np.asarray(Image.open(rgb_path).convert("RGB"))[:, :, ::-1]
         if "npy" in depth_path:
             depth = normalize_depth(np.load(depth_path), 0.25, 1.5)
@@ -98,4 +101,7 @@ class lmffNet:
             t = torch.from_numpy(np.ascontiguousarray(img)).to(self.device)
             return qengine.resize_u8(t, H, W, linear).cpu().numpy()
 
-        return self.predict_arrays(resize(bgr, True), resize(depth, False))
+        depth = resize(depth, False)
+        if self.inpaint:
+            depth = inpaint_depth(depth)                # foreground_segmentation/predictor.py:77
+        return self.predict_arrays(resize(bgr, True), depth)

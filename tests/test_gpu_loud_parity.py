@@ -16,6 +16,7 @@ import pytest
 import torch
 
 from oracle import encode_np, postproc_ref
+from tests import fp64_anchor as fa
 from oracle.network_torch import ArchCfg, MaskRefinerNet
 from quber_amd import arch, engine, synth
 
@@ -68,76 +69,136 @@ def _rel(got, ref):
     return float((got - ref).abs().max() / max(1.0, float(ref.abs().max())))
 
 
-_PLAN_REF = {}
+_PLAN = {}
+MODES = {"f32": 0, "bf16x3": 3}
 
 
-def _plan_reference(h, w, b, n):
-    """scene, calibrated loud weights and the oracle's taps / heads for a configuration - computed once per size (host time)."""
+def _plan_results(h, w, b, n):
+    """Everything the benchmarked-plan tests assert on, computed ONCE per configuration:
+      * the scene and the calibrated loud weights;
+      * per arithmetic mode (exact fp32 MFMA, bf16x3): the HIP path's encode, taps, logits, post-processing, masks, and the
+        same for frame 0 alone (batch 1 on the batch-b engine);
+      * the oracle streamed frame by frame in float32 AND float64 on a worker thread (fa.OracleStream; batch 1, as the
+        reference runs), while this thread evaluates the oracle's post-processing of every candidate's logits:
+        max |x - fp64| per tap / head for HIP and for the fp32 oracle (fa.AnchorErrors), the explanation of every
+        flipped label pixel (fa.explain_label_flips), and the classic HIP-vs-fp32-oracle distances."""
     key = (h, w, b, n)
-    if key not in _PLAN_REF:
-        batch, offs, image = _scene(7, b, h, w, n)
-        sd = loud_state_dict(0, image, offs, n)
-        taps = {}
-        with torch.no_grad():
-            ref = _oracle(sd)(image, torch.from_numpy(offs), taps)
-        _PLAN_REF.clear()                                    # one configuration at a time: the taps are large
-        _PLAN_REF[key] = (batch, offs, sd, taps, ref, {})
-    return _PLAN_REF[key]
-
-
-@pytest.mark.parametrize("h,w,b,n,dtype", [(480, 640, 16, 20, 0), (480, 640, 16, 20, 3), (720, 1280, 1, 30, 0), (720, 1280, 1, 30, 3)],
-                         ids=["b16-640x480-f32", "b16-640x480-bf16x3", "b1-1280x720-f32", "b1-1280x720-bf16x3"])
-def test_benchmarked_plan_taps_heads_and_instances(h, w, b, n, dtype):
-    """BASELINE.json configs[1] (batch 16, 640x480, N = 20) and configs[2] (1280x720, N = 30) on the default plan, in the
-    exact fp32 MFMA mode (compute_dtype 0) and in the fp32-equivalent bf16x3 mode (compute_dtype 3) - the SAME bars."""
-    batch, offs, sd, taps, ref, e2e = _plan_reference(h, w, b, n)
-    qc = engine.make_config(h, w, max_batch=b, max_instances=n)
-    qc.compute_dtype = dtype
-    eng = engine.Engine(qc, "cuda:0")
-    eng.load_state_dict(sd)
+    if key in _PLAN:
+        return _PLAN[key]
+    _PLAN.clear()                                            # one configuration at a time
+    batch, offs, image = _scene(7, b, h, w, n)
+    sd = loud_state_dict(0, image, offs, n)
+    stream = fa.OracleStream(sd, image, offs)                # starts computing now
     masks = torch.from_numpy(batch["masks"]).cuda()
     bgr, dep = torch.from_numpy(batch["rgb"]).cuda(), torch.from_numpy(batch["depth"]).cuda()
-    enc = eng.encode(masks)
-    np.testing.assert_array_equal(enc.cpu().numpy().view(np.uint32), offs.view(np.uint32))        # a1 bit-exact
-    lg = eng.forward(bgr, dep, enc)
-    post = eng.postprocess(lg)
-    mx = int(post["count"].max().item())
-    pm = eng.extract_masks(post, max(mx, 1)).cpu().numpy()
-    lgc = lg.cpu()
-    for name in ("res2", "res3", "res5", "y", "feat_eee_boundary", "z1", "feat_center"):
-        got = eng.debug_tensor(name, b).cpu().permute(0, 3, 1, 2)
-        assert _rel(got, taps[name]) < TOL, name
-    _check_heads(lgc, ref, ("foreground", "center", "offset", "eee_boundary"))
+    modes = {}
+    for mode, dtype in MODES.items():
+        qc = engine.make_config(h, w, max_batch=b, max_instances=n)
+        qc.compute_dtype = dtype
+        eng = engine.Engine(qc, "cuda:0")
+        eng.load_state_dict(sd)
+        enc = eng.encode(masks)
+        lg = eng.forward(bgr, dep, enc)
+        post = eng.postprocess(lg)
+        mx = int(post["count"].max().item())
+        pm = eng.extract_masks(post, max(mx, 1)).cpu().numpy()
+        m = {"enc": enc.cpu().numpy(), "lg": lg.cpu(), "post": {k: v.cpu() for k, v in post.items()}, "pm": pm,
+             "taps": {name: eng.debug_tensor(name, b).cpu().permute(0, 3, 1, 2) for name in fa.TAPS},
+             "anchor": fa.AnchorErrors(), "flips": [], "flip_error": None, "dec": [], "inst": [],
+             "tap_rel32": {name: 0.0 for name in fa.TAPS}}
+        if b > 1:
+            lg1 = eng.forward(bgr[:1], dep[:1], enc[:1])
+            m["lg1"], m["pan1"] = lg1.cpu(), eng.postprocess(lg1)["panoptic"][0].cpu()
+        eng.close()
+        modes[mode] = m
+    del masks, bgr, dep
+    torch.cuda.empty_cache()
+    lg32 = []
+    for fr in stream:
+        i = fr["i"]
+        l32, l64 = fa.cat_heads(fr["out32"]), fa.cat_heads(fr["out64"])
+        lg32.append(l32)
+        dec32 = fa.decide(l32[0])
+        for m in modes.values():
+            for name in fa.TAPS:
+                t32, t64, th = fr["taps32"][name], fr["taps64"][name], m["taps"][name][i:i + 1]
+                m["anchor"].add(name, th, t32, t64, scale=max(1.0, float(t64.abs().max())))
+                m["tap_rel32"][name] = max(m["tap_rel32"][name], _rel(th, t32))
+            m["anchor"].add_heads(m["lg"][i:i + 1], l32, l64)
+            # a8-a11 by the oracle on the HIP logits (shared by the bit-exactness checks and the flip explanation)
+            dec = fa.decide(m["lg"][i])
+            m["dec"].append(dec)
+            m["inst"].append(postproc_ref.extract_instances(dec["pan"], m["lg"][i, 0:1], m["lg"][i, 1:2]))
+            try:
+                m["flips"].append(fa.explain_label_flips(None, None, l64[0], pan_hip=m["post"]["panoptic"][i], dec_hip=dec, dec_o32=dec32))
+            except AssertionError as e:                      # reported by the test of that mode, not by whichever ran first
+                m["flip_error"] = m["flip_error"] or f"frame {i}: {e}"
+    for m in modes.values():
+        del m["taps"]
+    lg32 = torch.cat(lg32)
+    ref = {"foreground": lg32[:, 0:1], "center": lg32[:, 1:2], "offset": lg32[:, 2:4], "eee_boundary": lg32[:, 4:8]}
+    _PLAN[key] = {"offs": offs, "ref": ref, "lg32": lg32, "modes": modes}
+    return _PLAN[key]
+
+
+PLAN_CASES = [(480, 640, 16, 20, "f32"), (480, 640, 16, 20, "bf16x3"), (720, 1280, 1, 30, "f32"), (720, 1280, 1, 30, "bf16x3")]
+PLAN_IDS = ["b16-640x480-f32", "b16-640x480-bf16x3", "b1-1280x720-f32", "b1-1280x720-bf16x3"]
+
+
+@pytest.mark.parametrize("h,w,b,n,mode", PLAN_CASES, ids=PLAN_IDS)
+def test_benchmarked_plan_taps_heads_and_instances(h, w, b, n, mode):
+    """BASELINE.json configs[1] (batch 16, 640x480, N = 20) and configs[2] (1280x720, N = 30) on the default plan, in the
+    exact fp32 MFMA mode (compute_dtype 0) and in the fp32-equivalent bf16x3 mode (compute_dtype 3) - the SAME bars."""
+    R = _plan_results(h, w, b, n)
+    m, ref = R["modes"][mode], R["ref"]
+    np.testing.assert_array_equal(m["enc"].view(np.uint32), R["offs"].view(np.uint32))            # a1 bit-exact
+    for name, v in m["tap_rel32"].items():
+        assert v < TOL, (name, v)
+    _check_heads(m["lg"], ref, ("foreground", "center", "offset", "eee_boundary"))
     # a8-a11 on the HIP logits: bit-exact against the oracle's post-processing of the same logits, with K ~ N instances
-    ks, same = [], []
+    post, pm, ks = m["post"], m["pm"], []
     for i in range(b):
-        o = postproc_ref.postprocess(lgc[i, 0:1], lgc[i, 1:2], lgc[i, 2:4])
+        o = m["inst"][i]
         k = len(o["labels"])
         ks.append(k)
-        np.testing.assert_array_equal(post["panoptic"][i].cpu().numpy(), o["panoptic"].numpy())
+        np.testing.assert_array_equal(post["panoptic"][i].numpy(), m["dec"][i]["pan"].numpy())
         assert int(post["count"][i]) == k
-        np.testing.assert_array_equal(post["labels"][i, :k].cpu().numpy(), o["labels"].numpy())
+        np.testing.assert_array_equal(post["labels"][i, :k].numpy(), o["labels"].numpy())
         if k:
-            np.testing.assert_array_equal(post["boxes"][i, :k].cpu().numpy(), o["boxes"].numpy())
+            np.testing.assert_array_equal(post["boxes"][i, :k].numpy(), o["boxes"].numpy())
             np.testing.assert_array_equal(pm[i, :k].astype(bool), o["masks"].numpy())
-            np.testing.assert_allclose(post["scores"][i, :k].cpu().numpy(), o["scores"].numpy(), rtol=2e-5, atol=1e-6)
-        # end to end (HIP logits -> HIP labels) against (oracle logits -> oracle labels): threshold-straddling pixels may flip
-        if i % 4 == 0:                      # (the oracle's grouping takes ~1 s per frame on the host: every fourth frame)
-            if i not in e2e:
-                e2e[i] = postproc_ref.postprocess(ref["foreground"][i], ref["center"][i], ref["offset"][i])["panoptic"]
-            same.append(float((post["panoptic"][i].cpu() == e2e[i]).float().mean()))
+            np.testing.assert_allclose(post["scores"][i, :k].numpy(), o["scores"].numpy(), rtol=2e-5, atol=1e-6)
     assert np.mean(ks) >= 15, ks
-    assert min(same) > 0.9999, same
     if b > 1:
         # the same frame alone: every layer's algorithm is fixed at plan time, so only the split-K partitioning (a
         # re-association of the same fp32 sums, chosen per launch) differs - the batch-1 result meets the same bars
-        lg1 = eng.forward(bgr[:1], dep[:1], enc[:1]).cpu()
+        lg1 = m["lg1"]
         _check_heads(lg1, {k: v[:1] for k, v in ref.items()}, ("foreground", "center", "offset", "eee_boundary"))
-        d1 = (lg1[0] - lgc[0]).abs()
+        d1 = (lg1[0] - m["lg"][0]).abs()
         assert float(d1[[0, 1, 4, 5, 6, 7]].max()) < TOL and float(d1[2:4].max()) < TOL * STRIDE
-        p1 = eng.postprocess(lg1.cuda())["panoptic"][0].cpu()
-        assert float((p1 == post["panoptic"][0].cpu()).float().mean()) > 0.9999
-    eng.close()
+        assert float((m["pan1"] == post["panoptic"][0]).float().mean()) > 0.9999
+
+
+@pytest.mark.parametrize("h,w,b,n,mode", PLAN_CASES, ids=PLAN_IDS)
+def test_benchmarked_plan_float64_anchor(h, w, b, n, mode):
+    """The stated tolerance ("within 1e-4 (float) / bit-exact (label maps)", BASELINE.json north_star) adjudicated against a
+    float64 evaluation of the oracle network on ALL frames of the benchmarked plan (tests/fp64_anchor.py):
+      (b) per tap and per head, max |HIP - fp64| <= 1.5 x max |oracle_fp32 - fp64|: the HIP path is no further from the
+          exact result than the reference's own fp32 arithmetic (taps relative to the tap's magnitude; heads in head units,
+          the offset planes also in raw pixels, where the x4 of model.py:700 makes the literal 1e-4 unreachable for fp32
+          on either side);
+      (d) the literal 1e-4 against the fp32 oracle on fg / centre / error logits and on the offsets in head units;
+      (c) every pixel where the label map of the HIP path differs from the oracle's (oracle logits -> oracle labels) is a
+          float64 near-tie of the decision that produced it (margins = the stated tolerance), none unexplained."""
+    R = _plan_results(h, w, b, n)
+    m = R["modes"][mode]
+    tot = fa.summarize(m["flips"])
+    print(f"\n[{PLAN_IDS[PLAN_CASES.index((h, w, b, n, mode))]}] float64 anchor\n{m['anchor'].table()}\nlabel flips: {tot}")
+    ok, bad = m["anchor"].verdict()
+    assert ok, "\n".join(bad)
+    assert m["flip_error"] is None, m["flip_error"]
+    assert len(m["flips"]) == b
+    assert tot["label_map_equal_fraction"] > 0.9999, tot
 
 
 VARIANTS = {

@@ -121,12 +121,14 @@ def test_metrics_oracle_matches_reference(path):
 def test_munkres_matches_vendored_solver():
     import json
     from conftest import GOLDEN
-    from quber_amd.eval.assignment import munkres_assign
+    from oracle.assign_py import assign as oracle_assign            # the oracle's own scalar-loop solver
+    from quber_amd.eval.assignment import munkres_assign           # the product's numpy-mask solver
     z = np.load(os.path.join(GOLDEN, "munkres_cases.npz"))
     exp = json.load(open(os.path.join(GOLDEN, "munkres_expected.json")))
     for k in z.files:
         m = z[k]
         assert [list(a) for a in munkres_assign(m.max() - m)] == exp[k], k
+        assert [list(a) for a in oracle_assign(m.max() - m)] == exp[k], k
 
 
 def test_cv2_resize_restatement_hand_derived():
