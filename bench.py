@@ -66,6 +66,9 @@ def parse():
                     help="host-inclusive mode: inputs start in pinned host memory and the refined masks end there every step "
                          "(double-buffered H2D / D2H on copy streams, as the reference's timed region includes them); "
                          "reported as host_io, never as `value`")
+    ap.add_argument("--predict-calls", type=int, default=60,
+                    help="calls of the drop-in MaskRefinerPredictor.predict() timed for `predict_api` (numpy in -> "
+                         "pred_masks.numpy() out, one frame per call as the reference runs; 0 = skip)")
     ap.add_argument("--foreground-filter", action="store_true",
                     help="also run the reference adapter's LMFFNet foreground post-filter on the refined masks in every "
                          "step (eval/refiner_model.py:273-277; off for the headline metric, which is the refiner path)")
@@ -408,6 +411,8 @@ def main():
                            out_masks=out_masks, max_inst=max_inst), gpu_step)
         if host_io is not None:
             line["host_io"] = host_io
+        if world == 1 and a.predict_calls > 0 and a.dtype == "f32":
+            line["predict_api"] = predict_api_run(a, sd, host, dev)
         if a.dtype == "f32" and world == 1 and not a.no_split_mode:
             line["fp32_equivalent_bf16x3"] = split_mode_run(a, make_engine, sd, gpu_step_args=(masks, bgr, depth, offsets, max_inst),
                                                             exact_logits=logits, exact_pan=post["panoptic"])
@@ -456,6 +461,69 @@ def split_mode_run(a, make_engine, sd, gpu_step_args, exact_logits, exact_pan):
                          "the exact fp32 MFMA mode"}
     eng.close()
     return out
+
+
+def predict_api_run(a, sd, host, dev):
+    """The call eval/run_eval.py actually makes, timed as the reference times it (eval/refiner_model.py:265-271):
+        start; output = predictor.predict(rgb, depth, masks)[0]; masks = output['instances'].to('cpu').pred_masks.numpy(); stop
+    numpy arrays in, numpy masks out, one frame per call (predictor.py:358), cycling through the frames of the step.
+    Beside it, the engine's own batch-1 step on resident inputs (encode + network + grouping + extraction of the same
+    number of masks) - what the API call would cost with no host side at all - and the general batched path fed one frame."""
+    import torch
+    from quber_amd import engine
+    from quber_amd.maskrefiner.predictor import MaskRefinerPredictor
+    B, H, W, N = a.batch, a.height, a.width, a.instances
+    pred = MaskRefinerPredictor(None, device=str(dev), state_dict=sd)
+
+    def call(i):
+        t0 = time.perf_counter()
+        out = pred.predict(host["rgb"][i % B], host["depth"][i % B], host["masks"][i % B])[0]
+        m = out["instances"].to("cpu").pred_masks.numpy() if "instances" in out else []
+        return time.perf_counter() - t0, len(m)
+
+    def series(n):
+        for i in range(5):
+            call(i)
+        r = [call(i) for i in range(n)]
+        return np.array([t for t, _ in r]) * 1e3, [k for _, k in r]
+
+    fast, ks = series(max(a.predict_calls, 10))
+    pred.fast_path = False
+    general, _ = series(max(a.predict_calls // 3, 10))
+    # engine-only batch-1 step on resident inputs
+    eng = pred.model.engine_for(H, W, 1, N)
+    masks = torch.from_numpy(host["masks"][:1]).to(dev)
+    bgr, depth = torch.from_numpy(host["rgb"][:1]).to(dev), torch.from_numpy(host["depth"][:1]).to(dev)
+    offsets = torch.empty((1, 3, H, W), dtype=torch.float32, device=dev)
+    logits = torch.empty((1, eng.planes, H, W), dtype=torch.float32, device=dev)
+    post = eng.alloc_post(1)
+    om = torch.empty((1, max(ks[0], 1), H, W), dtype=torch.uint8, device=dev)
+
+    def step():
+        eng.encode(masks, offsets)
+        eng.forward(bgr, depth, offsets, logits)
+        eng.postprocess(logits, post)
+        eng.extract_masks(post, om.shape[1], om)
+
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(max(a.predict_calls, 10)):
+        t0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    eng_ms = float(np.median(ts))
+    med = float(np.median(fast))
+    return {"median_ms_per_call": med, "p10_p90_ms": [float(np.percentile(fast, 10)), float(np.percentile(fast, 90))],
+            "calls": len(fast), "value": N / (med * 1e-3), "unit": "refined masks/s",
+            "engine_batch1_step_ms": eng_ms, "over_engine_step": med / eng_ms,
+            "general_batched_path_ms_per_call": float(np.median(general)),
+            "instances_out_per_call_mean": float(np.mean(ks)),
+            "note": "MaskRefinerPredictor.predict(rgb, depth, masks) + output['instances'].to('cpu').pred_masks.numpy(), numpy in / "
+                    "numpy out, one frame per call (the reference's timed region, eval/refiner_model.py:265-271); "
+                    "engine_batch1_step = the same frame on resident device buffers, no host side"}
 
 
 def host_io_run(a, eng, host, offsets, logits, post, max_inst, dev):

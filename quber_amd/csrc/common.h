@@ -110,7 +110,7 @@ bool winograd_eligible(int k, int stride, int pad, int dil, int Cin, int Cout);
 bool winograd_m6_channels_ok(int Cin, int Cout);
 size_t winograd_ws_floats(int B, int H, int W, int Cin, int Cout, int G, int dil, int m);
 double winograd_mac_ratio(int H, int W, int dil, int m);
-extern int g_winograd, g_wino_min_cin, g_wino_max_ratio, g_wino_variant, g_wino_min_cout, g_wino_pairs;
+extern int g_winograd, g_wino_min_cin, g_wino_max_ratio, g_wino_variant, g_wino_min_cout, g_wino_pairs, g_wino_chunk_mb;
 extern int g_tile_128x64;
 extern int g_force_split, g_force_tile, g_tail_split, g_persist, g_persist_min_nk, g_persist_debug, g_persist_min_tiles;
 // persistent launch of the implicit GEMM (conv_persist.hip); p.mtiles / ntiles / vec_out filled in by the caller

@@ -140,7 +140,7 @@ constexpr int wino_out_waves(int O, int V) { return O == 4 ? (V == 4 ? 2 : 3) : 
 template <int O, int V>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(wino_in_waves(O, V)))) void wino_input_kernel(const float* __restrict__ in, int B, int H, int W, int CV, int in_cs,
                                                          long in_gs, int TH, int TW, int d, float* __restrict__ v, long v_gs,
-                                                         const WinoNorm np) {
+                                                         const WinoNorm np, int Ball, int boff) {
     constexpr int T = O + 2;
     using VT = Vec<V>;
     const int g = blockIdx.z;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(wino_in_wav
     const float* base = in + (long)ta.b * H * W * in_cs + c;
     VT nsc, nbi;
     if (np.stats) {
-        const double* sb = np.stats + (((long)g * B + ta.b) * np.groups + c / np.cpg) * 2;
+        const double* sb = np.stats + (((long)g * Ball + boff + ta.b) * np.groups + c / np.cpg) * 2;
         const double mean = sb[0] / np.n;
         double var = sb[1] / np.n - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(wino_out_wa
                                                           int TH, int TW, int d, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int ss_gs, int relu,
                                                           float* __restrict__ out, int out_cs, long out_gs,
-                                                          double* __restrict__ gn_sum, int gn_groups, int gn_cpg) {
+                                                          double* __restrict__ gn_sum, int gn_groups, int gn_cpg, int Ball, int boff) {
     constexpr int T = O + 2;
     using VT = Vec<V>;
     const int g = blockIdx.z;
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(wino_out_wa
         if (threadIdx.x < 128) {
             const double v = gacc[threadIdx.x];
             const int b = b0 + (threadIdx.x >> 6);
-            if (v != 0.0 && b < B) atomicAdd(&gn_sum[(((long)g * B + b) * gn_groups) * 2 + (threadIdx.x & 63)], v);
+            if (v != 0.0 && b < B) atomicAdd(&gn_sum[(((long)g * Ball + boff + b) * gn_groups) * 2 + (threadIdx.x & 63)], v);
         }
     }
 }
@@ -399,60 +399,78 @@ double winograd_mac_ratio(int H, int W, int dil, int m) {
     return (double)((m + 2) * (m + 2)) * wino_tiles(H, W, dil, m) / (9.0 * H * W);
 }
 
+int g_wino_chunk_mb = 0;      // key 20: largest V | M footprint (MiB) of one pass over a layer; 0 = the whole batch at once
+
 template <int O, int V>     // V: channels per thread in the transforms
-static int run_winograd(const WinoP& q, int B, int G, hipStream_t st) {
+static int run_winograd(const WinoP& q, int Ball, int G, hipStream_t st) {
     constexpr int P = (O + 2) * (O + 2);
     const View& in = q.in;
     const View& out = q.out;
     const int H = in.H, W = in.W, Cin = in.C, Cout = out.C, d = q.dil;
     const int TH = tiles_1d(H, d, O), TW = tiles_1d(W, d, O);
-    const long tiles = (long)B * wino_tiles(H, W, d, O);
-    if (tiles * P >= (1L << 31) / 2) return fail("winograd: too many tiles");
-    if (winograd_ws_floats(B, H, W, Cin, Cout, G, d, O) > q.ws_floats) return fail("winograd: workspace too small");
-    float* v = q.ws;
-    float* m = q.ws + (size_t)G * P * tiles * Cin;
-    auto grid = [&](int CV) {
-        return CV <= 256 ? dim3((unsigned)((tiles + 256 / CV - 1) / (256 / CV)), 1, G) : dim3((unsigned)tiles, CV / 256, G);
-    };
+    const long tiles_pf = wino_tiles(H, W, d, O);
+    if ((long)Ball * tiles_pf * P >= (1L << 31) / 2) return fail("winograd: too many tiles");
+    // Frames per pass.  The intermediates V | M of a pass are rewritten in place by the next one; kept below the Infinity
+    // Cache (256 MiB) they are written and re-read on the die instead of through HBM (tools/wino_subbatch_probe.py).
+    int cb = Ball;
+    if (g_wino_chunk_mb > 0) {
+        const double per_frame = 4.0 * G * P * (double)tiles_pf * (Cin + Cout);
+        cb = (int)((double)g_wino_chunk_mb * 1048576.0 / per_frame);
+        if (cb < 1) cb = 1;
+        if (cb > Ball) cb = Ball;
+        cb = (Ball + (Ball + cb - 1) / cb - 1) / ((Ball + cb - 1) / cb);     // equal passes
+    }
+    if (winograd_ws_floats(cb, H, W, Cin, Cout, G, d, O) > q.ws_floats) return fail("winograd: workspace too small");
     WinoNorm np = q.norm;
     if (np.stats) {
         if (np.groups <= 0 || Cin % np.groups || (Cin / np.groups) % 4) return fail("winograd: fused GroupNorm needs 4 | channels per group");
         np.cpg = Cin / np.groups;
         np.n = (double)H * W * np.cpg;
     }
-    {   // activations in once, V = P / m^2 times their size out
-        ProfScope prof("wino_input", 4.0 * G * Cin * ((double)B * H * W + (double)P * tiles), 0.0, st);
-        hipLaunchKernelGGL((wino_input_kernel<O, V>), grid(Cin / V), dim3(256), 0, st, in.p, B, H, W, Cin / V, in.cs, in.gs, TH, TW,
-                           d, v, (long)P * tiles * Cin, np);
-    }
-    QB_CHECK(hipGetLastError());
-    ConvP p{};
-    p.in = v; p.w = q.u; p.out = m;
-    p.B = 1; p.H = (int)tiles; p.W = 1; p.Cin = Cin; p.in_cs = Cin;
-    p.OH = (int)tiles; p.OW = 1; p.Cout = Cout; p.out_cs = Cout;
-    p.K = Cin; p.Kpad = Cin;
-    p.kh = 1; p.kw = 1; p.stride = 1; p.pad = 0; p.dil = 1;
-    p.M = (int)tiles; p.ohw = (int)tiles;
-    p.in_gs = tiles * Cin; p.out_gs = tiles * Cout; p.w_gs = (long)Cout * Cin;
-    p.ws = q.splitk_ws; p.ws_floats = q.splitk_floats;
-    p.tag = "wino_gemm";
-    p.bf16 = q.dtype == 3 ? 3 : 0;
-    int rc = launch_conv(p, G * P, st);
-    if (rc) return rc;
     // GroupNorm sums in the output transform when a block's tiles meet at most two images and vectors stay inside a group
     const int CVo = Cout / V, per_iter = CVo <= 256 ? 256 / CVo : 1;
     const bool gn_here = q.gn_sum && q.gn_groups > 0 && q.gn_groups <= 32 && (Cout / q.gn_groups) % 4 == 0 &&
-                         wino_tiles(H, W, d, O) >= (long)per_iter * OUT_ITERS;
-    dim3 og = grid(CVo);
-    og.x = (og.x + OUT_ITERS - 1) / OUT_ITERS;
-    {   // M in once, the layer's output out once
-        ProfScope prof("wino_output", 4.0 * G * Cout * ((double)P * tiles + (double)B * H * W), 0.0, st);
-        hipLaunchKernelGGL((wino_output_kernel<O, V>), og, dim3(256), 0, st, m, (long)P * tiles * Cout, B, H, W, CVo, TH, TW, d,
-                           q.scale, q.shift, q.ss_gs, q.relu, out.p, out.cs, out.gs, gn_here ? q.gn_sum : nullptr, q.gn_groups,
-                           q.gn_groups ? Cout / q.gn_groups : 1);
+                         tiles_pf >= (long)per_iter * OUT_ITERS;
+    for (int b0 = 0; b0 < Ball; b0 += cb) {
+        const int B = Ball - b0 < cb ? Ball - b0 : cb;
+        const long tiles = (long)B * tiles_pf;
+        float* v = q.ws;
+        float* m = q.ws + (size_t)G * P * tiles * Cin;
+        auto grid = [&](int CV) {
+            return CV <= 256 ? dim3((unsigned)((tiles + 256 / CV - 1) / (256 / CV)), 1, G) : dim3((unsigned)tiles, CV / 256, G);
+        };
+        const float* in_p = in.p + (size_t)b0 * H * W * in.cs;
+        float* out_p = out.p + (size_t)b0 * H * W * out.cs;
+        {   // activations in once, V = P / m^2 times their size out
+            ProfScope prof("wino_input", 4.0 * G * Cin * ((double)B * H * W + (double)P * tiles), 0.0, st);
+            hipLaunchKernelGGL((wino_input_kernel<O, V>), grid(Cin / V), dim3(256), 0, st, in_p, B, H, W, Cin / V, in.cs, in.gs, TH,
+                               TW, d, v, (long)P * tiles * Cin, np, Ball, b0);
+        }
+        QB_CHECK(hipGetLastError());
+        ConvP p{};
+        p.in = v; p.w = q.u; p.out = m;
+        p.B = 1; p.H = (int)tiles; p.W = 1; p.Cin = Cin; p.in_cs = Cin;
+        p.OH = (int)tiles; p.OW = 1; p.Cout = Cout; p.out_cs = Cout;
+        p.K = Cin; p.Kpad = Cin;
+        p.kh = 1; p.kw = 1; p.stride = 1; p.pad = 0; p.dil = 1;
+        p.M = (int)tiles; p.ohw = (int)tiles;
+        p.in_gs = tiles * Cin; p.out_gs = tiles * Cout; p.w_gs = (long)Cout * Cin;
+        p.ws = q.splitk_ws; p.ws_floats = q.splitk_floats;
+        p.tag = "wino_gemm";
+        p.bf16 = q.dtype == 3 ? 3 : 0;
+        int rc = launch_conv(p, G * P, st);
+        if (rc) return rc;
+        dim3 og = grid(CVo);
+        og.x = (og.x + OUT_ITERS - 1) / OUT_ITERS;
+        {   // M in once, the layer's output out once
+            ProfScope prof("wino_output", 4.0 * G * Cout * ((double)P * tiles + (double)B * H * W), 0.0, st);
+            hipLaunchKernelGGL((wino_output_kernel<O, V>), og, dim3(256), 0, st, m, (long)P * tiles * Cout, B, H, W, CVo, TH, TW, d,
+                               q.scale, q.shift, q.ss_gs, q.relu, out_p, out.cs, out.gs, gn_here ? q.gn_sum : nullptr, q.gn_groups,
+                               q.gn_groups ? Cout / q.gn_groups : 1, Ball, b0);
+        }
+        QB_CHECK(hipGetLastError());
     }
-    QB_CHECK(hipGetLastError());
-    if (q.gn_sum && !gn_here) return launch_gn_stats(out, B, G, q.gn_groups, q.gn_sum, st, false);
+    if (q.gn_sum && !gn_here) return launch_gn_stats(out, Ball, G, q.gn_groups, q.gn_sum, st, false);
     return 0;
 }
 

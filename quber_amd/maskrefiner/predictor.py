@@ -33,6 +33,35 @@ def load_checkpoint(path):
     return {k: (v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in sd.items()}
 
 
+class _FrameStaging:
+    """Buffers of the batch-1 call path for one frame size, allocated once: ONE pinned host block and ONE device block for the
+    frame's inputs (bgr | depth | initial masks -> a single H2D copy per call), the device-side intermediates, and pinned
+    host blocks for what comes back (the small per-instance tables; the refined masks, double-buffered)."""
+
+    def __init__(self, eng, n_cap):
+        H, W, dev = eng.H, eng.W, eng.device
+        hw = H * W
+        self.n_cap = n_cap
+        self.pin_in = torch.empty(6 * hw + n_cap * hw, dtype=torch.uint8).pin_memory()
+        self.np_in = self.pin_in.numpy()
+        self.dev_in = torch.empty(self.pin_in.shape, dtype=torch.uint8, device=dev)
+        self.offsets = torch.empty((1, 3, H, W), dtype=torch.float32, device=dev)
+        self.post = eng.alloc_post(1)
+        self.pin_count = torch.empty((1,), dtype=torch.int32).pin_memory()
+        self.pin_masks = [None, None]                # grown to the largest count seen, in steps of 16 instances
+        self.hw = (H, W)
+        self.slot = 0
+        self.done = torch.cuda.Event()
+
+    def host_masks(self, k):
+        self.slot ^= 1
+        buf = self.pin_masks[self.slot]
+        if buf is None or buf.shape[0] < k:
+            buf = torch.empty(((k + 15) // 16 * 16,) + self.hw, dtype=torch.bool).pin_memory()
+            self.pin_masks[self.slot] = buf
+        return buf[:k]
+
+
 class RefinerModel:
     """The ``predictor.model`` object: ``model(list[dict]) -> list[dict]`` in the detectron2 convention
     (reference MaskRefiner.forward, model.py:115-358).  Engines are cached per (H, W, batch capacity)."""
@@ -42,6 +71,7 @@ class RefinerModel:
         self.state_dict = state_dict
         self.device = torch.device(device)
         self._engines = {}
+        self._staging = {}
         self.training = False
 
     def eval(self):
@@ -59,7 +89,16 @@ class RefinerModel:
             eng = qengine.Engine(qc, self.device)
             eng.load_state_dict(self.state_dict)
             self._engines[key] = eng
+            self._staging.pop(key, None)
         return eng
+
+    def staging_for(self, eng, n_masks):
+        key = (eng.H, eng.W)
+        stg = self._staging.get(key)
+        if stg is None or stg.n_cap < n_masks:
+            stg = _FrameStaging(eng, max(64, n_masks))
+            self._staging[key] = stg
+        return stg
 
     # -- device-side pipeline on already-resident tensors --
     def run(self, bgr, depth, offsets):
@@ -69,34 +108,82 @@ class RefinerModel:
         post = eng.postprocess(logits)
         return eng, logits, post
 
+    def frame_dict(self, eng, logits_b, post, b, k, masks_b):
+        """The reference's output dict of one frame (model.py:304-356) from the device-side results."""
+        qc = eng.qcfg
+        ncls, o = qc.error_classes, 4
+        r = {"sem_seg": logits_b[0:1], "panoptic_seg": (post["panoptic"][b], None)}
+        if qc.eee_boundary_on:                       # model.py:310-313
+            r["eee_boundary"] = logits_b[o:o + ncls]
+            o += ncls
+        if qc.eee_mask_on:
+            r["eee_mask"] = logits_b[o:o + ncls]
+        if k > 0:
+            labels = post["labels"][b, :k]
+            inst = Instances((eng.H, eng.W))
+            inst.pred_masks = masks_b
+            inst.scores = post["scores"][b, :k]
+            inst.pred_boxes = Boxes(post["boxes"][b, :k])
+            inst.pred_classes = (torch.div(labels, LABEL_DIVISOR, rounding_mode="floor") - 1).to(torch.int64)
+            r["instances"] = inst
+        return r
+
     def results(self, eng, logits, post):
         """One D2H of the small per-frame tables, then mask extraction for exactly max(count) slots."""
         B = logits.shape[0]
         count = post["count"].cpu().numpy()
         kmax = int(count.max()) if B else 0
         masks = eng.extract_masks(post, kmax) if kmax > 0 else None
-        out = []
-        qc = eng.qcfg
-        ncls, o = qc.error_classes, 4
-        for b in range(B):
-            r = {"sem_seg": logits[b, 0:1], "panoptic_seg": (post["panoptic"][b], None)}
-            o = 4
-            if qc.eee_boundary_on:                       # model.py:310-313
-                r["eee_boundary"] = logits[b, o:o + ncls]
-                o += ncls
-            if qc.eee_mask_on:
-                r["eee_mask"] = logits[b, o:o + ncls]
-            k = int(count[b])
-            if k > 0:
-                labels = post["labels"][b, :k]
-                inst = Instances((eng.H, eng.W))
-                inst.pred_masks = masks[b, :k].bool()
-                inst.scores = post["scores"][b, :k]
-                inst.pred_boxes = Boxes(post["boxes"][b, :k])
-                inst.pred_classes = (torch.div(labels, LABEL_DIVISOR, rounding_mode="floor") - 1).to(torch.int64)
-                r["instances"] = inst
-            out.append(r)
-        return out
+        return [self.frame_dict(eng, logits[b], post, b, int(count[b]), masks[b, :int(count[b])].bool() if count[b] > 0 else None)
+                for b in range(B)]
+
+    def predict_one(self, bgr, depth, masks):
+        """The reference's call path (one frame per call, predictor.py:287-359) with nothing allocated per call but the
+        outputs: the inputs go through one pinned block and ONE H2D copy; the instance count comes back through a pinned
+        word; exactly `count` masks are extracted and their D2H copy is started at once (Instances.prefetch_host), so that
+        the caller's ``output['instances'].to('cpu').pred_masks`` (eval/refiner_model.py:267-271) finds it done."""
+        H, W = bgr.shape[:2]
+        n = int(masks.shape[0])
+        eng = self.engine_for(H, W, 1, n)
+        stg = self.staging_for(eng, n)
+        hw = H * W
+        two = depth is not None
+        used = (6 if two else 3) * hw + n * hw
+        stg.done.synchronize()                       # the previous call's H2D copy has read the pinned block
+        np.copyto(stg.np_in[:3 * hw].reshape(H, W, 3), bgr, casting="unsafe")
+        o = 3 * hw
+        if two:
+            np.copyto(stg.np_in[o:o + 3 * hw].reshape(H, W, 3), depth, casting="unsafe")
+            o += 3 * hw
+        if n:
+            # the encoder tests the mask bytes for non-zero (csrc/encode.hip), so uint8 / bool masks upload as they are
+            np.copyto(stg.np_in[o:o + n * hw].reshape(n, H, W), masks.view(np.uint8) if masks.dtype == np.bool_ else masks, casting="unsafe")
+        stg.dev_in[:used].copy_(stg.pin_in[:used], non_blocking=True)
+        stg.done.record()
+        d_bgr = stg.dev_in[:3 * hw].view(1, H, W, 3)
+        d_dep = stg.dev_in[3 * hw:6 * hw].view(1, H, W, 3) if two else None
+        if n:
+            eng.encode(stg.dev_in[o:o + n * hw].view(1, n, H, W), stg.offsets)
+        else:
+            stg.offsets.zero_()
+        logits = eng.forward(d_bgr, d_dep, stg.offsets)            # fresh tensor: owned by the caller through the dict
+        post = eng.postprocess(logits, stg.post)
+        stg.pin_count.copy_(post["count"], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        k = int(stg.pin_count[0])
+        post_out = {"panoptic": post["panoptic"].clone(), "labels": post["labels"].clone(), "scores": post["scores"].clone(),
+                    "boxes": post["boxes"].clone()}
+        masks_b = None
+        if k > 0:
+            masks_b = eng.extract_masks(post, k)[0].view(torch.bool)      # the kernel writes 0 / 1 bytes
+        r = self.frame_dict(eng, logits[0], post_out, 0, k, masks_b)
+        if k > 0:
+            host = stg.host_masks(k)
+            host.copy_(masks_b, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            r["instances"].prefetch_host(pred_masks=(host, ev))
+        return r
 
     def __call__(self, batched_inputs):
         dev = self.device
@@ -114,7 +201,7 @@ class RefinerModel:
 
 class MaskRefinerPredictor:
     def __init__(self, config_file=None, dataset_name="uoais_sim_val_panoptic", weights_file=None, device="cuda:0",
-                 seed=0):
+                 seed=0, state_dict=None):
         if config_file is None:
             self.cfg = qconfig.canonical_cfg()
         else:
@@ -130,7 +217,9 @@ class MaskRefinerPredictor:
         if path is not None and not os.path.exists(path) and config_file is not None:
             # the reference derives the path from the config location (predictor.py:222-225)
             path = config_file.replace(".yaml", "/{}".format(weights_file)).replace("configs", "output")
-        if path is not None and os.path.exists(path):
+        if state_dict is not None:                       # weights handed over in memory (bench / tests)
+            sd, path = state_dict, "<state_dict>"
+        elif path is not None and os.path.exists(path):
             sd = load_checkpoint(path)
         else:
             if weights_file is not None:
@@ -139,11 +228,20 @@ class MaskRefinerPredictor:
         self.cfg.MODEL.WEIGHTS = path or "<synthetic seed %d>" % seed
         self.model = RefinerModel(self.cfg, sd, device)
         self.device = torch.device(device)
+        self.fast_path = os.environ.get("QUBER_PREDICT_FAST", "1") != "0"     # 0: the general batched path for single frames too
 
     # -- reference signature (predictor.py:287) --
     def predict(self, rgb_img, depth_img=None, perturbed_masks=None):
         masks = np.zeros((0,) + rgb_img.shape[:2], np.uint8) if perturbed_masks is None else np.asarray(perturbed_masks)
-        return self.predict_batch(rgb_img[None], None if depth_img is None else depth_img[None], [masks])
+        if not self.fast_path or masks.dtype not in (np.uint8, np.bool_) or masks.ndim != 3:
+            return self.predict_batch(rgb_img[None], None if depth_img is None else depth_img[None], [masks])
+        if self.depth_on and depth_img is None:
+            raise ValueError("this config has INPUT.DEPTH_ON: a depth image is required")
+        if not self.rgb_on:                               # depth-only: the image IS the depth map (predictor.py:296-298)
+            rgb_img, depth_img = depth_img, None
+        elif not self.depth_on:
+            depth_img = None
+        return [self.model.predict_one(rgb_img, depth_img, masks)]
 
     def predict_batch(self, rgb_imgs, depth_imgs, masks_list):
         """rgb_imgs/depth_imgs: u8 [B,H,W,3] arrays; masks_list: B arrays u8/bool [N_b,H,W].  -> list of B dicts."""

@@ -53,8 +53,21 @@ class Instances:
             return len(v)
         return 0
 
+    def prefetch_host(self, **host):
+        """name -> (pinned host tensor, event): a device-to-host copy of that field already in flight.  `to('cpu')` then
+        waits for the event and hands out a fresh copy of the pinned buffer instead of issuing a blocking copy."""
+        self._host = host
+
     def to(self, *args, **kwargs):
         out = Instances(self._image_size)
+        host = getattr(self, "_host", None) or {}
+        dev = args[0] if args else kwargs.get("device")
+        cpu = str(dev) == "cpu"
         for k, v in self._fields.items():
-            out.set(k, v.to(*args, **kwargs) if hasattr(v, "to") else v)
+            if cpu and k in host:
+                buf, ev = host[k]
+                ev.synchronize()
+                out.set(k, buf.clone())          # the pinned staging buffer is reused by later calls: the caller owns a copy
+            else:
+                out.set(k, v.to(*args, **kwargs) if hasattr(v, "to") else v)
         return out
