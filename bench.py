@@ -141,7 +141,6 @@ def cpu_baseline(sd, h, w, n, frames, grad_frames, eng=None, batch_eng=None, bat
     from oracle.network_torch import ArchCfg, MaskRefinerNet
     from quber_amd import synth
     model, cores, usable = cpu_info()
-    torch.set_num_threads(cores)
     net = MaskRefinerNet(ArchCfg(repeat_fusion=True)).eval()
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
 
@@ -155,6 +154,16 @@ def cpu_baseline(sd, h, w, n, frames, grad_frames, eng=None, batch_eng=None, bat
         ref = postproc_ref.postprocess(out["foreground"][0], out["center"][0], out["offset"][0])
         return time.perf_counter() - t0, out, ref
 
+    # the thread count that serves the baseline best (more is not faster: batch-1 convolutions of this size lose to the
+    # fork / join and cache traffic of 128 threads): one frame per candidate after a warm-up frame, the fastest is used
+    probe = {}
+    sc0 = synth.make_scene(99, h, w, n)
+    for t in sorted({c for c in (8, 16, 32, 64, cores) if c <= usable}):
+        torch.set_num_threads(t)
+        one(sc0, False)
+        probe[t] = one(sc0, False)[0]
+    threads = min(probe, key=probe.get)
+    torch.set_num_threads(threads)
     res = {}
     for name, grad, cnt in (("no_grad", False, frames), ("grad", True, grad_frames)):
         if cnt <= 0:
@@ -206,10 +215,12 @@ def cpu_baseline(sd, h, w, n, frames, grad_frames, eng=None, batch_eng=None, bat
                   "label_map_equal_fraction": tot["label_map_equal_fraction"], "label_flips": tot,
                   "fg_iou": min(iou), "oracle_instances_per_frame": ks}
     best = max(res.values(), key=lambda r: r["masks_per_s"])
-    return {"value": best["masks_per_s"], "unit": "refined masks/s", "cores": cores, "kind": "port",
-            "cpu_model": model, "usable_cpus": usable, "torch": torch.__version__, "variants": res, "parity_vs_hip": parity,
+    return {"value": best["masks_per_s"], "unit": "refined masks/s", "cores": threads, "kind": "port",
+            "cpu_model": model, "physical_cores": cores, "usable_cpus": usable, "torch": torch.__version__,
+            "threads_probe_s_per_frame": {str(k): v for k, v in probe.items()}, "variants": res, "parity_vs_hip": parity,
             "sample": f"{frames} frames {w}x{h} N={n} batch 1 under no_grad + {grad_frames} with the autograd graph, median per "
-                      f"frame, first sample dropped; reference-style execution (fusion stack per key)"}
+                      f"frame, first sample dropped; reference-style execution (fusion stack per key); torch.set_num_threads = the "
+                      f"fastest of {sorted(probe)} on one probe frame each (`cores` = that count)"}
 
 
 def dry_main(a, world, rank):

@@ -12,8 +12,21 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def oracle_threads():
+    """Host threads for the oracle.  More is not faster: on the GPU box (2 x 64-core EPYC, torch default 128 threads) one
+    640x480 frame through the fp32 oracle takes 2.10 s with 128 threads, 0.79 s with 64, 0.24 s with 16, 0.30 s with 8
+    (tests/oracle_threads_probe.py, profiles/r03c_oracle_threads.txt)."""
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return int(os.environ.get("QUBER_ORACLE_THREADS", min(16, usable)))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    import torch
+    torch.set_num_threads(oracle_threads())
 
 
 def golden(prefix):

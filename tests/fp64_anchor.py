@@ -73,8 +73,11 @@ class OracleStream:
         self.n = image.shape[0]
         offs = torch.as_tensor(offs)
 
+        nthreads = torch.get_num_threads()
+
         def work():
             try:
+                torch.set_num_threads(nthreads)              # the OpenMP thread count is per calling thread
                 net32 = build_net(sd, torch.float32, **kw)
                 net64 = build_net(sd, torch.float64, **kw) if fp64 else None
                 for i in range(self.n):
