@@ -238,12 +238,33 @@ def dry_main(a, world, rank):
     digest = hashlib.sha256(np.concatenate([np.asarray(sd[k]).ravel()[:64] for k in specs]).tobytes()).hexdigest()[:12]
     B, H, W = a.batch, 32, 48
     local = torch.full((B, H, W), float(rank), dtype=torch.float32)
+    got, pending, gather_s, step_ms = None, None, 0.0, []
     t0 = time.perf_counter()
-    got = None
-    for _ in range(a.steps):
-        got = qdist.gather_label_maps(local, [B] * world, dst=0) if world > 1 else local
+    for _ in range(a.steps):                     # the step loop of the real run: asynchronous gather, waited one step later
+        ts = time.perf_counter()
+        if world > 1:
+            tg = time.perf_counter()
+            if pending is not None:
+                got = pending.wait()
+            pending = qdist.gather_label_maps(local, [B] * world, dst=0, async_op=True)
+            gather_s += time.perf_counter() - tg
+        else:
+            got = local
+        step_ms.append((time.perf_counter() - ts) * 1e3)
+    if pending is not None:
+        tg = time.perf_counter()
+        got = pending.wait()
+        gather_s += time.perf_counter() - tg
     elapsed = time.perf_counter() - t0
-    ranks = [{"rank": rank, "world_size": world, "device": "cpu", "weights": digest}]
+    alone = None
+    if world > 1:
+        tg = time.perf_counter()
+        qdist.gather_label_maps(local, [B] * world, dst=0)
+        alone = (time.perf_counter() - tg) * 1e3
+    ranks = [{"rank": rank, "world_size": world, "device": "cpu", "device_name": "cpu (dry)", "backend": dist.get_backend() if world > 1 else None,
+              "weights": digest, "step_ms_median": float(np.median(step_ms)), "step_ms_max": float(np.max(step_ms)),
+              "elapsed_ms_per_step": elapsed / a.steps * 1e3, "gather_ms_per_step": gather_s / a.steps * 1e3,
+              "gather_alone_ms": alone, "instances_out": 0, "frames": B}]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -258,7 +279,12 @@ def dry_main(a, world, rank):
                           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                           "dry": True, "config": {"workload": "dry run: rendezvous + broadcast + gather only"},
-                          "rccl_ranks": ranks}), flush=True)
+                          "rccl_ranks": ranks,
+                          "gather": None if world == 1 else {
+                              "ms_per_step_max_over_ranks": max(r["gather_ms_per_step"] for r in ranks),
+                              "alone_ms_max_over_ranks": max((r["gather_alone_ms"] or 0.0) for r in ranks),
+                              "bytes_per_rank_per_step": B * H * W * 4},
+                          "roofline": None, "cpu_baseline": None}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -283,7 +309,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         backend = os.environ.get("QUBER_DIST_BACKEND", "nccl")     # "gloo": rehearsal of the N > 1 path on one GPU
-        local = local % max(torch.cuda.device_count(), 1)
+        ndev = torch.cuda.device_count()                           # (counting devices does not initialise the GPU)
+        if backend == "nccl" and ndev < a.gpus:
+            sys.exit(f"bench.py: --gpus {a.gpus} over RCCL needs {a.gpus} visible GPUs, this node shows {ndev} "
+                     f"(HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?); QUBER_DIST_BACKEND=gloo rehearses the N > 1 path on fewer")
+        local = local % max(ndev, 1)
         torch.cuda.set_device(local)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
@@ -368,6 +398,7 @@ def main():
             gpu_step()
 
     pending = [None]      # the label-map gather of the previous step: it travels over xGMI while this step computes
+    gather_host_s = [0.0]  # host time inside the gather calls (issue + wait) - what the gather costs the step loop
 
     def step():
         if graph is not None:
@@ -375,18 +406,23 @@ def main():
         else:
             gpu_step()
         if dist is not None and not a.no_gather:
+            t_g = time.perf_counter()
             if pending[0] is not None:
                 pending[0].wait()
             pending[0] = qdist.gather_label_maps(post["panoptic"], counts, dst=0, async_op=True)
+            gather_host_s[0] += time.perf_counter() - t_g
 
     def drain():
         if pending[0] is not None:
+            t_g = time.perf_counter()
             pending[0].wait()
             pending[0] = None
+            gather_host_s[0] += time.perf_counter() - t_g
 
     for _ in range(a.warmup):
         step()
     drain()
+    gather_host_s[0] = 0.0
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -402,8 +438,26 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]
+    # the gather alone, synchronous, nothing beside it: what a step would pay if it were NOT overlapped
+    gather_alone_ms = None
+    if dist is not None and not a.no_gather:
+        ts = []
+        for _ in range(5):
+            dist.barrier()
+            torch.cuda.synchronize()
+            t_g = time.perf_counter()
+            qdist.gather_label_maps(post["panoptic"], counts, dst=0)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t_g) * 1e3)
+        gather_alone_ms = float(np.median(ts[1:]))
+    cnt_host = post["count"].cpu().numpy()
     rank_info = {"rank": rank, "world_size": dist.get_world_size() if dist is not None else 1, "device": str(dev),
-                 "device_name": torch.cuda.get_device_name(dev), "backend": dist.get_backend() if dist is not None else None}
+                 "device_name": torch.cuda.get_device_name(dev), "backend": dist.get_backend() if dist is not None else None,
+                 "step_ms_median": float(np.median(step_ms)), "step_ms_max": float(np.max(step_ms)),
+                 "elapsed_ms_per_step": elapsed / a.steps * 1e3,
+                 "gather_ms_per_step": gather_host_s[0] / a.steps * 1e3 if dist is not None else 0.0,
+                 "gather_alone_ms": gather_alone_ms,
+                 "instances_out": int(cnt_host.sum()), "frames": int(B)}
     ranks = [rank_info]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
@@ -666,6 +720,13 @@ def report(a, eng, world, elapsed, ranks, center_bias, sd, host, step_ms, t, gpu
                    "instances_out_per_frame_mean": float(count.mean()),
                    "instances_out_per_frame_min_max": [int(count.min()), int(count.max())]},
         "rccl_ranks": ranks,
+        "gather": None if world == 1 else {
+            "ms_per_step_max_over_ranks": max(r["gather_ms_per_step"] for r in ranks),
+            "alone_ms_max_over_ranks": max((r["gather_alone_ms"] or 0.0) for r in ranks),
+            "bytes_per_rank_per_step": B * H * W * 4,
+            "note": "ms_per_step = host time inside the asynchronous gather's issue + wait calls per step (what the overlapped "
+                    "gather costs the step loop); alone = one synchronous gather with nothing beside it (what it would cost "
+                    "un-overlapped); per-rank values and step medians in rccl_ranks"},
         "roofline": {"bound": "mfma", "achieved": ex_tf, "peak": peak, "unit": "TFLOP/s", "frac": ex_tf / peak,
                      "traffic": traffic, "traffic_note": traffic_note,
                      "kernel": "conv_igemm (all instantiations).  achieved = FLOPs the matrix pipe EXECUTES per step (2*M*K*N of "

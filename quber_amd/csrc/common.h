@@ -53,6 +53,8 @@ struct ConvP {
     const float* in2;
     int in2_cs, H2, W2, stride2, K1, pk_in2_bytes;
     long in2_gs;
+    int acc_chunk;       // K-slices per accumulation chunk (two-level fp32 accumulation: the MFMA accumulator is folded into a
+                         // second register set every acc_chunk slices); 0 = one sequential chain over K
     int bf16;            // quber_config.compute_dtype: 0 = fp32 MFMA, 1 = bf16 / 2 = fp16 operands, 3 = fp32 operands split into 3 bf16 terms
 };
 
@@ -111,7 +113,7 @@ bool winograd_m6_channels_ok(int Cin, int Cout);
 size_t winograd_ws_floats(int B, int H, int W, int Cin, int Cout, int G, int dil, int m);
 double winograd_mac_ratio(int H, int W, int dil, int m);
 extern int g_winograd, g_wino_min_cin, g_wino_max_ratio, g_wino_variant, g_wino_min_cout, g_wino_pairs, g_wino_chunk_mb;
-extern int g_tile_128x64;
+extern int g_tile_128x64, g_acc_chunk;
 extern int g_force_split, g_force_tile, g_tail_split, g_persist, g_persist_min_nk, g_persist_debug, g_persist_min_tiles;
 // persistent launch of the implicit GEMM (conv_persist.hip); p.mtiles / ntiles / vec_out filled in by the caller
 template <int BM, int BN, int WM, int WN> int launch_conv_persistent(ConvP p, int G, int bpc, hipStream_t st);

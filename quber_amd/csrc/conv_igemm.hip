@@ -58,8 +58,12 @@ constexpr int NPL(int dt) { return dt == 3 ? 3 : 1; }     // bf16 planes per ope
 // out short pieces while the last whole tiles drain.
 // The K range is derived without a division (host-computed kchunk): a 64-bit division here costs hipcc ~50 VGPRs over
 // the whole kernel and a wave per SIMD; as written all instantiations allocate the same registers.
+// waves per SIMD the kernel is compiled for: two accumulator sets (the MFMA chain and the chunk sums, below) cost the
+// 128-row tiles their third resident block; the 64x64 tiles keep five
+constexpr int igemm_occupancy(int BM, int BN, int DT = 0) { return BM == 64 ? 5 : (BM * BN >= 128 * 128 || (BM == 256 && DT == 3)) ? 2 : 3; }
+
 template <int BM, int BN, int WM, int WN, int MODE, int DT = 0>
-__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
+__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(igemm_occupancy(BM, BN, DT)))) void conv_igemm_f32(const ConvP p) {
     constexpr int NTH = WM * WN * 64;
     constexpr int RPP = NTH / 8;      // tile rows covered by one pass of the loader
     constexpr int TM = BM / WM / 32;
@@ -322,6 +326,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
                 acc[i][j] = c;
             }
     };
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto mma = [&](int buf, int ks) __attribute__((always_inline)) {
         const float* ap = &As[buf * BM * PITCH + (wm * TM * 32 + r) * PITCH + 4 * h];
         const float* bp = &Bs[buf * BN * PITCH + (wn * 32 + r) * PITCH + 4 * h];
@@ -334,12 +339,26 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                // exact fp32: the chain of a K-slice starts from zero (SrcC = 0) and is added to `top` when the slice is done
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, ks == 0 ? zero16 : acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
             }
     };
+    // Two-level accumulation: the chain of fp32 additions behind an output is cut into chunks - one K-slice (32 k) in the
+    // exact fp32 mode, p.acc_chunk slices in the bf16x3 mode - whose sums are added in a second register set.  The rounding
+    // error of a sum grows with the length of its chain: one chain over K = 128 ... 4608 left the network 2-4x further from
+    // a float64 evaluation than the CPU reference's blocked reduction is; chunked, the two are level, Winograd layers
+    // included (tests/fp64_anchor.py, profiles/r03f_anchor_chunk.md).
+    f32x16 top[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) top[i][j][e] = 0.f;
+    int fold_in = p.acc_chunk;
     gload(0);
     lstore(0);
     __syncthreads();
@@ -354,6 +373,22 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
         } else {
 #pragma unroll
             for (int ks = 0; ks < BK / 8; ++ks) mma(0, ks);
+        }
+        if constexpr (DT == 0) {                   // every slice is a chunk
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) top[i][j] += acc[i][j];
+        } else if (kt + 1 == nk || (DT == 3 && --fold_in == 0)) {      // bf16x3: chunks of p.acc_chunk slices; 16-bit operand
+            fold_in = p.acc_chunk;                                      // modes: one chain (the epilogue reads `top`)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    top[i][j] += acc[i][j];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                }
         }
         __syncthreads();
         if (kt + 1 < nk) {
@@ -393,7 +428,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_f32(const ConvP p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                smem[row * SP + wn * 32 + r] = acc[i][j][e];
+                smem[row * SP + wn * 32 + r] = top[i][j][e];
             }
         __syncthreads();
         const int nb = n0 + j * SW;    // first channel of this pass
@@ -551,15 +586,17 @@ int g_tail_split = 1;      // key 5: split the ragged last round of large launch
 //     (nk/S + c) * W(blocks per CU)  [+ lat + (2S+1) * outputs * per_float   if S > 1]
 // where W counts rounds, a partly filled last round being cheaper than a full one (a lone block runs faster).
 struct SplitModel { double c, thr1, thr2, per_float, lat; };
-constexpr SplitModel kModel3 = {3.9, 0.74, 0.995, 1.09e-7, 13.7};   // 3 resident blocks per CU (128x128, 256x32)
-constexpr SplitModel kModel7 = {7.5, 0.0, 0.0, 6.05e-7, 40.0};      // 7 resident blocks per CU (64x64)
+// (fitted in round 1 with 3 / 7 resident blocks per CU; since the two-level accumulation of round 3 the 128x128 tiles run
+// 2 and the 64x64 tiles 5 - igemm_occupancy() - and the constants are used as they are)
+constexpr SplitModel kModel3 = {3.9, 0.74, 0.995, 1.09e-7, 13.7};   // 2-3 resident blocks per CU (128x128, 256x32, 128x64)
+constexpr SplitModel kModel7 = {7.5, 0.0, 0.0, 6.05e-7, 40.0};      // 5 resident blocks per CU (64x64)
 constexpr int kMinSlicesPerSplit = 6;
 
 static double launch_cost(long blocks, int nk, double outputs, int S, int bpc, const SplitModel& m) {
     const long per_cu = (blocks * S + 255) / 256;
     const long q = per_cu / bpc, rem = per_cu % bpc;
     double W = (double)bpc * q;
-    if (rem) W += bpc == 3 ? (rem == 1 ? 1.0 / m.thr1 : 2.0 / m.thr2) : (rem > 0.55 * bpc ? (double)rem : 0.55 * bpc);
+    if (rem) W += bpc <= 3 ? (rem == 1 ? 1.0 / m.thr1 : 2.0 / m.thr2) : (rem > 0.55 * bpc ? (double)rem : 0.55 * bpc);
     double t = ((double)nk / S + m.c) * W;
     if (S > 1) t += m.lat + (2.0 * S + 1.0) * outputs * m.per_float;
     return t;
@@ -570,7 +607,7 @@ static int choose_split(const ConvP& p, int G, int BM, int BN, int bpc) {
     if (!p.ws) return 1;
     const long blocks = (long)((p.M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN) * G;
     const double outputs = (double)G * p.M * p.Cout;
-    const SplitModel& m = bpc == 3 ? kModel3 : kModel7;
+    const SplitModel& m = bpc <= 3 ? kModel3 : kModel7;
     int best = 1;
     double best_t = launch_cost(blocks, nk, outputs, 1, bpc, m);
     for (int S = 2; S <= 16 && nk / S >= kMinSlicesPerSplit; ++S) {
@@ -642,9 +679,9 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
     // sharing every tile's K between all resident blocks writes more partial tiles than that model's 2-8 partitions)
     if (g_persist && ((BM == 128 && BN == 128) || (g_persist == 2 && (BM == BN || BM == 256))) && !skip && p.ws && conv_persistent_ok(p) &&
         (long)p.mtiles * p.ntiles * G >= g_persist_min_tiles &&
-        ((long)p.mtiles * p.ntiles * G >= 256L * (BM == 64 ? 7 : 3) || nk >= g_persist_min_nk)) {      // several tiles per block, or K worth sharing
+        ((long)p.mtiles * p.ntiles * G >= 256L * (BM == 64 ? 5 : 2) || nk >= g_persist_min_nk)) {      // several tiles per block, or K worth sharing
         if (p.bf16 == 3 && (BM == 256 || (BM == 64 && nk <= 8))) exact_fallback();
-        const int bpc = BM == 64 ? (p.bf16 == 3 ? 5 : 7) : (p.bf16 == 3 ? 2 : 3);
+        const int bpc = BM == 64 ? 5 : 2;          // conv_persist.hip: pk_occupancy()
         if (p.ws_floats >= conv_persistent_ws_floats(BM, BN, bpc)) {
             {
                 ProfScope prof(tag, conv_bytes, conv_flops, st);
@@ -657,7 +694,7 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
     }
     // Split tail: with more than one round of tiles, cut the tiles of the ragged last round into 2^shift K-pieces that
     // together fill about one more (short) round; taken when the model prices it below the launch chosen so far.
-    constexpr int BPC = (BM == 64) ? 7 : 3;
+    constexpr int BPC = igemm_occupancy(BM, BN);
     const long slots = 256L * BPC, tiles = (long)p.mtiles * p.ntiles, blocks_all = tiles * G;
     if (p.ws && !p.bf16 && g_tail_split && g_force_split == 0 && BM == 128 && blocks_all > slots && nk >= 32) {
         const long nfull = (blocks_all / slots) * slots / G / p.ntiles * p.ntiles;    // per group, whole tile rows
@@ -727,7 +764,11 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
     return gn_separate();
 }
 
-int launch_conv(const ConvP& p, int G, hipStream_t st) {
+int g_acc_chunk = 2;      // key 21: K-slices per accumulation chunk (default 2 = 64 k; 0 = one chain over K)
+
+int launch_conv(const ConvP& p0, int G, hipStream_t st) {
+    ConvP p = p0;
+    p.acc_chunk = g_acc_chunk;
     if (p.Cin % 4 || p.in_cs % 4 || p.Kpad % BK || p.K > p.Kpad)
         return fail("conv: Cin / channel stride must be multiples of 4 and Kpad a multiple of 32");
     if (((uintptr_t)p.in & 15) || ((uintptr_t)p.w & 15) || (p.in_gs & 3) || (p.w_gs & 3))
@@ -749,14 +790,14 @@ int launch_conv(const ConvP& p, int G, hipStream_t st) {
     // memory-bound residual 1x1 layers with a short K (res2-4 conv3): 64x64, whose 7 resident blocks per CU keep more
     // loads in flight.  Otherwise 128x128, split when the model says so; 64x64 again for launches too small for that.
     const int nk = p.Kpad / BK;
-    if (p.Cout <= 32) return run<256, 32, 4, 1>(p, G, choose_split(p, G, 256, 32, 3), st);
+    if (p.Cout <= 32) return run<256, 32, 4, 1>(p, G, choose_split(p, G, 256, 32, igemm_occupancy(256, 32)), st);
     // 33-64 output channels without a residual, at least a round of tiles: 128x64 (each wave 64x32: the weight fragments
     // are read from LDS half as often as with 64x64 tiles; +3-5 % on stem.conv3 / res2 conv1, conv2 - tools/tile_ab.py)
     if (g_tile_128x64 && p.Cout <= 64 && p.Cout > 32 && !p.res && (long)((p.M + 127) / 128) * G >= 1024) return run<128, 64, 2, 2>(p, G, 1, st);
-    if (p.Cout <= 64 || (p.res && nk <= 8 && p.Cout >= 128)) return run<64, 64, 2, 2>(p, G, choose_split(p, G, 64, 64, 7), st);
+    if (p.Cout <= 64 || (p.res && nk <= 8 && p.Cout >= 128)) return run<64, 64, 2, 2>(p, G, choose_split(p, G, 64, 64, igemm_occupancy(64, 64)), st);
     const long tiles128 = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * G;
-    const int s128 = choose_split(p, G, 128, 128, 3);
-    if (tiles128 < 64 || (tiles128 < 384 && s128 == 1)) return run<64, 64, 2, 2>(p, G, choose_split(p, G, 64, 64, 7), st);
+    const int s128 = choose_split(p, G, 128, 128, igemm_occupancy(128, 128));
+    if (tiles128 < 64 || (tiles128 < 384 && s128 == 1)) return run<64, 64, 2, 2>(p, G, choose_split(p, G, 64, 64, igemm_occupancy(64, 64)), st);
     return run<128, 128, 2, 2>(p, G, s128, st);
 }
 

@@ -75,7 +75,8 @@ __device__ unsigned long long g_pk_span[2048 * 4];      // per block: kernel ent
 #define PK_STAMP(i) do {} while (0)
 #endif
 // resident blocks per CU the kernel is built for (= waves per SIMD: a block is one wave on each SIMD)
-constexpr int pk_occupancy(int BM, int DT) { return BM == 64 ? (DT == 3 ? 5 : 7) : (DT == 3 ? 2 : 3); }
+// (two accumulator sets since round 3 - the MFMA chain and the chunk sums, see `fold` below: 64 + 64 registers for a 128x128 tile)
+constexpr int pk_occupancy(int BM, int DT) { return BM == 64 ? 5 : 2; }
 
 // All global accesses go through buffer descriptors (base + 32-bit byte offset, hardware range check):
 //   * an out-of-image tap, or a lane whose channel is past Cout, adds OOB to its offset - loads return 0 and stores are
@@ -151,8 +152,14 @@ void conv_igemm_pk(const ConvP p) {
     // the packed weights, shifts added), which keeps the shortcut's output out of HBM altogether
     constexpr bool DUAL = EPI == 3;
     __shared__ double gacc[GN ? 2 * 32 * 2 : 1];       // [image b0 / b0 + 1][norm group][sum, sum of squares] of the tile being stored
-    constexpr int SMEM_FLOATS = DT ? NPL(DT) * (BM + BN) * PITCH_H / 2 : (BM + BN) * PITCH;
+    // Two K-slice images for the exact fp32 kernel on 128x128 tiles (2 blocks per CU: 2 x 72 KiB of the 160 KiB): the next
+    // slice is stored into the image nobody reads while this one is multiplied, and ONE barrier per slice publishes it -
+    // with two resident blocks instead of three there is less to hide a second barrier and the store phase behind.
+    constexpr int NBUF = (DT == 0 && BM == 128 && BN == 128) ? 2 : 1;
+    constexpr int IMG_FLOATS = DT ? NPL(DT) * (BM + BN) * PITCH_H / 2 : (BM + BN) * PITCH;
+    constexpr int SMEM_FLOATS = NBUF * IMG_FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+    int buf = 0;                        // image being multiplied (NBUF == 2)
     float* const As = smem;
     float* const Bs = smem + BM * PITCH;
     using H16 = typename Half16<DT>::T;
@@ -350,10 +357,11 @@ void conv_igemm_pk(const ConvP p) {
 #pragma unroll
             for (int i = 0; i < BL; ++i) split(rb[i], &Bh[(lrow + RPP * i) * PITCH_H + kq], BN * PITCH_H);
         } else {
+            const int o = NBUF == 2 ? (buf ^ 1) * IMG_FLOATS : 0;
 #pragma unroll
-            for (int i = 0; i < AL; ++i) *reinterpret_cast<f32x4*>(&As[(lrow + RPP * i) * PITCH + kq]) = ra[i];
+            for (int i = 0; i < AL; ++i) *reinterpret_cast<f32x4*>(&As[o + (lrow + RPP * i) * PITCH + kq]) = ra[i];
 #pragma unroll
-            for (int i = 0; i < BL; ++i) *reinterpret_cast<f32x4*>(&Bs[(lrow + RPP * i) * PITCH + kq]) = rb[i];
+            for (int i = 0; i < BL; ++i) *reinterpret_cast<f32x4*>(&Bs[o + (lrow + RPP * i) * PITCH + kq]) = rb[i];
         }
     };
 
@@ -361,6 +369,28 @@ void conv_igemm_pk(const ConvP p) {
     const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, h = lane >> 5;
     f32x16 acc[TM][TN];
+    // Two-level accumulation: `acc` is the MFMA chain of at most p.acc_chunk K-slices; `top` sums the chunks.  The rounding
+    // error of an fp32 sum grows with the length of its chain: one chain over K = 128 ... 4608 left the network 2-4x
+    // further from a float64 evaluation than the CPU reference's blocked reduction is (tests/fp64_anchor.py); with chunks
+    // of 64 k the two are level, Winograd layers included (profiles/r03f_anchor_chunk.md).
+    f32x16 top[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    auto fold = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                top[i][j] += acc[i][j];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            }
+    };
+    int fold_in = 0;               // K-slices until the next fold
 
     auto mma_slice = [&]() __attribute__((always_inline)) {
         if constexpr (DT == 3) {
@@ -391,10 +421,14 @@ void conv_igemm_pk(const ConvP p) {
                     }
             }
         } else {
+            // exact fp32: the chain of a K-slice starts from zero (SrcC = 0 of its first MFMA) and is added to `top` when the
+            // slice is done - 16 MFMA steps (32 k) per chain, K / 32 additions above them
+            const int o = NBUF == 2 ? buf * IMG_FLOATS : 0;
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int k8 = 0; k8 < BK / 8; ++k8) {
-                const float* ap = &As[(wm * TM * 32 + r) * PITCH + 4 * h];
-                const float* bp = &Bs[(wn * 32 + r) * PITCH + 4 * h];
+                const float* ap = &As[o + (wm * TM * 32 + r) * PITCH + 4 * h];
+                const float* bp = &Bs[o + (wn * 32 + r) * PITCH + 4 * h];
                 f32x4 a[TM], b[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(ap + i * 32 * PITCH + k8 * 8);
@@ -404,12 +438,16 @@ void conv_igemm_pk(const ConvP p) {
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, k8 == 0 ? zero : acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
                     }
             }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) top[i][j] += acc[i][j];
         }
     };
 
@@ -489,7 +527,7 @@ void conv_igemm_pk(const ConvP p) {
                 if constexpr (RES) {
                     if (tt * 4 + g4 + 1 < TM * TN * 4) rv_next = buf_load4(rs_res, res_off(tt * 4 + g4 + 1));
                 }
-                float a0 = acc[i][j][4 * g4], a1 = acc[i][j][4 * g4 + 1], a2 = acc[i][j][4 * g4 + 2], a3 = acc[i][j][4 * g4 + 3];
+                float a0 = top[i][j][4 * g4], a1 = top[i][j][4 * g4 + 1], a2 = top[i][j][4 * g4 + 2], a3 = top[i][j][4 * g4 + 3];
                 quad_transpose(a0, a1, a2, a3, q0, q1);
                 f32x4 v = {a0, a1, a2, a3};
 #pragma unroll
@@ -537,8 +575,16 @@ void conv_igemm_pk(const ConvP p) {
             if (more) setup();
         }
         if (more) gload();                 // the next K-slice: of this segment, or the first one of the next segment
-        if (cur) mma_slice();
-        __syncthreads();                   // every wave is done with the slice in LDS
+        if (cur) {
+            mma_slice();
+            if constexpr (DT == 3) {
+                if (last || --fold_in == 0) {  // a chunk is complete (or the tile: the epilogue reads `top`)
+                    fold();
+                    fold_in = p.acc_chunk;
+                }
+            }
+        }
+        if constexpr (NBUF == 1) __syncthreads();   // every wave is done with the slice in LDS
         if (last) PK_STAMP(1);
         if (more) lstore();
         if (last) {
@@ -567,7 +613,8 @@ void conv_igemm_pk(const ConvP p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                    for (int e = 0; e < 16; ++e) top[i][j][e] = 0.f;      // (`acc` is zero after the fold that ended the last tile)
+            fold_in = p.acc_chunk;         // 0: never reaches zero by decrements - one chain over the whole K
             c_m0 = n_m0; c_n0 = n_n0; c_g = n_g; c_slot = s_slot;
             nseg = s_k1 - s_k0;
             c_raw = nseg != nkt;
@@ -579,7 +626,8 @@ void conv_igemm_pk(const ConvP p) {
         } else {
             ++kt;
         }
-        __syncthreads();                   // the next slice is in LDS
+        __syncthreads();                   // the next slice is in LDS (NBUF == 2: and every wave is done with the one just multiplied)
+        if constexpr (NBUF == 2) buf ^= 1;
         if constexpr (GN) {
             if (last && fin_gn) {          // every wave has added its sums: out to the layer's accumulators, LDS cleared for the next tile
                 if (t < 128) {
@@ -790,6 +838,7 @@ bool conv_persistent_ok(const ConvP& p) {
 // launch is not covered (the caller then runs the two convolutions separately), 0 on success, -1 on a launch error.
 int launch_conv_dual(ConvP p, int G, hipStream_t st) {
     if (!g_persist || !p.in2 || !p.ws) return 1;
+    p.acc_chunk = g_acc_chunk;
     if (p.kh != 1 || p.kw != 1 || p.pad != 0 || p.stride != 1 || p.kmode || p.K1 % BK || p.K1 <= 0 || p.K1 >= p.Kpad || p.K != p.Kpad ||
         p.Kpad % BK || p.in_cs % 4 || p.in2_cs % 4 || ((uintptr_t)p.in & 15) || ((uintptr_t)p.in2 & 15) || (p.in_gs & 3) || (p.in2_gs & 3))
         return 1;
@@ -806,7 +855,7 @@ int launch_conv_dual(ConvP p, int G, hipStream_t st) {
     const long tiles128 = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * G;
     if (tiles128 < g_persist_min_tiles) return 1;          // small batches: the two separate launches with their split-K model
     const bool big = tiles128 >= 192 && p.Cout > 64;
-    const int bpc = big ? (p.bf16 == 3 ? 2 : 3) : (p.bf16 == 3 ? 5 : 7);
+    const int bpc = big ? 2 : 5;                           // pk_occupancy()
     const int BMs = big ? 128 : 64;
     if (p.ws_floats < conv_persistent_ws_floats(BMs, BMs, bpc)) return 1;
     p.mtiles = (p.M + BMs - 1) / BMs;

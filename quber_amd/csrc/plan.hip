@@ -1091,6 +1091,7 @@ void quber_set_tuning(int32_t key, int32_t value) {
         }
     }
     if (key == 4) g_force_tile = value;    // force the tile shape: 1 = 64x64, 2 = 128x128, 4 = 256x32 (0 = automatic)
+    if (key == 21) g_acc_chunk = value;       // two-level fp32 accumulation: K-slices per chunk (0 = off)
     if (key == 20) g_wino_chunk_mb = value;   // Winograd layers in passes whose V | M intermediates stay below this many MiB (0 = whole batch)
     if (key == 19) g_tile_128x64 = value;     // 128x64 tiles for the 33-64 channel convolutions (default 1)
     if (key == 18) g_fuse_shortcut = value;   // acts at plan time: 0 = keep the projection shortcut a convolution of its own

@@ -207,15 +207,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(wino_in_wav
     }
 }
 
-// A block handles OUT_ITERS groups of tiles; with `gn_sum` it also accumulates the GroupNorm sums of what it stores
-// (fp64, LDS per block, one global atomic per (image, group) per block - as the direct kernel's epilogue does).
+// A block handles `iters` (<= OUT_ITERS) groups of tiles - fewer when the launch would otherwise not fill the chip (one
+// frame: 1200 tiles of 128 channels are 38 blocks at 4 groups each) - and with `gn_sum` it also accumulates the GroupNorm
+// sums of what it stores (fp64, LDS per block, one global atomic per (image, group) per block - as the direct kernel's
+// epilogue does).
 constexpr int OUT_ITERS = 4;
 template <int O, int V>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(wino_out_waves(O, V)))) void wino_output_kernel(const float* __restrict__ m, long m_gs, int B, int OH, int OW, int CV,
                                                           int TH, int TW, int d, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int ss_gs, int relu,
                                                           float* __restrict__ out, int out_cs, long out_gs,
-                                                          double* __restrict__ gn_sum, int gn_groups, int gn_cpg, int Ball, int boff) {
+                                                          double* __restrict__ gn_sum, int gn_groups, int gn_cpg, int Ball, int boff, int iters) {
     constexpr int T = O + 2;
     using VT = Vec<V>;
     const int g = blockIdx.z;
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(wino_out_wa
     const long per_img = (long)d * d * TH * TW;
     const long tiles = (long)B * per_img;
     const int step = tpb ? tpb : 1;                  // tiles per iteration
-    const long tile0 = (long)blockIdx.x * step * OUT_ITERS;
+    const long tile0 = (long)blockIdx.x * step * iters;
     const bool lane_ok = cv < CV && (!tpb || (int)(threadIdx.x / CV) < tpb);
     __shared__ double gacc[2 * 32 * 2];              // [image b0 / b0+1][group][sum, sum of squares]
     const int b0 = (int)(tile0 / per_img);
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(wino_out_wa
         sc = vload<V>(scale + g * ss_gs + c);
         sh = vload<V>(shift + g * ss_gs + c);
     }
-    for (int it = 0; it < OUT_ITERS; ++it) {
+    for (int it = 0; it < iters; ++it) {
         const long tile = tile0 + (long)it * step + (tpb ? threadIdx.x / CV : 0);
         if (!lane_ok || tile >= tiles) continue;
         const TileAt ta = locate(tile, TH, TW, d);
@@ -429,8 +431,14 @@ static int run_winograd(const WinoP& q, int Ball, int G, hipStream_t st) {
     }
     // GroupNorm sums in the output transform when a block's tiles meet at most two images and vectors stay inside a group
     const int CVo = Cout / V, per_iter = CVo <= 256 ? 256 / CVo : 1;
+    // groups of tiles per block of the output transform: 4, fewer while the grid would stay below ~8 blocks per CU
+    int iters = OUT_ITERS;
+    {
+        const long groups = CVo <= 256 ? ((long)Ball * tiles_pf + per_iter - 1) / per_iter : (long)Ball * tiles_pf * (CVo / 256);
+        while (iters > 1 && groups * G / iters < 2048) iters >>= 1;
+    }
     const bool gn_here = q.gn_sum && q.gn_groups > 0 && q.gn_groups <= 32 && (Cout / q.gn_groups) % 4 == 0 &&
-                         tiles_pf >= (long)per_iter * OUT_ITERS;
+                         tiles_pf >= (long)per_iter * iters;
     for (int b0 = 0; b0 < Ball; b0 += cb) {
         const int B = Ball - b0 < cb ? Ball - b0 : cb;
         const long tiles = (long)B * tiles_pf;
@@ -461,12 +469,12 @@ static int run_winograd(const WinoP& q, int Ball, int G, hipStream_t st) {
         int rc = launch_conv(p, G * P, st);
         if (rc) return rc;
         dim3 og = grid(CVo);
-        og.x = (og.x + OUT_ITERS - 1) / OUT_ITERS;
+        og.x = (og.x + iters - 1) / iters;
         {   // M in once, the layer's output out once
             ProfScope prof("wino_output", 4.0 * G * Cout * ((double)P * tiles + (double)B * H * W), 0.0, st);
             hipLaunchKernelGGL((wino_output_kernel<O, V>), og, dim3(256), 0, st, m, (long)P * tiles * Cout, B, H, W, CVo, TH, TW, d,
                                q.scale, q.shift, q.ss_gs, q.relu, out_p, out.cs, out.gs, gn_here ? q.gn_sum : nullptr, q.gn_groups,
-                               q.gn_groups ? Cout / q.gn_groups : 1, Ball, b0);
+                               q.gn_groups ? Cout / q.gn_groups : 1, Ball, b0, iters);
         }
         QB_CHECK(hipGetLastError());
     }

@@ -26,6 +26,27 @@ def test_self_launch_two_ranks_dry():
     assert [x["rank"] for x in j["rccl_ranks"]] == [0, 1]
     assert all(x["world_size"] == 2 for x in j["rccl_ranks"])
     assert len({x["weights"] for x in j["rccl_ranks"]}) == 1        # every rank holds rank 0's weights after the broadcast
+    # the N > 1 line explains itself: per-rank step medians, what the (overlapped) gather cost the loop, what it costs alone
+    for x in j["rccl_ranks"]:
+        for k in ("step_ms_median", "step_ms_max", "elapsed_ms_per_step", "gather_ms_per_step", "gather_alone_ms", "instances_out",
+                  "frames", "backend", "device"):
+            assert k in x, k
+        assert x["backend"] == "gloo" and x["frames"] == 3 and x["gather_alone_ms"] > 0
+    g = j["gather"]
+    assert g["bytes_per_rank_per_step"] == 3 * 32 * 48 * 4
+    assert g["ms_per_step_max_over_ranks"] == max(x["gather_ms_per_step"] for x in j["rccl_ranks"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+
+
+def test_nccl_preflight_needs_enough_gpus():
+    # one rank of a 2-rank RCCL launch on a node that shows fewer GPUs than --gpus: a clear error before any process group
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"],
+                       env=_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "visible GPUs" in (r.stderr + r.stdout)
 
 
 def test_world_size_mismatch_is_an_error():
