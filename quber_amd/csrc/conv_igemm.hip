@@ -60,7 +60,7 @@ constexpr int NPL(int dt) { return dt == 3 ? 3 : 1; }     // bf16 planes per ope
 // the whole kernel and a wave per SIMD; as written all instantiations allocate the same registers.
 // waves per SIMD the kernel is compiled for: two accumulator sets (the MFMA chain and the chunk sums, below) cost the
 // 128-row tiles their third resident block; the 64x64 tiles keep five
-constexpr int igemm_occupancy(int BM, int BN, int DT = 0) { return BM == 64 ? 5 : (BM * BN >= 128 * 128 || (BM == 256 && DT == 3)) ? 2 : 3; }
+constexpr int igemm_occupancy(int BM, int BN, int DT = 0) { return BM == 64 ? (DT == 0 ? 6 : 5) : (BM * BN >= 128 * 128 || (BM == 256 && DT == 3)) ? 2 : 3; }
 
 template <int BM, int BN, int WM, int WN, int MODE, int DT = 0>
 __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(igemm_occupancy(BM, BN, DT)))) void conv_igemm_f32(const ConvP p) {
@@ -70,7 +70,8 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(ig
     constexpr int TN = BN / WN / 32;
     constexpr int AL = BM / RPP;      // float4 loads per thread per K-slice (A)
     constexpr int BL = BN / RPP;      // (B)
-    constexpr int NBUF = 1;
+    // two K-slice images (one barrier per slice) for the exact fp32 kernel on 128x128 tiles, as conv_igemm_pk: 2 x 72 KiB per CU
+    constexpr int NBUF = (DT == 0 && BM == 128 && BN == 128) ? 2 : 1;
     static_assert(BM % RPP == 0 && BN % RPP == 0, "loader geometry");
     constexpr int SW = WN * 32;        // columns staged per epilogue pass
     constexpr int SP = SW + 4;         // staging pitch (floats)
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(ig
             for (int ks = 0; ks < BK / 16; ++ks) mma_h(0, ks);
         } else {
 #pragma unroll
-            for (int ks = 0; ks < BK / 8; ++ks) mma(0, ks);
+            for (int ks = 0; ks < BK / 8; ++ks) mma(NBUF == 2 ? (kt & 1) : 0, ks);
         }
         if constexpr (DT == 0) {                   // every slice is a chunk
 #pragma unroll
@@ -390,10 +391,15 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(ig
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
                 }
         }
-        __syncthreads();
-        if (kt + 1 < nk) {
-            lstore(0);
+        if constexpr (NBUF == 2) {
+            if (kt + 1 < nk) lstore((kt + 1) & 1);      // the image nobody reads: its readers passed the barrier of slice kt - 1
             __syncthreads();
+        } else {
+            __syncthreads();
+            if (kt + 1 < nk) {
+                lstore(0);
+                __syncthreads();
+            }
         }
     }
 

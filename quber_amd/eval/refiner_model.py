@@ -103,7 +103,9 @@ class MaskRefiner:
             return np.ascontiguousarray(img)
         return qengine.resize_u8(self._dev(img), h, w, linear).cpu().numpy()
 
-    def predict(self, rgb_path, depth_path, initial_masks, fg_mask=None):
+    def _load(self, rgb_path, depth_path, initial_masks):
+        """File reading and the adapter's pre-processing of one frame (eval/refiner_model.py:224-263): everything before the
+        reference's timer starts.  Safe to run on a worker thread (predict_stream): its device work goes to a side stream."""
         rgb = np.asarray(Image.open(rgb_path).convert("RGB"))[:, :, ::-1]        # BGR like cv2.imread
         initial_masks = np.asarray(initial_masks)
         if initial_masks.dtype == np.bool_:
@@ -112,10 +114,7 @@ class MaskRefiner:
             h, w = resize_shortest_edge_shape(rgb.shape[0], rgb.shape[1], 800, 1333)
             rgb = self._resize(rgb, h, w, linear=True)                           # cv2.resize(rgb_img, (w, h))
             initial_masks = np.array([self._resize(m, h, w, linear=False) for m in initial_masks])   # INTER_NEAREST
-            start = time.time()
-            output = self.refiner_predictor.predict(np.ascontiguousarray(rgb), None, initial_masks)[0]
-            refined = output["instances"].to("cpu").pred_masks.numpy() if "instances" in output else []
-            return refined, output, time.time() - start, None
+            return {"rgb": np.ascontiguousarray(rgb), "depth": None, "masks": initial_masks, "zero_depth": None}
         depth = np.load(depth_path) if "npy" in depth_path else np.asarray(Image.open(depth_path))
         rgb = self._resize(rgb, H, W, linear=True)                               # cv2.resize(rgb_img, (W, H))
         zero_depth = np.where(depth == 0)
@@ -127,9 +126,18 @@ class MaskRefiner:
         depth = self._resize(depth, H, W, linear=False)                          # cv2.resize(..., INTER_NEAREST)
         if self.inpaint:
             depth = inpaint_depth(depth)                                         # refiner_model.py:255
+        return {"rgb": np.ascontiguousarray(rgb), "depth": depth, "masks": initial_masks, "zero_depth": zero_depth}
 
+    def _refine(self, fr):
+        """The reference's timed region and what follows it (eval/refiner_model.py:265-297) on a loaded frame."""
+        if self.dataset == "armbench":
+            start = time.time()
+            output = self.refiner_predictor.predict(fr["rgb"], None, fr["masks"])[0]
+            refined = output["instances"].to("cpu").pred_masks.numpy() if "instances" in output else []
+            return refined, output, time.time() - start, None
+        rgb, depth, zero_depth = fr["rgb"], fr["depth"], fr["zero_depth"]
         start = time.time()
-        output = self.refiner_predictor.predict(np.ascontiguousarray(rgb), depth, initial_masks)[0]
+        output = self.refiner_predictor.predict(rgb, depth, fr["masks"])[0]
         if "instances" not in output:
             refined = []
         else:
@@ -152,3 +160,29 @@ class MaskRefiner:
                 out.append(m)
             refined = np.asarray(out)
         return refined, output, elapsed, fg
+
+    def predict(self, rgb_path, depth_path, initial_masks, fg_mask=None):
+        return self._refine(self._load(rgb_path, depth_path, initial_masks))
+
+    def predict_stream(self, items):
+        """items: iterable of (rgb_path, depth_path, initial_masks[, fg_mask]) -> yields predict()'s tuple per item, in order.
+        The reference's evaluation loop (eval/eval_utils.py:277) calls predict() frame after frame; the host side of a frame -
+        file decoding and, above all, the TELEA depth in-painting (14 ms, three times the refiner's GPU time) - is independent of
+        the previous frame's refinement, so it runs one frame ahead on a worker thread (the in-painting is a ctypes call and
+        releases the GIL; the worker's device work - resize, depth normalisation - goes to its own HIP stream)."""
+        from concurrent.futures import ThreadPoolExecutor
+        side = torch.cuda.Stream(device=self.refiner_predictor.device)
+
+        def load(item):
+            with torch.cuda.stream(side):
+                return self._load(item[0], item[1], item[2])
+
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            it = iter(items)
+            nxt = next(it, None)
+            fut = pool.submit(load, nxt) if nxt is not None else None
+            while fut is not None:
+                fr = fut.result()
+                nxt = next(it, None)
+                fut = pool.submit(load, nxt) if nxt is not None else None
+                yield self._refine(fr)

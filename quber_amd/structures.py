@@ -67,7 +67,9 @@ class Instances:
             if cpu and k in host:
                 buf, ev = host[k]
                 ev.synchronize()
-                out.set(k, buf.clone())          # the pinned staging buffer is reused by later calls: the caller owns a copy
+                # the pinned staging buffer is reused by later calls: the caller owns a copy - in ordinary (pageable) memory:
+                # clone() of a pinned tensor allocates PINNED memory again (a hipHostMalloc of several MB: 90 ms every few calls)
+                out.set(k, torch.empty(buf.shape, dtype=buf.dtype).copy_(buf))
             else:
                 out.set(k, v.to(*args, **kwargs) if hasattr(v, "to") else v)
         return out

@@ -178,6 +178,28 @@ def test_adapter_from_files(tmp_path):
             assert not masks[:, :10, :10].any()            # OCID zero-depth masking (refiner_model.py:279-288)
 
 
+def test_adapter_stream_equals_sequential(tmp_path):
+    """MaskRefiner.predict_stream: the host side of frame i + 1 (file decoding, resize, TELEA in-painting) on a worker
+    thread while frame i is refined - the same results as predict() called frame after frame, in the same order."""
+    from PIL import Image
+    from quber_amd.eval.refiner_model import MaskRefiner
+    items = []
+    for i in range(4):
+        sc = synth.make_scene(20 + i, 480, 640, 5)
+        Image.fromarray(sc["rgb"][:, :, ::-1].copy()).save(tmp_path / f"rgb{i}.png")
+        depth_mm = (sc["depth"][:, :, 0].astype(np.uint16) * 5 + 300)
+        depth_mm[40 + 10 * i:70 + 10 * i, 100:180] = 0                      # a hole to in-paint
+        Image.fromarray(depth_mm).save(tmp_path / f"depth{i}.png")
+        items.append((str(tmp_path / f"rgb{i}.png"), str(tmp_path / f"depth{i}.png"), sc["masks"] != 0, None))
+    ref = MaskRefiner(None, None, dataset="OSD")
+    seq = [ref.predict(*it) for it in items]
+    got = list(ref.predict_stream(items))
+    assert len(got) == len(seq)
+    for (m0, o0, _, _), (m1, o1, _, _) in zip(seq, got):
+        np.testing.assert_array_equal(np.asarray(m0), np.asarray(m1))
+        assert torch.equal(o0["sem_seg"], o1["sem_seg"]) and torch.equal(o0["panoptic_seg"][0], o1["panoptic_seg"][0])
+
+
 def test_adapter_armbench_branch(tmp_path):
     """eval/refiner_model.py:226-244: RGB only, image resized to shortest edge 800 / longest 1333 with cv2.resize, the
     initial masks with INTER_NEAREST, refined masks returned at THAT size, fg_mask None."""

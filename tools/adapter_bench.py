@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""End-to-end rate of the evaluation adapter (quber_amd/eval/refiner_model.py:MaskRefiner), file -> refined masks, as
+eval/eval_utils.py:277 drives it: predict() frame after frame against predict_stream() (host pre-processing one frame
+ahead on a worker thread).  Synthetic 640x480 frames with depth holes (so the TELEA in-painting has work), written to a
+temporary directory as PNG.  GPU box only.  usage: tools/adapter_bench.py [frames=40] [instances=20]"""
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+from PIL import Image
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from quber_amd import arch, synth  # noqa: E402
+from quber_amd.eval.refiner_model import MaskRefiner, inpaint_depth  # noqa: E402
+
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+with tempfile.TemporaryDirectory() as d:
+    items = []
+    rng = np.random.default_rng(0)
+    for i in range(8):
+        sc = synth.make_scene(30 + i, 480, 640, N)
+        Image.fromarray(sc["rgb"][:, :, ::-1].copy()).save(os.path.join(d, f"rgb{i}.png"))
+        mm = sc["depth"][:, :, 0].astype(np.uint16) * 5 + 300
+        for _ in range(12):                                            # ~8 000 zero-depth pixels in a dozen holes
+            y, x = int(rng.integers(0, 440)), int(rng.integers(0, 600))
+            mm[y:y + 22, x:x + 30] = 0
+        Image.fromarray(mm).save(os.path.join(d, f"depth{i}.png"))
+        items.append((os.path.join(d, f"rgb{i}.png"), os.path.join(d, f"depth{i}.png"), sc["masks"] != 0, None))
+    ref = MaskRefiner(None, None, dataset="OSD")
+    ref.refiner_predictor.model.state_dict = arch.init_state_dict(seed=0, loud_heads=True, center_bias=-1.68)
+    ref.refiner_predictor.model._engines.clear()
+    work = [items[i % 8] for i in range(F)]
+    for it in items[:3]:
+        ref.predict(*it)
+    t0 = time.perf_counter()
+    refined = [ref.predict(*it)[2] for it in work]
+    seq = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    out = list(ref.predict_stream(work))
+    stream = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for it in work[:8]:
+        ref._load(*it[:3])
+    load = (time.perf_counter() - t0) / 8
+    fr = ref._load(*items[0][:3])
+    t0 = time.perf_counter()
+    inpaint_depth(np.ascontiguousarray(np.where(fr["depth"] > 0, fr["depth"], 0)))
+    print(f"{F} frames 640x480, N = {N}: predict() frame after frame {F / seq:.1f} frames/s ({seq / F * 1e3:.2f} ms/frame; reference-timed region "
+          f"median {np.median(refined) * 1e3:.2f} ms); predict_stream() {F / stream:.1f} frames/s ({stream / F * 1e3:.2f} ms/frame); "
+          f"host pre-processing alone (file decode + resize + normalise + TELEA) {load * 1e3:.2f} ms/frame")
