@@ -164,25 +164,33 @@ class MaskRefiner:
     def predict(self, rgb_path, depth_path, initial_masks, fg_mask=None):
         return self._refine(self._load(rgb_path, depth_path, initial_masks))
 
-    def predict_stream(self, items):
+    def predict_stream(self, items, workers=2):
         """items: iterable of (rgb_path, depth_path, initial_masks[, fg_mask]) -> yields predict()'s tuple per item, in order.
         The reference's evaluation loop (eval/eval_utils.py:277) calls predict() frame after frame; the host side of a frame -
-        file decoding and, above all, the TELEA depth in-painting (14 ms, three times the refiner's GPU time) - is independent of
-        the previous frame's refinement, so it runs one frame ahead on a worker thread (the in-painting is a ctypes call and
-        releases the GIL; the worker's device work - resize, depth normalisation - goes to its own HIP stream)."""
+        file decoding and, above all, the TELEA depth in-painting (9-14 ms, two to three times the refiner's GPU time) - is
+        independent of the previous frame's refinement, so it runs ahead on `workers` threads (the in-painting is a ctypes call
+        and releases the GIL; the workers' device work - resize, depth normalisation - goes to their own HIP stream)."""
+        from collections import deque
         from concurrent.futures import ThreadPoolExecutor
-        side = torch.cuda.Stream(device=self.refiner_predictor.device)
+        dev = self.refiner_predictor.device
+        sides = {}
 
         def load(item):
+            import threading
+            side = sides.setdefault(threading.get_ident(), torch.cuda.Stream(device=dev))
             with torch.cuda.stream(side):
                 return self._load(item[0], item[1], item[2])
 
-        with ThreadPoolExecutor(max_workers=1) as pool:
+        with ThreadPoolExecutor(max_workers=max(1, workers)) as pool:
             it = iter(items)
-            nxt = next(it, None)
-            fut = pool.submit(load, nxt) if nxt is not None else None
-            while fut is not None:
-                fr = fut.result()
+            ahead = deque()
+            for item in it:
+                ahead.append(pool.submit(load, item))
+                if len(ahead) > workers:
+                    break
+            while ahead:
+                fr = ahead.popleft().result()
                 nxt = next(it, None)
-                fut = pool.submit(load, nxt) if nxt is not None else None
+                if nxt is not None:
+                    ahead.append(pool.submit(load, nxt))
                 yield self._refine(fr)

@@ -36,7 +36,7 @@ def load_checkpoint(path):
 class _FrameStaging:
     """Buffers of the batch-1 call path for one frame size, allocated once: ONE pinned host block and ONE device block for the
     frame's inputs (bgr | depth | initial masks, uploaded in a few pipelined pieces), the device-side intermediates, and pinned
-    host blocks for what comes back (the small per-instance tables; the refined masks, double-buffered)."""
+    word for the instance count."""
 
     def __init__(self, eng, n_cap):
         H, W, dev = eng.H, eng.W, eng.device
@@ -48,18 +48,7 @@ class _FrameStaging:
         self.offsets = torch.empty((1, 3, H, W), dtype=torch.float32, device=dev)
         self.post = eng.alloc_post(1)
         self.pin_count = torch.empty((1,), dtype=torch.int32).pin_memory()
-        self.pin_masks = [None, None]                # grown to the largest count seen, in steps of 16 instances
-        self.hw = (H, W)
-        self.slot = 0
         self.done = torch.cuda.Event()
-
-    def host_masks(self, k):
-        self.slot ^= 1
-        buf = self.pin_masks[self.slot]
-        if buf is None or buf.shape[0] < k:
-            buf = torch.empty(((k + 15) // 16 * 16,) + self.hw, dtype=torch.bool).pin_memory()
-            self.pin_masks[self.slot] = buf
-        return buf[:k]
 
 
 class RefinerModel:
@@ -140,8 +129,7 @@ class RefinerModel:
     def predict_one(self, bgr, depth, masks):
         """The reference's call path (one frame per call, predictor.py:287-359) with nothing allocated per call but the
         outputs: the inputs go through one pinned block in a few pipelined H2D copies; the instance count comes back through
-        a pinned word; exactly `count` masks are extracted and their D2H copy is started at once (Instances.prefetch_host), so
-        that the caller's ``output['instances'].to('cpu').pred_masks`` (eval/refiner_model.py:267-271) finds it done."""
+        a pinned word and exactly `count` masks are extracted."""
         H, W = bgr.shape[:2]
         n = int(masks.shape[0])
         eng = self.engine_for(H, W, 1, n)
@@ -181,14 +169,9 @@ class RefinerModel:
         masks_b = None
         if k > 0:
             masks_b = eng.extract_masks(post, k)[0].view(torch.bool)      # the kernel writes 0 / 1 bytes
-        r = self.frame_dict(eng, logits[0], post_out, 0, k, masks_b)
-        if k > 0:
-            host = stg.host_masks(k)
-            host.copy_(masks_b, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            r["instances"].prefetch_host(pred_masks=(host, ev))
-        return r
+        # (the caller's ``.to('cpu')`` of the masks is a plain D2H copy into fresh pageable memory: 0.17 ms for 5 MB, which a
+        # prefetch into a pinned buffer plus the copy out of it does not beat - tools/predict_profile.py)
+        return self.frame_dict(eng, logits[0], post_out, 0, k, masks_b)
 
     def __call__(self, batched_inputs):
         dev = self.device

@@ -53,23 +53,8 @@ class Instances:
             return len(v)
         return 0
 
-    def prefetch_host(self, **host):
-        """name -> (pinned host tensor, event): a device-to-host copy of that field already in flight.  `to('cpu')` then
-        waits for the event and hands out a fresh copy of the pinned buffer instead of issuing a blocking copy."""
-        self._host = host
-
     def to(self, *args, **kwargs):
         out = Instances(self._image_size)
-        host = getattr(self, "_host", None) or {}
-        dev = args[0] if args else kwargs.get("device")
-        cpu = str(dev) == "cpu"
         for k, v in self._fields.items():
-            if cpu and k in host:
-                buf, ev = host[k]
-                ev.synchronize()
-                # the pinned staging buffer is reused by later calls: the caller owns a copy - in ordinary (pageable) memory:
-                # clone() of a pinned tensor allocates PINNED memory again (a hipHostMalloc of several MB: 90 ms every few calls)
-                out.set(k, torch.empty(buf.shape, dtype=buf.dtype).copy_(buf))
-            else:
-                out.set(k, v.to(*args, **kwargs) if hasattr(v, "to") else v)
+            out.set(k, v.to(*args, **kwargs) if hasattr(v, "to") else v)
         return out

@@ -46,6 +46,16 @@ with tempfile.TemporaryDirectory() as d:
     for it in work[:8]:
         ref._load(*it[:3])
     load = (time.perf_counter() - t0) / 8
+    # what the load consists of (one frame)
+    import torch
+    from quber_amd import engine as qengine
+    ph = {}
+    t = time.perf_counter(); rgb = np.asarray(Image.open(items[0][0]).convert("RGB"))[:, :, ::-1]; ph["decode rgb png"] = time.perf_counter() - t
+    t = time.perf_counter(); dep = np.asarray(Image.open(items[0][1])); ph["decode depth png"] = time.perf_counter() - t
+    t = time.perf_counter(); z = np.where(dep == 0); ph["np.where(depth == 0)"] = time.perf_counter() - t
+    t = time.perf_counter(); d3 = qengine.normalize_depth(ref._dev(np.array(dep)), 250.0, 1500.0)[0].cpu().numpy(); ph["normalize_depth (device, incl. copies)"] = time.perf_counter() - t
+    t = time.perf_counter(); inpaint_depth(d3); ph["inpaint_depth (host TELEA)"] = time.perf_counter() - t
+    print({k: round(v * 1e3, 2) for k, v in ph.items()})
     fr = ref._load(*items[0][:3])
     t0 = time.perf_counter()
     inpaint_depth(np.ascontiguousarray(np.where(fr["depth"] > 0, fr["depth"], 0)))
