@@ -443,15 +443,22 @@ static int run_winograd(const WinoP& q, int Ball, int G, hipStream_t st) {
         const int B = Ball - b0 < cb ? Ball - b0 : cb;
         const long tiles = (long)B * tiles_pf;
         float* v = q.ws;
-        float* m = q.ws + (size_t)G * P * tiles * Cin;
         auto grid = [&](int CV) {
             return CV <= 256 ? dim3((unsigned)((tiles + 256 / CV - 1) / (256 / CV)), 1, G) : dim3((unsigned)tiles, CV / 256, G);
         };
         const float* in_p = in.p + (size_t)b0 * H * W * in.cs;
         float* out_p = out.p + (size_t)b0 * H * W * out.cs;
+        // Several groups reading ONE input (the heads of a hierarchy level: in.gs == 0): V is computed once and every
+        // group's GEMMs read it (was: G identical copies written and re-read - 1 GB per step for the three heads)
+        const bool shared_v = G > 1 && in.gs == 0 && !np.stats;
+        const int Gv = shared_v ? 1 : G;
+        float* m = q.ws + (size_t)Gv * P * tiles * Cin;
+        auto grid_v = [&](int CV) {
+            return CV <= 256 ? dim3((unsigned)((tiles + 256 / CV - 1) / (256 / CV)), 1, Gv) : dim3((unsigned)tiles, CV / 256, Gv);
+        };
         {   // activations in once, V = P / m^2 times their size out
-            ProfScope prof("wino_input", 4.0 * G * Cin * ((double)B * H * W + (double)P * tiles), 0.0, st);
-            hipLaunchKernelGGL((wino_input_kernel<O, V>), grid(Cin / V), dim3(256), 0, st, in_p, B, H, W, Cin / V, in.cs, in.gs, TH,
+            ProfScope prof("wino_input", 4.0 * Gv * Cin * ((double)B * H * W + (double)P * tiles), 0.0, st);
+            hipLaunchKernelGGL((wino_input_kernel<O, V>), grid_v(Cin / V), dim3(256), 0, st, in_p, B, H, W, Cin / V, in.cs, in.gs, TH,
                                TW, d, v, (long)P * tiles * Cin, np, Ball, b0);
         }
         QB_CHECK(hipGetLastError());
@@ -466,8 +473,17 @@ static int run_winograd(const WinoP& q, int Ball, int G, hipStream_t st) {
         p.ws = q.splitk_ws; p.ws_floats = q.splitk_floats;
         p.tag = "wino_gemm";
         p.bf16 = q.dtype == 3 ? 3 : 0;
-        int rc = launch_conv(p, G * P, st);
-        if (rc) return rc;
+        if (shared_v) {
+            for (int g = 0; g < G; ++g) {          // P position-GEMMs per group, all on the one V
+                p.w = q.u + (size_t)g * P * Cout * Cin;
+                p.out = m + (size_t)g * P * tiles * Cout;
+                const int rc = launch_conv(p, P, st);
+                if (rc) return rc;
+            }
+        } else {
+            const int rc = launch_conv(p, G * P, st);
+            if (rc) return rc;
+        }
         dim3 og = grid(CVo);
         og.x = (og.x + iters - 1) / iters;
         {   // M in once, the layer's output out once

@@ -162,10 +162,12 @@ def decide(lg):
     return {"fg": fg[0], "ctr": ctr, "cid": cid, "pan": postproc_ref.merge(ins, fg)[0]}
 
 
-def explain_label_flips(lg_hip, lg_o32, lg_64, pan_hip=None, top_k=200, threshold=0.3, nms_kernel=7, dec_hip=None, dec_o32=None):
+def explain_label_flips(lg_hip, lg_o32, lg_64, pan_hip=None, top_k=200, threshold=0.3, nms_kernel=7, dec_hip=None, dec_o32=None,
+                        eps_logit=None, eps_dist=None):
     """One frame.  lg_hip, lg_o32 f32 [8,H,W] (or their precomputed decide() results); lg_64 float64 [8,H,W]; pan_hip: the HIP
     path's own label map (checked equal to the oracle's post-processing of the HIP logits).  Returns a dict of counts;
     raises AssertionError on an unexplained flip."""
+    EPS_LOGIT_, EPS_DIST_ = (EPS_LOGIT if eps_logit is None else eps_logit), (EPS_DIST if eps_dist is None else eps_dist)
     dh = dec_hip if dec_hip is not None else decide(lg_hip)
     do = dec_o32 if dec_o32 is not None else decide(lg_o32)
     h, w = dh["fg"].shape
@@ -202,7 +204,7 @@ def explain_label_flips(lg_hip, lg_o32, lg_64, pan_hip=None, top_k=200, threshol
                 gaps.append(abs(v - kth) / 2.0)
             g = min(gaps)
             rep["max_centre_gap_at_C"] = max(rep["max_centre_gap_at_C"], g)
-            assert g <= EPS_LOGIT, (f"centre ({y},{x}) is in one centre list only but is no float64 near-tie: c64 = {v:.6f}, "
+            assert g <= EPS_LOGIT_, (f"centre ({y},{x}) is in one centre list only but is no float64 near-tie: c64 = {v:.6f}, "
                                     f"|c-0.3| = {gaps[0]:.2e}, NMS gap/2 = {gaps[1]:.2e}")
     common = set_h & set_o
     # ---- per-pixel classes ----
@@ -213,7 +215,7 @@ def explain_label_flips(lg_hip, lg_o32, lg_64, pan_hip=None, top_k=200, threshol
         m = fg64[py[a], px[a]].abs()
         rep["A_fg_threshold"] = int(a.sum())
         rep["max_abs_fg64_at_A"] = float(m.max())
-        assert float(m.max()) <= EPS_LOGIT, f"foreground flip away from the threshold: |fg64| = {float(m.max()):.2e}"
+        assert float(m.max()) <= EPS_LOGIT_, f"foreground flip away from the threshold: |fg64| = {float(m.max()):.2e}"
     rest = ~a
     ch, co = cid_h[py, px], cid_o[py, px]
     b = rest & (ch != co)
@@ -233,7 +235,7 @@ def explain_label_flips(lg_hip, lg_o32, lg_64, pan_hip=None, top_k=200, threshol
             gap = (dist(ch[b][is_common]) - dist(co[b][is_common])).abs()
             rep["B_argmin_tie"] = int(is_common.sum())
             rep["max_dist_gap_at_B"] = float(gap.max())
-            assert float(gap.max()) <= EPS_DIST, f"argmin flip between centres {float(gap.max()):.2e} px apart in float64 (bar {EPS_DIST:.2e})"
+            assert float(gap.max()) <= EPS_DIST_, f"argmin flip between centres {float(gap.max()):.2e} px apart in float64 (bar {EPS_DIST_:.2e})"
     d = rest & (ch == co)
     if bool(d.any()):
         # same foreground decision, same centre: the label differs because an instance crossed the 512-px filter in one map

@@ -40,25 +40,37 @@ def report(a):
     plan, B = meta["plan"], meta["batch"]
     convs = [p for p in plan if p[1] == "conv"]
     allk = sorted(csv.DictReader(open(a.trace)), key=lambda r: int(r["Start_Timestamp"]))
-    idx = [i for i, r in enumerate(allk) if "conv_igemm" in r["Kernel_Name"]]
-    n = len(convs)
-    assert len(idx) % n == 0 and len(idx) >= n, (len(idx), n)
     dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+    name = lambda r: r["Kernel_Name"]
+    # one group of launches per convolution op: [wino_input] conv_igemm+ (pk_fixup | splitk_reduce)* [wino_output]; a Winograd op
+    # whose groups share one input transform (the heads of a level) has several GEMM launches between its two transforms
+    groups, i = [], 0
+    while i < len(allk):
+        n_ = name(allk[i])
+        if "wino_input" in n_:
+            j = i + 1
+            while j < len(allk) and "wino_output" not in name(allk[j]):
+                j += 1
+            groups.append(("winograd", allk[i:j + 1]))
+            i = j + 1
+        elif "conv_igemm" in n_:
+            j = i + 1
+            while j < len(allk) and any(t in name(allk[j]) for t in ("splitk_reduce", "pk_fixup")):
+                j += 1
+            groups.append(("direct", allk[i:j]))
+            i = j
+        else:
+            i += 1
+    n = len(convs)
+    assert len(groups) % n == 0 and len(groups) >= n, (len(groups), n)
     tot_t = tot_f = 0.0
     out = ["| # | layer (first weight key) | path, GEMM tile | GFLOP (batch %d, algorithmic) | ms | TFLOP/s |" % B,
            "|---|---|---|---|---|---|"]
-    for i, (c, k) in enumerate(zip(convs, idx[-n:])):
-        r = allk[k]
-        ms, path = dur(r), "direct"
-        if k > 0 and "wino_input" in allk[k - 1]["Kernel_Name"]:
-            ms += dur(allk[k - 1])
-            path = "winograd"
-        nxt = k + 1
-        while nxt < len(allk) and any(t in allk[nxt]["Kernel_Name"] for t in ("splitk_reduce", "pk_fixup", "wino_output")):
-            ms += dur(allk[nxt])
-            nxt += 1
+    for i, (c, (path, ks)) in enumerate(zip(convs, groups[-n:])):
+        ms = sum(dur(r) for r in ks)
+        r = next(k for k in ks if "conv_igemm" in name(k))
         fl = c[2] * B
-        tile = ("persistent " if "conv_igemm_pk" in r["Kernel_Name"] else "") + r["Kernel_Name"].split("<")[1].split(">")[0].replace(" ", "")
+        tile = ("persistent " if "conv_igemm_pk" in name(r) else "") + name(r).split("<")[1].split(">")[0].replace(" ", "")
         out.append("| %d | %s | %s %s | %.1f | %.3f | %.1f |" % (i, c[0].replace("backbone.", "b.").replace("ins_embed_head.", "h."),
                                                                path, tile, fl / 1e9, ms, fl / ms / 1e9))
         tot_t += ms
