@@ -216,6 +216,8 @@ int quber_inpaint_telea_u8(const uint8_t* host_img, const uint8_t* host_mask, in
 /* ---- introspection / kernel-level entry points used by the parity tests and the benchmark ---- */
 /* device pointer + NHWC geometry of a named intermediate of the last quber_forward ("res2", "res3", "res5", "y", ...) */
 int quber_debug_tensor(quber_ctx* ctx, const char* name, float** dev_ptr, int32_t* dims4, int32_t* channel_stride);
+/* bytes per element of that intermediate: 4 (fp32), or 2 (fp16) in the fp16 data path (compute_dtype 2); 0 = no such tensor */
+int32_t quber_debug_tensor_elem_size(quber_ctx* ctx, const char* name);
 /* algorithmic FLOPs of one forward at batch 1 (2 * MACs of every convolution) */
 double quber_forward_flops(quber_ctx* ctx);
 /* FLOPs the matrix pipe actually executes per forward at batch 1: a layer planned as Winograd F(m x m,3x3) counts

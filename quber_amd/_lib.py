@@ -62,6 +62,7 @@ SIGNATURES = {
     "quber_inpaint_telea_u8": (C.c_int, [_P, _P, _I, _I, _I, _P]),
     "quber_resize_u8": (C.c_int, [_P, _I, _I, _I, _P, _I, _I, _I, _P]),
     "quber_debug_tensor": (C.c_int, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(_I * 4), C.POINTER(_I)]),
+    "quber_debug_tensor_elem_size": (C.c_int32, [_P, C.c_char_p]),
     "quber_forward_flops": (C.c_double, [_P]),
     "quber_forward_flops_executed": (C.c_double, [_P]),
     "quber_set_tuning": (None, [_I, _I]),

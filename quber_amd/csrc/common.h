@@ -11,10 +11,12 @@ namespace quber {
 // `gs` is the element distance between the G independent operand sets of one grouped launch
 // (blockIdx.z), e.g. the rgb / depth encoder streams.
 struct View {
-    float* p = nullptr;
+    float* p = nullptr;      // base address (typed float* whatever the element type: never indexed directly - use at())
     int B = 0, H = 0, W = 0, C = 0;
-    int cs = 0;
-    long gs = 0;
+    int cs = 0;              // channel stride of a pixel, in elements
+    long gs = 0;             // group stride, in elements
+    int es = 4;              // element size in bytes: 4 = fp32 (default), 2 = fp16 (the fp16 data path, compute_dtype 2)
+    float* at(long elems) const { return p ? reinterpret_cast<float*>(reinterpret_cast<char*>(p) + elems * es) : nullptr; }
 };
 
 struct ConvP {
@@ -53,6 +55,7 @@ struct ConvP {
     const float* in2;
     int in2_cs, H2, W2, stride2, K1, pk_in2_bytes;
     long in2_gs;
+    int es;              // element size of the activations (in / in2 / res / out): 4 = fp32, 2 = fp16 in HBM (conv_igemm_f32 DT 4)
     int acc_chunk;       // K-slices per accumulation chunk (two-level fp32 accumulation: the MFMA accumulator is folded into a
                          // second register set every acc_chunk slices); 0 = one sequential chain over K
     int bf16;            // quber_config.compute_dtype: 0 = fp32 MFMA, 1 = bf16 / 2 = fp16 operands, 3 = fp32 operands split into 3 bf16 terms
@@ -126,7 +129,7 @@ int launch_conv_dual(ConvP p, int G, hipStream_t st);   // 0 done, 1 not covered
 int pk_read_stamps(unsigned long long* dst, int n);
 int pk_read_span(unsigned long long* dst, int n);
 #endif
-int launch_preprocess(const uint8_t* rgb, const uint8_t* depth, const float* offs, float* x, int B, int Bcap,
+int launch_preprocess(const uint8_t* rgb, const uint8_t* depth, const float* offs, const View& x, int B, int Bcap,
                       int H, int W, const float* mean6, const float* std6, int streams, hipStream_t st);
 int launch_maxpool3x3s2(const View& in, const View& out, int B, int G, hipStream_t st);
 int launch_zero(void* p, size_t bytes, hipStream_t st);

@@ -42,6 +42,7 @@ constexpr int PITCH = 36;
 // MFMAs take 6/16 of the time of the fp32 MFMAs they replace.
 template <int DT> struct Half16 { using T = __bf16; };
 template <> struct Half16<2> { using T = _Float16; };
+template <> struct Half16<4> { using T = _Float16; };     // DT 4: fp16 activations and weights in HBM (the fp16 data path)
 constexpr int PITCH_H = 40;   // 16-bit elements per LDS row
 constexpr int NPL(int dt) { return dt == 3 ? 3 : 1; }     // bf16 planes per operand
 
@@ -71,11 +72,14 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(ig
     constexpr int AL = BM / RPP;      // float4 loads per thread per K-slice (A)
     constexpr int BL = BN / RPP;      // (B)
     // two K-slice images (one barrier per slice) for the exact fp32 kernel on 128x128 tiles, as conv_igemm_pk: 2 x 72 KiB per CU
-    constexpr int NBUF = (DT == 0 && BM == 128 && BN == 128) ? 2 : 1;
+    constexpr int NBUF = ((DT == 0 || DT == 4) && BM == 128 && BN == 128) ? 2 : 1;
+    // DT 4 (fp16 in HBM): the K-slice image holds the operands' bytes as they are - a row of 32 floats is a row of 64 halfs,
+    // so the loader, the image and its pitch are those of the fp32 kernel and a slice carries twice the K
+    constexpr bool RAW = DT == 0 || DT == 4;
     static_assert(BM % RPP == 0 && BN % RPP == 0, "loader geometry");
     constexpr int SW = WN * 32;        // columns staged per epilogue pass
     constexpr int SP = SW + 4;         // staging pitch (floats)
-    constexpr int KSLICE_FLOATS = DT ? NPL(DT) * NBUF * (BM + BN) * PITCH_H / 2 : NBUF * (BM + BN) * PITCH;
+    constexpr int KSLICE_FLOATS = !RAW ? NPL(DT) * NBUF * (BM + BN) * PITCH_H / 2 : NBUF * (BM + BN) * PITCH;
     constexpr int SMEM_FLOATS = KSLICE_FLOATS > BM * SP ? KSLICE_FLOATS : BM * SP;
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     float* const As = smem;
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(ig
             for (int i = 0; i < BL; ++i) split(rb[i], &Bh[(lrow + RPP * i) * PITCH_H + kq], BN * PITCH_H);
             return;
         }
-        if constexpr (DT != 0) {
+        if constexpr (!RAW) {
 #pragma unroll
             for (int i = 0; i < AL; ++i) {
                 const f32x4 v = aok[i] ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -300,6 +304,21 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(ig
                 if constexpr (DT == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
                 else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
             }
+    };
+    // fp16 in HBM (DT 4): the image rows are PITCH floats = 2 * PITCH halfs; MFMA step ks multiplies k = 16 ks + 8 h + (0..7) of the
+    // slice's 64 halfs: one 16-byte fragment read per operand tile, at the byte offsets the fp32 kernel reads its f32x4 from
+    auto mma_raw16 = [&](int buf, int ks) __attribute__((always_inline)) {
+        const H16* ap = reinterpret_cast<const H16*>(&As[buf * BM * PITCH + (wm * TM * 32 + r) * PITCH]) + 8 * h + ks * 16;
+        const H16* bp = reinterpret_cast<const H16*>(&Bs[buf * BN * PITCH + (wn * 32 + r) * PITCH]) + 8 * h + ks * 16;
+        h16x8 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const h16x8*>(ap + i * 32 * 2 * PITCH);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const h16x8*>(bp + j * WN * 32 * 2 * PITCH);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
     };
     // bf16x3: three fragments per operand tile, six MFMAs per output tile and k-step, smallest partial products first
     auto mma_x3 = [&](int ks) __attribute__((always_inline)) {
@@ -368,6 +387,9 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(ig
         if constexpr (DT == 3) {
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) mma_x3(ks);
+        } else if constexpr (DT == 4) {
+#pragma unroll
+            for (int ks = 0; ks < BK / 8; ++ks) mma_raw16(NBUF == 2 ? (kt & 1) : 0, ks);
         } else if constexpr (DT != 0) {
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) mma_h(0, ks);
@@ -408,10 +430,16 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(ig
     // stores (and residual loads) are 16 bytes per lane over WN*32 consecutive channels of a pixel.
     // raw: partial tile into slab (partition s, group g) = ws[(s*G + g) * ws_rows * Cout ...], rows counted from
     // ws_row0; the affine, residual and ReLU are applied by splitk_reduce_kernel after the slabs have been summed
+    // (DT 4: the tensors are fp16 - out / res are element pointers of 2 bytes, the split-K workspace stays fp32)
+    constexpr bool HOUT = DT == 4;
     float* __restrict__ out = raw ? p.ws + (((long)part * gridDim.z + g) * p.ws_rows - p.ws_row0) * (long)p.Cout
-                                  : p.out + (long)g * p.out_gs;
+                                  : HOUT ? reinterpret_cast<float*>(reinterpret_cast<H16*>(p.out) + (long)g * p.out_gs)
+                                         : p.out + (long)g * p.out_gs;
     const int out_cs = raw ? p.Cout : p.out_cs;
-    const float* __restrict__ res = (p.res && !raw) ? p.res + (long)g * p.res_gs : nullptr;
+    const float* __restrict__ res = (p.res && !raw) ? (HOUT ? reinterpret_cast<const float*>(reinterpret_cast<const H16*>(p.res) + (long)g * p.res_gs)
+                                                             : p.res + (long)g * p.res_gs)
+                                                    : nullptr;
+    const bool hstore = HOUT && !raw;
     const float* __restrict__ scale = (p.scale && !raw) ? p.scale + g * p.ss_gs : nullptr;
     const float* __restrict__ shift = (p.shift && !raw) ? p.shift + g * p.ss_gs : nullptr;
     const bool relu = p.relu && !raw;
@@ -455,7 +483,13 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(ig
                         v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
                     }
                     if (res) {
-                        const float4 rv = *reinterpret_cast<const float4*>(res + (long)m * p.res_cs + n);
+                        float4 rv;
+                        if constexpr (HOUT) {
+                            const h16x4 rh = *reinterpret_cast<const h16x4*>(reinterpret_cast<const H16*>(res) + (long)m * p.res_cs + n);
+                            rv = make_float4((float)rh.x, (float)rh.y, (float)rh.z, (float)rh.w);
+                        } else {
+                            rv = *reinterpret_cast<const float4*>(res + (long)m * p.res_cs + n);
+                        }
                         v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
                     }
                     if (relu) {
@@ -466,7 +500,13 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(ig
                         v.x = v.x > 0.f ? v.x : v.x * sl.x; v.y = v.y > 0.f ? v.y : v.y * sl.y;
                         v.z = v.z > 0.f ? v.z : v.z * sl.z; v.w = v.w > 0.f ? v.w : v.w * sl.w;
                     }
-                    *reinterpret_cast<float4*>(out + (long)m * out_cs + n) = v;
+                    if (hstore) {           // rounded once to fp16; the GroupNorm sums are of the stored values
+                        const h16x4 hv = {(H16)v.x, (H16)v.y, (H16)v.z, (H16)v.w};
+                        *reinterpret_cast<h16x4*>(reinterpret_cast<H16*>(out) + (long)m * out_cs + n) = hv;
+                        v = make_float4((float)hv.x, (float)hv.y, (float)hv.z, (float)hv.w);
+                    } else {
+                        *reinterpret_cast<float4*>(out + (long)m * out_cs + n) = v;
+                    }
                     if (gn) {
                         const double a = (double)v.x + (double)v.y + (double)v.z + (double)v.w;
                         const double b = (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
@@ -493,10 +533,11 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(ig
                 if (m < p.M && n < p.Cout) {
                     float v = smem[row * SP + q];
                     if (scale) v = fmaf(v, scale[n], shift[n]);
-                    if (res) v += res[(long)m * p.res_cs + n];
+                    if (res) v += HOUT ? (float)reinterpret_cast<const H16*>(res)[(long)m * p.res_cs + n] : res[(long)m * p.res_cs + n];
                     if (relu) v = fmaxf(v, 0.f);
                     if (prelu) v = v > 0.f ? v : v * prelu[n];
-                    out[(long)m * out_cs + n] = v;
+                    if (hstore) reinterpret_cast<H16*>(out)[(long)m * out_cs + n] = (H16)v;
+                    else out[(long)m * out_cs + n] = v;
                 }
             }
         }
@@ -640,12 +681,12 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
     auto gn_separate = [&]() {
         if (!gn_sep) return 0;
         View o;
-        o.p = p.out; o.B = p.B; o.H = p.OH; o.W = p.OW; o.C = p.Cout; o.cs = p.out_cs; o.gs = p.out_gs;
+        o.p = p.out; o.B = p.B; o.H = p.OH; o.W = p.OW; o.C = p.Cout; o.cs = p.out_cs; o.gs = p.out_gs; o.es = p.es;
         return launch_gn_stats(o, p.B, G, p.gn_groups, gn_sum, st, false);
     };
     const int nk = p.Kpad / BK;
     if (p.ws && g_force_split > 0) S = g_force_split;
-    if (!p.ws || S < 1) S = 1;
+    if (!p.ws || S < 1 || p.es == 2) S = 1;
     if (S > nk) S = nk;
     while (S > 1 && (size_t)S * G * p.M * p.Cout > p.ws_floats) --S;
     p.kchunk = (nk + S - 1) / S;
@@ -657,9 +698,10 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
     p.tail_shift = 0;
     const dim3 block(WM * WN * 64);
     // stage profile: algorithmic traffic = the input tensor, the weights and the output (+ residual) once each
-    const double out_bytes = 4.0 * G * (double)p.M * p.Cout;
+    // (fp16 data path: Cin / K are in 4-byte units here - two halfs each - so the input and weight bytes come out right)
+    const double out_bytes = (double)p.es * G * (double)p.M * p.Cout;
     const double conv_bytes = 4.0 * G * ((double)p.B * p.H * p.W * p.Cin + (double)p.Cout * p.K) + out_bytes * (p.res ? 2.0 : 1.0);
-    const double conv_flops = 2.0 * G * (double)p.M * p.K * p.Cout;
+    const double conv_flops = 2.0 * G * (double)p.M * p.K * p.Cout * (p.es == 2 ? 2.0 : 1.0);
     const char* tag = p.tag ? p.tag : "conv_gemm";
     // a launch of the bf16x3 mode that keeps the exact fp32 MFMA kernel is profiled under its own stage, so that the
     // bench prices each matrix pipe with the work it actually executed
@@ -735,6 +777,13 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
     // residual) and the 32-column head layers on 256x32 tiles lose occupancy to its three LDS planes and gain nothing
     // (profiles/r02j_conv_layers_dtype{0,3}.md): they keep the exact fp32 MFMA kernel, which is at least as accurate.
     if (p.bf16 == 3 && (BM == 256 || (BM == 64 && nk <= 8))) exact_fallback();
+    if (p.es == 2) {        // fp16 data path: one K pass (the loop is 16x shorter than the fp32 one), padded filter rows skipped
+        ProfScope prof(tag, conv_bytes, conv_flops, st);
+        if (skip) hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 3, 4>), dim3(p.mtiles * p.ntiles, 1, G), block, 0, st, p);
+        else hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 0, 4>), dim3(p.mtiles * p.ntiles, 1, G), block, 0, st, p);
+        QB_CHECK(hipGetLastError());
+        return gn_separate();
+    }
     if (p.bf16) {
         {
             ProfScope prof(tag, conv_bytes, conv_flops, st);
@@ -775,6 +824,15 @@ int g_acc_chunk = 2;      // key 21: K-slices per accumulation chunk (default 2 
 int launch_conv(const ConvP& p0, int G, hipStream_t st) {
     ConvP p = p0;
     p.acc_chunk = g_acc_chunk;
+    if (p.es != 2) p.es = 4;
+    if (p.es == 2) {
+        // fp16 data path (activations and packed weights are fp16 in HBM): the kernel moves the operands as 4-byte units, so
+        // every K-side quantity is handed over in units of two halfs; Cout / M and the output strides stay in elements
+        if (p.bf16 != 2) return fail("conv: fp16 tensors need compute_dtype 2");
+        if (p.Cin % 8 || p.in_cs % 8 || p.Kpad % 64 || p.K % 2 || (p.in_gs & 7) || (p.w_gs & 1) || p.in2 || p.prelu)
+            return fail("conv (fp16 data path): Cin / channel stride must be multiples of 8 and Kpad a multiple of 64");
+        p.Cin /= 2; p.in_cs /= 2; p.K /= 2; p.Kpad /= 2; p.in_gs /= 2; p.w_gs /= 2;
+    }
     if (p.Cin % 4 || p.in_cs % 4 || p.Kpad % BK || p.K > p.Kpad)
         return fail("conv: Cin / channel stride must be multiples of 4 and Kpad a multiple of 32");
     if (((uintptr_t)p.in & 15) || ((uintptr_t)p.w & 15) || (p.in_gs & 3) || (p.w_gs & 3))

@@ -10,6 +10,24 @@
 
 namespace quber {
 
+// Activation element type of a tensor (View::es): float, or _Float16 in the fp16 data path (quber_config.compute_dtype 2).
+// Every kernel below computes in fp32 whatever the storage type; ldv4 / stv4 move 4 consecutive channels (16 or 8 bytes).
+using half_t = _Float16;
+template <class T> __device__ inline float4 ldv4(const T* p);
+template <> __device__ inline float4 ldv4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ inline float4 ldv4<half_t>(const half_t* p) {
+    using h4 = __attribute__((ext_vector_type(4))) half_t;
+    const h4 v = *reinterpret_cast<const h4*>(p);
+    return make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
+}
+template <class T> __device__ inline void stv4(T* p, float4 v);
+template <> __device__ inline void stv4<float>(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+template <> __device__ inline void stv4<half_t>(half_t* p, float4 v) {
+    using h4 = __attribute__((ext_vector_type(4))) half_t;
+    *reinterpret_cast<h4*>(p) = h4{(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
+}
+template <class T> static inline const T* cptr(const View& v) { return reinterpret_cast<const T*>(v.p); }
+
 static inline int cap_grid(long work, int per_block) {
     long g = (work + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -20,9 +38,10 @@ static inline int cap_grid(long work, int per_block) {
 // ------------------------------------------------------------------------------------------------
 // u8 HWC rgb + u8 HWC depth + f32 planar offsets -> two 8-channel NHWC stream inputs
 // x[0] = [(bgr - mean)/std, heat, off_y, off_x, 0, 0],  x[1] = [(depth - mean)/std, heat, off_y, off_x, 0, 0]
+template <class T>
 __global__ void preprocess_kernel(const uint8_t* __restrict__ rgb, const uint8_t* __restrict__ depth,
-                                  const float* __restrict__ offs, float* __restrict__ x, int B, long gstride,
-                                  int streams, int HW, float m0, float m1, float m2, float m3, float m4, float m5, float s0,
+                                  const float* __restrict__ offs, T* __restrict__ x, int B, long gstride,
+                                  int streams, int HW, int xc, float m0, float m1, float m2, float m3, float m4, float m5, float s0,
                                   float s1, float s2, float s3, float s4, float s5) {
     const long total = (long)B * HW;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -38,33 +57,42 @@ __global__ void preprocess_kernel(const uint8_t* __restrict__ rgb, const uint8_t
         a.z = ((float)r[2] - m2) / s2;
         a.w = heat;
         c.x = oy; c.y = ox; c.z = 0.f; c.w = 0.f;
-        float4* dst = reinterpret_cast<float4*>(x + i * 8);
-        dst[0] = a;
-        dst[1] = c;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        T* dst = x + i * xc;
+        stv4(dst, a);
+        stv4(dst + 4, c);
+        for (int e = 8; e < xc; e += 4) stv4(dst + e, z);
         if (streams == 2) {
             a.x = ((float)d[0] - m3) / s3;
             a.y = ((float)d[1] - m4) / s4;
             a.z = ((float)d[2] - m5) / s5;
-            dst = reinterpret_cast<float4*>(x + gstride + i * 8);
-            dst[0] = a;
-            dst[1] = c;
+            dst = x + gstride + i * xc;
+            stv4(dst, a);
+            stv4(dst + 4, c);
+            for (int e = 8; e < xc; e += 4) stv4(dst + e, z);
         }
     }
 }
 
-int launch_preprocess(const uint8_t* rgb, const uint8_t* depth, const float* offs, float* x, int B, int Bcap,
+int launch_preprocess(const uint8_t* rgb, const uint8_t* depth, const float* offs, const View& x, int B, int Bcap,
                       int H, int W, const float* mean6, const float* std6, int streams, hipStream_t st) {
     const long total = (long)B * H * W;
-    ProfScope prof("preprocess", (double)total * (3.0 * streams + 12.0 + 32.0 * streams), 0.0, st);
-    hipLaunchKernelGGL(preprocess_kernel, dim3(cap_grid(total, 256)), dim3(256), 0, st, rgb, depth, offs, x, B,
-                       (long)Bcap * H * W * 8, streams, H * W, mean6[0], mean6[1], mean6[2], mean6[3], mean6[4], mean6[5],
+    ProfScope prof("preprocess", (double)total * (3.0 * streams + 12.0 + (double)x.es * x.C * streams), 0.0, st);
+    if (x.es == 2)
+        hipLaunchKernelGGL(preprocess_kernel<half_t>, dim3(cap_grid(total, 256)), dim3(256), 0, st, rgb, depth, offs, (half_t*)x.p, B,
+                           (long)Bcap * H * W * x.C, streams, H * W, x.C, mean6[0], mean6[1], mean6[2], mean6[3], mean6[4], mean6[5],
+                           std6[0], std6[1], std6[2], std6[3], std6[4], std6[5]);
+    else
+    hipLaunchKernelGGL(preprocess_kernel<float>, dim3(cap_grid(total, 256)), dim3(256), 0, st, rgb, depth, offs, x.p, B,
+                       (long)Bcap * H * W * x.C, streams, H * W, x.C, mean6[0], mean6[1], mean6[2], mean6[3], mean6[4], mean6[5],
                        std6[0], std6[1], std6[2], std6[3], std6[4], std6[5]);
     QB_CHECK(hipGetLastError());
     return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void maxpool_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C4,
+template <class T>
+__global__ void maxpool_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int H, int W, int C4,
                                int in_cs, int OH, int OW, int out_cs, long in_gs, long out_gs) {
     in += blockIdx.y * in_gs;
     out += blockIdx.y * out_gs;
@@ -85,19 +113,24 @@ __global__ void maxpool_kernel(const float* __restrict__ in, float* __restrict__
             for (int dx = 0; dx < 3; ++dx) {
                 const int ix = ox * 2 - 1 + dx;
                 if ((unsigned)ix >= (unsigned)W) continue;
-                const float4 v = *reinterpret_cast<const float4*>(in + ((long)(b * H + iy) * W + ix) * in_cs + c4 * 4);
+                const float4 v = ldv4(in + ((long)(b * H + iy) * W + ix) * in_cs + c4 * 4);
                 m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
             }
         }
-        *reinterpret_cast<float4*>(out + ((long)(b * OH + oy) * OW + ox) * out_cs + c4 * 4) = m;
+        stv4(out + ((long)(b * OH + oy) * OW + ox) * out_cs + c4 * 4, m);
     }
 }
 
 int launch_maxpool3x3s2(const View& in, const View& out, int B, int G, hipStream_t st) {
     const long total = (long)B * out.H * out.W * (in.C / 4);
-    ProfScope prof("maxpool", 4.0 * G * B * in.C * ((double)in.H * in.W + (double)out.H * out.W), 0.0, st);
-    hipLaunchKernelGGL(maxpool_kernel, dim3(cap_grid(total, 256), G), dim3(256), 0, st, in.p, out.p, B, in.H, in.W,
-                       in.C / 4, in.cs, out.H, out.W, out.cs, in.gs, out.gs);
+    ProfScope prof("maxpool", (double)in.es * G * B * in.C * ((double)in.H * in.W + (double)out.H * out.W), 0.0, st);
+    if (in.es != out.es) return fail("maxpool: mixed element types");
+    if (in.es == 2)
+        hipLaunchKernelGGL(maxpool_kernel<half_t>, dim3(cap_grid(total, 256), G), dim3(256), 0, st, cptr<half_t>(in), (half_t*)out.p, B,
+                           in.H, in.W, in.C / 4, in.cs, out.H, out.W, out.cs, in.gs, out.gs);
+    else
+        hipLaunchKernelGGL(maxpool_kernel<float>, dim3(cap_grid(total, 256), G), dim3(256), 0, st, in.p, out.p, B, in.H, in.W,
+                           in.C / 4, in.cs, out.H, out.W, out.cs, in.gs, out.gs);
     QB_CHECK(hipGetLastError());
     return 0;
 }
@@ -105,7 +138,8 @@ int launch_maxpool3x3s2(const View& in, const View& out, int B, int G, hipStream
 // ------------------------------------------------------------------------------------------------
 // GroupNorm statistics: sum and sum of squares per (group-of-launch g, sample b, norm group), in fp64.
 // grid = (chunks, B, G); every block streams a contiguous run of pixels with float4 loads.
-__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ in, int HW, int C, int cs, long gs,
+template <class T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ in, int HW, int C, int cs, long gs,
                                                        long bstride, int groups, int ppb, double* __restrict__ stats,
                                                        int B) {
     __shared__ double acc[64 * 2];
@@ -113,7 +147,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     if (t < 128) acc[t] = 0.0;
     __syncthreads();
     const int b = blockIdx.y, g = blockIdx.z;
-    const float* base = in + g * gs + b * bstride;
+    const T* base = in + g * gs + b * bstride;
     const int C4 = C >> 2;
     const int cpg = C / groups;
     const int p0 = blockIdx.x * ppb;
@@ -127,7 +161,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
         if (row >= rows || c4 >= C4) continue;   // idle lanes when 256 is not a multiple of the row width
         double s = 0.0, ss = 0.0;
         for (int pix = p0 + row; pix < p1; pix += rows) {
-            const float4 v = *reinterpret_cast<const float4*>(base + (long)pix * cs + c4 * 4);
+            const float4 v = ldv4(base + (long)pix * cs + c4 * 4);
             if (cpg >= 4) {
                 s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
                 ss += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
@@ -187,9 +221,13 @@ int launch_gn_stats(const View& in, int B, int G, int groups, double* stats, hip
     }
     const int ppb = gn_pixels_per_block(HW, in.C, B, G);
     const int chunks = (HW + ppb - 1) / ppb;
-    ProfScope prof("gn_stats", 4.0 * G * B * (double)HW * in.C, 0.0, st);
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks, B, G), dim3(256), 0, st, in.p, HW, in.C, in.cs, in.gs,
-                       (long)HW * in.cs, groups, ppb, stats, B);
+    ProfScope prof("gn_stats", (double)in.es * G * B * (double)HW * in.C, 0.0, st);
+    if (in.es == 2)
+        hipLaunchKernelGGL(gn_stats_kernel<half_t>, dim3(chunks, B, G), dim3(256), 0, st, cptr<half_t>(in), HW, in.C, in.cs, in.gs,
+                           (long)HW * in.cs, groups, ppb, stats, B);
+    else
+        hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(chunks, B, G), dim3(256), 0, st, in.p, HW, in.C, in.cs, in.gs,
+                           (long)HW * in.cs, groups, ppb, stats, B);
     QB_CHECK(hipGetLastError());
     return 0;
 }
@@ -197,7 +235,8 @@ int launch_gn_stats(const View& in, int B, int G, int groups, double* stats, hip
 // y = relu(x*scale + bias), scale = rstd*gamma, bias = beta - mean*scale  (torch's GroupNorm CPU form).
 // mean / rstd come from the fp64 sums of gn_stats_kernel.  A thread keeps one 16-byte channel column: its four
 // (scale, bias) pairs are computed once, the pixel loop is load - fma - store with no index arithmetic beyond an add.
-__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int HW,
+template <class T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int HW,
                                                        int C, int in_cs, int out_cs, long in_gs, long out_gs, int groups,
                                                        const double* __restrict__ stats, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, int param_gs, int relu, int ppb,
@@ -233,7 +272,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
             bi[j] = bt[j] - (float)mean * sc[j];
         }
         for (int pix = p0 + row; pix < p1; pix += rows) {
-            const float4 v = *reinterpret_cast<const float4*>(in + (long)pix * in_cs + c4 * 4);
+            const float4 v = ldv4(in + (long)pix * in_cs + c4 * 4);
             float4 o;
             o.x = fmaf(v.x, sc[0], bi[0]);
             o.y = fmaf(v.y, sc[1], bi[1]);
@@ -242,7 +281,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
             if (relu) {
                 o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
             }
-            *reinterpret_cast<float4*>(out + (long)pix * out_cs + c4 * 4) = o;
+            stv4(out + (long)pix * out_cs + c4 * 4, o);
         }
     }
 }
@@ -251,10 +290,16 @@ int launch_gn_apply(const View& in, const View& out, int B, int G, int groups, c
                     const float* gamma, const float* beta, int param_gs, float eps, int relu, hipStream_t st) {
     const int HW = in.H * in.W;
     const int ppb = gn_pixels_per_block(HW, in.C, B, G);
-    ProfScope prof("gn_apply", 8.0 * G * B * (double)HW * in.C, 0.0, st);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((HW + ppb - 1) / ppb, B, G), dim3(256), 0, st, in.p, out.p, B, HW, in.C,
-                       in.cs, out.cs, in.gs, out.gs, groups, stats, gamma, beta, param_gs, relu, ppb,
-                       (double)HW * (in.C / groups), eps);
+    ProfScope prof("gn_apply", 2.0 * in.es * G * B * (double)HW * in.C, 0.0, st);
+    if (in.es != out.es) return fail("groupnorm: mixed element types");
+    if (in.es == 2)
+        hipLaunchKernelGGL(gn_apply_kernel<half_t>, dim3((HW + ppb - 1) / ppb, B, G), dim3(256), 0, st, cptr<half_t>(in), (half_t*)out.p,
+                           B, HW, in.C, in.cs, out.cs, in.gs, out.gs, groups, stats, gamma, beta, param_gs, relu, ppb,
+                           (double)HW * (in.C / groups), eps);
+    else
+        hipLaunchKernelGGL(gn_apply_kernel<float>, dim3((HW + ppb - 1) / ppb, B, G), dim3(256), 0, st, in.p, out.p, B, HW, in.C,
+                           in.cs, out.cs, in.gs, out.gs, groups, stats, gamma, beta, param_gs, relu, ppb,
+                           (double)HW * (in.C / groups), eps);
     QB_CHECK(hipGetLastError());
     return 0;
 }
@@ -270,7 +315,8 @@ __device__ inline void bilin_src(int o, float scale, int in_size, int& i0, int& 
     l1 = s - (float)i0;
 }
 
-__global__ void bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C4,
+template <class T>
+__global__ void bilinear_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int H, int W, int C4,
                                 int in_cs, int OH, int OW, int out_cs, float sy, float sx) {
     const long total = (long)B * OH * OW * C4;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -285,32 +331,38 @@ __global__ void bilinear_kernel(const float* __restrict__ in, float* __restrict_
         bilin_src(oy, sy, H, y0, y1, ly);
         bilin_src(ox, sx, W, x0, x1, lx);
         const float hy = 1.f - ly, hx = 1.f - lx;
-        const float* base = in + (long)b * H * W * in_cs + c4 * 4;
-        const float4 v00 = *reinterpret_cast<const float4*>(base + ((long)y0 * W + x0) * in_cs);
-        const float4 v01 = *reinterpret_cast<const float4*>(base + ((long)y0 * W + x1) * in_cs);
-        const float4 v10 = *reinterpret_cast<const float4*>(base + ((long)y1 * W + x0) * in_cs);
-        const float4 v11 = *reinterpret_cast<const float4*>(base + ((long)y1 * W + x1) * in_cs);
+        const T* base = in + (long)b * H * W * in_cs + c4 * 4;
+        const float4 v00 = ldv4(base + ((long)y0 * W + x0) * in_cs);
+        const float4 v01 = ldv4(base + ((long)y0 * W + x1) * in_cs);
+        const float4 v10 = ldv4(base + ((long)y1 * W + x0) * in_cs);
+        const float4 v11 = ldv4(base + ((long)y1 * W + x1) * in_cs);
         float4 r;
         r.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
         r.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
         r.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
         r.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
-        *reinterpret_cast<float4*>(out + ((long)(b * OH + oy) * OW + ox) * out_cs + c4 * 4) = r;
+        stv4(out + ((long)(b * OH + oy) * OW + ox) * out_cs + c4 * 4, r);
     }
 }
 
 int launch_bilinear(const View& in, const View& out, int B, hipStream_t st) {
     const long total = (long)B * out.H * out.W * (in.C / 4);
-    ProfScope prof("bilinear", 4.0 * B * in.C * ((double)in.H * in.W + (double)out.H * out.W), 0.0, st);
-    hipLaunchKernelGGL(bilinear_kernel, dim3(cap_grid(total, 256)), dim3(256), 0, st, in.p, out.p, B, in.H, in.W,
-                       in.C / 4, in.cs, out.H, out.W, out.cs, (float)in.H / (float)out.H, (float)in.W / (float)out.W);
+    ProfScope prof("bilinear", (double)in.es * B * in.C * ((double)in.H * in.W + (double)out.H * out.W), 0.0, st);
+    if (in.es != out.es) return fail("bilinear: mixed element types");
+    if (in.es == 2)
+        hipLaunchKernelGGL(bilinear_kernel<half_t>, dim3(cap_grid(total, 256)), dim3(256), 0, st, cptr<half_t>(in), (half_t*)out.p, B, in.H,
+                           in.W, in.C / 4, in.cs, out.H, out.W, out.cs, (float)in.H / (float)out.H, (float)in.W / (float)out.W);
+    else
+        hipLaunchKernelGGL(bilinear_kernel<float>, dim3(cap_grid(total, 256)), dim3(256), 0, st, in.p, out.p, B, in.H, in.W,
+                           in.C / 4, in.cs, out.H, out.W, out.cs, (float)in.H / (float)out.H, (float)in.W / (float)out.W);
     QB_CHECK(hipGetLastError());
     return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
 // global average pool: grid (C/64, B); 256 threads = 16 float4 channel columns x 16 pixel lanes, fp64 sums
-__global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ in, float* __restrict__ out, int HW,
+template <class T>
+__global__ __launch_bounds__(256) void avgpool_kernel(const T* __restrict__ in, T* __restrict__ out, int HW,
                                                       int C, int in_cs, int out_cs) {
     __shared__ double part[16][64];
     const int col = threadIdx.x & 15, lane = threadIdx.x >> 4;
@@ -319,7 +371,7 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ 
     double s[4] = {0.0, 0.0, 0.0, 0.0};
     if (c < C)      // C % 4 == 0: a float4 column is inside the tensor or entirely outside
         for (int p = lane; p < HW; p += 16) {
-            const float4 v = *reinterpret_cast<const float4*>(in + ((long)b * HW + p) * in_cs + c);
+            const float4 v = ldv4(in + ((long)b * HW + p) * in_cs + c);
             s[0] += (double)v.x; s[1] += (double)v.y; s[2] += (double)v.z; s[3] += (double)v.w;
         }
 #pragma unroll
@@ -329,15 +381,20 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ 
         double t = 0.0;
 #pragma unroll
         for (int l = 0; l < 16; ++l) t += part[l][threadIdx.x];
-        out[(long)b * out_cs + blockIdx.x * 64 + threadIdx.x] = (float)(t / (double)HW);
+        out[(long)b * out_cs + blockIdx.x * 64 + threadIdx.x] = (T)(float)(t / (double)HW);
     }
 }
 
 int launch_avgpool(const View& in, const View& out, int B, hipStream_t st) {
     if (in.C % 4 || in.cs % 4 || ((uintptr_t)in.p & 15)) return fail("avgpool: channels must come in aligned groups of 4");
-    ProfScope prof("avgpool", 4.0 * B * in.C * ((double)in.H * in.W + 1.0), 0.0, st);
-    hipLaunchKernelGGL(avgpool_kernel, dim3((in.C + 63) / 64, B), dim3(256), 0, st, in.p, out.p, in.H * in.W, in.C,
-                       in.cs, out.cs);
+    if (in.es != out.es) return fail("avgpool: mixed element types");
+    ProfScope prof("avgpool", (double)in.es * B * in.C * ((double)in.H * in.W + 1.0), 0.0, st);
+    if (in.es == 2)
+        hipLaunchKernelGGL(avgpool_kernel<half_t>, dim3((in.C + 63) / 64, B), dim3(256), 0, st, cptr<half_t>(in), (half_t*)out.p,
+                           in.H * in.W, in.C, in.cs, out.cs);
+    else
+        hipLaunchKernelGGL(avgpool_kernel<float>, dim3((in.C + 63) / 64, B), dim3(256), 0, st, in.p, out.p, in.H * in.W, in.C,
+                           in.cs, out.cs);
     QB_CHECK(hipGetLastError());
     return 0;
 }
@@ -345,10 +402,10 @@ int launch_avgpool(const View& in, const View& out, int B, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // 1x1 predictor on the 32-channel head features -> planar quarter-resolution logits q[B][q_nch][h*w],
 // optionally also softmax over its `cout` classes into an NHWC channel slice (the 'pred' fusion target).
-template <int CIN>
-__global__ void predictor_kernel(const float* __restrict__ in, int in_cs, const float* __restrict__ w,
+template <class T, int CIN = 32>
+__global__ void predictor_kernel(const T* __restrict__ in, int in_cs, const float* __restrict__ w,
                                  const float* __restrict__ bias, int cout, float* __restrict__ q, int q_ch0,
-                                 int q_nch, float* __restrict__ sm, int sm_cs, int act, int B, int HW) {
+                                 int q_nch, T* __restrict__ sm, int sm_cs, int act, int B, int HW) {
     __shared__ float ws[4 * CIN + 4];
     for (int i = threadIdx.x; i < cout * CIN; i += blockDim.x) ws[i] = w[i];
     if (threadIdx.x < cout) ws[4 * CIN + threadIdx.x] = bias[threadIdx.x];
@@ -356,10 +413,10 @@ __global__ void predictor_kernel(const float* __restrict__ in, int in_cs, const 
     const long total = (long)B * HW;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         float x[CIN];
-        const float4* src = reinterpret_cast<const float4*>(in + i * in_cs);
+        const T* src = in + i * in_cs;
 #pragma unroll
         for (int j = 0; j < CIN / 4; ++j) {
-            const float4 v = src[j];
+            const float4 v = ldv4(src + 4 * j);
             x[4 * j] = v.x; x[4 * j + 1] = v.y; x[4 * j + 2] = v.z; x[4 * j + 3] = v.w;
         }
         const long b = i / HW, pix = i - b * HW;
@@ -373,64 +430,81 @@ __global__ void predictor_kernel(const float* __restrict__ in, int in_cs, const 
             q[((long)b * q_nch + q_ch0 + k) * HW + pix] = a;
         }
         if (sm && act == 2) {
-            for (int k = 0; k < cout; ++k) sm[i * sm_cs + k] = 1.f / (1.f + expf(-o[k]));
+            for (int k = 0; k < cout; ++k) sm[i * sm_cs + k] = (T)(1.f / (1.f + expf(-o[k])));
         } else if (sm) {
             float mx = o[0];
             for (int k = 1; k < cout; ++k) mx = fmaxf(mx, o[k]);
             float e[4], s = 0.f;
             for (int k = 0; k < cout; ++k) { e[k] = expf(o[k] - mx); s += e[k]; }
-            for (int k = 0; k < cout; ++k) sm[i * sm_cs + k] = e[k] / s;
+            for (int k = 0; k < cout; ++k) sm[i * sm_cs + k] = (T)(e[k] / s);
         }
     }
 }
 
 int launch_predictor(const View& in, const float* w, const float* bias, int cout, float* q, int q_ch0, int q_nch,
                      float* softmax_dst, int softmax_cs, int act, int B, hipStream_t st) {
+    // softmax_dst: a channel slice of an activation buffer - same element type as `in`
     if (in.C != 32 || cout > 4) return fail("predictor: expects 32 input channels and <= 4 outputs");
     const long total = (long)B * in.H * in.W;
-    ProfScope prof("predictor", 4.0 * total * (32.0 + cout * (softmax_dst ? 2.0 : 1.0)), 2.0 * total * 32.0 * cout, st);
-    hipLaunchKernelGGL(predictor_kernel<32>, dim3(cap_grid(total, 256)), dim3(256), 0, st, in.p, in.cs, w, bias, cout,
-                       q, q_ch0, q_nch, softmax_dst, softmax_cs, act, B, in.H * in.W);
+    ProfScope prof("predictor", total * ((double)in.es * 32.0 + 4.0 * cout + (softmax_dst ? (double)in.es * cout : 0.0)), 2.0 * total * 32.0 * cout, st);
+    if (in.es == 2)
+        hipLaunchKernelGGL((predictor_kernel<half_t, 32>), dim3(cap_grid(total, 256)), dim3(256), 0, st, cptr<half_t>(in), in.cs, w, bias,
+                           cout, q, q_ch0, q_nch, (half_t*)softmax_dst, softmax_cs, act, B, in.H * in.W);
+    else
+        hipLaunchKernelGGL((predictor_kernel<float, 32>), dim3(cap_grid(total, 256)), dim3(256), 0, st, in.p, in.cs, w, bias, cout,
+                           q, q_ch0, q_nch, softmax_dst, softmax_cs, act, B, in.H * in.W);
     QB_CHECK(hipGetLastError());
     return 0;
 }
 
-__global__ void copy_channels_kernel(const float* __restrict__ in, float* __restrict__ out, long pixels, int C4,
+template <class T>
+__global__ void copy_channels_kernel(const T* __restrict__ in, T* __restrict__ out, long pixels, int C4,
                                      int in_cs, int out_cs) {
     const long total = pixels * C4;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long pix = i / C4;
         const int c4 = (int)(i - pix * C4);
-        *reinterpret_cast<float4*>(out + pix * out_cs + c4 * 4) = *reinterpret_cast<const float4*>(in + pix * in_cs + c4 * 4);
+        stv4(out + pix * out_cs + c4 * 4, ldv4(in + pix * in_cs + c4 * 4));
     }
 }
 
-__global__ void add_channels_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+template <class T>
+__global__ void add_channels_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out,
                                     long pixels, int C4, int a_cs, int b_cs, int out_cs) {
     const long total = pixels * C4;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long pix = i / C4;
         const int c4 = (int)(i - pix * C4);
-        const float4 x = *reinterpret_cast<const float4*>(a + pix * a_cs + c4 * 4);
-        const float4 y = *reinterpret_cast<const float4*>(b + pix * b_cs + c4 * 4);
-        *reinterpret_cast<float4*>(out + pix * out_cs + c4 * 4) = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+        const float4 x = ldv4(a + pix * a_cs + c4 * 4);
+        const float4 y = ldv4(b + pix * b_cs + c4 * 4);
+        stv4(out + pix * out_cs + c4 * 4, make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w));
     }
 }
 
 int launch_add_channels(const View& a, const View& b, const View& out, int B, hipStream_t st) {
     const long pixels = (long)B * a.H * a.W;
-    ProfScope prof("add_channels", 12.0 * pixels * a.C, 0.0, st);
-    hipLaunchKernelGGL(add_channels_kernel, dim3(cap_grid(pixels * (a.C / 4), 256)), dim3(256), 0, st, a.p, b.p, out.p,
-                       pixels, a.C / 4, a.cs, b.cs, out.cs);
+    ProfScope prof("add_channels", 3.0 * a.es * pixels * a.C, 0.0, st);
+    if (a.es != b.es || a.es != out.es) return fail("add: mixed element types");
+    if (a.es == 2)
+        hipLaunchKernelGGL(add_channels_kernel<half_t>, dim3(cap_grid(pixels * (a.C / 4), 256)), dim3(256), 0, st, cptr<half_t>(a),
+                           cptr<half_t>(b), (half_t*)out.p, pixels, a.C / 4, a.cs, b.cs, out.cs);
+    else
+        hipLaunchKernelGGL(add_channels_kernel<float>, dim3(cap_grid(pixels * (a.C / 4), 256)), dim3(256), 0, st, a.p, b.p, out.p,
+                           pixels, a.C / 4, a.cs, b.cs, out.cs);
     QB_CHECK(hipGetLastError());
     return 0;
 }
 
 int launch_copy_channels(const View& in, const View& out, int B, hipStream_t st) {
     const long pixels = (long)B * in.H * in.W;
-    ProfScope prof("copy_channels", 8.0 * pixels * in.C, 0.0, st);
-    hipLaunchKernelGGL(copy_channels_kernel, dim3(cap_grid(pixels * (in.C / 4), 256)), dim3(256), 0, st, in.p, out.p,
-                       pixels, in.C / 4, in.cs, out.cs);
+    ProfScope prof("copy_channels", 2.0 * in.es * pixels * in.C, 0.0, st);
+    if (in.es != out.es) return fail("copy: mixed element types");
+    if (in.es == 2)
+        hipLaunchKernelGGL(copy_channels_kernel<half_t>, dim3(cap_grid(pixels * (in.C / 4), 256)), dim3(256), 0, st, cptr<half_t>(in),
+                           (half_t*)out.p, pixels, in.C / 4, in.cs, out.cs);
+    else
+        hipLaunchKernelGGL(copy_channels_kernel<float>, dim3(cap_grid(pixels * (in.C / 4), 256)), dim3(256), 0, st, in.p, out.p,
+                           pixels, in.C / 4, in.cs, out.cs);
     QB_CHECK(hipGetLastError());
     return 0;
 }

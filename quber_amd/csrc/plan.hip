@@ -108,7 +108,7 @@ struct quber_ctx {
     size_t splitk_floats = 0;
     float* wino_ws = nullptr;     // V | M of the Winograd layers (sized for the largest one at max_batch)
     size_t wino_floats = 0;
-    float* X = nullptr;   // [2][Bmax][H][W][8]
+    View X;               // [2][Bmax][H][W][8] (16 channels of fp16 in the fp16 data path)
     float* q = nullptr;   // [Bmax][planes][H/4][W/4]
     const uint8_t* cur_bgr = nullptr;
     const uint8_t* cur_depth = nullptr;
@@ -151,7 +151,11 @@ struct Builder {
     std::string err;
     int Bmax, H, W;
 
-    Builder(quber_ctx* ctx, bool d) : c(ctx), dry(d), Bmax(ctx->cfg.max_batch), H(ctx->cfg.height), W(ctx->cfg.width) {}
+    int aes = 4;        // element size of the activation tensors: 2 in the fp16 data path (quber_config.compute_dtype 2)
+
+    Builder(quber_ctx* ctx, bool d) : c(ctx), dry(d), Bmax(ctx->cfg.max_batch), H(ctx->cfg.height), W(ctx->cfg.width) {
+        if (ctx->cfg.compute_dtype == 2 && ctx->cfg.with_network == 1) aes = 2;
+    }
 
     // ---- host weights ----
     const float* hw(const std::string& name, int64_t numel) {
@@ -186,6 +190,12 @@ struct Builder {
         if (hipMemset(p, 0, bytes ? bytes : 16) != hipSuccess && err.empty()) err = "hipMemset of a new buffer failed";
         return p;
     }
+    float* upload16(const std::vector<_Float16>& v) {
+        float* d = (float*)dalloc_bytes(v.size() * sizeof(_Float16));
+        if (d && hipMemcpy(d, v.data(), v.size() * sizeof(_Float16), hipMemcpyHostToDevice) != hipSuccess && err.empty())
+            err = "upload of " + std::to_string(v.size()) + " halfs failed";
+        return d;
+    }
     float* upload(const std::vector<float>& v) {
         float* d = (float*)dalloc_bytes(v.size() * sizeof(float));
         if (d && hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess && err.empty())
@@ -196,11 +206,12 @@ struct Builder {
         View v;
         v.B = Bmax; v.H = h; v.W = w; v.C = C; v.cs = C;
         v.gs = (long)Bmax * h * w * C;
-        v.p = (float*)dalloc_bytes(sizeof(float) * (size_t)v.gs * G);
+        v.es = aes;
+        v.p = (float*)dalloc_bytes((size_t)aes * (size_t)v.gs * G);
         return v;
     }
     static View slice(View v, int coff, int C, long gs = -1) {
-        if (v.p) v.p += coff;
+        v.p = v.at(coff);
         v.C = C;
         if (gs >= 0) v.gs = gs;
         return v;
@@ -214,14 +225,15 @@ struct Builder {
                    const std::vector<float>& shift, const std::vector<float>& prelu, const View* res, bool relu) {
         const int G = (int)w.size();
         const int Cin = in.C, Cout = out.C;
-        const int K = k * k * Cin, Kpad = (K + 31) / 32 * 32;
+        const int KS = aes == 2 ? 64 : 32;        // K-slice of the kernel in elements (32 four-byte units: 64 halfs in the fp16 data path)
+        const int K = k * k * Cin, Kpad = (K + KS - 1) / KS * KS;
         const int OHp = (in.H + 2 * pad - dil * (k - 1) - 1) / stride + 1;
         // dilated 3x3 whose top / bottom filter rows are padding for >= 20 % of the (row, tap) pairs and that cannot take the
         // Winograd path: tap-major K order so that blocks can skip those rows (conv_igemm.hip MODE 3 / 4)
-        const bool skip_rows = k == 3 && stride == 1 && dil > 1 && Cin % 32 == 0 && cin_real == Cin && 10 * 2 * pad >= 2 * 3 * OHp &&
+        const bool skip_rows = k == 3 && stride == 1 && dil > 1 && Cin % KS == 0 && cin_real == Cin && 10 * 2 * pad >= 2 * 3 * OHp &&
                                !(winograd_eligible(k, stride, pad, dil, Cin, out.C) && !res && prelu.empty() &&
                                  std::min(winograd_mac_ratio(in.H, in.W, dil, 4), winograd_mac_ratio(in.H, in.W, dil, 2)) <= g_wino_max_ratio / 100.0 && g_winograd != 1);
-        const int kmode = (k > 1 && Cin % 32 == 0 && !skip_rows) ? 1 : 0;   // slice-major K order for the 3x3 layers
+        const int kmode = (k > 1 && Cin % KS == 0 && !skip_rows) ? 1 : 0;   // slice-major K order for the 3x3 layers
         const int OH = (in.H + 2 * pad - dil * (k - 1) - 1) / stride + 1;
         const int OW = (in.W + 2 * pad - dil * (k - 1) - 1) / stride + 1;
         if (dry) return;
@@ -238,12 +250,21 @@ struct Builder {
                 float* dst = &packed[((size_t)g * Cout + o) * Kpad];
                 for (int ci = 0; ci < cin_real; ++ci)
                     for (int t = 0; t < k * k; ++t) {
-                        const size_t kk = kmode ? ((size_t)(ci / 32) * k * k + t) * 32 + ci % 32 : (size_t)t * Cin + ci;
+                        const size_t kk = kmode ? ((size_t)(ci / KS) * k * k + t) * KS + ci % KS : (size_t)t * Cin + ci;
                         dst[kk] = w[g][((size_t)o * cin_real + ci) * k * k + t];
                     }
             }
         ConvP p{};
-        p.in = in.p; p.w = upload(packed);
+        p.in = in.p;
+        if (aes == 2) {                          // weights rounded to fp16 once, here
+            std::vector<_Float16> ph(packed.size());
+            for (size_t i = 0; i < packed.size(); ++i) ph[i] = (_Float16)packed[i];
+            p.w = upload16(ph);
+        } else {
+            p.w = upload(packed);
+        }
+        p.es = aes;
+        if (in.es != aes || out.es != aes || (res && res->es != aes)) { if (err.empty()) err = "internal: element type mismatch at " + name; return; }
         p.scale = affine ? upload(scale) : nullptr;
         p.shift = affine ? upload(shift) : nullptr;
         p.prelu = prelu.empty() ? nullptr : upload(prelu);
@@ -374,7 +395,7 @@ struct Builder {
     // modes, views past 2 GiB) run the two original ops.
     void fuse_shortcut(const std::vector<std::string>& n3, const std::vector<std::string>& ns, const View& y, int mid,
                        const View& x, int cin, int stride, const View& out) {
-        if (dry || !g_fuse_shortcut || c->ops.size() < 2) return;
+        if (dry || !g_fuse_shortcut || c->ops.size() < 2 || aes != 4) return;
         const int G = (int)n3.size(), Cout = out.C, Kd = mid + cin;
         if (mid % 32 || cin % 32 || y.C != mid || x.C != cin) return;
         std::vector<float> packed((size_t)G * Cout * Kd), ones((size_t)G * Cout, 1.f), shift((size_t)G * Cout);
@@ -502,8 +523,9 @@ struct Builder {
         }
 
         // ---------------- input + stems (both streams as G = 2) ----------------
-        View X = make(8, H, W, NS);
-        if (!dry) c->X = X.p;
+        // (fp16 data path: 16 channels - the loader steps through a filter tap in units of 8 four-byte words)
+        View X = make(aes == 2 ? 16 : 8, H, W, NS);
+        if (!dry) c->X = X;
         View s1 = make(32, h2, w2, NS), s2 = make(32, h2, w2, NS), s3 = make(64, h2, w2, NS);
         conv(two("stem.conv1", false), X, 6, s1, 3, 2, 1, 1, AF_FROZEN_BN, nullptr, true);
         conv(two("stem.conv2", false), s1, 32, s2, 3, 1, 1, 1, AF_FROZEN_BN, nullptr, true);
@@ -641,7 +663,7 @@ struct Builder {
             if (cf.fusion_pred)
                 for (int k : levels[i - 1]) wd += hch[k];
             ypw[i] = wd;
-            YP[i] = make((wd + 3) / 4 * 4, h4, w4);
+            YP[i] = make(aes == 2 ? (wd + 7) / 8 * 8 : (wd + 3) / 4 * 4, h4, w4);      // whole 16-byte units per pixel
         }
         View cat2 = make(32 + 128, h4, w4), t32 = make(32, h4, w4), t128 = make(128, h4, w4);
         conv_gn(Hd + "decoder.res2.project_conv", F[0], t32, slice(cat2, 0, 32), 1, 1);
@@ -700,12 +722,12 @@ struct Builder {
                 const float* pw = hw(Hd + HN[k] + "_predictor.predictor.weight", (int64_t)hch[k] * 32);
                 const float* pb = hw(Hd + HN[k] + "_predictor.predictor.bias", hch[k]);
                 View in = feat;
-                if (in.p) in.p += (long)j * feat.gs;
+                in.p = feat.at((long)j * feat.gs);
                 if (!dry) c->taps[std::string("feat_") + HN[k]] = in;
                 float* act_dst = nullptr;
                 int act_cs = 0;
                 if (next && cf.fusion_pred) {
-                    act_dst = YP[i + 1].p ? YP[i + 1].p + act_off : nullptr;
+                    act_dst = YP[i + 1].at(act_off);
                     act_cs = YP[i + 1].cs;
                     act_off += hch[k];
                 }
@@ -825,7 +847,7 @@ struct LmffBuilder {
         const int H = b.H, W = b.W, h2 = H / 2, w2 = W / 2, h4 = H / 4, w4 = W / 4, h8 = H / 8, w8 = W / 8;
         const int ncls = 3;
         View X = b.make(8, H, W);
-        if (!dry) c->X = X.p;
+        if (!dry) c->X = X;
         View x6 = Builder::slice(X, 0, 6);
         // Init block
         View i0 = b.make(32, h2, w2), i1 = b.make(32, h2, w2);
@@ -1214,7 +1236,7 @@ int quber_forward(quber_ctx* c, const uint8_t* bgr, const uint8_t* depth, const 
         if (!bgr || !depth || !logits) return fail("null tensor");
         hipStream_t s2 = (hipStream_t)stream;
         c->cur_out = logits;
-        int r2 = launch_lmff_preprocess(bgr, depth, (long)batch * c->cfg.height * c->cfg.width, c->X, s2);
+        int r2 = launch_lmff_preprocess(bgr, depth, (long)batch * c->cfg.height * c->cfg.width, c->X.p, s2);
         for (size_t i = 0; !r2 && i < c->ops.size(); ++i) r2 = c->ops[i].run(batch, s2);
         return r2;
     }
@@ -1336,6 +1358,11 @@ int quber_debug_tensor(quber_ctx* c, const char* name, float** ptr, int32_t* dim
     dims4[0] = it->second.B; dims4[1] = it->second.H; dims4[2] = it->second.W; dims4[3] = it->second.C;
     *cs = it->second.cs;
     return 0;
+}
+int32_t quber_debug_tensor_elem_size(quber_ctx* c, const char* name) {
+    if (!c || !name) return 0;
+    auto it = c->taps.find(name);
+    return it == c->taps.end() ? 0 : it->second.es;
 }
 
 // ---------------- stand-alone ops (tests / micro-benchmarks) ----------------

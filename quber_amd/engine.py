@@ -276,12 +276,13 @@ class Engine:
         p, dims, cs = C.c_void_p(), (C.c_int32 * 4)(), C.c_int32()
         _lib.check(self.lib.quber_debug_tensor(self.h, name.encode(), C.byref(p), C.byref(dims), C.byref(cs)))
         Bm, H, W, Cc = list(dims)
+        es = self.lib.quber_debug_tensor_elem_size(self.h, name.encode())       # 2: the fp16 data path stores activations as fp16
         n = (batch * H * W - 1) * cs.value + Cc        # the view may be a channel slice of a wider buffer
-        buf = torch.empty(n, dtype=torch.float32, device=self.device)
+        buf = torch.empty(n, dtype=torch.float16 if es == 2 else torch.float32, device=self.device)
         torch.cuda.synchronize(self.device)
         hip = C.CDLL("libamdhip64.so")
         hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-        rc = hip.hipMemcpy(C.c_void_p(buf.data_ptr()), p, n * 4, 3)
+        rc = hip.hipMemcpy(C.c_void_p(buf.data_ptr()), p, n * es, 3)
         if rc != 0:
             raise _lib.QuberError(f"hipMemcpy failed ({rc})")
-        return torch.as_strided(buf, (batch, H, W, Cc), (H * W * cs.value, W * cs.value, cs.value, 1))
+        return torch.as_strided(buf, (batch, H, W, Cc), (H * W * cs.value, W * cs.value, cs.value, 1)).float()
