@@ -59,9 +59,21 @@ constexpr int NPL(int dt) { return dt == 3 ? 3 : 1; }     // bf16 planes per ope
 // out short pieces while the last whole tiles drain.
 // The K range is derived without a division (host-computed kchunk): a 64-bit division here costs hipcc ~50 VGPRs over
 // the whole kernel and a wave per SIMD; as written all instantiations allocate the same registers.
+#ifndef QB_H16_NBUF
+#define QB_H16_NBUF 1      // K-slice images of the fp16 kernel on 128x128 tiles (build-time A/B: one image and three resident
+                           // blocks measured 18.2 ms of convolutions at 1024x1024 batch 8, two images and two blocks 18.8)
+#endif
+#ifndef QB_H16_OCC
+#define QB_H16_OCC 3
+#endif
 // waves per SIMD the kernel is compiled for: two accumulator sets (the MFMA chain and the chunk sums, below) cost the
 // 128-row tiles their third resident block; the 64x64 tiles keep five
-constexpr int igemm_occupancy(int BM, int BN, int DT = 0) { return BM == 64 ? (DT == 0 ? 6 : 5) : (BM * BN >= 128 * 128 || (BM == 256 && DT == 3)) ? 2 : 3; }
+constexpr int igemm_occupancy(int BM, int BN, int DT = 0) {
+    if (DT == 4 && BM * BN >= 128 * 128) return QB_H16_OCC;
+    if (DT == 4 && BM == 64 && BN == 64) return 7;        // HBM-bound residual layers: blocks in flight are what they live on
+    if (BM * BN >= 128 * 128 || (BM == 256 && DT == 3)) return 2;
+    return BM == 64 ? (DT == 0 ? 6 : 5) : 3;
+}
 
 template <int BM, int BN, int WM, int WN, int MODE, int DT = 0>
 __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(igemm_occupancy(BM, BN, DT)))) void conv_igemm_f32(const ConvP p) {
@@ -72,7 +84,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(ig
     constexpr int AL = BM / RPP;      // float4 loads per thread per K-slice (A)
     constexpr int BL = BN / RPP;      // (B)
     // two K-slice images (one barrier per slice) for the exact fp32 kernel on 128x128 tiles, as conv_igemm_pk: 2 x 72 KiB per CU
-    constexpr int NBUF = ((DT == 0 || DT == 4) && BM == 128 && BN == 128) ? 2 : 1;
+    constexpr int NBUF = ((DT == 0 || (DT == 4 && QB_H16_NBUF == 2)) && BM == 128 && BN == 128) ? 2 : 1;
     // DT 4 (fp16 in HBM): the K-slice image holds the operands' bytes as they are - a row of 32 floats is a row of 64 halfs,
     // so the loader, the image and its pitch are those of the fp32 kernel and a slice carries twice the K
     constexpr bool RAW = DT == 0 || DT == 4;
@@ -158,7 +170,12 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(ig
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
         const int m = m0 + lrow + RPP * i;
-        if (m < p.M) {
+        if (m < p.M && p.kh == 1 && p.stride == 1 && p.pad == 0) {
+            // 1x1, stride 1: output pixel m reads input pixel m - no divisions (the short-K residual layers are all prologue)
+            iy0[i] = 0;
+            ix0[i] = 0;
+            rowp[i] = in + (long)m * p.in_cs;
+        } else if (m < p.M) {
             const int ohw = p.OH * p.OW;
             const int b = m / ohw;
             const int rem = m - b * ohw;
@@ -371,6 +388,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(ig
     // error of a sum grows with the length of its chain: one chain over K = 128 ... 4608 left the network 2-4x further from
     // a float64 evaluation than the CPU reference's blocked reduction is; chunked, the two are level, Winograd layers
     // included (tests/fp64_anchor.py, profiles/r03f_anchor_chunk.md).
+    constexpr bool TWO = DT == 0 || DT == 3;       // the 16-bit operand modes keep one chain (their tolerance is 100x wider)
     f32x16 top[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -402,8 +420,8 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(ig
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) top[i][j] += acc[i][j];
-        } else if (kt + 1 == nk || (DT == 3 && --fold_in == 0)) {      // bf16x3: chunks of p.acc_chunk slices; 16-bit operand
-            fold_in = p.acc_chunk;                                      // modes: one chain (the epilogue reads `top`)
+        } else if (TWO && (kt + 1 == nk || --fold_in == 0)) {           // bf16x3: chunks of p.acc_chunk slices
+            fold_in = p.acc_chunk;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -462,11 +480,67 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(ig
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                smem[row * SP + wn * 32 + r] = top[i][j][e];
+                smem[row * SP + wn * 32 + r] = TWO ? top[i][j][e] : acc[i][j][e];
             }
         __syncthreads();
         const int nb = n0 + j * SW;    // first channel of this pass
-        if (p.vec_out) {
+        if (HOUT && hstore && p.vec_out == 2) {
+            // fp16 tensors: 8 channels = 16 bytes per lane (stores, residual loads); the two float4 halves may sit in different norm groups
+            constexpr int CPR8 = SW / 8;
+            static_assert(NTH % CPR8 == 0, "a thread keeps its channel column across the rows of a pass");
+            double sa0 = 0.0, qa0 = 0.0, sa1 = 0.0, qa1 = 0.0, sb0 = 0.0, qb0 = 0.0, sb1 = 0.0, qb1 = 0.0;
+#pragma unroll
+            for (int c = t; c < BM * CPR8; c += NTH) {
+                const int row = c / CPR8, q = (c - row * CPR8) * 8;
+                const int m = m0 + row, n = nb + q;
+                if (m < p.M && n < p.Cout) {
+                    float v[8];
+                    *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(&smem[row * SP + q]);
+                    *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(&smem[row * SP + q + 4]);
+                    if (scale) {
+                        float sc[8], sh[8];
+                        *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(scale + n);
+                        *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(scale + n + 4);
+                        *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(shift + n);
+                        *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(shift + n + 4);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
+                    }
+                    if (res) {
+                        const h16x8 rh = *reinterpret_cast<const h16x8*>(reinterpret_cast<const H16*>(res) + (long)m * p.res_cs + n);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += (float)rh[e];
+                    }
+                    h16x8 hv;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        if (relu) v[e] = fmaxf(v[e], 0.f);
+                        hv[e] = (H16)v[e];
+                        v[e] = (float)hv[e];
+                    }
+                    *reinterpret_cast<h16x8*>(reinterpret_cast<H16*>(out) + (long)m * out_cs + n) = hv;
+                    if (gn) {
+                        const double a = (double)v[0] + (double)v[1] + (double)v[2] + (double)v[3];
+                        const double b = (double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2] + (double)v[3] * v[3];
+                        const double a2 = (double)v[4] + (double)v[5] + (double)v[6] + (double)v[7];
+                        const double b2 = (double)v[4] * v[4] + (double)v[5] * v[5] + (double)v[6] * v[6] + (double)v[7] * v[7];
+                        if (m < m_next) { sa0 += a; qa0 += b; sb0 += a2; qb0 += b2; } else { sa1 += a; qa1 += b; sb1 += a2; qb1 += b2; }
+                    }
+                }
+            }
+            if (gn) {
+                const int n = nb + (t % CPR8) * 8;
+                if (n < p.Cout) {
+                    const int g0 = n / p.gn_cpg, g1 = (n + 4) / p.gn_cpg;
+                    atomicAdd(&gacc[g0 * 2], sa0); atomicAdd(&gacc[g0 * 2 + 1], qa0);
+                    atomicAdd(&gacc[g1 * 2], sb0); atomicAdd(&gacc[g1 * 2 + 1], qb0);
+                    if (sa1 != 0.0 || qa1 != 0.0 || sb1 != 0.0 || qb1 != 0.0) {
+                        atomicAdd(&gacc[64 + g0 * 2], sa1); atomicAdd(&gacc[64 + g0 * 2 + 1], qa1);
+                        atomicAdd(&gacc[64 + g1 * 2], sb1); atomicAdd(&gacc[64 + g1 * 2 + 1], qb1);
+                    }
+                }
+            }
+        } else if (p.vec_out) {
             constexpr int CPR = SW / 4;  // float4 chunks per row
             static_assert(NTH % CPR == 0, "a thread keeps its channel column across the rows of a pass");
             double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
@@ -673,6 +747,9 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
                 (!p.res || ((p.res_cs % 4 == 0) && (((uintptr_t)p.res & 15) == 0) && (p.res_gs % 4 == 0))) &&
                 (!p.scale || ((((uintptr_t)p.scale & 15) == 0) && (p.ss_gs % 4 == 0))) &&
                 (!p.prelu || ((((uintptr_t)p.prelu & 15) == 0) && (p.ss_gs % 4 == 0)));
+    if (p.es == 2 && p.vec_out && p.Cout % 8 == 0 && p.out_cs % 8 == 0 && p.out_gs % 8 == 0 && !p.prelu &&
+        (!p.res || (p.res_cs % 8 == 0 && p.res_gs % 8 == 0)) && (!p.scale || (p.ss_gs % 8 == 0 && (((uintptr_t)p.scale & 31) == 0))))
+        p.vec_out = 2;        // fp16 tensors: 16-byte accesses of 8 channels
     // GroupNorm sums in the epilogue: 16-byte stores, whole float4s inside one norm group, at most 32 groups, and images
     // of at least one tile of rows (a tile then meets at most two images); otherwise a separate pass over the output
     const bool gn_sep = p.gn_sum && !(p.vec_out && p.gn_cpg % 4 == 0 && p.gn_groups <= 32 && p.ohw >= BM && p.ohw >= 8);
@@ -725,7 +802,7 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
     // K-slices of the remainder
     // (launches of a few dozen tiles - small batches - keep the one-tile-per-block kernel and its fitted split-K model:
     // sharing every tile's K between all resident blocks writes more partial tiles than that model's 2-8 partitions)
-    if (g_persist && ((BM == 128 && BN == 128) || (g_persist == 2 && (BM == BN || BM == 256))) && !skip && p.ws && conv_persistent_ok(p) &&
+    if (g_persist && ((BM == 128 && BN == 128) || (g_persist == 2 && (BM == BN || BM == 256))) && BN <= 128 && !skip && p.ws && conv_persistent_ok(p) &&
         (long)p.mtiles * p.ntiles * G >= g_persist_min_tiles &&
         ((long)p.mtiles * p.ntiles * G >= 256L * (BM == 64 ? 5 : 2) || nk >= g_persist_min_nk)) {      // several tiles per block, or K worth sharing
         if (p.bf16 == 3 && (BM == 256 || (BM == 64 && nk <= 8))) exact_fallback();
@@ -858,6 +935,8 @@ int launch_conv(const ConvP& p0, int G, hipStream_t st) {
     // 33-64 output channels without a residual, at least a round of tiles: 128x64 (each wave 64x32: the weight fragments
     // are read from LDS half as often as with 64x64 tiles; +3-5 % on stem.conv3 / res2 conv1, conv2 - tools/tile_ab.py)
     if (g_tile_128x64 && p.Cout <= 64 && p.Cout > 32 && !p.res && (long)((p.M + 127) / 128) * G >= 1024) return run<128, 64, 2, 2>(p, G, 1, st);
+    // (64 x 256 tiles for the residual 1x1 layers - input rows read once, 512-byte row segments - measured 30-50 % SLOWER than
+    // 64x64 in both the fp32 and the fp16 path, profiles/r03x_tile_64x256_rejected.txt: those layers live on blocks in flight)
     if (p.Cout <= 64 || (p.res && nk <= 8 && p.Cout >= 128)) return run<64, 64, 2, 2>(p, G, choose_split(p, G, 64, 64, igemm_occupancy(64, 64)), st);
     const long tiles128 = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * G;
     const int s128 = choose_split(p, G, 128, 128, igemm_occupancy(128, 128));

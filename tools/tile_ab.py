@@ -12,7 +12,10 @@ LAYERS = [("stem.conv3 3x3 32>64 @240x320 x2", 32, 240, 320, 32, 64, 3, 1, 1, Fa
           ("res2.conv2 3x3 64>64 @120x160 x2", 32, 120, 160, 64, 64, 3, 1, 1, False),
           ("res2.conv1 1x1 256>64 @120x160 x2", 32, 120, 160, 256, 64, 1, 1, 1, False),
           ("decoder.project 1x1 256>48-ish (64) @120x160", 16, 120, 160, 256, 64, 1, 1, 1, False),
-          ("res2.conv3 1x1 64>256 +res @120x160 x2", 32, 120, 160, 64, 256, 1, 1, 1, True)]
+          ("res2.conv3 1x1 64>256 +res @120x160 x2", 32, 120, 160, 64, 256, 1, 1, 1, True),
+          ("res3.conv3 1x1 128>512 +res @60x80 x2", 32, 60, 80, 128, 512, 1, 1, 1, True),
+          ("res4.conv3 1x1 256>1024 +res @30x40 x2", 32, 30, 40, 256, 1024, 1, 1, 1, True),
+          ("res5.conv3 1x1 512>2048 +res @30x40 x2", 32, 30, 40, 512, 2048, 1, 1, 1, True)]
 lib.quber_set_tuning(13, 0)
 for (name, B, H, W, Cin, Cout, k, s, d, res) in LAYERS:
     x = torch.randn(B, H, W, Cin, device="cuda"); w = torch.randn(Cout, Cin, k, k, device="cuda") / np.sqrt(Cin * k * k)
