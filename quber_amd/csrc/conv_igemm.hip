@@ -802,11 +802,13 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
     // K-slices of the remainder
     // (launches of a few dozen tiles - small batches - keep the one-tile-per-block kernel and its fitted split-K model:
     // sharing every tile's K between all resident blocks writes more partial tiles than that model's 2-8 partitions)
-    if (g_persist && ((BM == 128 && BN == 128) || (g_persist == 2 && (BM == BN || BM == 256))) && BN <= 128 && !skip && p.ws && conv_persistent_ok(p) &&
+    // (fp16 data path: only the fused projection shortcuts - launch_conv_dual - go persistent: with 16x the matrix rate the
+    // persistent kernel's per-slice tap arithmetic costs the 3x3 layers 30 %, profiles/r04a_f16_persistent_all_rejected.md)
+    if (g_persist && p.es != 2 && ((BM == 128 && BN == 128) || (g_persist == 2 && (BM == BN || BM == 256))) && BN <= 128 && !skip && p.ws && conv_persistent_ok(p) &&
         (long)p.mtiles * p.ntiles * G >= g_persist_min_tiles &&
-        ((long)p.mtiles * p.ntiles * G >= 256L * (BM == 64 ? 5 : 2) || nk >= g_persist_min_nk)) {      // several tiles per block, or K worth sharing
+        ((long)p.mtiles * p.ntiles * G >= 256L * (p.es == 2 ? 3 : BM == 64 ? 5 : 2) || nk >= g_persist_min_nk)) {      // several tiles per block, or K worth sharing
         if (p.bf16 == 3 && (BM == 256 || (BM == 64 && nk <= 8))) exact_fallback();
-        const int bpc = BM == 64 ? 5 : 2;          // conv_persist.hip: pk_occupancy()
+        const int bpc = p.es == 2 ? 3 : BM == 64 ? 5 : 2;          // conv_persist.hip: pk_occupancy()
         if (p.ws_floats >= conv_persistent_ws_floats(BM, BN, bpc)) {
             {
                 ProfScope prof(tag, conv_bytes, conv_flops, st);

@@ -28,6 +28,7 @@ constexpr int BK = 32;
 constexpr int PITCH = 36;
 template <int DT> struct Half16 { using T = __bf16; };
 template <> struct Half16<2> { using T = _Float16; };
+template <> struct Half16<4> { using T = _Float16; };     // DT 4: the fp16 data path (fp16 activations and weights in HBM)
 constexpr int PITCH_H = 40;
 constexpr int NPL(int dt) { return dt == 3 ? 3 : 1; }
 
@@ -76,7 +77,7 @@ __device__ unsigned long long g_pk_span[2048 * 4];      // per block: kernel ent
 #endif
 // resident blocks per CU the kernel is built for (= waves per SIMD: a block is one wave on each SIMD)
 // (two accumulator sets since round 3 - the MFMA chain and the chunk sums, see `fold` below: 64 + 64 registers for a 128x128 tile)
-constexpr int pk_occupancy(int BM, int DT) { return BM == 64 ? 5 : 2; }
+constexpr int pk_occupancy(int BM, int DT) { return DT == 4 ? 3 : BM == 64 ? 5 : 2; }
 
 // All global accesses go through buffer descriptors (base + 32-bit byte offset, hardware range check):
 //   * an out-of-image tap, or a lane whose channel is past Cout, adds OOB to its offset - loads return 0 and stores are
@@ -128,6 +129,20 @@ __device__ __forceinline__ void quad_transpose(float& a0, float& a1, float& a2, 
     a2 = q1 ? b2 : y0;
     a3 = q1 ? b3 : y1;
 }
+// 4 halfs (8 bytes) of the fp16 data path
+using h16x4_t = __attribute__((ext_vector_type(4))) _Float16;
+__device__ __forceinline__ f32x4 buf_load4h(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0);
+    const h16x4_t hv = __builtin_bit_cast(h16x4_t, v);
+    return f32x4{(float)hv.x, (float)hv.y, (float)hv.z, (float)hv.w};
+}
+__device__ __forceinline__ h16x4_t buf_store4h(f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voff) {
+    using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+    const h16x4_t hv = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hv), r, voff, 0, 0);
+    return hv;
+}
 __device__ __forceinline__ void buf_store4(f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voff) {
     using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
@@ -145,7 +160,11 @@ void conv_igemm_pk(const ConvP p) {
     constexpr int AL = BM / RPP;
     constexpr int BL = BN / RPP;
     static_assert(BM % RPP == 0 && BN % RPP == 0, "loader geometry");
-    static_assert(DT == 0 || DT == 3, "16-bit operand modes keep the one-tile-per-block kernel");
+    static_assert(DT == 0 || DT == 3 || DT == 4, "the fp32-activation 16-bit operand modes keep the one-tile-per-block kernel");
+    // DT 4 (fp16 data path): operands travel as raw 4-byte units (two halfs), exactly like conv_igemm_f32<.., 4>: the loader,
+    // the LDS image and its pitch are the fp32 kernel's, a K-slice carries 64 halfs, outputs / residuals are fp16
+    constexpr bool H16IO = DT == 4;
+    constexpr bool TWO = DT != 4;          // two-level accumulation (the 16-bit mode keeps one chain: its tolerance is 100x wider)
     constexpr bool RES = EPI == 1, GN = EPI == 2;
     // EPI 3: a 1x1 convolution whose K runs over TWO inputs - p.K1 channels of `in` (stride 1), then the channels of `in2`
     // sampled with stride p.stride2: a bottleneck's conv3 and its projection shortcut as one GEMM (BN scales folded into
@@ -156,7 +175,7 @@ void conv_igemm_pk(const ConvP p) {
     // slice is stored into the image nobody reads while this one is multiplied, and ONE barrier per slice publishes it -
     // with two resident blocks instead of three there is less to hide a second barrier and the store phase behind.
     constexpr int NBUF = (DT == 0 && BM == 128 && BN == 128) ? 2 : 1;
-    constexpr int IMG_FLOATS = DT ? NPL(DT) * (BM + BN) * PITCH_H / 2 : (BM + BN) * PITCH;
+    constexpr int IMG_FLOATS = DT == 3 ? NPL(DT) * (BM + BN) * PITCH_H / 2 : (BM + BN) * PITCH;
     constexpr int SMEM_FLOATS = NBUF * IMG_FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     int buf = 0;                        // image being multiplied (NBUF == 2)
@@ -420,6 +439,21 @@ void conv_igemm_pk(const ConvP p) {
                         acc[i][j] = c;
                     }
             }
+        } else if constexpr (DT == 4) {
+#pragma unroll
+            for (int ks = 0; ks < BK / 8; ++ks) {           // 64 halfs per slice: four k16 steps
+                const H16* ap = reinterpret_cast<const H16*>(&As[(wm * TM * 32 + r) * PITCH]) + 8 * h + ks * 16;
+                const H16* bp = reinterpret_cast<const H16*>(&Bs[(wn * 32 + r) * PITCH]) + 8 * h + ks * 16;
+                h16x8 a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const h16x8*>(ap + i * 32 * 2 * PITCH);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const h16x8*>(bp + j * WN * 32 * 2 * PITCH);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
         } else {
             // exact fp32: the chain of a K-slice starts from zero (SrcC = 0 of its first MFMA) and is added to `top` when the
             // slice is done - 16 MFMA steps (32 k) per chain, K / 32 additions above them
@@ -467,15 +501,20 @@ void conv_igemm_pk(const ConvP p) {
 #endif
     auto epilogue = [&]() __attribute__((always_inline)) {
         const long tile_org = (long)c_m0 * p.out_cs + c_n0;
+        // element size of the tensors this tile touches: the split-K workspace is fp32 always, out / res are fp16 in the fp16 data path
+        const unsigned oes = (H16IO && !c_raw) ? 2u : 4u;
+        const char* const out_base = reinterpret_cast<const char*>(p.out) + ((long)c_g * p.out_gs + tile_org) * (H16IO ? 2 : 4);
         const __amdgpu_buffer_rsrc_t rs_out =
-            make_rsrc(c_raw ? p.ws + (long)c_slot * (BM * BN) : p.out + (long)c_g * p.out_gs + tile_org,
-                      p.pk_debug == 1 ? 0 : c_raw ? BM * BN * 4 : (int)(((long)p.M * p.out_cs - tile_org) * 4));
-        const unsigned out_cs4 = (c_raw ? BN : p.out_cs) * 4;
+            make_rsrc(c_raw ? reinterpret_cast<const void*>(p.ws + (long)c_slot * (BM * BN)) : reinterpret_cast<const void*>(out_base),
+                      p.pk_debug == 1 ? 0 : c_raw ? BM * BN * 4 : (int)(((long)p.M * p.out_cs - tile_org) * oes));
+        const unsigned out_cs4 = (c_raw ? BN : p.out_cs) * oes;
         const long res_org = (long)c_m0 * p.res_cs + c_n0;
+        constexpr unsigned RES_ES = H16IO ? 2u : 4u;
         __amdgpu_buffer_rsrc_t rs_res = rs_out;
         if constexpr (RES)
-            rs_res = make_rsrc(p.res + (long)c_g * p.res_gs + res_org, c_raw ? 0 : (int)(((long)p.M * p.res_cs - res_org) * 4));
-        const unsigned res_cs4 = p.res_cs * 4;
+            rs_res = make_rsrc(reinterpret_cast<const char*>(p.res) + ((long)c_g * p.res_gs + res_org) * RES_ES,
+                               c_raw ? 0 : (int)(((long)p.M * p.res_cs - res_org) * RES_ES));
+        const unsigned res_cs4 = p.res_cs * RES_ES;
         const bool affine = p.scale != nullptr && !c_raw;
         const float lo = (p.relu && !c_raw) ? 0.f : -__builtin_inff();     // ReLU as max(y, lo)
         const gf32x4_ptr scale = uniform_gptr(p.scale + c_g * p.ss_gs + c_n0);      // 16-byte aligned: c_n0 % 64 == 0, host checks the base
@@ -512,22 +551,24 @@ void conv_igemm_pk(const ConvP p) {
         // ... and the residual one row group ahead of its use, issued before the stores of the group in hand
         auto res_off = [&](int s) __attribute__((always_inline)) -> unsigned {
             const int tt = s >> 2, g4 = s & 3, j = tt / TM, i = tt % TM;
-            return nok[j] ? ((wm * TM + i) * 32 + lrow + g4 * 8) * res_cs4 + ((j * WN + wn) * 32 + lcol4) * 4 : OOB;
+            return nok[j] ? ((wm * TM + i) * 32 + lrow + g4 * 8) * res_cs4 + ((j * WN + wn) * 32 + lcol4) * RES_ES : OOB;
         };
         f32x4 rv_next = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (RES) rv_next = buf_load4(rs_res, res_off(0));
+        if constexpr (RES) rv_next = H16IO ? buf_load4h(rs_res, res_off(0)) : buf_load4(rs_res, res_off(0));
         double s0 = 0.0, q0s = 0.0, s1 = 0.0, q1s = 0.0;
 #pragma unroll
         for (int tt = 0; tt < TM * TN; ++tt) {
             const int j = tt / TM, i = tt % TM;
-            const unsigned vo = nok[j] ? ((wm * TM + i) * 32 + lrow) * out_cs4 + ((j * WN + wn) * 32 + lcol4) * 4 : OOB;
+            const unsigned vo = nok[j] ? ((wm * TM + i) * 32 + lrow) * out_cs4 + ((j * WN + wn) * 32 + lcol4) * oes : OOB;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const f32x4 rv = rv_next;
                 if constexpr (RES) {
-                    if (tt * 4 + g4 + 1 < TM * TN * 4) rv_next = buf_load4(rs_res, res_off(tt * 4 + g4 + 1));
+                    if (tt * 4 + g4 + 1 < TM * TN * 4)
+                        rv_next = H16IO ? buf_load4h(rs_res, res_off(tt * 4 + g4 + 1)) : buf_load4(rs_res, res_off(tt * 4 + g4 + 1));
                 }
-                float a0 = top[i][j][4 * g4], a1 = top[i][j][4 * g4 + 1], a2 = top[i][j][4 * g4 + 2], a3 = top[i][j][4 * g4 + 3];
+                const f32x16& fin = TWO ? top[i][j] : acc[i][j];
+                float a0 = fin[4 * g4], a1 = fin[4 * g4 + 1], a2 = fin[4 * g4 + 2], a3 = fin[4 * g4 + 3];
                 quad_transpose(a0, a1, a2, a3, q0, q1);
                 f32x4 v = {a0, a1, a2, a3};
 #pragma unroll
@@ -536,7 +577,12 @@ void conv_igemm_pk(const ConvP p) {
                     if constexpr (RES) y += rv[x];
                     v[x] = fmaxf(y, lo);
                 }
-                buf_store4(v, rs_out, vo + g4 * 8 * out_cs4);
+                if (H16IO && !c_raw) {            // rounded once to fp16; the GroupNorm sums are of the stored values
+                    const h16x4_t hv = buf_store4h(v, rs_out, vo + g4 * 8 * out_cs4);
+                    v = f32x4{(float)hv.x, (float)hv.y, (float)hv.z, (float)hv.w};
+                } else {
+                    buf_store4(v, rs_out, vo + g4 * 8 * out_cs4);
+                }
                 if constexpr (GN) {
                     const int row = (wm * TM + i) * 32 + (int)lrow + g4 * 8;
                     if (gn && nok[j] && row < rows) {
@@ -613,7 +659,10 @@ void conv_igemm_pk(const ConvP p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) top[i][j][e] = 0.f;      // (`acc` is zero after the fold that ended the last tile)
+                    for (int e = 0; e < 16; ++e) {
+                        if constexpr (TWO) top[i][j][e] = 0.f;            // (`acc` is zero after the fold that ended the last tile)
+                        else acc[i][j][e] = 0.f;
+                    }
             fold_in = p.acc_chunk;         // 0: never reaches zero by decrements - one chain over the whole K
             c_m0 = n_m0; c_n0 = n_n0; c_g = n_g; c_slot = s_slot;
             nseg = s_k1 - s_k0;
@@ -663,8 +712,11 @@ __global__ __launch_bounds__(256) void pk_fixup_kernel(const ConvP p, int P) {
     const float* __restrict__ scale = p.scale ? p.scale + g * p.ss_gs : nullptr;
     const float* __restrict__ shift = p.shift ? p.shift + g * p.ss_gs : nullptr;
     const float* __restrict__ prelu = p.prelu ? p.prelu + g * p.ss_gs : nullptr;
-    const float* __restrict__ res = p.res ? p.res + (long)g * p.res_gs : nullptr;
-    float* __restrict__ out = p.out + (long)g * p.out_gs;
+    const bool h16 = p.es == 2;                        // fp16 data path: out / res are fp16 (the partial tiles are fp32 always)
+    const float* __restrict__ res = p.res ? (h16 ? reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(p.res) + (long)g * p.res_gs)
+                                                 : p.res + (long)g * p.res_gs)
+                                          : nullptr;
+    float* __restrict__ out = h16 ? reinterpret_cast<float*>(reinterpret_cast<_Float16*>(p.out) + (long)g * p.out_gs) : p.out + (long)g * p.out_gs;
     // first piece: the tail of block bf's share (slot 1 unless that share starts exactly here); the others start a share
     const float* first = p.ws + (long)(2 * (bf * 8 + xcd) + (pk_u0(pl, bf) < ua ? 1 : 0)) * (BM * BN);
     __shared__ double gacc[2 * 32 * 2];
@@ -695,7 +747,13 @@ __global__ __launch_bounds__(256) void pk_fixup_kernel(const ConvP p, int P) {
             v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
         }
         if (res) {
-            const float4 rv = *reinterpret_cast<const float4*>(res + (long)m * p.res_cs + n);
+            float4 rv;
+            if (h16) {
+                const h16x4_t rh = *reinterpret_cast<const h16x4_t*>(reinterpret_cast<const _Float16*>(res) + (long)m * p.res_cs + n);
+                rv = make_float4((float)rh.x, (float)rh.y, (float)rh.z, (float)rh.w);
+            } else {
+                rv = *reinterpret_cast<const float4*>(res + (long)m * p.res_cs + n);
+            }
             v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
         }
         if (p.relu) {
@@ -706,7 +764,13 @@ __global__ __launch_bounds__(256) void pk_fixup_kernel(const ConvP p, int P) {
             v.x = v.x > 0.f ? v.x : v.x * sl.x; v.y = v.y > 0.f ? v.y : v.y * sl.y;
             v.z = v.z > 0.f ? v.z : v.z * sl.z; v.w = v.w > 0.f ? v.w : v.w * sl.w;
         }
-        *reinterpret_cast<float4*>(out + (long)m * p.out_cs + n) = v;
+        if (h16) {
+            const h16x4_t hv = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+            *reinterpret_cast<h16x4_t*>(reinterpret_cast<_Float16*>(out) + (long)m * p.out_cs + n) = hv;
+            v = make_float4((float)hv.x, (float)hv.y, (float)hv.z, (float)hv.w);
+        } else {
+            *reinterpret_cast<float4*>(out + (long)m * p.out_cs + n) = v;
+        }
         if (gn) {
             const double a = (double)v.x + (double)v.y + (double)v.z + (double)v.w;
             const double b = (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
@@ -753,7 +817,16 @@ int launch_conv_persistent(ConvP p, int G, int bpc, hipStream_t st) {
     p.pk_in_bytes = (int)((long)p.B * p.H * p.W * p.in_cs * 4);
     p.pk_debug = g_persist_debug;
     const int epi = p.in2 ? 3 : p.gn_sum ? 2 : p.res ? 1 : 0;       // host: never two of them (conv_persistent_ok)
-    if (p.bf16 == 3) {
+    if (p.es == 2) {
+        if constexpr (BM == 128 && BN == 128) {          // the fp16 data path goes persistent on 128x128 tiles only
+            if (epi == 3) hipLaunchKernelGGL((conv_igemm_pk<BM, BN, WM, WN, 4, 3>), dim3(P), block, 0, st, p);
+            else if (epi == 2) hipLaunchKernelGGL((conv_igemm_pk<BM, BN, WM, WN, 4, 2>), dim3(P), block, 0, st, p);
+            else if (epi == 1) hipLaunchKernelGGL((conv_igemm_pk<BM, BN, WM, WN, 4, 1>), dim3(P), block, 0, st, p);
+            else hipLaunchKernelGGL((conv_igemm_pk<BM, BN, WM, WN, 4, 0>), dim3(P), block, 0, st, p);
+        } else {
+            return fail("persistent convolution: the fp16 data path has 128x128 tiles only");
+        }
+    } else if (p.bf16 == 3) {
         if (epi == 3) hipLaunchKernelGGL((conv_igemm_pk<BM, BN, WM, WN, 3, 3>), dim3(P), block, 0, st, p);
         else if (epi == 2) hipLaunchKernelGGL((conv_igemm_pk<BM, BN, WM, WN, 3, 2>), dim3(P), block, 0, st, p);
         else if (epi == 1) hipLaunchKernelGGL((conv_igemm_pk<BM, BN, WM, WN, 3, 1>), dim3(P), block, 0, st, p);
@@ -829,8 +902,9 @@ int conv_persistent_fixup(int T, int P, int nk, int min_slices, int xcd, int j, 
 // sums, 16-byte-aligned channel counts, every view below 2 GiB (32-bit buffer offsets)
 bool conv_persistent_ok(const ConvP& p) {
     const long lim = (long)1 << 31;
-    return (p.bf16 == 0 || p.bf16 == 3) && p.vec_out && !p.prelu && !(p.gn_sum && p.res) && !(p.in2 && (p.res || p.gn_sum)) &&
-           (long)p.B * p.H * p.W * p.in_cs * 4 < lim && (long)p.M * p.out_cs * 4 < lim &&
+    // (fp16 data path, es == 2: in_cs / Kpad are in 4-byte units by now - launch_conv - so the operand sizes come out in bytes)
+    return (p.bf16 == 0 || p.bf16 == 3 || (p.bf16 == 2 && p.es == 2)) && p.vec_out && !p.prelu && !(p.gn_sum && p.res) &&
+           !(p.in2 && (p.res || p.gn_sum)) && (long)p.B * p.H * p.W * p.in_cs * 4 < lim && (long)p.M * p.out_cs * 4 < lim &&
            (!p.res || (long)p.M * p.res_cs * 4 < lim) && (long)p.Cout * p.Kpad * 4 < lim;
 }
 
@@ -839,6 +913,13 @@ bool conv_persistent_ok(const ConvP& p) {
 int launch_conv_dual(ConvP p, int G, hipStream_t st) {
     if (!g_persist || !p.in2 || !p.ws) return 1;
     p.acc_chunk = g_acc_chunk;
+    if (p.es == 2) {        // fp16 data path: K-side quantities in 4-byte units (two halfs), as launch_conv hands them over
+        if (p.bf16 != 2 || p.Cin % 8 || p.in_cs % 8 || p.in2_cs % 8 || p.Kpad % 64 || p.K1 % 64 || (p.in_gs & 7) || (p.in2_gs & 7) || (p.w_gs & 1))
+            return 1;
+        p.Cin /= 2; p.in_cs /= 2; p.in2_cs /= 2; p.K /= 2; p.Kpad /= 2; p.K1 /= 2; p.in_gs /= 2; p.in2_gs /= 2; p.w_gs /= 2;
+    } else {
+        p.es = 4;
+    }
     if (p.kh != 1 || p.kw != 1 || p.pad != 0 || p.stride != 1 || p.kmode || p.K1 % BK || p.K1 <= 0 || p.K1 >= p.Kpad || p.K != p.Kpad ||
         p.Kpad % BK || p.in_cs % 4 || p.in2_cs % 4 || ((uintptr_t)p.in & 15) || ((uintptr_t)p.in2 & 15) || (p.in_gs & 3) || (p.in2_gs & 3))
         return 1;
@@ -855,7 +936,8 @@ int launch_conv_dual(ConvP p, int G, hipStream_t st) {
     const long tiles128 = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * G;
     if (tiles128 < g_persist_min_tiles) return 1;          // small batches: the two separate launches with their split-K model
     const bool big = tiles128 >= 192 && p.Cout > 64;
-    const int bpc = big ? 2 : 5;                           // pk_occupancy()
+    if (p.es == 2 && !big) return 1;                       // the fp16 data path has the 128x128 persistent kernel only
+    const int bpc = big ? (p.es == 2 ? 3 : 2) : 5;         // pk_occupancy()
     const int BMs = big ? 128 : 64;
     if (p.ws_floats < conv_persistent_ws_floats(BMs, BMs, bpc)) return 1;
     p.mtiles = (p.M + BMs - 1) / BMs;

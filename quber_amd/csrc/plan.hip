@@ -395,9 +395,10 @@ struct Builder {
     // modes, views past 2 GiB) run the two original ops.
     void fuse_shortcut(const std::vector<std::string>& n3, const std::vector<std::string>& ns, const View& y, int mid,
                        const View& x, int cin, int stride, const View& out) {
-        if (dry || !g_fuse_shortcut || c->ops.size() < 2 || aes != 4) return;
+        if (dry || !g_fuse_shortcut || c->ops.size() < 2) return;
         const int G = (int)n3.size(), Cout = out.C, Kd = mid + cin;
-        if (mid % 32 || cin % 32 || y.C != mid || x.C != cin) return;
+        const int KS = aes == 2 ? 64 : 32;         // K-slice in elements
+        if (mid % KS || cin % KS || y.C != mid || x.C != cin) return;
         std::vector<float> packed((size_t)G * Cout * Kd), ones((size_t)G * Cout, 1.f), shift((size_t)G * Cout);
         for (int g = 0; g < G; ++g) {
             const float* w3 = hw(n3[g] + ".weight", (int64_t)Cout * mid);
@@ -423,7 +424,15 @@ struct Builder {
             }
         }
         ConvP p{};
-        p.in = y.p; p.in2 = x.p; p.w = upload(packed); p.scale = upload(ones); p.shift = upload(shift); p.out = out.p;
+        p.in = y.p; p.in2 = x.p; p.scale = upload(ones); p.shift = upload(shift); p.out = out.p;
+        if (aes == 2) {
+            std::vector<_Float16> ph(packed.size());
+            for (size_t i = 0; i < packed.size(); ++i) ph[i] = (_Float16)packed[i];
+            p.w = upload16(ph);
+        } else {
+            p.w = upload(packed);
+        }
+        p.es = aes;
         p.H = y.H; p.W = y.W; p.Cin = mid; p.in_cs = y.cs; p.in_gs = y.gs;
         p.H2 = x.H; p.W2 = x.W; p.in2_cs = x.cs; p.in2_gs = x.gs; p.stride2 = stride; p.K1 = mid;
         p.OH = out.H; p.OW = out.W; p.Cout = Cout; p.out_cs = out.cs; p.out_gs = out.gs;
