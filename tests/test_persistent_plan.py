@@ -22,6 +22,9 @@ CASES = [
     (777, 512, 33, 4),        # bf16x3 occupancy (512 blocks), odd everything
     (5000, 1792, 9, 4),       # 64x64 tiles: 7 blocks per CU
     (96, 768, 1, 4),          # single-slice tiles
+    (2400, 512, 128, 4),      # round 3: two resident blocks per CU (two accumulator sets): fusion_res5.conv = 4 rounds + 352 tiles shared
+    (10800, 512, 8, 0),       # Winograd GEMM on 512 blocks: 21 rounds + 48 whole remainder tiles
+    (1200, 1280, 16, 0),      # 64x64 tiles at 5 blocks per CU
 ]
 
 

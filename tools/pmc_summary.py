@@ -12,11 +12,31 @@ convs = [p for p in meta["plan"] if p[1] == "conv"]
 B = meta["batch"]
 d = collections.OrderedDict()
 for r in csv.DictReader(open(counters_csv)):
-    if "conv_igemm" not in r["Kernel_Name"] or "splitk" in r["Kernel_Name"]:
-        continue
-    x = d.setdefault(r["Dispatch_Id"], {"ns": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})
+    x = d.setdefault(r["Dispatch_Id"], {"name": r["Kernel_Name"], "ns": int(r["End_Timestamp"]) - int(r["Start_Timestamp"]),
+                                        "t0": int(r["Start_Timestamp"])})
     x[r["Counter_Name"]] = float(r["Counter_Value"])
-rows = list(d.values())[-len(convs):]
+# one group of GEMM launches per convolution op (a Winograd op whose groups share one input transform launches several)
+disp = sorted(d.values(), key=lambda v: v["t0"])
+groups, i = [], 0
+while i < len(disp):
+    n_ = disp[i]["name"]
+    if "wino_input" in n_:
+        j = i + 1
+        while j < len(disp) and "wino_output" not in disp[j]["name"]:
+            j += 1
+        groups.append([v for v in disp[i:j + 1] if "conv_igemm" in v["name"]])
+        i = j + 1
+    elif "conv_igemm" in n_:
+        groups.append([disp[i]])
+        i += 1
+    else:
+        i += 1
+rows = []
+for g in groups[-len(convs):]:
+    v = {"ns": sum(x["ns"] for x in g)}
+    for k in ("GRBM_GUI_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_LDS_BANK_CONFLICT", "SQ_BUSY_CYCLES"):
+        v[k] = sum(x.get(k, 0.0) for x in g)
+    rows.append(v)
 print("| layer | ms | TFLOP/s | MFMA busy (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs)) | eff. clock GHz | mean waves per CU | LDS bank conflicts |")
 print("|---|---|---|---|---|---|---|")
 tb = ta = tf = tn = 0.0
