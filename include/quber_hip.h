@@ -62,8 +62,10 @@ typedef struct quber_config {
                                         3 = fp32-equivalent on the bf16 matrix pipe: every fp32 operand split into 3 bf16 terms,
                                         6 exact partial products per multiply, fp32 accumulation (dropped terms < 2^-26; same
                                         plan, same 1e-4 bar, 6/16 of the matrix time),
-                                        2 = fp16 operands, fp32 accumulation (BASELINE.json configs[4] "fp16 MFMA path" stand-in;
-                                        own tolerance, tests/test_gpu_loud_parity.py), 1 = bf16 operands likewise (8x coarser) */
+                                        2 = the fp16 data path (BASELINE.json configs[4] "fp16 MFMA path" stand-in): activations and
+                                        packed weights fp16 in device memory, fp32 accumulation, fp32 norm statistics and logits;
+                                        own tolerance (tests/test_gpu_loud_parity.py HALF_TOL),
+                                        1 = bf16 operands on fp32 tensors (8x coarser) */
     int32_t encode_legacy_f32;       /* a1 offset arithmetic (predictor.py:345-346, `np.float64 scalar - float32 array`):
                                         0 = numpy >= 2 promotion (float64, rounded once; what the reference computes when run
                                         under this image's numpy 2.2, pinned by tests/golden/encode_*.npz);
@@ -248,7 +250,10 @@ double quber_forward_flops_executed(quber_ctx* ctx);
  * key 6 = Winograd path of the eligible 3x3 layers (acts at plan time): 0 = where it pays (default), 1 = never, 2 = always;
  * key 5 = split the ragged last round of large convolution launches into K-pieces: when the cost model
  *         favours it (1, default), never (0), whenever feasible (2);
- * key 4 = force the convolution tile shape (1 = 64x64, 2 = 128x128, 4 = 256x32; 0 = automatic) */
+ * key 4 = force the convolution tile shape (1 = 64x64, 2 = 128x128, 4 = 256x32; 0 = automatic);
+ * key 20 = Winograd layers in passes whose V | M intermediates stay below `value` MiB (0 = the whole batch at once, default;
+ *          measured slower at every size: profiles/r03c_wino_subbatch_rejected.md);
+ * key 21 = K-slices per accumulation chunk of the bf16x3 mode (default 2; the exact fp32 mode folds every slice) */
 void quber_set_tuning(int32_t key, int32_t value);
 /* Host view of the work distribution of a persistent convolution launch (csrc/conv_persist.hip), for the CPU tests: no GPU.
  * _segments: the work list of block `block` of a launch of `blocks` blocks over `tiles` tiles of `k_slices` K-slices each
