@@ -90,6 +90,11 @@ def load():
         raise QuberError(
             f"{LIB_PATH} not found: build it with `make -C quber_amd/csrc` (or __graft_entry__.build()); "
             "quber_amd has no CPU fallback")
+    # torch ships its own HIP runtime (torch/lib/libamdhip64.so); this library is linked against the system one by soname.
+    # Whichever is loaded first serves both - but loaded in the other order the process ends up with two runtimes and the
+    # second sees no device ("no HIP device available" from quber_create after __graft_entry__.build() had loaded this library
+    # before anything imported torch).  The host side is torch-based anyway: make the order deterministic.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
