@@ -501,6 +501,85 @@ def test_conv_igemm_bf16x3_meets_the_fp32_bar(case):
 
 
 @pytest.mark.gpu
+def test_bf16x3_split_reproduces_every_fp32_operand_class():
+    """Why compute_dtype 3 may be called fp32-equivalent, as a property of the KERNEL (not of a numpy model of it).
+    A 1x1 convolution whose weight matrix is diag(b) turns the kernel into y[m][n] = a[m][n] * b[n]: one product per output,
+    so the split itself is what is measured.
+      * b = 1: y must equal a BIT FOR BIT for every fp32 a with |a| >= 2^-100 (normals over 227 binades; +-0 by value): x1 + x2 +
+        x3 (three round-to-nearest bf16 terms) reproduces all 24 significand bits and bf16 shares fp32's exponent range.  Below
+        2^-100 the low-order terms x2, x3 themselves fall under bf16's smallest normal (2^-126) and the matrix pipe flushes them:
+        the result degrades towards plain bf16 precision at the very bottom of the range, with an ABSOLUTE error below 2^-125
+        (1e-38) - subnormal and near-minimum operands are the one class the mode does not reproduce exactly.  Non-finite operands
+        stay non-finite: nan gives nan; +-inf gives NaN, not inf - the partial product inf * (the zero low-order term of the other
+        operand) is NaN by IEEE rules, which no ordering of the six products avoids (masking it costs two VALU ops per operand
+        element = 4.4 % of the mode's throughput, measured and not kept).
+      * random a, b: |y - a*b (float64)| <= 2^-22 |a b|.  The dropped partial products (a2 b3, a3 b2, a3 b3) are below 2^-26 |ab|
+        and each kept product is exact in fp32, but the six are summed inside the bf16 MFMA, which aligns its addends to the
+        largest with few guard bits: the measured worst case is 1.43e-7 |ab| = 1.2 fp32 ulp (the exact fp32 MFMA kernel, one
+        product per output: 0.5 ulp, printed beside it).  Over a K-long sum the difference disappears in the accumulation error
+        (kernel-level bars and the float64 anchor are the same for both modes)."""
+    lib = _lib.load()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    Cn, Mrows = 128, 128 * 384          # 384 tiles of 128x128: the launch the bf16x3 kernel takes (narrow / short launches keep the exact kernel)
+    g = torch.Generator().manual_seed(0)
+    # operand classes: every exponent from the smallest normal to the largest, random mantissas; subnormals; +-0; inf / nan
+    exps = torch.arange(-126, 128).repeat_interleave(8)
+    mant = 1.0 + torch.rand(exps.numel(), generator=g, dtype=torch.float64)
+    normals = (mant * torch.pow(torch.tensor(2.0, dtype=torch.float64), exps.double())).float()
+    normals = normals[torch.isfinite(normals)]
+    sub = torch.tensor([1.4e-45, 3e-45, 1e-42, 5.877e-39, 1.1754942e-38, -1.4e-45, -7e-41], dtype=torch.float32)
+    vals = torch.cat([normals, -normals, sub, torch.tensor([0.0, -0.0])])
+    a = torch.zeros(Mrows * Cn)
+    a[:vals.numel()] = vals
+    a = a.view(1, Mrows, 1, Cn).contiguous()
+    w = torch.eye(Cn).view(Cn, Cn, 1, 1).contiguous()
+
+    def run(x, wt, mode=3):
+        xd, wd = x.cuda(), wt.cuda()
+        y = torch.empty(1, x.shape[1], 1, Cn, device="cuda")
+        packed = torch.empty(Cn * Cn, device="cuda")
+        lib.quber_set_tuning(12, mode)
+        try:
+            _lib.check(lib.quber_op_conv2d(p(xd), 1, x.shape[1], 1, Cn, p(wd), Cn, 1, 1, 0, 1, p(None), p(None), p(None), 0, p(packed), p(y), st))
+        finally:
+            lib.quber_set_tuning(12, 0)
+        return y.cpu()
+
+    y = run(a, w)
+    big = a.abs() >= 2.0 ** -100
+    big = (big | (a == 0)).view_as(y)
+    # (-0 comes back as +0: an output is a sum over the other, zero, columns of the identity - IEEE addition, not the split)
+    bad = (y.view(torch.int32) != a.view_as(y).view(torch.int32)) & big & (a.view_as(y) != 0)
+    assert bool((y[a.view_as(y) == 0] == 0).all())
+    assert not bool(bad.any()), ("fp32 operands >= 2^-100 not reproduced bit for bit", a.view_as(y)[bad][:8].tolist(), y[bad][:8].tolist(),
+                                 int(bad.sum()), float(a.view_as(y)[bad].abs().min()), float(a.view_as(y)[bad].abs().max()))
+    assert float((y - a.view_as(y)).abs()[~big].max()) <= 2.0 ** -125          # the bottom of the range: bf16 underflow of the low terms
+    first_inexact = float(a.view_as(y).abs()[(y != a.view_as(y))].max()) if bool((y != a.view_as(y)).any()) else 0.0
+    print(f"\nbf16x3 split: largest operand not reproduced exactly: {first_inexact:.3e} (2^{np.log2(max(first_inexact, 1e-45)):.1f})")
+    # non-finite operands stay non-finite (their rows are kept apart from the finite ones)
+    sp = torch.zeros(1, Mrows, 1, Cn)
+    sp[0, 0, 0, :] = float("inf")
+    sp[0, 1, 0, :] = float("-inf")
+    sp[0, 2, 0, :] = float("nan")
+    ones = torch.ones(Cn, Cn, 1, 1)
+    ys = run(sp, ones)[0, :, 0]
+    assert not torch.isfinite(ys[0]).any() and not torch.isfinite(ys[1]).any() and torch.isnan(ys[2]).all()
+    assert (ys[3:] == 0).all()
+    # products: the dropped terms are bounded as claimed
+    ar = (torch.randn(Mrows * Cn, generator=g, dtype=torch.float64) * torch.pow(torch.tensor(2.0, dtype=torch.float64),
+          torch.randint(-20, 20, (Mrows * Cn,), generator=g).double())).float().view(1, Mrows, 1, Cn)
+    b = (torch.randn(Cn, generator=g, dtype=torch.float64) * torch.pow(torch.tensor(2.0, dtype=torch.float64),
+         torch.randint(-20, 20, (Cn,), generator=g).double())).float()
+    yp = run(ar, torch.diag(b).view(Cn, Cn, 1, 1).contiguous())
+    exact = ar.double() * b.double().view(1, 1, 1, Cn)
+    rel = ((yp.double() - exact).abs() / exact.abs().clamp_min(1e-300)).max().item()
+    rel0 = ((run(ar, torch.diag(b).view(Cn, Cn, 1, 1).contiguous(), mode=0).double() - exact).abs() / exact.abs().clamp_min(1e-300)).max().item()
+    print(f"single product, worst relative error: bf16x3 {rel:.3e} ({rel * 2 ** 23:.2f} ulp), exact fp32 MFMA {rel0:.3e} ({rel0 * 2 ** 23:.2f} ulp)")
+    assert rel <= 2.0 ** -22 and rel0 <= 2.0 ** -24 * 1.0001, (rel, rel0)
+
+
+@pytest.mark.gpu
 def test_conv_refuses_narrow_inputs_for_3x3():
     """fewer than 8 input channels under a 3x3 filter: refused loudly (the loader's tap stepping assumes >= 8 per tap)"""
     lib = _lib.load()
