@@ -159,27 +159,37 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ in,
     for (int cp = 0; cp < C4; cp += colsper) {
         const int c4 = cp + col;
         if (row >= rows || c4 >= C4) continue;   // idle lanes when 256 is not a multiple of the row width
-        double s = 0.0, ss = 0.0;
-        for (int pix = p0 + row; pix < p1; pix += rows) {
-            const float4 v = ldv4(base + (long)pix * cs + c4 * 4);
-            if (cpg >= 4) {
-                s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
-                ss += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
-            } else {
-                // cpg in {1,2}: a float4 spans several norm groups
-                const float e[4] = {v.x, v.y, v.z, v.w};
+        // a lane keeps its four channels over all its pixels: four (sum, sum of squares) pairs in registers, folded into the norm
+        // groups once at the end - whatever the channels per group (32-channel heads have ONE channel per group: the per-element
+        // LDS atomics of the first version ran those passes at 1 TB/s)
+        double s[4] = {0.0, 0.0, 0.0, 0.0}, ss[4] = {0.0, 0.0, 0.0, 0.0};
+        int pix = p0 + row;
+        for (; pix + 3 * rows < p1; pix += 4 * rows) {        // four independent 16-byte loads in flight per lane
+            float4 v[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int grp = (c4 * 4 + j) / cpg;
-                    atomicAdd(&acc[grp * 2], (double)e[j]);
-                    atomicAdd(&acc[grp * 2 + 1], (double)e[j] * e[j]);
-                }
+            for (int u = 0; u < 4; ++u) v[u] = ldv4(base + (long)(pix + u * rows) * cs + c4 * 4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s[0] += (double)v[u].x; s[1] += (double)v[u].y; s[2] += (double)v[u].z; s[3] += (double)v[u].w;
+                ss[0] += (double)v[u].x * v[u].x; ss[1] += (double)v[u].y * v[u].y; ss[2] += (double)v[u].z * v[u].z; ss[3] += (double)v[u].w * v[u].w;
             }
+        }
+        for (; pix < p1; pix += rows) {
+            const float4 v = ldv4(base + (long)pix * cs + c4 * 4);
+            s[0] += (double)v.x; s[1] += (double)v.y; s[2] += (double)v.z; s[3] += (double)v.w;
+            ss[0] += (double)v.x * v.x; ss[1] += (double)v.y * v.y; ss[2] += (double)v.z * v.z; ss[3] += (double)v.w * v.w;
         }
         if (cpg >= 4) {
             const int grp = (c4 * 4) / cpg;
-            atomicAdd(&acc[grp * 2], s);
-            atomicAdd(&acc[grp * 2 + 1], ss);
+            atomicAdd(&acc[grp * 2], (s[0] + s[1]) + (s[2] + s[3]));
+            atomicAdd(&acc[grp * 2 + 1], (ss[0] + ss[1]) + (ss[2] + ss[3]));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int grp = (c4 * 4 + j) / cpg;
+                atomicAdd(&acc[grp * 2], s[j]);
+                atomicAdd(&acc[grp * 2 + 1], ss[j]);
+            }
         }
     }
     __syncthreads();
