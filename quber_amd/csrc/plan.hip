@@ -87,7 +87,11 @@ struct Op {
     std::string name;   // first weight key (convs / norms) or a short tag
     double flops;       // algorithmic FLOPs at batch 1 (convolutions only)
     int launches;       // kernel launches per run (memsets not counted)
+    int lane = 0;       // 0 = the caller's stream; 1.. = a side stream of the context (small batches only, see quber_forward)
+    int ctl = 0;        // 1 = fork `lane` here (it may start once the main stream has reached this point), 2 = join it
 };
+constexpr int LANES = 6;            // side lanes: fusion_res2, fusion_res3, three ASPP branches (+1 spare)
+constexpr int LANE_BATCH = 2;       // side lanes are used up to this batch (their workspaces are sized for it)
 
 struct quber_ctx {
     quber_config cfg;
@@ -108,6 +112,15 @@ struct quber_ctx {
     size_t splitk_floats = 0;
     float* wino_ws = nullptr;     // V | M of the Winograd layers (sized for the largest one at max_batch)
     size_t wino_floats = 0;
+    // side lanes (batch <= LANE_BATCH): independent branches of the network on streams of their own, each with its own workspaces
+    hipStream_t lane_stream[LANES] = {};
+    hipEvent_t lane_fork[LANES] = {}, lane_join[LANES] = {};
+    float* lane_wino_ws[LANES] = {};
+    size_t lane_wino_floats[LANES] = {};
+    float* lane_splitk_ws[LANES] = {};
+    size_t lane_splitk_floats = 0;
+    bool lanes_built = false;     // the plan contains fork / join points
+    bool lanes_on = false;        // ... and this forward uses them
     View X;               // [2][Bmax][H][W][8] (16 channels of fp16 in the fp16 data path)
     float* q = nullptr;   // [Bmax][planes][H/4][W/4]
     const uint8_t* cur_bgr = nullptr;
@@ -141,6 +154,7 @@ struct DeferredNorm {
 };
 struct LastConv { std::shared_ptr<GnFuse> fuse; const float* out = nullptr; int G = 0, C = 0; };
 
+static int g_lanes = 1;           // key 24: side lanes for batches <= LANE_BATCH (0 = everything on the caller's stream)
 static int g_fuse_shortcut = 1;   // key 18 (plan time): conv3 + projection shortcut of a bottleneck as one dual-input GEMM
 
 struct Builder {
@@ -151,6 +165,7 @@ struct Builder {
     std::string err;
     int Bmax, H, W;
 
+    int cur_lane = 0;   // lane of the ops being emitted (0 = main)
     int aes = 4;        // element size of the activation tensors: 2 in the fp16 data path (quber_config.compute_dtype 2)
 
     Builder(quber_ctx* ctx, bool d) : c(ctx), dry(d), Bmax(ctx->cfg.max_batch), H(ctx->cfg.height), W(ctx->cfg.width) {
@@ -321,6 +336,10 @@ struct Builder {
                 wq.dtype = c->cfg.compute_dtype;
                 const size_t need = winograd_ws_floats(Bmax, in.H, in.W, Cin, Cout, G, dil, m);
                 if (need > c->wino_floats) c->wino_floats = need;
+                if (cur_lane) {
+                    const size_t ln = winograd_ws_floats(std::min(Bmax, LANE_BATCH), in.H, in.W, Cin, Cout, G, dil, m);
+                    if (ln > c->lane_wino_floats[cur_lane]) c->lane_wino_floats[cur_lane] = ln;
+                }
             }
         }
         std::shared_ptr<DeferredNorm> norm;
@@ -331,10 +350,14 @@ struct Builder {
         pending_norm.reset();
         auto fuse = std::make_shared<GnFuse>();
         last_conv = {fuse, out.p, G, Cout};
-        c->ops.push_back({[p, G, ctx, fuse, wq, wino, norm](int B, hipStream_t st) mutable {
+        const int L = cur_lane;
+        c->ops.push_back({[p, G, ctx, fuse, wq, wino, norm, L](int B, hipStream_t st) mutable {
+            const bool side = L && ctx->lanes_on;                  // on a side lane: that lane's workspaces
+            float* const sk_ws = side ? ctx->lane_splitk_ws[L] : ctx->splitk_ws;
+            const size_t sk_floats = side ? ctx->lane_splitk_floats : ctx->splitk_floats;
             if (wino) {
-                wq.ws = ctx->wino_ws; wq.ws_floats = ctx->wino_floats;
-                wq.splitk_ws = ctx->splitk_ws; wq.splitk_floats = ctx->splitk_floats;
+                wq.ws = side ? ctx->lane_wino_ws[L] : ctx->wino_ws; wq.ws_floats = side ? ctx->lane_wino_floats[L] : ctx->wino_floats;
+                wq.splitk_ws = sk_ws; wq.splitk_floats = sk_floats;
                 wq.gn_sum = fuse->sums; wq.gn_groups = fuse->groups;
                 if (norm) {                      // read the producer's pre-normalisation tensor and normalise on load
                     wq.in = norm->in;
@@ -344,13 +367,14 @@ struct Builder {
             }
             p.B = B;
             p.M = B * p.OH * p.OW;
-            p.ws = ctx->splitk_ws;
-            p.ws_floats = ctx->splitk_floats;
+            p.ws = sk_ws;
+            p.ws_floats = sk_floats;
             p.gn_sum = fuse->sums;
             p.gn_groups = fuse->groups;
             p.gn_cpg = fuse->groups ? p.Cout / fuse->groups : 0;
             return launch_conv(p, G, st);
         }, OP_CONV, name, 2.0 * OH * OW * (double)cin_real * k * k * Cout * G, 1});
+        c->ops.back().lane = cur_lane;
     }
 
     // refiner convolutions: `names` = one detectron2 Conv2d key prefix per group (e.g. "backbone.rgb_backbone.stem.conv1")
@@ -494,10 +518,31 @@ struct Builder {
             if (dn && dn->absorbed) return 0;      // the consumer normalises while it loads
             return launch_gn_apply(in, out, B, G, 32, stats, dg, db, C, 1e-5f, 1, st);
         }, OP_NORM, names[0], 0.0, fused ? 1 : 2});
+        c->ops.back().lane = cur_lane;
     }
 
     void op(std::function<int(int, hipStream_t)> f) {
-        if (!dry) c->ops.push_back({std::move(f), OP_OTHER, "elementwise", 0.0, 1});
+        if (!dry) {
+            c->ops.push_back({std::move(f), OP_OTHER, "elementwise", 0.0, 1});
+            c->ops.back().lane = cur_lane;
+        }
+    }
+    // Side lanes.  fork(L): the ops emitted until join(L) with cur_lane = L form a branch that depends on nothing emitted after
+    // this point and whose results nothing needs before join(L): at small batches, where a launch fills a fraction of the chip,
+    // quber_forward runs it on a stream of its own beside what the main stream does meanwhile (the later ResNet stages beside
+    // the fusion convolutions of the earlier ones; the ASPP branches beside each other).
+    void fork(int L) {
+        if (dry) return;
+        c->ops.push_back({nullptr, OP_OTHER, "fork", 0.0, 0});
+        c->ops.back().lane = L; c->ops.back().ctl = 1;
+        cur_lane = L;
+        c->lanes_built = true;
+    }
+    void back_to_main() { cur_lane = 0; }
+    void join(int L) {
+        if (dry) return;
+        c->ops.push_back({nullptr, OP_OTHER, "join", 0.0, 0});
+        c->ops.back().lane = L; c->ops.back().ctl = 2;
     }
 
     // conv (no bias) -> GN -> ReLU, the [d2] Conv2d(norm=GN, activation=relu) pattern
@@ -544,6 +589,38 @@ struct Builder {
 
         // ---------------- res2..res5 ----------------
         View cat[4];  // concatenated [rgb | depth] stage outputs
+        // ---------------- backbone fusion (resnet.py:472-485), emitted right after its stage ----------------
+        View F[4];
+        const int fch[4] = {256, 512, 1024, 2048};
+        auto emit_fusion = [&](int s) {
+            if (NS == 1) {   // build_resnet_deeplab_fusion_backbone: the stage outputs feed the head directly
+                F[s] = cat[s];
+                if (!dry) c->taps["res" + std::to_string(s + 2)] = F[s];
+                return;
+            }
+            const std::string n = "backbone.fusion_res" + std::to_string(s + 2) + ".";
+            const int C = fch[s], fh = cat[s].H, fw = cat[s].W;
+            View t = make(C, fh, fw), a = make(C, fh, fw);
+            if (cf.fusion_add) {   // FUSION_STRATEGY "add" (resnet.py:502-503): rgb + depth, no 1x1 reduction
+                View ra = slice(cat[s], 0, C), rb = slice(cat[s], C, C);
+                op([=](int B, hipStream_t st) { return launch_add_channels(ra, rb, a, B, st); });
+            } else {
+                conv({n + "conv"}, cat[s], 2 * C, t, 1, 1, 0, 1, AF_BIAS, nullptr, false);
+                gn_relu({n + "gn"}, t, a, s != 3 && cf.backbone_fusion_layers > 0);   // read only by conv0 below
+            }
+            if (s != 3) {
+                View b2 = make(C, fh, fw);
+                View cur = a, nxt = b2;
+                for (int i = 0; i < cf.backbone_fusion_layers; ++i) {
+                    conv({n + "conv" + std::to_string(i)}, cur, C, t, 3, 1, 1, 1, AF_BIAS, nullptr, false);
+                    gn_relu({n + "gn" + std::to_string(i)}, t, nxt, i + 1 < cf.backbone_fusion_layers);   // read only by the next conv
+                    std::swap(cur, nxt);
+                }
+                a = cur;
+            }
+            F[s] = a;
+            if (!dry) c->taps["res" + std::to_string(s + 2)] = a;
+        };
         int cin = 64, cout = 256, mid = 64, ch = h4, cw = w4;
         for (int s = 0; s < 4; ++s) {
             const int stage = s + 2;
@@ -578,40 +655,17 @@ struct Builder {
             }
             ch = oh; cw = ow;
             cout *= 2; mid *= 2;
+            // the fusion convolutions of this stage's output: a side lane for res2 / res3 (they run beside the later stages at small
+            // batches and are joined where the decoder first reads them), the main stream for res5 (the ASPP waits for it anyway)
+            if (s == 0 || s == 1) {
+                fork(1 + s);
+                emit_fusion(s);
+                back_to_main();
+            } else if (s == 3) {
+                emit_fusion(3);
+            }
         }
 
-        // ---------------- backbone fusion (resnet.py:472-485) ----------------
-        View F[4];
-        const int fch[4] = {256, 512, 1024, 2048};
-        for (int s : {0, 1, 3}) {
-            if (NS == 1) {   // build_resnet_deeplab_fusion_backbone: the stage outputs feed the head directly
-                F[s] = cat[s];
-                if (!dry) c->taps["res" + std::to_string(s + 2)] = F[s];
-                continue;
-            }
-            const std::string n = "backbone.fusion_res" + std::to_string(s + 2) + ".";
-            const int C = fch[s], fh = cat[s].H, fw = cat[s].W;
-            View t = make(C, fh, fw), a = make(C, fh, fw);
-            if (cf.fusion_add) {   // FUSION_STRATEGY "add" (resnet.py:502-503): rgb + depth, no 1x1 reduction
-                View ra = slice(cat[s], 0, C), rb = slice(cat[s], C, C);
-                op([=](int B, hipStream_t st) { return launch_add_channels(ra, rb, a, B, st); });
-            } else {
-                conv({n + "conv"}, cat[s], 2 * C, t, 1, 1, 0, 1, AF_BIAS, nullptr, false);
-                gn_relu({n + "gn"}, t, a, s != 3 && cf.backbone_fusion_layers > 0);   // read only by conv0 below
-            }
-            if (s != 3) {
-                View b2 = make(C, fh, fw);
-                View cur = a, nxt = b2;
-                for (int i = 0; i < cf.backbone_fusion_layers; ++i) {
-                    conv({n + "conv" + std::to_string(i)}, cur, C, t, 3, 1, 1, 1, AF_BIAS, nullptr, false);
-                    gn_relu({n + "gn" + std::to_string(i)}, t, nxt, i + 1 < cf.backbone_fusion_layers);   // read only by the next conv
-                    std::swap(cur, nxt);
-                }
-                a = cur;
-            }
-            F[s] = a;
-            if (!dry) c->taps["res" + std::to_string(s + 2)] = a;
-        }
         (void)h8; (void)w8;
 
         // ---------------- decoder ([d2] DeepLabV3PlusHead.layers) ----------------
@@ -620,7 +674,12 @@ struct Builder {
         View catA = make(1280, h16, w16), tA = make(256, h16, w16);
         conv_gn(A + "convs.0", F[3], tA, slice(catA, 0, 256), 1, 1);
         const int adil[3] = {6, 12, 18};
-        for (int i = 0; i < 3; ++i) conv_gn(A + "convs." + std::to_string(i + 1), F[3], tA, slice(catA, 256 * (i + 1), 256), 3, adil[i]);
+        for (int i = 0; i < 3; ++i) {        // the three dilated branches: lanes 3-5, each with a pre-norm buffer of its own
+            View tAi = make(256, h16, w16);
+            fork(3 + i);
+            conv_gn(A + "convs." + std::to_string(i + 1), F[3], tAi, slice(catA, 256 * (i + 1), 256), 3, adil[i]);
+            back_to_main();
+        }
         {
             View pooled = make(2048, 1, 1), pc = make(256, 1, 1);
             View f5 = F[3];
@@ -629,10 +688,12 @@ struct Builder {
             View dst = slice(catA, 1024, 256);
             op([=](int B, hipStream_t st) { return launch_bilinear(pc, dst, B, st); });
         }
+        for (int i = 0; i < 3; ++i) join(3 + i);
         View y5 = make(256, h16, w16);
         conv_gn(A + "project", catA, tA, y5, 1, 1);
 
         View cat3 = make(64 + 256, F[1].H, F[1].W), t64 = make(64, F[1].H, F[1].W), t128a = make(128, F[1].H, F[1].W);
+        join(2);                         // fusion_res3
         conv_gn(Hd + "decoder.res3.project_conv", F[1], t64, slice(cat3, 0, 64), 1, 1);
         {
             View dst = slice(cat3, 64, 256);
@@ -675,6 +736,7 @@ struct Builder {
             YP[i] = make(aes == 2 ? (wd + 7) / 8 * 8 : (wd + 3) / 4 * 4, h4, w4);      // whole 16-byte units per pixel
         }
         View cat2 = make(32 + 128, h4, w4), t32 = make(32, h4, w4), t128 = make(128, h4, w4);
+        join(1);                         // fusion_res2
         conv_gn(Hd + "decoder.res2.project_conv", F[0], t32, slice(cat2, 0, 32), 1, 1);
         {
             View dst = slice(cat2, 32, 128);
@@ -1060,6 +1122,11 @@ void quber_destroy(quber_ctx* c) {
     if (!c) return;
     if (c->prof && quber::g_prof == c->prof.get()) quber::g_prof = nullptr;
     for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);   // nothing useful to do with a failure while tearing down
+    for (int l = 1; l < LANES; ++l) {
+        if (c->lane_fork[l]) (void)hipEventDestroy(c->lane_fork[l]);
+        if (c->lane_join[l]) (void)hipEventDestroy(c->lane_join[l]);
+        if (c->lane_stream[l]) (void)hipStreamDestroy(c->lane_stream[l]);
+    }
     for (void* p : c->allocs) (void)hipFree(p);
     delete c;
 }
@@ -1095,6 +1162,16 @@ int quber_finalize_weights(quber_ctx* c) {
         b.build();
     }
     if (c->wino_floats) c->wino_ws = (float*)b.dalloc_bytes(sizeof(float) * c->wino_floats);
+    if (c->lanes_built) {          // side lanes: streams, fork / join events, workspaces sized for LANE_BATCH frames
+        c->lane_splitk_floats = (size_t)20 << 20;       // 80 MiB: the persistent kernel's 2 x 512 partial tiles of 128 x 128 are 64 MiB
+        for (int l = 1; l < LANES; ++l) {
+            QB_CHECK(hipStreamCreateWithFlags(&c->lane_stream[l], hipStreamNonBlocking));
+            QB_CHECK(hipEventCreateWithFlags(&c->lane_fork[l], hipEventDisableTiming));
+            QB_CHECK(hipEventCreateWithFlags(&c->lane_join[l], hipEventDisableTiming));
+            c->lane_splitk_ws[l] = (float*)b.dalloc_bytes(sizeof(float) * c->lane_splitk_floats);
+            if (c->lane_wino_floats[l]) c->lane_wino_ws[l] = (float*)b.dalloc_bytes(sizeof(float) * c->lane_wino_floats[l]);
+        }
+    }
     if (!b.err.empty()) {
         c->ops.clear();
         return fail(b.err);
@@ -1122,6 +1199,7 @@ void quber_set_tuning(int32_t key, int32_t value) {
         }
     }
     if (key == 4) g_force_tile = value;    // force the tile shape: 1 = 64x64, 2 = 128x128, 4 = 256x32 (0 = automatic)
+    if (key == 24) g_lanes = value;           // side lanes at small batches (default 1)
     if (key == 21) g_acc_chunk = value;       // two-level fp32 accumulation: K-slices per chunk (0 = off)
     if (key == 20) g_wino_chunk_mb = value;   // Winograd layers in passes whose V | M intermediates stay below this many MiB (0 = whole batch)
     if (key == 19) g_tile_128x64 = value;     // 128x64 tiles for the 33-64 channel convolutions (default 1)
@@ -1246,7 +1324,8 @@ int quber_forward(quber_ctx* c, const uint8_t* bgr, const uint8_t* depth, const 
         hipStream_t s2 = (hipStream_t)stream;
         c->cur_out = logits;
         int r2 = launch_lmff_preprocess(bgr, depth, (long)batch * c->cfg.height * c->cfg.width, c->X.p, s2);
-        for (size_t i = 0; !r2 && i < c->ops.size(); ++i) r2 = c->ops[i].run(batch, s2);
+        for (size_t i = 0; !r2 && i < c->ops.size(); ++i)
+            if (!c->ops[i].ctl) r2 = c->ops[i].run(batch, s2);
         return r2;
     }
     if (!bgr || (!depth && c->cfg.streams == 2) || !offs || !logits) return fail("null tensor");
@@ -1255,10 +1334,27 @@ int quber_forward(quber_ctx* c, const uint8_t* bgr, const uint8_t* depth, const 
     int rc = launch_preprocess(bgr, depth, offs, c->X, batch, c->cfg.max_batch, c->cfg.height, c->cfg.width,
                                c->cfg.pixel_mean, c->cfg.pixel_std, c->cfg.streams, st);
     if (rc) return rc;
+    // side lanes: at small batches the independent branches of the plan (Builder::fork / join) run on streams of the context
+    c->lanes_on = c->lanes_built && g_lanes && batch <= LANE_BATCH && c->lane_stream[1] != nullptr && quber::g_prof == nullptr;
     for (auto& op : c->ops) {
-        rc = op.run(batch, st);
+        if (op.ctl == 1) {
+            if (c->lanes_on) {
+                QB_CHECK(hipEventRecord(c->lane_fork[op.lane], st));
+                QB_CHECK(hipStreamWaitEvent(c->lane_stream[op.lane], c->lane_fork[op.lane], 0));
+            }
+            continue;
+        }
+        if (op.ctl == 2) {
+            if (c->lanes_on) {
+                QB_CHECK(hipEventRecord(c->lane_join[op.lane], c->lane_stream[op.lane]));
+                QB_CHECK(hipStreamWaitEvent(st, c->lane_join[op.lane], 0));
+            }
+            continue;
+        }
+        rc = op.run(batch, (c->lanes_on && op.lane) ? c->lane_stream[op.lane] : st);
         if (rc) return rc;
     }
+    c->lanes_on = false;
     return 0;
 }
 
@@ -1278,10 +1374,13 @@ int quber_forward_profiled(quber_ctx* c, const uint8_t* bgr, const uint8_t* dept
     int rc = launch_preprocess(bgr, depth, offs, c->X, batch, c->cfg.max_batch, c->cfg.height, c->cfg.width,
                                c->cfg.pixel_mean, c->cfg.pixel_std, c->cfg.streams, st);
     if (rc) return rc;
+    c->lanes_on = false;          // one stream: every op in plan order
     for (size_t i = 0; i < n; ++i) {
         QB_CHECK(hipEventRecord(c->prof_events[2 * i], st));
-        rc = c->ops[i].run(batch, st);
-        if (rc) return rc;
+        if (!c->ops[i].ctl) {
+            rc = c->ops[i].run(batch, st);
+            if (rc) return rc;
+        }
         QB_CHECK(hipEventRecord(c->prof_events[2 * i + 1], st));
     }
     QB_CHECK(hipStreamSynchronize(st));
