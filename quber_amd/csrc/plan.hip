@@ -90,7 +90,7 @@ struct Op {
     int lane = 0;       // 0 = the caller's stream; 1.. = a side stream of the context (small batches only, see quber_forward)
     int ctl = 0;        // 1 = fork `lane` here (it may start once the main stream has reached this point), 2 = join it
 };
-constexpr int LANES = 6;            // side lanes: fusion_res2, fusion_res3, three ASPP branches (+1 spare)
+constexpr int LANES = 3;            // side lanes 1, 2: the fusion convolutions of res2 and of res3
 constexpr int LANE_BATCH = 2;       // side lanes are used up to this batch (their workspaces are sized for it)
 
 struct quber_ctx {
@@ -121,6 +121,7 @@ struct quber_ctx {
     size_t lane_splitk_floats = 0;
     bool lanes_built = false;     // the plan contains fork / join points
     bool lanes_on = false;        // ... and this forward uses them
+    int lane_now = 0;             // lane of the op being launched (0 = the caller's stream): its workspaces are the ones to use
     View X;               // [2][Bmax][H][W][8] (16 channels of fp16 in the fp16 data path)
     float* q = nullptr;   // [Bmax][planes][H/4][W/4]
     const uint8_t* cur_bgr = nullptr;
@@ -352,7 +353,7 @@ struct Builder {
         last_conv = {fuse, out.p, G, Cout};
         const int L = cur_lane;
         c->ops.push_back({[p, G, ctx, fuse, wq, wino, norm, L](int B, hipStream_t st) mutable {
-            const bool side = L && ctx->lanes_on;                  // on a side lane: that lane's workspaces
+            const bool side = L && ctx->lane_now == L;             // launched on its side lane: that lane's workspaces
             float* const sk_ws = side ? ctx->lane_splitk_ws[L] : ctx->splitk_ws;
             const size_t sk_floats = side ? ctx->lane_splitk_floats : ctx->splitk_floats;
             if (wino) {
@@ -529,8 +530,8 @@ struct Builder {
     }
     // Side lanes.  fork(L): the ops emitted until join(L) with cur_lane = L form a branch that depends on nothing emitted after
     // this point and whose results nothing needs before join(L): at small batches, where a launch fills a fraction of the chip,
-    // quber_forward runs it on a stream of its own beside what the main stream does meanwhile (the later ResNet stages beside
-    // the fusion convolutions of the earlier ones; the ASPP branches beside each other).
+    // quber_forward runs it on a stream of its own beside what the main stream does meanwhile (the fusion convolutions of res2
+    // and res3 beside the later ResNet stages).
     void fork(int L) {
         if (dry) return;
         c->ops.push_back({nullptr, OP_OTHER, "fork", 0.0, 0});
@@ -674,12 +675,9 @@ struct Builder {
         View catA = make(1280, h16, w16), tA = make(256, h16, w16);
         conv_gn(A + "convs.0", F[3], tA, slice(catA, 0, 256), 1, 1);
         const int adil[3] = {6, 12, 18};
-        for (int i = 0; i < 3; ++i) {        // the three dilated branches: lanes 3-5, each with a pre-norm buffer of its own
-            View tAi = make(256, h16, w16);
-            fork(3 + i);
-            conv_gn(A + "convs." + std::to_string(i + 1), F[3], tAi, slice(catA, 256 * (i + 1), 256), 3, adil[i]);
-            back_to_main();
-        }
+        // (the three dilated branches on lanes of their own were measured too: no gain at batch 1 - 3.92 against 3.85 ms in the
+        // bf16x3 mode - so they stay on the caller's stream)
+        for (int i = 0; i < 3; ++i) conv_gn(A + "convs." + std::to_string(i + 1), F[3], tA, slice(catA, 256 * (i + 1), 256), 3, adil[i]);
         {
             View pooled = make(2048, 1, 1), pc = make(256, 1, 1);
             View f5 = F[3];
@@ -688,7 +686,6 @@ struct Builder {
             View dst = slice(catA, 1024, 256);
             op([=](int B, hipStream_t st) { return launch_bilinear(pc, dst, B, st); });
         }
-        for (int i = 0; i < 3; ++i) join(3 + i);
         View y5 = make(256, h16, w16);
         conv_gn(A + "project", catA, tA, y5, 1, 1);
 
@@ -1336,24 +1333,27 @@ int quber_forward(quber_ctx* c, const uint8_t* bgr, const uint8_t* depth, const 
     if (rc) return rc;
     // side lanes: at small batches the independent branches of the plan (Builder::fork / join) run on streams of the context
     c->lanes_on = c->lanes_built && g_lanes && batch <= LANE_BATCH && c->lane_stream[1] != nullptr && quber::g_prof == nullptr;
+    auto lane_used = [&](int l) { return c->lanes_on && l > 0; };
     for (auto& op : c->ops) {
         if (op.ctl == 1) {
-            if (c->lanes_on) {
+            if (lane_used(op.lane)) {
                 QB_CHECK(hipEventRecord(c->lane_fork[op.lane], st));
                 QB_CHECK(hipStreamWaitEvent(c->lane_stream[op.lane], c->lane_fork[op.lane], 0));
             }
             continue;
         }
         if (op.ctl == 2) {
-            if (c->lanes_on) {
+            if (lane_used(op.lane)) {
                 QB_CHECK(hipEventRecord(c->lane_join[op.lane], c->lane_stream[op.lane]));
                 QB_CHECK(hipStreamWaitEvent(st, c->lane_join[op.lane], 0));
             }
             continue;
         }
-        rc = op.run(batch, (c->lanes_on && op.lane) ? c->lane_stream[op.lane] : st);
+        c->lane_now = lane_used(op.lane) ? op.lane : 0;
+        rc = op.run(batch, c->lane_now ? c->lane_stream[op.lane] : st);
         if (rc) return rc;
     }
+    c->lane_now = 0;
     c->lanes_on = false;
     return 0;
 }

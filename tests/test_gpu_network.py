@@ -232,6 +232,37 @@ def test_adapter_armbench_branch(tmp_path):
     np.testing.assert_array_equal(got_off, encode_np.encode_initial_masks(exp_masks))
 
 
+@pytest.mark.parametrize("dtype", [0, 3], ids=["f32", "bf16x3"])
+def test_side_lanes_equal_one_stream(dtype):
+    """Batches <= 2 run the fusion convolutions of res2 / res3 on side streams of the context beside the later ResNet stages
+    (csrc/plan.hip: Builder::fork / join).  The results must equal the one-stream forward bit for bit - same launches, same
+    split-K choices, own workspaces per lane - and stay equal over repeated runs (no race on a shared buffer), also on an
+    engine built for a larger batch."""
+    lib = _lib.load()
+    h, w, n = 480, 640, 12
+    sd = arch.init_state_dict(seed=3, loud_heads=True, center_bias=-1.6)
+    qc = engine.make_config(h, w, max_batch=4, max_instances=n)
+    qc.compute_dtype = dtype
+    eng = engine.Engine(qc, "cuda:0")
+    eng.load_state_dict(sd)
+    try:
+        for b in (1, 2):
+            batch = synth.make_batch(50 + b, b, h, w, n)
+            bgr, dep = torch.from_numpy(batch["rgb"]).cuda(), torch.from_numpy(batch["depth"]).cuda()
+            off = eng.encode(torch.from_numpy(batch["masks"]).cuda())
+            lib.quber_set_tuning(24, 0)
+            one = eng.forward(bgr, dep, off).clone()
+            taps = {k: eng.debug_tensor(k, b).clone() for k in ("res2", "res3", "res5", "y")}
+            lib.quber_set_tuning(24, 1)
+            for _ in range(12):
+                assert torch.equal(eng.forward(bgr, dep, off), one)
+            for k, v in taps.items():
+                assert torch.equal(eng.debug_tensor(k, b), v), k
+    finally:
+        lib.quber_set_tuning(24, 1)
+        eng.close()
+
+
 def test_config2_1280x720_hipgraph_steady_state():
     """BASELINE.json configs[2]: 1280x720, 30 instances, the whole step captured in one hipGraph.  The replayed graph must
     give the eager results bit for bit on new inputs (it reads the device buffers, not captured values), the logits match
