@@ -5,7 +5,7 @@ import torch
 
 from oracle.network_torch import ArchCfg, MaskRefinerNet
 from oracle import encode_np, postproc_ref
-from quber_amd import arch, engine, synth
+from quber_amd import _lib, arch, engine, synth
 from quber_amd.maskrefiner.predictor import MaskRefinerPredictor
 
 pytestmark = pytest.mark.gpu
