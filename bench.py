@@ -33,7 +33,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide, "Peak BF16/FP16 MFMA" (dense)
 HBM_PEAK_GBPS = 8000.0          # same guide, "HBM3E peak BW" (spec; 6.29 TB/s measured float4 copy)
 
 # stage tags (quber_profile_stage) of the convolution family and of the HBM-bound stages reported in `hbm_stages`
-CONV_GEMM = ("conv_gemm", "wino_gemm")
+CONV_GEMM = ("conv_gemm", "wino_gemm", "wino_fused")   # wino_fused: a Winograd layer as ONE kernel (transforms inside), priced on what it multiplies
 CONV_GEMM_F32PIPE = ("conv_gemm_f32pipe",)   # launches of the bf16x3 mode that keep the exact fp32 MFMA kernel (short K, narrow tiles)
 CONV_FAMILY = CONV_GEMM + CONV_GEMM_F32PIPE + ("splitk_reduce", "wino_input", "wino_output")
 HBM_STAGES = ("encode_reduce", "encode_paint", "errmaps_pack", "errmaps_erode", "errmaps_quadruple", "preprocess", "wino_input",

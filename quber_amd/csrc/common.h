@@ -91,6 +91,7 @@ struct WinoNorm {
 struct WinoP {
     View in, out;            // NHWC views; groups via View::gs
     const float* u;          // transformed weights [G][16][Cout][Cin]
+    const float* uf;         // F(4x4) only: the same weights in the operand order of the single-kernel form (wino_fused.hip), or null
     const float* scale;      // per-channel affine of the epilogue ([G][Cout], stride ss_gs) or null
     const float* shift;
     int ss_gs, relu;
@@ -115,6 +116,14 @@ bool winograd_eligible(int k, int stride, int pad, int dil, int Cin, int Cout);
 bool winograd_m6_channels_ok(int Cin, int Cout);
 size_t winograd_ws_floats(int B, int H, int W, int Cin, int Cout, int G, int dil, int m);
 double winograd_mac_ratio(int H, int W, int dil, int m);
+// single-kernel F(4x4,3x3) (wino_fused.hip)
+bool winograd_fused_ok(const WinoP& q, int B);
+int launch_conv_winograd_fused(const WinoP& q, int B, int G, hipStream_t st);
+void winograd_fused_pack_host(const float* u, int Cout, int Cin, float* uf);
+int launch_winograd_fused_pack(const float* u, int Cout, int Cin, float* uf, hipStream_t st);
+size_t winograd_fused_ws_floats(int B, int Cin, int G);
+int winograd_fused_prepare();
+extern int g_wino_fused, g_wino_fused_max_cin;
 extern int g_winograd, g_wino_min_cin, g_wino_max_ratio, g_wino_variant, g_wino_min_cout, g_wino_pairs, g_wino_chunk_mb;
 extern int g_tile_128x64, g_acc_chunk;
 extern int g_force_split, g_force_tile, g_tail_split, g_persist, g_persist_min_nk, g_persist_debug, g_persist_min_tiles;

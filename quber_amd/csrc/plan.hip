@@ -155,6 +155,7 @@ struct DeferredNorm {
 };
 struct LastConv { std::shared_ptr<GnFuse> fuse; const float* out = nullptr; int G = 0, C = 0; };
 
+static int g_op_wino_reuse = 0;   // key 26
 static int g_lanes = 1;           // key 24: side lanes for batches <= LANE_BATCH (0 = everything on the caller's stream)
 static int g_fuse_shortcut = 1;   // key 18 (plan time): conv3 + projection shortcut of a bottleneck as one dual-input GEMM
 
@@ -333,14 +334,13 @@ struct Builder {
                 std::vector<float> u((size_t)G * P * Cout * Cin);
                 for (int g = 0; g < G; ++g) winograd_weights_host(w[g], Cout, Cin, m, &u[(size_t)g * P * Cout * Cin]);
                 wq.in = in; wq.out = out; wq.u = upload(u);
+                if (m == 4 && c->cfg.compute_dtype == 0 && Cout % 32 == 0 && g_wino_fused && Cin <= g_wino_fused_max_cin) {     // operand order of the single-kernel form
+                    std::vector<float> uf(u.size());
+                    for (int g = 0; g < G; ++g) winograd_fused_pack_host(&u[(size_t)g * P * Cout * Cin], Cout, Cin, &uf[(size_t)g * P * Cout * Cin]);
+                    wq.uf = upload(uf);
+                }
                 wq.scale = p.scale; wq.shift = p.shift; wq.ss_gs = Cout; wq.relu = relu; wq.dil = dil; wq.m = m;
                 wq.dtype = c->cfg.compute_dtype;
-                const size_t need = winograd_ws_floats(Bmax, in.H, in.W, Cin, Cout, G, dil, m);
-                if (need > c->wino_floats) c->wino_floats = need;
-                if (cur_lane) {
-                    const size_t ln = winograd_ws_floats(std::min(Bmax, LANE_BATCH), in.H, in.W, Cin, Cout, G, dil, m);
-                    if (ln > c->lane_wino_floats[cur_lane]) c->lane_wino_floats[cur_lane] = ln;
-                }
             }
         }
         std::shared_ptr<DeferredNorm> norm;
@@ -349,6 +349,19 @@ struct Builder {
             norm->absorbed = true;
         }
         pending_norm.reset();
+        if (wino) {     // workspace: V | M of the three-kernel pipeline, or only the fused GroupNorm's coefficients of the single-kernel form
+            WinoP probe = wq;
+            if (norm) probe.in = norm->in;           // what the layer will read (in place -> the pipeline)
+            const bool fusedk = wq.uf && winograd_fused_ok(probe, Bmax);
+            if (fusedk && winograd_fused_prepare() && err.empty()) err = "winograd (fused): cannot raise the kernels' LDS limit";
+            const size_t need = fusedk ? winograd_fused_ws_floats(Bmax, Cin, G) : winograd_ws_floats(Bmax, in.H, in.W, Cin, Cout, G, dil, wq.m);
+            if (need > c->wino_floats) c->wino_floats = need;
+            if (cur_lane) {
+                const int lb = std::min(Bmax, LANE_BATCH);
+                const size_t ln = fusedk ? winograd_fused_ws_floats(lb, Cin, G) : winograd_ws_floats(lb, in.H, in.W, Cin, Cout, G, dil, wq.m);
+                if (ln > c->lane_wino_floats[cur_lane]) c->lane_wino_floats[cur_lane] = ln;
+            }
+        }
         auto fuse = std::make_shared<GnFuse>();
         last_conv = {fuse, out.p, G, Cout};
         const int L = cur_lane;
@@ -610,12 +623,16 @@ struct Builder {
                 gn_relu({n + "gn"}, t, a, s != 3 && cf.backbone_fusion_layers > 0);   // read only by conv0 below
             }
             if (s != 3) {
-                View b2 = make(C, fh, fw);
-                View cur = a, nxt = b2;
+                // a convolution that absorbs the GroupNorm before it reads that norm's INPUT (the previous convolution's raw
+                // output): raw outputs alternate between two buffers so that no layer reads the tensor it writes (the
+                // single-kernel Winograd layer reads input halos while other blocks store)
+                View b2 = make(C, fh, fw), t2 = make(C, fh, fw);
+                View cur = a, nxt = b2, traw = t2, tprev = t;
                 for (int i = 0; i < cf.backbone_fusion_layers; ++i) {
-                    conv({n + "conv" + std::to_string(i)}, cur, C, t, 3, 1, 1, 1, AF_BIAS, nullptr, false);
-                    gn_relu({n + "gn" + std::to_string(i)}, t, nxt, i + 1 < cf.backbone_fusion_layers);   // read only by the next conv
+                    conv({n + "conv" + std::to_string(i)}, cur, C, traw, 3, 1, 1, 1, AF_BIAS, nullptr, false);
+                    gn_relu({n + "gn" + std::to_string(i)}, traw, nxt, i + 1 < cf.backbone_fusion_layers);   // read only by the next conv
                     std::swap(cur, nxt);
+                    std::swap(traw, tprev);
                 }
                 a = cur;
             }
@@ -698,7 +715,8 @@ struct Builder {
         }
         View u3 = make(128, F[1].H, F[1].W), y3 = make(128, F[1].H, F[1].W);
         conv_gn(Hd + "decoder.res3.fuse_conv.0", cat3, t128a, u3, 3, 1, true);    // u3 is read only by fuse_conv.1
-        conv_gn(Hd + "decoder.res3.fuse_conv.1", u3, t128a, y3, 3, 1);
+        View t128b = make(128, F[1].H, F[1].W);           // (not t128a: fuse_conv.1 reads it - the absorbed norm's input)
+        conv_gn(Hd + "decoder.res3.fuse_conv.1", u3, t128b, y3, 3, 1);
 
         // ---------------- prediction heads: generic hierarchy (model.py:738-762) ----------------
         // head ids: 0 foreground, 1 center, 2 offset, 3 eee_mask, 4 eee_boundary
@@ -742,7 +760,8 @@ struct Builder {
         View u2 = make(128, h4, w4);
         conv_gn(Hd + "decoder.res2.fuse_conv.0", cat2, t128, u2, 3, 1, true);      // u2 is read only by fuse_conv.1
         View y = nlev > 1 ? slice(YP[1], 0, 128) : make(128, h4, w4);
-        conv_gn(Hd + "decoder.res2.fuse_conv.1", u2, t128, y, 3, 1);
+        View t128c = make(128, h4, w4);                   // (not t128: fuse_conv.1 reads it - the absorbed norm's input)
+        conv_gn(Hd + "decoder.res2.fuse_conv.1", u2, t128c, y, 3, 1);
         for (int i = 2; i < nlev; ++i) {
             View dst = slice(YP[i], 0, 128);
             op([=](int B, hipStream_t st) { return launch_copy_channels(y, dst, B, st); });
@@ -1198,6 +1217,9 @@ void quber_set_tuning(int32_t key, int32_t value) {
     if (key == 4) g_force_tile = value;    // force the tile shape: 1 = 64x64, 2 = 128x128, 4 = 256x32 (0 = automatic)
     if (key == 24) g_lanes = value;           // side lanes at small batches (default 1)
     if (key == 21) g_acc_chunk = value;       // two-level fp32 accumulation: K-slices per chunk (0 = off)
+    if (key == 27) g_wino_fused_max_cin = value;  // plan time: widest input (channels) the single-kernel Winograd form takes (default 128)
+    if (key == 26) g_op_wino_reuse = value;   // timing harness: quber_op_conv3x3_winograd reuses the transformed filters its previous call left in u / ws
+    if (key == 25) g_wino_fused = value;      // plan time: the F(4x4) Winograd layers of the exact fp32 mode as ONE kernel (wino_fused.hip); 0 = the three-kernel pipeline
     if (key == 20) g_wino_chunk_mb = value;   // Winograd layers in passes whose V | M intermediates stay below this many MiB (0 = whole batch)
     if (key == 19) g_tile_128x64 = value;     // 128x64 tiles for the 33-64 channel convolutions (default 1)
     if (key == 18) g_fuse_shortcut = value;   // acts at plan time: 0 = keep the projection shortcut a convolution of its own
@@ -1551,13 +1573,26 @@ int quber_op_conv3x3_winograd(const float* x, int32_t B, int32_t h, int32_t w, i
     if (!winograd_eligible(3, 1, dil, dil, cin, cout)) return fail("winograd: unsupported channel counts");
     if ((scale == nullptr) != (shift == nullptr)) return fail("winograd: scale and shift go together");
     if (m != 2 && m != 4 && m != 6) return fail("winograd: the output tile edge is 2, 4 or 6");
-    int rc = launch_winograd_weights(w_oihw, cout, cin, m, u, st);
+    int rc = g_op_wino_reuse ? 0 : launch_winograd_weights(w_oihw, cout, cin, m, u, st);
     if (rc) return rc;
     WinoP q{};
     q.in = mkview(x, B, h, w, cin); q.out = mkview(y, B, h, w, cout);
     q.u = u; q.scale = scale; q.shift = shift; q.ss_gs = 0; q.relu = relu; q.dil = dil; q.m = m;
     q.dtype = g_op_bf16;
     q.ws = ws; q.ws_floats = (size_t)ws_floats;
+    // the single-kernel form where it applies and the workspace also holds its filter order (36 * cout * cin floats)
+    if (m == 4 && g_wino_fused && cout % 32 == 0 && (size_t)ws_floats >= (size_t)36 * cout * cin) {
+        q.uf = ws;
+        if (winograd_fused_ok(q, B)) {
+            rc = winograd_fused_prepare();
+            if (rc) return rc;
+            rc = g_op_wino_reuse ? 0 : launch_winograd_fused_pack(u, cout, cin, ws, st);
+            if (rc) return rc;
+            q.ws = ws + (size_t)36 * cout * cin; q.ws_floats = (size_t)ws_floats - (size_t)36 * cout * cin;
+        } else {
+            q.uf = nullptr;
+        }
+    }
     q.splitk_ws = g_op_ws; q.splitk_floats = g_op_ws ? g_op_ws_floats : 0;
     return launch_conv_winograd(q, B, 1, st);
 }

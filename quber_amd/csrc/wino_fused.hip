@@ -1,0 +1,708 @@
+// Winograd F(4x4,3x3) as ONE kernel (exact fp32 MFMA mode): the same arithmetic as winograd.hip's three-kernel pipeline -
+//     Y = A^T [ (G g G^T) .* (B^T d B) ] A     (reference: the plain F.conv2d of detectron2's Conv2d, see winograd.hip)
+// - but the transformed activations V and the products M never exist in HBM.  The three-kernel form writes V (2.25x the
+// layer's input), reads it back in the GEMM, writes M (2.25x the output) and reads that back: 27 GB of the 81 GB the
+// convolution family moves per 16-frame step (profiles/r03_final_conv_hbm_traffic.json), and two HBM-bound passes that
+// take 5.2 ms of the 37 ms step.
+//
+// A block owns 32 consecutive Winograd tiles x 32 output channels x ALL 36 transform positions, for the whole K = Cin:
+//   * accumulators: 36 positions x (32 tiles x 32 channels) = 36 MFMA 32x32 tiles, nine per wave (144 registers), and the
+//     second level of the two-level fp32 accumulation beside them (another 144; conv_persist.hip `top`): a block is one
+//     wave per SIMD with the whole 512-register file - there is no second wave to hide latency behind, so everything is
+//     software-pipelined inside the wave;
+//   * a round = 16 input channels.  Thread (tile, channel pair) loads its 6x6 input patch straight from the NHWC tensor
+//     (8-byte buffer loads, range-checked: the zero padding and the tiles past the end cost no predicates), transforms it
+//     in registers on packed fp32 (B^T d B on channel pairs) and stores the 36 values into the LDS image of the NEXT
+//     round while the matrix pipe multiplies the current one: 2 x 72 KB of LDS, one barrier per round;
+//   * the B operand (transformed filters) is packed per (32-channel chunk, 8-channel K-slice, position) as the 1 KB a
+//     wave's MFMA pair consumes and goes global -> registers, each wave loading only its nine positions;
+//   * epilogue: the 36 x 32 x 32 sums go through LDS once (the 144 KB the two images occupied), thread (tile, 4
+//     channels) applies A^T . A, the affine, the ReLU, accumulates the GroupNorm sums and stores 16 pixels x 16 bytes.
+// HBM traffic of a layer: its input (re-read per 32-channel chunk through L2: the chunks of a tile block are neighbours
+// on one XCD), its output, the filters.
+#include "common.h"
+#include "winograd_xf.h"
+
+namespace quber {
+
+int g_wino_fused_max_cin = 128;   // key 27: widest input the single-kernel form takes (its two accumulation chains are Cin / 2 long)
+int g_wino_fused = 1;         // key 25: 1 = the eligible F(4x4) layers of the exact fp32 mode take this kernel, 0 = never
+
+using namespace wxf;
+
+// element i of the packed filter array [Cout/32][Cin/8][36][64 lanes][4] <- index into U [36][Cout][Cin]:
+// lane l of the wave multiplying position p supplies output channel l % 32 and input channels 4 * (l / 32) + e of the slice
+__host__ __device__ inline long fused_src(long i, int Cout, int Cin) {
+    const int e = (int)(i & 3), l = (int)((i >> 2) & 63);
+    long r = i >> 8;
+    const int p = (int)(r % 36);
+    r /= 36;
+    const int ks = (int)(r % (Cin / 8)), cc = (int)(r / (Cin / 8));
+    return ((long)p * Cout + cc * 32 + (l & 31)) * Cin + ks * 8 + 4 * (l >> 5) + e;
+}
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+#ifndef WF_SPLIT
+#define WF_SPLIT 7                              // positions (of a wave's 9) that get an accumulator set per slice; see `SPLIT` in the kernels
+#endif
+#ifndef WF_SKIP
+#define WF_SKIP 0                               // diagnostic builds only (tools/wino_fused_ablate.sh): bit 0 no patch loads, 1 no filter loads, 2 no transforms, 4 no MFMA
+#endif
+constexpr int FT = 32;                          // tiles per block
+constexpr int FC = 32;                          // output channels per block
+constexpr int FK = 16;                          // input channels per round: two 8-channel MFMA slices
+constexpr int FP = 36;                          // transform positions
+constexpr int SLICE = FP * FT * 8;              // floats of one 8-channel slice image [position][tile][8]
+constexpr int STAGE = 2 * SLICE;                // ... of one round
+constexpr int M_FLOATS = FP * FT * FC;          // epilogue image [position][tile][32]  (== 2 * STAGE)
+constexpr int SMEM_BYTES = 2 * STAGE * 4 + 2 * 32 * 2 * 8;
+static_assert(M_FLOATS == 2 * STAGE, "the epilogue image overlays the two round images");
+constexpr unsigned OOBH = 0x40000000u;          // added once per invalid row and once per invalid column: past any view (host check)
+constexpr int RSRC_FLAGS = 0x00020000;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr, unsigned bytes) {
+    const unsigned long a = (unsigned long)ptr;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long)hi << 32) | lo), 0,
+                                             (int)__builtin_amdgcn_readfirstlane(bytes), RSRC_FLAGS);
+}
+__device__ __forceinline__ f32x2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+// y = B^T x on a channel pair, fused multiply-adds (points 0, +-3/4, +-3/2, inf; the constants are dyadic)
+__device__ __forceinline__ f32x2 fma2(float s, f32x2 a, f32x2 b) { return __builtin_elementwise_fma(f32x2{s, s}, a, b); }
+__device__ __forceinline__ void bt4(const f32x2* x, f32x2* y) {
+    const f32x2 e1 = fma2(-2.25f, x[2], x[4]), o1 = fma2(0.75f, x[3], -1.6875f * x[1]);
+    const f32x2 e2 = fma2(-0.5625f, x[2], x[4]), o2 = fma2(1.5f, x[3], -0.84375f * x[1]);
+    y[0] = fma2(1.265625f, x[0], fma2(-2.8125f, x[2], x[4]));
+    y[1] = e1 + o1;
+    y[2] = e1 - o1;
+    y[3] = e2 + o2;
+    y[4] = e2 - o2;
+    y[5] = fma2(1.265625f, x[1], fma2(-2.8125f, x[3], x[5]));
+}
+
+struct FusedArgs {
+    const float* in; long in_gs; int in_cs, H, W, Cin; unsigned in_bytes;
+    const float* uf; long uf_gs;                 // packed filters [G][Cout/32][Cin/8][36][64 lanes][4]
+    const float* coef; long coef_gs;             // fused GroupNorm of the input: [G][Ball][Cin][scale, bias], or null
+    int relu_in;
+    int Ball, boff, B;
+    const float* scale; const float* shift; int ss_gs, relu;
+    float* out; int out_cs; long out_gs; int Cout;
+    int TH, TW, d; long tiles, per_img; int NC, NB;     // 32-channel chunks, blocks = tile blocks x NC
+    double* gn_sum; int gn_groups, gn_cpg;
+};
+
+template <bool NORM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_fused_kernel(const FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    double* const gacc = reinterpret_cast<double*>(smem + 2 * STAGE);     // [image b0 / b0 + 1][norm group][sum, sum of squares]
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);        // wave-uniform: its offsets belong in scalar registers
+    const int g = blockIdx.z;
+    // XCD-aware order: blocks b and b + 8 share an XCD.  Each XCD takes one contiguous run of (tile block, channel
+    // chunk) pairs, chunk fastest: the NC blocks that read the same input tiles run side by side on one L2.
+    const int xcd = blockIdx.x & 7, bq_ = a.NB >> 3, br = a.NB & 7;
+    const int vb = (xcd < br ? xcd * (bq_ + 1) : br * (bq_ + 1) + (xcd - br) * bq_) + (blockIdx.x >> 3);
+    const int tb = vb / a.NC, cc = vb - tb * a.NC;
+    if (t < 128) gacc[t] = 0.0;                  // published by the barriers of the K loop
+
+    // ---- loader role: tile lt of the block, channel pair q of the round ----
+    const int lt = t >> 3, q = t & 7;
+    const long tile = (long)tb * FT + lt;
+    const bool tvalid = tile < a.tiles;
+    const TileAt ta = locate(tvalid ? tile : 0, a.TH, a.TW, a.d);
+    const int y0 = a.d * (4 * ta.ty - 1) + ta.py, x0 = a.d * (4 * ta.tx - 1) + ta.px;
+    const unsigned pix = (unsigned)a.in_cs * 4u;
+    const unsigned base = (unsigned)((ta.b * a.H + y0) * a.W + x0) * pix + (unsigned)q * 8u;      // may be "negative": wraps, fixed by the valid offsets
+    unsigned rowbase[6], colterm[6];
+    bool edge = false;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const bool ok = tvalid && (unsigned)(y0 + i * a.d) < (unsigned)a.H;
+        rowbase[i] = ok ? base + (unsigned)(i * a.d * a.W) * pix : OOBH;
+        edge |= !ok;
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const bool ok = (unsigned)(x0 + j * a.d) < (unsigned)a.W;
+        colterm[j] = ok ? (unsigned)(j * a.d) * pix : OOBH;
+        edge |= !ok;
+    }
+    // some tile of this wave touches the zero padding (wave-uniform: the interior waves skip the masking of the fused GroupNorm)
+    const bool border = NORM && __any(edge);
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in + (long)g * a.in_gs, a.in_bytes);
+    const int nslice = a.Cin / 8;
+    const __amdgpu_buffer_rsrc_t rs_u = make_rsrc(a.uf + (long)g * a.uf_gs + (long)cc * nslice * (FP * 256), (unsigned)nslice * (FP * 1024u));
+    const float* coef = NORM ? a.coef + (long)g * a.coef_gs + ((long)(a.boff + ta.b) * a.Cin + 2 * q) * 2 : nullptr;
+
+    // The fp32 MFMA runs on the SIMD's fp32 lanes: vector instructions of the same wave do NOT execute beside it
+    // (SQ_VALU_MFMA_COEXEC_CYCLES = 0, profiles/r05h_fused_pmc.txt), so every vector instruction of the loop adds its issue
+    // time to the 64 cycles per MFMA.  Hence: the transforms on packed fp32 (channel pairs: half the instructions), and a
+    // register budget that leaves the compiler no reason to shuffle values between the two register files.
+    f32x2 dd[6][6];
+    f32x4 cf = {1.f, 0.f, 1.f, 0.f};
+    const int R = a.Cin / FK;
+    auto gload_row = [&](int i, int r) __attribute__((always_inline)) {
+        const unsigned so = (unsigned)r * (FK * 4u);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+#if (WF_SKIP & 1)
+            asm volatile("" : "+v"(dd[i][j]) : "s"(so));
+#else
+            dd[i][j] = buf_load2(rs_in, rowbase[i] + colterm[j], so);
+#endif
+        }
+    };
+    auto gload_coef = [&](int r) __attribute__((always_inline)) {
+        if constexpr (NORM) cf = *reinterpret_cast<const f32x4*>(coef + (long)r * (FK * 2));
+    };
+    // column j: the producer's GroupNorm (+ ReLU) on the in-image pixels (the padding stays zero), then t = B^T d in place
+    auto col_pass = [&](int j) __attribute__((always_inline)) {
+        f32x2 col[6], tc[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            f32x2 v = dd[i][j];
+            if constexpr (NORM) {
+                v = __builtin_elementwise_fma(v, f32x2{cf.x, cf.z}, f32x2{cf.y, cf.w});
+                if (a.relu_in) v = __builtin_elementwise_max(v, f32x2{0.f, 0.f});
+                if (border) v = v * ((rowbase[i] == OOBH || colterm[j] == OOBH) ? 0.f : 1.f);     // the padding stays zero
+            }
+            col[i] = v;
+        }
+        bt4(col, tc);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dd[i][j] = tc[i];
+    };
+    // row i: (B^T d) B, stored into round image `vs`
+    auto row_pass = [&](int i, float* vs) __attribute__((always_inline)) {
+        float* dst = vs + (q >> 2) * SLICE + lt * 8 + 2 * (q & 3);
+        f32x2 row[6];
+        bt4(dd[i], row);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x2*>(dst + (i * 6 + j) * (FT * 8)) = row[j];
+    };
+
+    // ---- MFMA role: positions wave * 9 .. + 8, all 32 tiles x 32 channels ----
+    // Two accumulator sets, one per 8-channel slice of a round: each is a chain over HALF of K (64 of the 128 input channels
+    // this kernel is used up to - the chain length class the anchor test passes with margin, profiles/r03f_anchor_chunk.md),
+    // and the two are added once, in the epilogue.  No second-level addition runs inside the loop, where every vector
+    // instruction would add its issue time to the MFMAs'.
+    constexpr int SPLIT = WF_SPLIT;              // positions (of the wave's 9) with a chain per slice; the rest keep one chain
+    f32x16 acc[2][9];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int pi = 0; pi < 9; ++pi)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[s2][pi][e] = 0.f;
+    const int a_off = (wave * 9) * (FT * 8) + (lane & 31) * 8 + (lane >> 5) * 4;     // floats inside a slice image
+    const unsigned b_voff = (unsigned)lane * 16u;
+    const unsigned b_pos = (unsigned)(wave * 9) * 1024u;
+    // B operand: a ring of BR registers sets, the operand of global step g (= 18 r + k) requested BR steps ahead
+    constexpr int BR = 6;
+    f32x4 bq[BR];
+    // operand of step kk (0 .. 17 + BR; 18 and up: the next round) of round r; past the last slice the load is out of range (zeros)
+    auto bload = [&](int slot, int r, int kk) __attribute__((always_inline)) {
+        const int sl = 2 * r + kk / 9, pi = kk % 9;
+#if (WF_SKIP & 2)
+        asm volatile("" : "+v"(bq[slot]) : "s"(sl));
+#else
+        bq[slot] = buf_load4(rs_u, sl < nslice ? b_voff : 0x80000000u, (unsigned)sl * (FP * 1024u) + b_pos + (unsigned)pi * 1024u);
+#endif
+    };
+    // One round (16 input channels) = 18 steps: 2 slices x 9 positions, a step = the 4 dependent MFMAs of one position plus
+    // a share of the other work; sched_barrier keeps every share in its step.  At the start of round r the thread's registers
+    // hold its patch of round r + 1 after the column pass (t = B^T d):
+    //   steps 0-5    row pass i of that patch -> 6 stores into image r + 1, then row i of the patch of round r + 2 is requested
+    //   steps 12-17  column pass j of the patch of round r + 2 (requested >= 7 steps earlier)
+    auto round = [&](const float* vs, float* vn, const int r, const int kbase) __attribute__((always_inline)) {
+        const int r2 = r + 2 < R ? r + 2 : R - 1;                  // past the end: the last round again (never multiplied)
+        f32x4 av_next = *reinterpret_cast<const f32x4*>(vs + a_off);
+#pragma unroll
+        for (int k = 0; k < 18; ++k) {
+            const int s = k / 9, pi = k % 9;
+            const f32x4 av = av_next;
+            if (k + 1 < 18) av_next = *reinterpret_cast<const f32x4*>(vs + ((k + 1) / 9) * SLICE + a_off + ((k + 1) % 9) * (FT * 8));
+            const f32x4 bv = bq[(kbase + k) % BR];
+#if (WF_SKIP & 16)
+            acc[pi < SPLIT ? s : 0][pi][0] += av.x * bv.x + av.y * bv.y + av.z * bv.z + av.w * bv.w;
+#else
+            f32x16& ac = acc[pi < SPLIT ? s : 0][pi];
+            ac = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, ac, 0, 0, 0);
+            ac = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, ac, 0, 0, 0);
+            ac = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, ac, 0, 0, 0);
+            ac = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, ac, 0, 0, 0);
+#endif
+            bload((kbase + k) % BR, r, k + BR);
+#if !(WF_SKIP & 4)
+            if (k < 6) { row_pass(k, vn); gload_row(k, r2); }
+            if (k == 6) gload_coef(r2);
+            if (k >= 12) col_pass(k - 12);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    float* const st0 = smem;
+    float* const st1 = smem + STAGE;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) gload_row(i, 0);
+    gload_coef(0);
+#pragma unroll
+    for (int g0 = 0; g0 < BR; ++g0) bload(g0, 0, g0);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) col_pass(j);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { row_pass(i, st0); gload_row(i, 1); }
+    gload_coef(1);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) col_pass(j);
+    __syncthreads();
+    static_assert(36 % BR == 0, "the ring index is static over a pair of rounds");
+    for (int r = 0; r < ((WF_SKIP & 64) ? 0 : R); r += 2) {         // Cin % 32 == 0: rounds come in pairs
+        round(st0, st1, r, 0);
+        __syncthreads();
+        round(st1, st0, r + 1, 18);
+        __syncthreads();
+    }
+
+    // ---- epilogue: sums -> LDS [position][tile][32 channels] -> A^T . A per (tile, 4 channels) ----
+#if (WF_SKIP & 32)
+    if (acc[0][0][0] != 12345.f) return;
+#endif
+    const int h = lane >> 5, rr = lane & 31;
+#pragma unroll
+    for (int pi = 0; pi < 9; ++pi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            smem[((wave * 9 + pi) * FT + 8 * (e >> 2) + 4 * h + (e & 3)) * FC + rr] = pi < SPLIT ? acc[0][pi][e] + acc[1][pi][e] : acc[0][pi][e];
+    __syncthreads();
+    using VT = Vec<4>;
+    const int c = cc * FC + 4 * q;
+    VT s[4][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        VT col[6], sj[4];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) col[i] = vload<4>(smem + ((i * 6 + j) * FT + lt) * FC + 4 * q);
+        at<4>(col, sj);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[i][j] = sj[i];
+    }
+    VT sc, sh;
+    if (a.scale) {
+        sc = vload<4>(a.scale + g * a.ss_gs + c);
+        sh = vload<4>(a.shift + g * a.ss_gs + c);
+    }
+    const int b0 = (int)(((long)tb * FT) / a.per_img);
+    double sa = 0.0, sq = 0.0;
+    float* const out = a.out + (long)g * a.out_gs + c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        VT row[4];
+        at<4>(s[i], row);
+        const int oy = a.d * (4 * ta.ty + i) + ta.py;
+        if (!tvalid || oy >= a.H) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ox = a.d * (4 * ta.tx + j) + ta.px;
+            if (ox >= a.W) continue;
+            VT y = row[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (a.scale) y.v[e] = fmaf(y.v[e], sc.v[e], sh.v[e]);
+                if (a.relu) y.v[e] = fmaxf(y.v[e], 0.f);
+                sa += (double)y.v[e];
+                sq += (double)y.v[e] * y.v[e];
+            }
+            vstore<4>(out + (((long)ta.b * a.H + oy) * a.W + ox) * a.out_cs, y);
+        }
+    }
+    if (a.gn_sum) {
+        if (tvalid && (sa != 0.0 || sq != 0.0)) {
+            const int grp = c / a.gn_cpg, o = ta.b == b0 ? 0 : 64;
+            atomicAdd(&gacc[o + grp * 2], sa);
+            atomicAdd(&gacc[o + grp * 2 + 1], sq);
+        }
+        __syncthreads();
+        if (t < 128) {
+            const double v = gacc[t];
+            const int b = b0 + (t >> 6);
+            if (v != 0.0 && b < a.B) atomicAdd(&a.gn_sum[(((long)g * a.Ball + a.boff + b) * a.gn_groups) * 2 + (t & 63)], v);
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The same layer on 16 tiles x 64 output channels per block (64 | Cout), v_mfma_f32_16x16x4_f32, rounds of 32 input channels.
+// Against the 32 x 32 form above: a transformed patch value now meets 64 output channels instead of 32 - the input
+// transform is recomputed by every block of a tile group, and beside the fp32 MFMA its vector instructions are pure
+// overhead (~8 cycles each, nothing co-executes: tools/micro/mfma_f32_shadow.hip) - and the 16 lanes of a tile read the
+// whole 128-byte line of a pixel's 32 channels (the 16-channel rounds fetched every line twice).
+namespace w64 {
+constexpr int FT = 16, FC = 64, FK = 32;
+constexpr int SLICE = FP * FT * 16;             // floats of one 16-channel slice image [position][tile][16]
+constexpr int STAGE = 2 * SLICE;
+static_assert(FP * FT * FC == 2 * STAGE, "the epilogue image overlays the two round images");
+constexpr int SMEM_BYTES = 2 * STAGE * 4 + 2 * 32 * 2 * 8;
+}  // namespace w64
+
+// element i of [Cout/64][Cin/16][36][4 column blocks][64 lanes][4] <- index into U [36][Cout][Cin]: lane l of the MFMA on
+// column block nt supplies output channel nt * 16 + l % 16 and input channels 4 * (l / 16) + e of the 16-channel slice
+__host__ __device__ inline long fused64_src(long i, int Cout, int Cin) {
+    const int e = (int)(i & 3), l = (int)((i >> 2) & 63), nt = (int)((i >> 8) & 3);
+    long r = i >> 10;
+    const int p = (int)(r % 36);
+    r /= 36;
+    const int ks = (int)(r % (Cin / 16)), cc = (int)(r / (Cin / 16));
+    return ((long)p * Cout + cc * 64 + nt * 16 + (l & 15)) * Cin + ks * 16 + 4 * (l >> 4) + e;
+}
+
+template <bool NORM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_fused64_kernel(const FusedArgs a) {
+    constexpr int FT = w64::FT, FC = w64::FC, FK = w64::FK, SLICE = w64::SLICE, STAGE = w64::STAGE;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    double* const gacc = reinterpret_cast<double*>(smem + 2 * STAGE);
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int g = blockIdx.z;
+    const int xcd = blockIdx.x & 7, bq_ = a.NB >> 3, br = a.NB & 7;
+    const int vb = (xcd < br ? xcd * (bq_ + 1) : br * (bq_ + 1) + (xcd - br) * bq_) + (blockIdx.x >> 3);
+    const int tb = vb / a.NC, cc = vb - tb * a.NC;
+    if (t < 128) gacc[t] = 0.0;
+
+    // ---- loader role: tile lt of the block, channel pair q of the round's 32 channels ----
+    const int lt = t >> 4, q = t & 15;
+    const long tile = (long)tb * FT + lt;
+    const bool tvalid = tile < a.tiles;
+    const TileAt ta = locate(tvalid ? tile : 0, a.TH, a.TW, a.d);
+    const int y0 = a.d * (4 * ta.ty - 1) + ta.py, x0 = a.d * (4 * ta.tx - 1) + ta.px;
+    const unsigned pix = (unsigned)a.in_cs * 4u;
+    const unsigned base = (unsigned)((ta.b * a.H + y0) * a.W + x0) * pix + (unsigned)q * 8u;
+    unsigned rowbase[6], colterm[6];
+    bool edge = false;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const bool ok = tvalid && (unsigned)(y0 + i * a.d) < (unsigned)a.H;
+        rowbase[i] = ok ? base + (unsigned)(i * a.d * a.W) * pix : OOBH;
+        edge |= !ok;
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const bool ok = (unsigned)(x0 + j * a.d) < (unsigned)a.W;
+        colterm[j] = ok ? (unsigned)(j * a.d) * pix : OOBH;
+        edge |= !ok;
+    }
+    // some tile of this wave touches the zero padding (wave-uniform: the interior waves skip the masking of the fused GroupNorm)
+    const bool border = NORM && __any(edge);
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in + (long)g * a.in_gs, a.in_bytes);
+    const int nslice = a.Cin / 16;
+    const __amdgpu_buffer_rsrc_t rs_u = make_rsrc(a.uf + (long)g * a.uf_gs + (long)cc * nslice * (FP * 1024), (unsigned)nslice * (FP * 4096u));
+    const float* coef = NORM ? a.coef + (long)g * a.coef_gs + ((long)(a.boff + ta.b) * a.Cin + 2 * q) * 2 : nullptr;
+
+    f32x2 dd[6][6];
+    f32x4 cf = {1.f, 0.f, 1.f, 0.f};
+    const int R = a.Cin / FK;                    // rounds with data; an odd count is followed by one round of zero filters
+    auto gload_row = [&](int i, int r) __attribute__((always_inline)) {
+        const unsigned so = (unsigned)r * (FK * 4u);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) dd[i][j] = buf_load2(rs_in, rowbase[i] + colterm[j], so);
+    };
+    auto gload_coef = [&](int r) __attribute__((always_inline)) {
+        if constexpr (NORM) cf = *reinterpret_cast<const f32x4*>(coef + (long)r * (FK * 2));
+    };
+    auto col_pass = [&](int j) __attribute__((always_inline)) {
+        f32x2 col[6], tc[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            f32x2 v = dd[i][j];
+            if constexpr (NORM) {
+                v = __builtin_elementwise_fma(v, f32x2{cf.x, cf.z}, f32x2{cf.y, cf.w});
+                if (a.relu_in) v = __builtin_elementwise_max(v, f32x2{0.f, 0.f});
+                if (border) v = v * ((rowbase[i] == OOBH || colterm[j] == OOBH) ? 0.f : 1.f);     // the padding stays zero
+            }
+            col[i] = v;
+        }
+        bt4(col, tc);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dd[i][j] = tc[i];
+    };
+    auto row_pass = [&](int i, float* vs) __attribute__((always_inline)) {
+        float* dst = vs + (q >> 3) * SLICE + lt * 16 + 2 * (q & 7);
+        f32x2 row[6];
+        bt4(dd[i], row);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x2*>(dst + (i * 6 + j) * (FT * 16)) = row[j];
+    };
+
+    // ---- MFMA role: positions wave * 9 .. + 8; per position 16 tiles x 4 column blocks of 16 channels ----
+    // two accumulator sets, one per 16-channel slice of a round (see the 32 x 32 kernel): chains over half of K, added in the epilogue
+    constexpr int SPLIT = WF_SPLIT;
+    f32x4 acc[2][9][4];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int pi = 0; pi < 9; ++pi)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[s2][pi][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int a_off = (wave * 9) * (FT * 16) + (lane & 15) * 16 + (lane >> 4) * 4;     // floats inside a slice image
+    const unsigned b_voff = (unsigned)lane * 16u;
+    const unsigned b_pos = (unsigned)(wave * 9) * 4096u;
+    constexpr int BR = 3;                        // the B operand (4 column blocks = 4 KB per step) is requested BR steps ahead
+    f32x4 bq[BR][4];
+    auto bload = [&](int slot, int r, int kk) __attribute__((always_inline)) {
+        const int sl = 2 * r + kk / 9, pi = kk % 9;
+        const unsigned vo = sl < nslice ? b_voff : 0x80000000u;         // past the last slice: out of range, zeros
+        const unsigned so = (unsigned)sl * (FP * 4096u) + b_pos + (unsigned)pi * 4096u;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) bq[slot][nt] = buf_load4(rs_u, vo + nt * 1024u, so);
+    };
+    // One round (32 input channels) = 18 steps: 2 slices x 9 positions, a step = 16 MFMAs (4 k-steps x 4 column blocks);
+    // the shares of the other work as in the 32 x 32 kernel
+    auto round = [&](const float* vs, float* vn, const int r, const int kbase) __attribute__((always_inline)) {
+        const int r2 = r + 2 < R ? r + 2 : R - 1;
+        f32x4 av_next = *reinterpret_cast<const f32x4*>(vs + a_off);
+#pragma unroll
+        for (int k = 0; k < 18; ++k) {
+            const int s2 = k / 9, pi = k % 9;
+            const f32x4 av = av_next;
+            if (k + 1 < 18) av_next = *reinterpret_cast<const f32x4*>(vs + ((k + 1) / 9) * SLICE + a_off + ((k + 1) % 9) * (FT * 16));
+            f32x4 bv[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) bv[nt] = bq[(kbase + k) % BR][nt];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    f32x4& ac = acc[pi < SPLIT ? s2 : 0][pi][nt];
+                    ac = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[nt][e], ac, 0, 0, 0);
+                }
+            bload((kbase + k) % BR, r, k + BR);
+            if (k < 6) { row_pass(k, vn); gload_row(k, r2); }
+            if (k == 6) gload_coef(r2);
+            if (k >= 12) col_pass(k - 12);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    float* const st0 = smem;
+    float* const st1 = smem + STAGE;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) gload_row(i, 0);
+    gload_coef(0);
+#pragma unroll
+    for (int g0 = 0; g0 < BR; ++g0) bload(g0, 0, g0);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) col_pass(j);
+    const int r1 = R > 1 ? 1 : 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { row_pass(i, st0); gload_row(i, r1); }
+    gload_coef(r1);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) col_pass(j);
+    __syncthreads();
+    static_assert(36 % BR == 0, "the ring index is static over a pair of rounds");
+    for (int r = 0; r < R; r += 2) {
+        round(st0, st1, r, 0);
+        __syncthreads();
+        round(st1, st0, r + 1, 18);              // r + 1 == R (odd R): multiplied by zero filters
+        __syncthreads();
+    }
+
+    // ---- epilogue: sums -> LDS [position][tile][64 channels] -> A^T . A per (tile, 4 channels) ----
+    // (the 16-channel column blocks of a row are stored XOR-swizzled by row / 4: the four lane groups of an MFMA result hold
+    // rows 4 apart, which would otherwise meet in the same banks)
+    const int hq = lane >> 4, rr = lane & 15;
+#pragma unroll
+    for (int pi = 0; pi < 9; ++pi)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                smem[((wave * 9 + pi) * FT + 4 * hq + e) * FC + ((nt ^ hq) << 4) + rr] = pi < SPLIT ? acc[0][pi][nt][e] + acc[1][pi][nt][e] : acc[0][pi][nt][e];
+    __syncthreads();
+    using VT = Vec<4>;
+    const int c = cc * FC + 4 * q;
+    const int csw = (((q >> 2) ^ ((lt >> 2) & 3)) << 4) + (q & 3) * 4;
+    VT s[4][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        VT col[6], sj[4];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) col[i] = vload<4>(smem + ((i * 6 + j) * FT + lt) * FC + csw);
+        at<4>(col, sj);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[i][j] = sj[i];
+    }
+    VT sc, sh;
+    if (a.scale) {
+        sc = vload<4>(a.scale + g * a.ss_gs + c);
+        sh = vload<4>(a.shift + g * a.ss_gs + c);
+    }
+    const int b0 = (int)(((long)tb * FT) / a.per_img);
+    double sa = 0.0, sq = 0.0;
+    float* const out = a.out + (long)g * a.out_gs + c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        VT row[4];
+        at<4>(s[i], row);
+        const int oy = a.d * (4 * ta.ty + i) + ta.py;
+        if (!tvalid || oy >= a.H) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ox = a.d * (4 * ta.tx + j) + ta.px;
+            if (ox >= a.W) continue;
+            VT y = row[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (a.scale) y.v[e] = fmaf(y.v[e], sc.v[e], sh.v[e]);
+                if (a.relu) y.v[e] = fmaxf(y.v[e], 0.f);
+            }
+            if (a.gn_sum) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sa += (double)y.v[e]; sq += (double)y.v[e] * y.v[e]; }
+            }
+            vstore<4>(out + (((long)ta.b * a.H + oy) * a.W + ox) * a.out_cs, y);
+        }
+    }
+    if (a.gn_sum) {
+        if (tvalid && (sa != 0.0 || sq != 0.0)) {
+            const int grp = c / a.gn_cpg, o = ta.b == b0 ? 0 : 64;
+            atomicAdd(&gacc[o + grp * 2], sa);
+            atomicAdd(&gacc[o + grp * 2 + 1], sq);
+        }
+        __syncthreads();
+        if (t < 128) {
+            const double v = gacc[t];
+            const int b = b0 + (t >> 6);
+            if (v != 0.0 && b < a.B) atomicAdd(&a.gn_sum[(((long)g * a.Ball + a.boff + b) * a.gn_groups) * 2 + (t & 63)], v);
+        }
+    }
+}
+
+// per-(image, channel) scale and bias of a GroupNorm whose sums are in `stats` (the arithmetic of wino_input_kernel)
+__global__ void wino_norm_coef_kernel(const WinoNorm np, int G, int Ball, int Cin, float* __restrict__ coef) {
+    const long n = (long)G * Ball * Cin;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cin);
+        const long gb = i / Cin;
+        const int g = (int)(gb / Ball);
+        const double* sb = np.stats + (gb * np.groups + c / np.cpg) * 2;
+        const double mean = sb[0] / np.n;
+        double var = sb[1] / np.n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)np.eps));
+        const float sc = rstd * np.gamma[g * np.param_gs + c];
+        coef[i * 2] = sc;
+        coef[i * 2 + 1] = np.beta[g * np.param_gs + c] - (float)mean * sc;
+    }
+}
+
+// U [36][Cout][Cin] (winograd.hip) -> the per-lane MFMA operand order of this kernel
+__global__ void wino_pack_fused_kernel(const float* __restrict__ u, int Cout, int Cin, float* __restrict__ uf) {
+    const long n = (long)FP * Cout * Cin;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        uf[i] = u[Cout % 64 == 0 ? fused64_src(i, Cout, Cin) : fused_src(i, Cout, Cin)];
+}
+
+}  // namespace
+
+void winograd_fused_pack_host(const float* u, int Cout, int Cin, float* uf) {
+    const long n = (long)FP * Cout * Cin;
+    for (long i = 0; i < n; ++i) uf[i] = u[Cout % 64 == 0 ? fused64_src(i, Cout, Cin) : fused_src(i, Cout, Cin)];
+}
+
+int launch_winograd_fused_pack(const float* u, int Cout, int Cin, float* uf, hipStream_t st) {
+    hipLaunchKernelGGL(wino_pack_fused_kernel, dim3(512), dim3(256), 0, st, u, Cout, Cin, uf);
+    QB_CHECK(hipGetLastError());
+    return 0;
+}
+
+// what the single-kernel form covers: F(4x4), exact fp32, fp32 tensors, 32 | Cin, 32 | Cout, views below 1 GiB
+bool winograd_fused_ok(const WinoP& q, int Ball) {
+    const View& in = q.in;
+    const View& out = q.out;
+    if (!g_wino_fused || q.m != 4 || q.dtype != 0 || !q.uf || in.es != 4 || out.es != 4) return false;
+    if (in.C % 32 || out.C % FC) return false;
+    if (in.p == out.p) return false;              // in place: blocks read input halos that other blocks are overwriting
+    if (in.C > g_wino_fused_max_cin) return false;   // the two accumulation chains are Cin / 2 long: the accuracy class of 64-channel chains up to 128
+    const double in_bytes = 4.0 * (((double)Ball * in.H * in.W - 1) * in.cs + in.C);
+    if (in_bytes > (double)0x3F000000u) return false;
+    if ((long)q.dil * in.W * in.cs * 4 * 6 > (1L << 26)) return false;
+    return true;
+}
+
+size_t winograd_fused_ws_floats(int B, int Cin, int G) { return (size_t)2 * G * B * Cin; }
+
+// The kernels use 145 KB of dynamic LDS: raise their limit on the current device.  Called when a plan is built and by the
+// stand-alone op - not from the launcher, which may run inside a hipGraph capture.
+int winograd_fused_prepare() {
+    QB_CHECK(hipFuncSetAttribute((const void*)wino_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+    QB_CHECK(hipFuncSetAttribute((const void*)wino_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+    QB_CHECK(hipFuncSetAttribute((const void*)wino_fused64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, w64::SMEM_BYTES));
+    QB_CHECK(hipFuncSetAttribute((const void*)wino_fused64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, w64::SMEM_BYTES));
+    return 0;
+}
+
+int launch_conv_winograd_fused(const WinoP& q, int Ball, int G, hipStream_t st) {
+    const View& in = q.in;
+    const View& out = q.out;
+    const int H = in.H, W = in.W, d = q.dil;
+    FusedArgs a{};
+    a.in = in.p; a.in_gs = in.gs; a.in_cs = in.cs; a.H = H; a.W = W; a.Cin = in.C;
+    a.in_bytes = (unsigned)(4 * (((long)Ball * H * W - 1) * in.cs + in.C));
+    a.uf = q.uf; a.uf_gs = (long)FP * out.C * in.C;
+    a.Ball = Ball; a.boff = 0; a.B = Ball;
+    a.scale = q.scale; a.shift = q.shift; a.ss_gs = q.ss_gs; a.relu = q.relu;
+    a.out = out.p; a.out_cs = out.cs; a.out_gs = out.gs; a.Cout = out.C;
+    a.TH = tiles_1d(H, d, 4); a.TW = tiles_1d(W, d, 4); a.d = d;
+    a.per_img = wino_tiles(H, W, d, 4);
+    a.tiles = (long)Ball * a.per_img;
+    const bool wide = out.C % 64 == 0;               // 16 tiles x 64 channels per block (wino_fused64_kernel), else 32 x 32
+    const int ft = wide ? w64::FT : FT;
+    a.NC = out.C / (wide ? w64::FC : FC);
+    const long tblocks = (a.tiles + ft - 1) / ft;
+    if (tblocks * a.NC >= (1L << 31)) return fail("winograd (fused): too many blocks");
+    a.NB = (int)(tblocks * a.NC);
+    const bool gn_here = q.gn_sum && q.gn_groups > 0 && q.gn_groups <= 32 && (out.C / q.gn_groups) % 4 == 0 && a.per_img >= ft;
+    a.gn_sum = gn_here ? q.gn_sum : nullptr; a.gn_groups = q.gn_groups; a.gn_cpg = q.gn_groups ? out.C / q.gn_groups : 1;
+    const bool norm = q.norm.stats != nullptr;
+    if (norm) {
+        WinoNorm np = q.norm;
+        if (np.groups <= 0 || in.C % np.groups) return fail("winograd (fused): GroupNorm groups do not divide the channels");
+        np.cpg = in.C / np.groups;
+        np.n = (double)H * W * np.cpg;
+        if (winograd_fused_ws_floats(Ball, in.C, G) > q.ws_floats) return fail("winograd (fused): workspace too small");
+        const long n = (long)G * Ball * in.C;
+        hipLaunchKernelGGL(wino_norm_coef_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, np, G, Ball, in.C, q.ws);
+        QB_CHECK(hipGetLastError());
+        a.coef = q.ws; a.coef_gs = (long)Ball * in.C * 2; a.relu_in = np.relu;
+    }
+    {
+        ProfScope prof("wino_fused", 4.0 * G * ((double)Ball * H * W * (in.C + out.C) + (double)FP * in.C * out.C),
+                       2.0 * G * FP * (double)a.tiles * in.C * out.C, st);
+        const void* fn32 = norm ? (const void*)wino_fused_kernel<true> : (const void*)wino_fused_kernel<false>;
+        const void* fn64 = norm ? (const void*)wino_fused64_kernel<true> : (const void*)wino_fused64_kernel<false>;
+        const void* fn = wide ? fn64 : fn32;
+        const int smem_bytes = wide ? w64::SMEM_BYTES : SMEM_BYTES;
+        void* args[] = {(void*)&a};
+        QB_CHECK(hipLaunchKernel(fn, dim3(a.NB, 1, G), dim3(256), args, smem_bytes, st));
+    }
+    QB_CHECK(hipGetLastError());
+    if (q.gn_sum && !gn_here) return launch_gn_stats(out, Ball, G, q.gn_groups, q.gn_sum, st, false);
+    return 0;
+}
+
+}  // namespace quber

@@ -856,6 +856,62 @@ def test_conv3x3_winograd_vs_float64(case, m):
         assert (y[b, oy, ox].cpu().double() - ref).abs().max().item() / scale < tol, (b, oy, ox)
 
 
+@pytest.mark.parametrize("case", [
+    # B, H, W, Cin, Cout, dilation, affine, relu, widest input admitted (tuning key 27)
+    (2, 30, 40, 128, 128, 1, True, True, 128),       # 16 tiles x 64 channels per block (wino_fused64_kernel)
+    (1, 31, 45, 128, 64, 1, True, False, 128),       # ragged last tile row / column
+    (3, 12, 16, 128, 32, 1, False, False, 128),      # 32 tiles x 32 channels per block (wino_fused_kernel): the 32-channel heads
+    (2, 30, 40, 96, 96, 2, True, True, 128),         # 96 output channels (32 x 32 blocks), dilation 2: phase sub-images
+    (1, 23, 37, 64, 128, 4, False, True, 128),       # phases of unequal size, two rounds of 32 channels
+    (5, 9, 7, 128, 256, 1, True, True, 128),         # 6 tiles per image: a block spans three images
+    (1, 30, 40, 160, 128, 1, True, True, 160),       # odd number of 32-channel rounds: the last one multiplies zero filters
+    (1, 30, 40, 320, 192, 1, True, True, 320),       # chains of 160 channels (opt-in width)
+])
+def test_conv3x3_winograd_single_kernel(case):
+    """F(4x4,3x3) as ONE kernel (wino_fused.hip) against the three-kernel pipeline on the same input, and against float64"""
+    B, H, W, Cin, Cout, dil, affine, relu, max_cin = case
+    lib = _lib.load()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) / np.sqrt(Cin * 9)
+    sc = torch.rand(Cout, device="cuda", generator=g) + 0.5 if affine else None
+    sh = torch.randn(Cout, device="cuda", generator=g) if affine else None
+    tiles = B * dil * dil * ((-(-H // dil) + 3) // 4) * ((-(-W // dil) + 3) // 4)
+    u = torch.empty(36 * Cout * Cin, device="cuda")
+    ws = torch.empty(36 * tiles * (Cin + Cout) + 36 * Cout * Cin, device="cuda")
+    ys = []
+    lib.quber_set_tuning(27, max_cin)
+    try:
+        for fused in (0, 1):
+            lib.quber_set_tuning(25, fused)
+            y = torch.full((B, H, W, Cout), float("nan"), device="cuda")
+            _lib.check(lib.quber_op_conv3x3_winograd(p(x), B, H, W, Cin, p(w), Cout, dil, 4, p(sc), p(sh), int(relu), p(u), p(ws),
+                                                     ws.numel(), p(y), st))
+            ys.append(y)
+    finally:
+        lib.quber_set_tuning(25, 1)
+        lib.quber_set_tuning(27, 128)
+    pipe, one = ys
+    assert torch.isfinite(one).all()
+    assert not torch.equal(pipe, one)                # the single kernel really ran (another accumulation order)
+    scale = max(1.0, pipe.abs().max().item())
+    assert (pipe - one).abs().max().item() / scale < 1e-5
+    xp = torch.nn.functional.pad(x.cpu().double(), (0, 0, dil, dil, dil, dil))
+    wc = w.cpu().double()
+    pts = [(0, 0, 0), (B - 1, H - 1, W - 1), (0, H - 1, 0), (B - 1, 0, W - 1), (0, H // 2, W - 1), (0, H - 1, W // 2)]
+    rng = np.random.default_rng(1)
+    pts += [(int(rng.integers(B)), int(rng.integers(H)), int(rng.integers(W))) for _ in range(40)]
+    for (b, oy, ox) in pts:
+        ref = torch.einsum("yxc,ocyx->o", xp[b, oy:oy + 2 * dil + 1:dil, ox:ox + 2 * dil + 1:dil, :], wc)
+        if affine:
+            ref = ref * sc.cpu().double() + sh.cpu().double()
+        if relu:
+            ref = ref.relu()
+        assert (one[b, oy, ox].cpu().double() - ref).abs().max().item() / scale < 2e-5, (b, oy, ox)
+
+
 def test_groupnorm_bilinear_maxpool_vs_torch():
     lib = _lib.load()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)

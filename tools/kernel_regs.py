@@ -8,7 +8,7 @@ import sys
 
 src = os.path.abspath(sys.argv[1])
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
-out = subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-mllvm", "-simplifycfg-sink-common=false",
+out = subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-mllvm", "-simplifycfg-sink-common=false", *(["-fno-slp-vectorize"] if "wino_fused" in src else []),
                       "--cuda-device-only", "-c", os.path.basename(src), "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"],
                      cwd=os.path.dirname(src), capture_output=True, text=True).stderr
 rows, cur = [], None
