@@ -78,17 +78,35 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned vo
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
-// y = B^T x on a channel pair, fused multiply-adds (points 0, +-3/4, +-3/2, inf; the constants are dyadic)
-__device__ __forceinline__ f32x2 fma2(float s, f32x2 a, f32x2 b) { return __builtin_elementwise_fma(f32x2{s, s}, a, b); }
+// y = B^T x on a channel pair (points 0, +-3/4, +-3/2, inf; the constants are dyadic), 12 fused multiply-adds on packed fp32.
+// Written as v_pk_fma_f32 by hand: left to instruction selection, half of these operations come out as two scalar ones -
+// and beside the fp32 MFMA every vector instruction costs its full issue time (tools/micro/mfma_f32_shadow.hip).
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 c, f32x2 b) {        // a * c + b, c = a uniform constant pair in scalar registers
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(c), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_fnma(f32x2 a, f32x2 c, f32x2 b) {       // b - a * c
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(d) : "v"(a), "s"(c), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_fma_v(f32x2 a, f32x2 c, f32x2 b) {      // a * c + b, all in vector registers
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(c), "v"(b));
+    return d;
+}
 __device__ __forceinline__ void bt4(const f32x2* x, f32x2* y) {
-    const f32x2 e1 = fma2(-2.25f, x[2], x[4]), o1 = fma2(0.75f, x[3], -1.6875f * x[1]);
-    const f32x2 e2 = fma2(-0.5625f, x[2], x[4]), o2 = fma2(1.5f, x[3], -0.84375f * x[1]);
-    y[0] = fma2(1.265625f, x[0], fma2(-2.8125f, x[2], x[4]));
-    y[1] = e1 + o1;
-    y[2] = e1 - o1;
-    y[3] = e2 + o2;
-    y[4] = e2 - o2;
-    y[5] = fma2(1.265625f, x[1], fma2(-2.8125f, x[3], x[5]));
+    const f32x2 k225 = {2.25f, 2.25f}, k05625 = {0.5625f, 0.5625f}, k075 = {0.75f, 0.75f}, k15 = {1.5f, 1.5f};
+    const f32x2 k1265625 = {1.265625f, 1.265625f}, k28125 = {2.8125f, 2.8125f};
+    const f32x2 t1 = pk_fnma(x[1], k225, x[3]), e1 = pk_fnma(x[2], k225, x[4]);
+    const f32x2 t2 = pk_fnma(x[1], k05625, x[3]), e2 = pk_fnma(x[2], k05625, x[4]);
+    y[0] = pk_fma(x[0], k1265625, pk_fnma(x[2], k28125, x[4]));
+    y[1] = pk_fma(t1, k075, e1);
+    y[2] = pk_fnma(t1, k075, e1);
+    y[3] = pk_fma(t2, k15, e2);
+    y[4] = pk_fnma(t2, k15, e2);
+    y[5] = pk_fma(x[1], k1265625, pk_fnma(x[3], k28125, x[5]));
 }
 
 struct FusedArgs {
@@ -141,6 +159,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     // some tile of this wave touches the zero padding (wave-uniform: the interior waves skip the masking of the fused GroupNorm)
     const bool border = NORM && __any(edge);
+    const float relu_lo = a.relu_in ? 0.f : -__builtin_inff();      // ReLU of the fused GroupNorm as max(v, lo)
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in + (long)g * a.in_gs, a.in_bytes);
     const int nslice = a.Cin / 8;
     const __amdgpu_buffer_rsrc_t rs_u = make_rsrc(a.uf + (long)g * a.uf_gs + (long)cc * nslice * (FP * 256), (unsigned)nslice * (FP * 1024u));
@@ -174,9 +193,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int i = 0; i < 6; ++i) {
             f32x2 v = dd[i][j];
             if constexpr (NORM) {
-                v = __builtin_elementwise_fma(v, f32x2{cf.x, cf.z}, f32x2{cf.y, cf.w});
-                if (a.relu_in) v = __builtin_elementwise_max(v, f32x2{0.f, 0.f});
-                if (border) v = v * ((rowbase[i] == OOBH || colterm[j] == OOBH) ? 0.f : 1.f);     // the padding stays zero
+                v = pk_fma_v(v, f32x2{cf.x, cf.z}, f32x2{cf.y, cf.w});
+                v.x = fmaxf(v.x, relu_lo); v.y = fmaxf(v.y, relu_lo);
+                if (border) {                    // a real (wave-uniform) branch: the interior waves pay nothing for the padding
+                    asm volatile("");
+                    if (rowbase[i] == OOBH || colterm[j] == OOBH) v = f32x2{0.f, 0.f};      // the padding stays zero
+                }
             }
             col[i] = v;
         }
@@ -256,16 +278,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     float* const st0 = smem;
     float* const st1 = smem + STAGE;
+    // prologue: the patches of rounds 0 and 1 are requested together (one exposure to the memory latency, not two; the
+    // accumulators' registers are still free to hold the second patch)
+    {
+        f32x2 d1[6][6];
+        const unsigned so1 = (unsigned)(R > 1 ? 1 : 0) * (FK * 4u);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) gload_row(i, 0);
-    gload_coef(0);
+        for (int i = 0; i < 6; ++i) gload_row(i, 0);
 #pragma unroll
-    for (int g0 = 0; g0 < BR; ++g0) bload(g0, 0, g0);
+        for (int i = 0; i < 6; ++i)
 #pragma unroll
-    for (int j = 0; j < 6; ++j) col_pass(j);
+            for (int j = 0; j < 6; ++j) d1[i][j] = buf_load2(rs_in, rowbase[i] + colterm[j], so1);
+        gload_coef(0);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { row_pass(i, st0); gload_row(i, 1); }
-    gload_coef(1);
+        for (int g0 = 0; g0 < BR; ++g0) bload(g0, 0, g0);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) col_pass(j);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) row_pass(i, st0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) dd[i][j] = d1[i][j];
+    }
+    gload_coef(R > 1 ? 1 : 0);
 #pragma unroll
     for (int j = 0; j < 6; ++j) col_pass(j);
     __syncthreads();
@@ -407,6 +443,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     // some tile of this wave touches the zero padding (wave-uniform: the interior waves skip the masking of the fused GroupNorm)
     const bool border = NORM && __any(edge);
+    const float relu_lo = a.relu_in ? 0.f : -__builtin_inff();      // ReLU of the fused GroupNorm as max(v, lo)
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in + (long)g * a.in_gs, a.in_bytes);
     const int nslice = a.Cin / 16;
     const __amdgpu_buffer_rsrc_t rs_u = make_rsrc(a.uf + (long)g * a.uf_gs + (long)cc * nslice * (FP * 1024), (unsigned)nslice * (FP * 4096u));
@@ -429,9 +466,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int i = 0; i < 6; ++i) {
             f32x2 v = dd[i][j];
             if constexpr (NORM) {
-                v = __builtin_elementwise_fma(v, f32x2{cf.x, cf.z}, f32x2{cf.y, cf.w});
-                if (a.relu_in) v = __builtin_elementwise_max(v, f32x2{0.f, 0.f});
-                if (border) v = v * ((rowbase[i] == OOBH || colterm[j] == OOBH) ? 0.f : 1.f);     // the padding stays zero
+                v = pk_fma_v(v, f32x2{cf.x, cf.z}, f32x2{cf.y, cf.w});
+                v.x = fmaxf(v.x, relu_lo); v.y = fmaxf(v.y, relu_lo);
+                if (border) {                    // a real (wave-uniform) branch: the interior waves pay nothing for the padding
+                    asm volatile("");
+                    if (rowbase[i] == OOBH || colterm[j] == OOBH) v = f32x2{0.f, 0.f};      // the padding stays zero
+                }
             }
             col[i] = v;
         }
@@ -499,16 +539,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     float* const st0 = smem;
     float* const st1 = smem + STAGE;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) gload_row(i, 0);
-    gload_coef(0);
-#pragma unroll
-    for (int g0 = 0; g0 < BR; ++g0) bload(g0, 0, g0);
-#pragma unroll
-    for (int j = 0; j < 6; ++j) col_pass(j);
+    // prologue: the patches of rounds 0 and 1 are requested together (one exposure to the memory latency, not two)
     const int r1 = R > 1 ? 1 : 0;
+    {
+        f32x2 d1[6][6];
+        const unsigned so1 = (unsigned)r1 * (FK * 4u);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { row_pass(i, st0); gload_row(i, r1); }
+        for (int i = 0; i < 6; ++i) gload_row(i, 0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) d1[i][j] = buf_load2(rs_in, rowbase[i] + colterm[j], so1);
+        gload_coef(0);
+#pragma unroll
+        for (int g0 = 0; g0 < BR; ++g0) bload(g0, 0, g0);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) col_pass(j);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) row_pass(i, st0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) dd[i][j] = d1[i][j];
+    }
     gload_coef(r1);
 #pragma unroll
     for (int j = 0; j < 6; ++j) col_pass(j);
