@@ -117,7 +117,7 @@ bool winograd_m6_channels_ok(int Cin, int Cout);
 size_t winograd_ws_floats(int B, int H, int W, int Cin, int Cout, int G, int dil, int m);
 double winograd_mac_ratio(int H, int W, int dil, int m);
 // single-kernel F(4x4,3x3) (wino_fused.hip)
-bool winograd_fused_ok(const WinoP& q, int B);
+bool winograd_fused_ok(const WinoP& q, int B, int G);
 int launch_conv_winograd_fused(const WinoP& q, int B, int G, hipStream_t st);
 void winograd_fused_pack_host(const float* u, int Cout, int Cin, float* uf);
 int launch_winograd_fused_pack(const float* u, int Cout, int Cin, float* uf, hipStream_t st);

@@ -334,7 +334,7 @@ struct Builder {
                 std::vector<float> u((size_t)G * P * Cout * Cin);
                 for (int g = 0; g < G; ++g) winograd_weights_host(w[g], Cout, Cin, m, &u[(size_t)g * P * Cout * Cin]);
                 wq.in = in; wq.out = out; wq.u = upload(u);
-                if (m == 4 && c->cfg.compute_dtype == 0 && Cout % 32 == 0 && g_wino_fused && Cin <= g_wino_fused_max_cin) {     // operand order of the single-kernel form
+                if (m == 4 && (c->cfg.compute_dtype == 0 || c->cfg.compute_dtype == 3) && Cout % 32 == 0 && g_wino_fused && Cin <= g_wino_fused_max_cin) {     // operand order of the single-kernel form
                     std::vector<float> uf(u.size());
                     for (int g = 0; g < G; ++g) winograd_fused_pack_host(&u[(size_t)g * P * Cout * Cin], Cout, Cin, &uf[(size_t)g * P * Cout * Cin]);
                     wq.uf = upload(uf);
@@ -352,7 +352,7 @@ struct Builder {
         if (wino) {     // workspace: V | M of the three-kernel pipeline, or only the fused GroupNorm's coefficients of the single-kernel form
             WinoP probe = wq;
             if (norm) probe.in = norm->in;           // what the layer will read (in place -> the pipeline)
-            const bool fusedk = wq.uf && winograd_fused_ok(probe, Bmax);
+            const bool fusedk = wq.uf && winograd_fused_ok(probe, Bmax, G);
             if (fusedk && winograd_fused_prepare() && err.empty()) err = "winograd (fused): cannot raise the kernels' LDS limit";
             const size_t need = fusedk ? winograd_fused_ws_floats(Bmax, Cin, G) : winograd_ws_floats(Bmax, in.H, in.W, Cin, Cout, G, dil, wq.m);
             if (need > c->wino_floats) c->wino_floats = need;
@@ -1583,7 +1583,7 @@ int quber_op_conv3x3_winograd(const float* x, int32_t B, int32_t h, int32_t w, i
     // the single-kernel form where it applies and the workspace also holds its filter order (36 * cout * cin floats)
     if (m == 4 && g_wino_fused && cout % 32 == 0 && (size_t)ws_floats >= (size_t)36 * cout * cin) {
         q.uf = ws;
-        if (winograd_fused_ok(q, B)) {
+        if (winograd_fused_ok(q, B, 1)) {
             rc = winograd_fused_prepare();
             if (rc) return rc;
             rc = g_op_wino_reuse ? 0 : launch_winograd_fused_pack(u, cout, cin, ws, st);

@@ -683,11 +683,14 @@ int launch_winograd_fused_pack(const float* u, int Cout, int Cin, float* uf, hip
     return 0;
 }
 
-// what the single-kernel form covers: F(4x4), exact fp32, fp32 tensors, 32 | Cin, 32 | Cout, views below 1 GiB
-bool winograd_fused_ok(const WinoP& q, int Ball) {
+// what the single-kernel form covers: F(4x4), fp32 tensors, the exact fp32 and the bf16x3 mode, 32 | Cin <= key 27, 32 | Cout, views below 1 GiB
+bool winograd_fused_ok(const WinoP& q, int Ball, int G) {
     const View& in = q.in;
     const View& out = q.out;
-    if (!g_wino_fused || q.m != 4 || q.dtype != 0 || !q.uf || in.es != 4 || out.es != 4) return false;
+    if (!g_wino_fused || q.m != 4 || (q.dtype != 0 && q.dtype != 3) || !q.uf || in.es != 4 || out.es != 4) return false;
+    // bf16x3 mode (fp32-equivalent): this exact fp32 kernel where it beats the pipeline's bf16x3 GEMMs + transforms - not the wide
+    // heads that share one input transform between their groups (profiles/r03_final_conv_layers_dtype3.md against r05t_layers.md)
+    if (q.dtype == 3 && G > 1 && in.gs == 0 && out.C >= 64) return false;
     if (in.C % 32 || out.C % FC) return false;
     if (in.p == out.p) return false;              // in place: blocks read input halos that other blocks are overwriting
     if (in.C > g_wino_fused_max_cin) return false;   // the two accumulation chains are Cin / 2 long: the accuracy class of 64-channel chains up to 128
@@ -744,7 +747,7 @@ int launch_conv_winograd_fused(const WinoP& q, int Ball, int G, hipStream_t st) 
         a.coef = q.ws; a.coef_gs = (long)Ball * in.C * 2; a.relu_in = np.relu;
     }
     {
-        ProfScope prof("wino_fused", 4.0 * G * ((double)Ball * H * W * (in.C + out.C) + (double)FP * in.C * out.C),
+        ProfScope prof(q.dtype == 3 ? "conv_gemm_f32pipe" : "wino_fused", 4.0 * G * ((double)Ball * H * W * (in.C + out.C) + (double)FP * in.C * out.C),
                        2.0 * G * FP * (double)a.tiles * in.C * out.C, st);
         const void* fn32 = norm ? (const void*)wino_fused_kernel<true> : (const void*)wino_fused_kernel<false>;
         const void* fn64 = norm ? (const void*)wino_fused64_kernel<true> : (const void*)wino_fused64_kernel<false>;

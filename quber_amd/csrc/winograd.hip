@@ -408,7 +408,7 @@ int launch_conv_winograd(const WinoP& q, int B, int G, hipStream_t st) {
     if (q.m == 6 && !winograd_m6_channels_ok(in.C, out.C)) return fail("winograd: channel counts unsupported by the 6x6 variant");
     if (in.cs % 4 || out.cs % 4 || ((uintptr_t)in.p & 15) || ((uintptr_t)out.p & 15) || (in.gs & 3) || (out.gs & 3))
         return fail("winograd: operands must be 16-byte aligned");
-    if (winograd_fused_ok(q, B)) return launch_conv_winograd_fused(q, B, G, st);
+    if (winograd_fused_ok(q, B, G)) return launch_conv_winograd_fused(q, B, G, st);
     if (q.m == 4 && g_wino_pairs && winograd_m6_channels_ok(in.C, out.C)) return run_winograd<4, 2>(q, B, G, st);
     return q.m == 6 ? run_winograd<6, 2>(q, B, G, st) : q.m == 4 ? run_winograd<4, 4>(q, B, G, st) : run_winograd<2, 4>(q, B, G, st);
 }

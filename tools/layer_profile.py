@@ -42,7 +42,7 @@ def report(a):
     allk = sorted(csv.DictReader(open(a.trace)), key=lambda r: int(r["Start_Timestamp"]))
     dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
     name = lambda r: r["Kernel_Name"]
-    # one group of launches per convolution op: [wino_input] conv_igemm+ (pk_fixup | splitk_reduce)* [wino_output]; a Winograd op
+    # one group of launches per convolution op: [wino_input] conv_igemm+ (pk_fixup | splitk_reduce)* [wino_output] | wino_fused; a Winograd op
     # whose groups share one input transform (the heads of a level) has several GEMM launches between its two transforms
     groups, i = [], 0
     while i < len(allk):
@@ -53,6 +53,9 @@ def report(a):
                 j += 1
             groups.append(("winograd", allk[i:j + 1]))
             i = j + 1
+        elif "wino_fused" in n_:                  # a Winograd layer as ONE kernel (wino_fused.hip)
+            groups.append(("winograd single-kernel", [allk[i]]))
+            i += 1
         elif "conv_igemm" in n_:
             j = i + 1
             while j < len(allk) and any(t in name(allk[j]) for t in ("splitk_reduce", "pk_fixup")):
@@ -68,9 +71,12 @@ def report(a):
            "|---|---|---|---|---|---|"]
     for i, (c, (path, ks)) in enumerate(zip(convs, groups[-n:])):
         ms = sum(dur(r) for r in ks)
-        r = next(k for k in ks if "conv_igemm" in name(k))
+        r = next(k for k in ks if "conv_igemm" in name(k) or "wino_fused" in name(k))
         fl = c[2] * B
-        tile = ("persistent " if "conv_igemm_pk" in name(r) else "") + name(r).split("<")[1].split(">")[0].replace(" ", "")
+        if "wino_fused" in name(r):
+            tile = "16 tiles x 64 ch" if "fused64" in name(r) else "32 tiles x 32 ch"
+        else:
+            tile = ("persistent " if "conv_igemm_pk" in name(r) else "") + name(r).split("<")[1].split(">")[0].replace(" ", "")
         out.append("| %d | %s | %s %s | %.1f | %.3f | %.1f |" % (i, c[0].replace("backbone.", "b.").replace("ins_embed_head.", "h."),
                                                                path, tile, fl / 1e9, ms, fl / ms / 1e9))
         tot_t += ms
