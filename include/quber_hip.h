@@ -253,7 +253,14 @@ double quber_forward_flops_executed(quber_ctx* ctx);
  * key 4 = force the convolution tile shape (1 = 64x64, 2 = 128x128, 4 = 256x32; 0 = automatic);
  * key 20 = Winograd layers in passes whose V | M intermediates stay below `value` MiB (0 = the whole batch at once, default;
  *          measured slower at every size: profiles/r03c_wino_subbatch_rejected.md);
- * key 21 = K-slices per accumulation chunk of the bf16x3 mode (default 2; the exact fp32 mode folds every slice) */
+ * key 21 = K-slices per accumulation chunk of the bf16x3 mode (default 2; the exact fp32 mode folds every slice);
+ * key 24 = side lanes at batches <= 2 (1, default) or everything on the caller's stream (0);
+ * key 25 = (acts at plan time) Winograd F(4x4,3x3) layers as ONE kernel - input transform, the 36 position GEMMs and the output
+ *          transform, no V | M intermediates in HBM (csrc/wino_fused.hip): 1 = the eligible layers (default), 0 = never;
+ * key 27 = (plan time) widest input, in channels, that takes the single-kernel form (default 128: its two accumulation chains are
+ *          Cin / 2 long, 64 channels being the chain class the float64-anchor test passes with margin; wider layers measured
+ *          no faster than the three-kernel pipeline inside the network: profiles/r05_wino_fused_layers.md);
+ * key 26 = timing harness: quber_op_conv3x3_winograd reuses the transformed filters of its previous call (u / ws untouched) */
 void quber_set_tuning(int32_t key, int32_t value);
 /* Host view of the work distribution of a persistent convolution launch (csrc/conv_persist.hip), for the CPU tests: no GPU.
  * _segments: the work list of block `block` of a launch of `blocks` blocks over `tiles` tiles of `k_slices` K-slices each
@@ -282,7 +289,8 @@ int quber_op_conv1x1_dual(const float* dev_y, const float* dev_x, int32_t batch,
                           const float* dev_ones, int32_t cout, int32_t relu, float* dev_out, void* stream);
 /* the same for a 3x3 / stride 1 / pad = dilation convolution through the Winograd F(m x m, 3x3) path, m = 2, 4 or 6
  * (cin >= 128 and a multiple of 32, cout >= 128): with P = (m+2)^2, dev_u_scratch holds P*cout*cin floats (transformed
- * weights), dev_ws at least P * batch * dil^2 * ceil(ceil(h/dil)/m) * ceil(ceil(w/dil)/m) * (cin + cout) floats */
+ * weights), dev_ws at least P * batch * dil^2 * ceil(ceil(h/dil)/m) * ceil(ceil(w/dil)/m) * (cin + cout) floats.
+ * m = 4 with cin <= key 27, 32 | cout and a dev_ws of at least 36 * cout * cin floats: the single-kernel form (key 25). */
 int quber_op_conv3x3_winograd(const float* dev_x, int32_t batch, int32_t h, int32_t w, int32_t cin,
                               const float* dev_w_oihw, int32_t cout, int32_t dil, int32_t m, const float* dev_scale,
                               const float* dev_shift,

@@ -195,12 +195,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if constexpr (NORM) {
                 v = pk_fma_v(v, f32x2{cf.x, cf.z}, f32x2{cf.y, cf.w});
                 v.x = fmaxf(v.x, relu_lo); v.y = fmaxf(v.y, relu_lo);
-                if (border) {                    // a real (wave-uniform) branch: the interior waves pay nothing for the padding
-                    asm volatile("");
-                    if (rowbase[i] == OOBH || colterm[j] == OOBH) v = f32x2{0.f, 0.f};      // the padding stays zero
-                }
             }
             col[i] = v;
+        }
+        if constexpr (NORM) {
+            if (border) {                        // a real (wave-uniform) branch: the interior waves pay nothing for the padding
+                asm volatile("");
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+                    if (rowbase[i] == OOBH || colterm[j] == OOBH) col[i] = f32x2{0.f, 0.f};     // the padding stays zero
+            }
         }
         bt4(col, tc);
 #pragma unroll
@@ -359,8 +363,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int e = 0; e < 4; ++e) {
                 if (a.scale) y.v[e] = fmaf(y.v[e], sc.v[e], sh.v[e]);
                 if (a.relu) y.v[e] = fmaxf(y.v[e], 0.f);
-                sa += (double)y.v[e];
-                sq += (double)y.v[e] * y.v[e];
+            }
+            if (a.gn_sum) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sa += (double)y.v[e]; sq += (double)y.v[e] * y.v[e]; }
             }
             vstore<4>(out + (((long)ta.b * a.H + oy) * a.W + ox) * a.out_cs, y);
         }
@@ -468,12 +474,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if constexpr (NORM) {
                 v = pk_fma_v(v, f32x2{cf.x, cf.z}, f32x2{cf.y, cf.w});
                 v.x = fmaxf(v.x, relu_lo); v.y = fmaxf(v.y, relu_lo);
-                if (border) {                    // a real (wave-uniform) branch: the interior waves pay nothing for the padding
-                    asm volatile("");
-                    if (rowbase[i] == OOBH || colterm[j] == OOBH) v = f32x2{0.f, 0.f};      // the padding stays zero
-                }
             }
             col[i] = v;
+        }
+        if constexpr (NORM) {
+            if (border) {                        // a real (wave-uniform) branch: the interior waves pay nothing for the padding
+                asm volatile("");
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+                    if (rowbase[i] == OOBH || colterm[j] == OOBH) col[i] = f32x2{0.f, 0.f};     // the padding stays zero
+            }
         }
         bt4(col, tc);
 #pragma unroll
