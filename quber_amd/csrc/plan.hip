@@ -323,9 +323,12 @@ struct Builder {
             if (r4 <= best && g_wino_variant != 2) { best = r4; wm = 4; }
             if (r2 <= lim && wm == 0) { best = r2; wm = 2; }                     // a forced larger variant does not fit: smaller tiles
             const bool has6 = wm != 0 && g_wino_variant == 6 && r6 <= 0.9 * best;
-            // Maps of a handful of tiles stay on the direct kernel, and so do the 64-channel layers unless the 6x6 variant
-            // was opted into (below 128 channels only it outweighs its transforms).
-            wino = wm != 0 && (g_winograd == 2 || (Cin < 128 ? has6 : (long)in.H * in.W >= 1024));
+            // Maps of a handful of tiles stay on the direct kernel.  The 64-channel layers (res2.conv2) lose to it as three
+            // kernels (below 128 channels only the opt-in 6x6 variant outweighs its transforms) but not as ONE: 0.25 against
+            // 0.43 ms per layer (wino_fused.hip; profiles/r05_wino_fused_layers.md).
+            const bool one_kernel = wm == 4 && g_wino_fused && (c->cfg.compute_dtype == 0 || c->cfg.compute_dtype == 3) && Cout % 32 == 0 &&
+                                    Cin <= g_wino_fused_max_cin;
+            wino = wm != 0 && (g_winograd == 2 || (Cin < 128 ? (has6 || (one_kernel && (long)in.H * in.W >= 1024)) : (long)in.H * in.W >= 1024));
             if (wino) {
                 const int m = has6 ? 6 : wm;
                 c->wino_flops += 2.0 * OH * OW * (double)cin_real * k * k * Cout * G;

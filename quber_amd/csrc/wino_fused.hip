@@ -109,6 +109,45 @@ __device__ __forceinline__ void bt4(const f32x2* x, f32x2* y) {
     y[5] = pk_fma(x[1], k1265625, pk_fnma(x[3], k28125, x[5]));
 }
 
+// y = A^T x on four channels (two packed pairs), 12 packed operations per pair: the epilogue's output transform
+struct PV { f32x2 lo, hi; };
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 c) {                 // c = a uniform constant pair in scalar registers
+    f32x2 d;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "s"(c));
+    return d;
+}
+__device__ __forceinline__ f32x2 at4_y(int o, f32x2 x0, f32x2 a, f32x2 b, f32x2 c, f32x2 d, f32x2 x5) {
+    const f32x2 k075 = {0.75f, 0.75f}, k15 = {1.5f, 1.5f}, k05625 = {0.5625f, 0.5625f}, k225 = {2.25f, 2.25f};
+    const f32x2 k0421875 = {0.421875f, 0.421875f}, k3375 = {3.375f, 3.375f};
+    if (o == 0) return pk_add(pk_add(x0, a), c);
+    if (o == 1) return pk_fma(d, k15, pk_mul(b, k075));
+    if (o == 2) return pk_fma(c, k225, pk_mul(a, k05625));
+    return pk_fma(b, k0421875, pk_fma(d, k3375, x5));
+}
+__device__ __forceinline__ void at4(const PV* x, PV* y) {
+    const f32x2 al = pk_add(x[1].lo, x[2].lo), bl = pk_sub(x[1].lo, x[2].lo), cl = pk_add(x[3].lo, x[4].lo), dl = pk_sub(x[3].lo, x[4].lo);
+    const f32x2 ah = pk_add(x[1].hi, x[2].hi), bh = pk_sub(x[1].hi, x[2].hi), ch = pk_add(x[3].hi, x[4].hi), dh = pk_sub(x[3].hi, x[4].hi);
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        y[o].lo = at4_y(o, x[0].lo, al, bl, cl, dl, x[5].lo);
+        y[o].hi = at4_y(o, x[0].hi, ah, bh, ch, dh, x[5].hi);
+    }
+}
+__device__ __forceinline__ PV ldpv(const float* p) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    return PV{f32x2{t.x, t.y}, f32x2{t.z, t.w}};
+}
+
 struct FusedArgs {
     const float* in; long in_gs; int in_cs, H, W, Cin; unsigned in_bytes;
     const float* uf; long uf_gs;                 // packed filters [G][Cout/32][Cin/8][36][64 lanes][4]
@@ -328,47 +367,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int e = 0; e < 16; ++e)
             smem[((wave * 9 + pi) * FT + 8 * (e >> 2) + 4 * h + (e & 3)) * FC + rr] = pi < SPLIT ? acc[0][pi][e] + acc[1][pi][e] : acc[0][pi][e];
     __syncthreads();
-    using VT = Vec<4>;
     const int c = cc * FC + 4 * q;
-    VT s[4][6];
+    PV s[4][6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-        VT col[6], sj[4];
+        PV col[6], sj[4];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) col[i] = vload<4>(smem + ((i * 6 + j) * FT + lt) * FC + 4 * q);
-        at<4>(col, sj);
+        for (int i = 0; i < 6; ++i) col[i] = ldpv(smem + ((i * 6 + j) * FT + lt) * FC + 4 * q);
+        at4(col, sj);
 #pragma unroll
         for (int i = 0; i < 4; ++i) s[i][j] = sj[i];
     }
-    VT sc, sh;
+    PV sc = {f32x2{1.f, 1.f}, f32x2{1.f, 1.f}}, sh = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
     if (a.scale) {
-        sc = vload<4>(a.scale + g * a.ss_gs + c);
-        sh = vload<4>(a.shift + g * a.ss_gs + c);
+        sc = ldpv(a.scale + g * a.ss_gs + c);
+        sh = ldpv(a.shift + g * a.ss_gs + c);
     }
+    const float lo = a.relu ? 0.f : -__builtin_inff();
     const int b0 = (int)(((long)tb * FT) / a.per_img);
     double sa = 0.0, sq = 0.0;
     float* const out = a.out + (long)g * a.out_gs + c;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        VT row[4];
-        at<4>(s[i], row);
+        PV row[4];
+        at4(s[i], row);
         const int oy = a.d * (4 * ta.ty + i) + ta.py;
         if (!tvalid || oy >= a.H) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int ox = a.d * (4 * ta.tx + j) + ta.px;
             if (ox >= a.W) continue;
-            VT y = row[j];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (a.scale) y.v[e] = fmaf(y.v[e], sc.v[e], sh.v[e]);
-                if (a.relu) y.v[e] = fmaxf(y.v[e], 0.f);
-            }
+            const f32x2 yl = pk_fma_v(row[j].lo, sc.lo, sh.lo), yh = pk_fma_v(row[j].hi, sc.hi, sh.hi);
+            const f32x4 y = {fmaxf(yl.x, lo), fmaxf(yl.y, lo), fmaxf(yh.x, lo), fmaxf(yh.y, lo)};
             if (a.gn_sum) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { sa += (double)y.v[e]; sq += (double)y.v[e] * y.v[e]; }
+                for (int e = 0; e < 4; ++e) { sa += (double)y[e]; sq += (double)y[e] * y[e]; }
             }
-            vstore<4>(out + (((long)ta.b * a.H + oy) * a.W + ox) * a.out_cs, y);
+            *reinterpret_cast<f32x4*>(out + (((long)ta.b * a.H + oy) * a.W + ox) * a.out_cs) = y;
         }
     }
     if (a.gn_sum) {
@@ -596,48 +631,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int e = 0; e < 4; ++e)
                 smem[((wave * 9 + pi) * FT + 4 * hq + e) * FC + ((nt ^ hq) << 4) + rr] = pi < SPLIT ? acc[0][pi][nt][e] + acc[1][pi][nt][e] : acc[0][pi][nt][e];
     __syncthreads();
-    using VT = Vec<4>;
     const int c = cc * FC + 4 * q;
     const int csw = (((q >> 2) ^ ((lt >> 2) & 3)) << 4) + (q & 3) * 4;
-    VT s[4][6];
+    PV s[4][6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-        VT col[6], sj[4];
+        PV col[6], sj[4];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) col[i] = vload<4>(smem + ((i * 6 + j) * FT + lt) * FC + csw);
-        at<4>(col, sj);
+        for (int i = 0; i < 6; ++i) col[i] = ldpv(smem + ((i * 6 + j) * FT + lt) * FC + csw);
+        at4(col, sj);
 #pragma unroll
         for (int i = 0; i < 4; ++i) s[i][j] = sj[i];
     }
-    VT sc, sh;
+    PV sc = {f32x2{1.f, 1.f}, f32x2{1.f, 1.f}}, sh = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
     if (a.scale) {
-        sc = vload<4>(a.scale + g * a.ss_gs + c);
-        sh = vload<4>(a.shift + g * a.ss_gs + c);
+        sc = ldpv(a.scale + g * a.ss_gs + c);
+        sh = ldpv(a.shift + g * a.ss_gs + c);
     }
+    const float lo = a.relu ? 0.f : -__builtin_inff();
     const int b0 = (int)(((long)tb * FT) / a.per_img);
     double sa = 0.0, sq = 0.0;
     float* const out = a.out + (long)g * a.out_gs + c;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        VT row[4];
-        at<4>(s[i], row);
+        PV row[4];
+        at4(s[i], row);
         const int oy = a.d * (4 * ta.ty + i) + ta.py;
         if (!tvalid || oy >= a.H) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int ox = a.d * (4 * ta.tx + j) + ta.px;
             if (ox >= a.W) continue;
-            VT y = row[j];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (a.scale) y.v[e] = fmaf(y.v[e], sc.v[e], sh.v[e]);
-                if (a.relu) y.v[e] = fmaxf(y.v[e], 0.f);
-            }
+            const f32x2 yl = pk_fma_v(row[j].lo, sc.lo, sh.lo), yh = pk_fma_v(row[j].hi, sc.hi, sh.hi);
+            const f32x4 y = {fmaxf(yl.x, lo), fmaxf(yl.y, lo), fmaxf(yh.x, lo), fmaxf(yh.y, lo)};
             if (a.gn_sum) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { sa += (double)y.v[e]; sq += (double)y.v[e] * y.v[e]; }
+                for (int e = 0; e < 4; ++e) { sa += (double)y[e]; sq += (double)y[e] * y[e]; }
             }
-            vstore<4>(out + (((long)ta.b * a.H + oy) * a.W + ox) * a.out_cs, y);
+            *reinterpret_cast<f32x4*>(out + (((long)ta.b * a.H + oy) * a.W + ox) * a.out_cs) = y;
         }
     }
     if (a.gn_sum) {

@@ -34,13 +34,15 @@ LAYERS = [("fusion_res2 256>256 @120x160", 1, 120, 160, 256, 256, 1),
           ("decoder.res2.fuse0 160>128 @120x160", 1, 120, 160, 160, 128, 1),
           ("head 128>128 @120x160", 1, 120, 160, 128, 128, 1),
           ("heads x3 128>128 @120x160", 3, 120, 160, 128, 128, 1),
+          ("res2.conv2 64>64 @120x160 (2 streams)", 2, 120, 160, 64, 64, 1),
+          ("stem.conv3 32>64 @240x320 (2 streams)", 2, 240, 320, 32, 64, 1),
           ("head 128>32 @120x160", 1, 120, 160, 128, 32, 1),
           ("head x3 128>32 @120x160", 3, 120, 160, 128, 32, 1)]
-print(f"| layer ({F} frames) | GFLOP | pipeline ms | fused ms | speed-up | fused TFLOP/s (executed) | diff | fused vs direct | pipeline vs direct |")
-print("|---|---|---|---|---|---|---|---|---|")
+print(f"| layer ({F} frames) | GFLOP | pipeline ms | fused ms | speed-up | fused TFLOP/s (executed) | diff | fused vs direct | pipeline vs direct | direct kernel ms |")
+print("|---|---|---|---|---|---|---|---|---|---|")
 
 
-def timed(fn):
+def timed(fn):  # noqa: E302
     ts = []
     for rd in range(6):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -64,7 +66,9 @@ for name, ipf, H, W, Cin, Cout, d in LAYERS:
     sc, sh = torch.rand(Cout, device="cuda", generator=g) + 0.5, torch.randn(Cout, device="cuda", generator=g)
     packed = torch.empty(Cout * 9 * Cin, device="cuda")
     yd = torch.empty(B, H, W, Cout, device="cuda")
-    _lib.check(lib.quber_op_conv2d(p(x), B, H, W, Cin, p(w), Cout, 3, 1, d, d, p(sc), p(sh), p(None), 1, p(packed), p(yd), st))
+    direct = lambda: _lib.check(lib.quber_op_conv2d(p(x), B, H, W, Cin, p(w), Cout, 3, 1, d, d, p(sc), p(sh), p(None), 1, p(packed), p(yd), st))
+    direct()
+    td = timed(direct)
     tiles = B * d * d * ((-(-H // d) + 3) // 4) * ((-(-W // d) + 3) // 4)
     u = torch.empty(36 * Cout * Cin, device="cuda")
     ws = torch.empty(max(36 * tiles * (Cin + Cout), 36 * Cout * Cin + 2 * B * Cin), device="cuda")
@@ -86,6 +90,6 @@ for name, ipf, H, W, Cin, Cout, d in LAYERS:
     e0 = (ys[0] - yd).abs().max().item() / scale
     fl = 2.0 * B * H * W * Cin * 9 * Cout
     ex = 2.0 * 36 * tiles * Cin * Cout
-    print("| %s | %.1f | %.3f | %.3f | %.2fx | %.1f | %.1e | %.1e | %.1e |" % (name, fl / 1e9, ts[0], ts[1], ts[0] / ts[1], ex / ts[1] / 1e9,
-                                                                            diff, e1, e0), flush=True)
+    print("| %s | %.1f | %.3f | %.3f | %.2fx | %.1f | %.1e | %.1e | %.1e | %.3f |" % (name, fl / 1e9, ts[0], ts[1], ts[0] / ts[1], ex / ts[1] / 1e9,
+                                                                                   diff, e1, e0, td), flush=True)
     del x, w, u, ws, ys, yd
