@@ -246,7 +246,8 @@ double quber_forward_flops_executed(quber_ctx* ctx);
  *         where it executes >= 10 % fewer multiplies still (2.5x the error at tap level, +4.5 % throughput at batch 16);
  *         the algorithm of every layer is fixed at plan time from its geometry alone, never from the batch of a launch;
  * key 8 = Winograd only while its multiplies are <= value % of the direct kernel's (dilated layers; default 67);
- * key 7 = smallest input width (channels) routed to the Winograd path (default 256);
+ * key 7 = smallest input width (channels) routed to the Winograd path (default 32; below 128 channels a layer takes it only
+ *         in the single-kernel form, key 25);
  * key 6 = Winograd path of the eligible 3x3 layers (acts at plan time): 0 = where it pays (default), 1 = never, 2 = always;
  * key 5 = split the ragged last round of large convolution launches into K-pieces: when the cost model
  *         favours it (1, default), never (0), whenever feasible (2);

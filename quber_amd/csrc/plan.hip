@@ -1236,7 +1236,7 @@ void quber_set_tuning(int32_t key, int32_t value) {
     if (key == 10) g_wino_min_cout = value;   // smallest output width eligible for the Winograd path (default 32)
     if (key == 9) g_wino_variant = value;     // Winograd output tile edge for the eligible layers: 0 = automatic (4 or 2), 2, 4, 6 (opt-in)
     if (key == 8) g_wino_max_ratio = value;   // Winograd only while executed / direct multiplies <= value % (default 67)
-    if (key == 7) g_wino_min_cin = value;  // smallest input width eligible for the Winograd path (default 256)
+    if (key == 7) g_wino_min_cin = value;  // smallest input width eligible for the Winograd path (default 32)
     if (key == 6) g_winograd = value;      // Winograd F(2x2,3x3) for the eligible 3x3 layers: 0 = where it pays, 1 = never, 2 = always
     if (key == 5) g_tail_split = value;    // split the ragged last round of large convolution launches (default 1)
     if (key == 3) g_force_split = value;   // force the number of K partitions of every convolution with a workspace (0 = automatic)

@@ -25,7 +25,7 @@
 
 namespace quber {
 
-int g_wino_fused_max_cin = 128;   // key 27: widest input the single-kernel form takes (its two accumulation chains are Cin / 2 long)
+int g_wino_fused_max_cin = 160;   // key 27: widest input the single-kernel form takes (its two accumulation chains are Cin / 2 long)
 int g_wino_fused = 1;         // key 25: 1 = the eligible F(4x4) layers of the exact fp32 mode take this kernel, 0 = never
 
 using namespace wxf;
@@ -438,6 +438,9 @@ constexpr int SMEM_BYTES = 2 * STAGE * 4 + 2 * 32 * 2 * 8;
 
 // element i of [Cout/64][Cin/16][36][4 column blocks][64 lanes][4] <- index into U [36][Cout][Cin]: lane l of the MFMA on
 // column block nt supplies output channel nt * 16 + l % 16 and input channels 4 * (l / 16) + e of the 16-channel slice
+// which kernel a layer takes: 16 tiles x 64 channels needs 64 | Cout and an even number of 32-channel rounds (an odd count would
+// run one round on zero filters; the 32 x 32 kernel's rounds are 16 channels)
+__host__ __device__ inline bool fused_wide(int Cout, int Cin) { return Cout % 64 == 0 && (Cin / 32) % 2 == 0; }
 __host__ __device__ inline long fused64_src(long i, int Cout, int Cin) {
     const int e = (int)(i & 3), l = (int)((i >> 2) & 63), nt = (int)((i >> 8) & 3);
     long r = i >> 10;
@@ -708,14 +711,14 @@ __global__ void wino_norm_coef_kernel(const WinoNorm np, int G, int Ball, int Ci
 __global__ void wino_pack_fused_kernel(const float* __restrict__ u, int Cout, int Cin, float* __restrict__ uf) {
     const long n = (long)FP * Cout * Cin;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        uf[i] = u[Cout % 64 == 0 ? fused64_src(i, Cout, Cin) : fused_src(i, Cout, Cin)];
+        uf[i] = u[fused_wide(Cout, Cin) ? fused64_src(i, Cout, Cin) : fused_src(i, Cout, Cin)];
 }
 
 }  // namespace
 
 void winograd_fused_pack_host(const float* u, int Cout, int Cin, float* uf) {
     const long n = (long)FP * Cout * Cin;
-    for (long i = 0; i < n; ++i) uf[i] = u[Cout % 64 == 0 ? fused64_src(i, Cout, Cin) : fused_src(i, Cout, Cin)];
+    for (long i = 0; i < n; ++i) uf[i] = u[fused_wide(Cout, Cin) ? fused64_src(i, Cout, Cin) : fused_src(i, Cout, Cin)];
 }
 
 int launch_winograd_fused_pack(const float* u, int Cout, int Cin, float* uf, hipStream_t st) {
@@ -767,7 +770,7 @@ int launch_conv_winograd_fused(const WinoP& q, int Ball, int G, hipStream_t st) 
     a.TH = tiles_1d(H, d, 4); a.TW = tiles_1d(W, d, 4); a.d = d;
     a.per_img = wino_tiles(H, W, d, 4);
     a.tiles = (long)Ball * a.per_img;
-    const bool wide = out.C % 64 == 0;               // 16 tiles x 64 channels per block (wino_fused64_kernel), else 32 x 32
+    const bool wide = fused_wide(out.C, in.C);       // 16 tiles x 64 channels per block (wino_fused64_kernel), else 32 x 32
     const int ft = wide ? w64::FT : FT;
     a.NC = out.C / (wide ? w64::FC : FC);
     const long tblocks = (a.tiles + ft - 1) / ft;

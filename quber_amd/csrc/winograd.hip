@@ -26,7 +26,7 @@ namespace quber {
 
 using namespace wxf;
 
-int g_wino_min_cin = 64;      // key 7 (test harness): smallest input width routed to this path
+int g_wino_min_cin = 32;      // key 7: smallest input width routed to this path (the 32-channel stem layers take the single-kernel form)
 int g_wino_max_ratio = 67;    // key 8: executed / direct multiplies (%) up to which a (dilated) layer takes this path
 int g_wino_variant = 0;       // key 9: output tile edge m for the eligible layers: 0 = automatic, 2, 4
 int g_wino_min_cout = 32;     // key 10: smallest output width routed to this path

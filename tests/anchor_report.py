@@ -50,7 +50,7 @@ def main():
                       "anchor": fa.AnchorErrors()}
         eng.close()
         for k, v in kv:
-            lib.quber_set_tuning(k, {6: 0, 13: 1, 3: 0, 9: 0, 20: 0, 21: 2, 25: 1, 27: 128}.get(k, 0))
+            lib.quber_set_tuning(k, {6: 0, 13: 1, 3: 0, 9: 0, 20: 0, 21: 2, 25: 1, 27: 160}.get(k, 0))
     for fr in fa.OracleStream(sd, image, offs):
         i = fr["i"]
         l32, l64 = fa.cat_heads(fr["out32"]), fa.cat_heads(fr["out64"])

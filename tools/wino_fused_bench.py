@@ -35,6 +35,7 @@ LAYERS = [("fusion_res2 256>256 @120x160", 1, 120, 160, 256, 256, 1),
           ("head 128>128 @120x160", 1, 120, 160, 128, 128, 1),
           ("heads x3 128>128 @120x160", 3, 120, 160, 128, 128, 1),
           ("res2.conv2 64>64 @120x160 (2 streams)", 2, 120, 160, 64, 64, 1),
+          ("stem.conv2 32>32 @240x320 (2 streams)", 2, 240, 320, 32, 32, 1),
           ("stem.conv3 32>64 @240x320 (2 streams)", 2, 240, 320, 32, 64, 1),
           ("head 128>32 @120x160", 1, 120, 160, 128, 32, 1),
           ("head x3 128>32 @120x160", 3, 120, 160, 128, 32, 1)]
