@@ -866,6 +866,9 @@ def test_conv3x3_winograd_vs_float64(case, m):
     (5, 9, 7, 128, 256, 1, True, True, 128),         # 6 tiles per image: a block spans three images
     (1, 30, 40, 160, 128, 1, True, True, 160),       # odd number of 32-channel rounds: the last one multiplies zero filters
     (1, 30, 40, 320, 192, 1, True, True, 320),       # chains of 160 channels (opt-in width)
+    (2, 24, 32, 32, 64, 1, True, True, 160),         # stem.conv3: one 32-channel round would be odd -> 32 x 32 blocks, 16-channel rounds
+    (2, 24, 32, 32, 32, 1, False, True, 160),        # stem.conv2
+    (2, 28, 36, 64, 64, 1, True, True, 160),         # res2.conv2
 ])
 def test_conv3x3_winograd_single_kernel(case):
     """F(4x4,3x3) as ONE kernel (wino_fused.hip) against the three-kernel pipeline on the same input, and against float64"""
