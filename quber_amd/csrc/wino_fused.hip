@@ -1,32 +1,38 @@
-// Winograd F(4x4,3x3) as ONE kernel (exact fp32 MFMA mode): the same arithmetic as winograd.hip's three-kernel pipeline -
+// A 3x3 / stride 1 convolution as ONE Winograd F(4x4,3x3) kernel: the same arithmetic as winograd.hip's three-kernel pipeline -
 //     Y = A^T [ (G g G^T) .* (B^T d B) ] A     (reference: the plain F.conv2d of detectron2's Conv2d, see winograd.hip)
 // - but the transformed activations V and the products M never exist in HBM.  The three-kernel form writes V (2.25x the
 // layer's input), reads it back in the GEMM, writes M (2.25x the output) and reads that back: 27 GB of the 81 GB the
-// convolution family moves per 16-frame step (profiles/r03_final_conv_hbm_traffic.json), and two HBM-bound passes that
-// take 5.2 ms of the 37 ms step.
-//
-// A block owns 32 consecutive Winograd tiles x 32 output channels x ALL 36 transform positions, for the whole K = Cin:
-//   * accumulators: 36 positions x (32 tiles x 32 channels) = 36 MFMA 32x32 tiles, nine per wave (144 registers), and the
-//     second level of the two-level fp32 accumulation beside them (another 144; conv_persist.hip `top`): a block is one
-//     wave per SIMD with the whole 512-register file - there is no second wave to hide latency behind, so everything is
-//     software-pipelined inside the wave;
-//   * a round = 16 input channels.  Thread (tile, channel pair) loads its 6x6 input patch straight from the NHWC tensor
-//     (8-byte buffer loads, range-checked: the zero padding and the tiles past the end cost no predicates), transforms it
-//     in registers on packed fp32 (B^T d B on channel pairs) and stores the 36 values into the LDS image of the NEXT
-//     round while the matrix pipe multiplies the current one: 2 x 72 KB of LDS, one barrier per round;
-//   * the B operand (transformed filters) is packed per (32-channel chunk, 8-channel K-slice, position) as the 1 KB a
-//     wave's MFMA pair consumes and goes global -> registers, each wave loading only its nine positions;
-//   * epilogue: the 36 x 32 x 32 sums go through LDS once (the 144 KB the two images occupied), thread (tile, 4
-//     channels) applies A^T . A, the affine, the ReLU, accumulates the GroupNorm sums and stores 16 pixels x 16 bytes.
-// HBM traffic of a layer: its input (re-read per 32-channel chunk through L2: the chunks of a tile block are neighbours
-// on one XCD), its output, the filters.
+// convolution family moved per 16-frame step (profiles/r03_final_conv_hbm_traffic.json), and two HBM-bound passes of 5.2 ms.
+// Used for the layers of up to 160 input channels (tuning key 27): there it beats the pipeline by 1.2-2.1x and, below 128
+// channels, the direct kernel by 1.2-1.7x (profiles/r05_wino_fused_layers.md); DESIGN.md section 4 has the measurements that
+// shaped it.  Two kernels:
+//   wino_fused64_kernel   16 tiles x 64 output channels per block, v_mfma_f32_16x16x4_f32, rounds of 32 input channels
+//                         (64 | Cout and an even number of rounds)
+//   wino_fused_kernel     32 tiles x 32 output channels per block, v_mfma_f32_32x32x2_f32, rounds of 16 input channels
+//                         (the 32- and 96-channel outputs, the 32- / 96- / 160-channel inputs)
+// Common structure.  A block owns its tiles x channels for ALL 36 transform positions and the whole K = Cin:
+//   * accumulators: nine positions per wave, 144 registers per set - a block is one wave per SIMD with the whole 512-register
+//     file; there is no second wave to hide latency behind, so everything is software-pipelined inside the wave, and since
+//     vector instructions never execute beside the fp32 MFMA (SQ_VALU_MFMA_COEXEC_CYCLES = 0; ~8 cycles each,
+//     tools/micro/mfma_f32_shadow.hip) the loop carries as few of them as possible: hand-packed transforms, scalar address
+//     arithmetic, no second-level addition (two accumulator sets, one per K-slice parity, added once in the epilogue);
+//   * thread (tile, channel pair) loads its 6x6 input patch straight from the NHWC tensor (8-byte buffer loads, range-checked:
+//     the zero padding and the tiles past the end cost no predicates), transforms it in registers (B^T d B on channel pairs)
+//     and stores the 36 values into the LDS image of the NEXT round while the matrix pipe multiplies the current one: 2 x 72 KB
+//     of LDS, one barrier per round; the producer's GroupNorm + ReLU can be applied on the way (WinoNorm);
+//   * the B operand (transformed filters) is packed in the order the MFMAs consume it (winograd_fused_pack_host) and goes
+//     global -> registers, each wave loading only its nine positions;
+//   * epilogue: the sums go through LDS once (the 144 KB the two images occupied), thread (tile, 4 channels) applies A^T . A,
+//     the affine, the ReLU, accumulates the GroupNorm sums and stores 16 pixels x 16 bytes.
+// HBM traffic of a layer: its input (re-read per channel chunk through L2: the chunks of a tile block are neighbours on one
+// XCD), its output, the filters.
 #include "common.h"
 #include "winograd_xf.h"
 
 namespace quber {
 
 int g_wino_fused_max_cin = 160;   // key 27: widest input the single-kernel form takes (its two accumulation chains are Cin / 2 long)
-int g_wino_fused = 1;         // key 25: 1 = the eligible F(4x4) layers of the exact fp32 mode take this kernel, 0 = never
+int g_wino_fused = 1;             // key 25: 1 = the eligible layers of the exact fp32 and bf16x3 modes take these kernels, 0 = never
 
 using namespace wxf;
 
@@ -51,7 +57,7 @@ using f32x2 = __attribute__((ext_vector_type(2))) float;
 #define WF_SPLIT 7                              // positions (of a wave's 9) that get an accumulator set per slice; see `SPLIT` in the kernels
 #endif
 #ifndef WF_SKIP
-#define WF_SKIP 0                               // diagnostic builds only (tools/wino_fused_ablate.sh): bit 0 no patch loads, 1 no filter loads, 2 no transforms, 4 no MFMA
+#define WF_SKIP 0                               // diagnostic builds of the 32 x 32 kernel only (tools/wino_fused_ablate.sh): bit 0 no patch loads, 1 no filter loads, 2 no transforms, 4 no MFMA, 5 no epilogue, 6 no K loop
 #endif
 constexpr int FT = 32;                          // tiles per block
 constexpr int FC = 32;                          // output channels per block
