@@ -270,13 +270,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // and the two are added once, in the epilogue.  No second-level addition runs inside the loop, where every vector
     // instruction would add its issue time to the MFMAs'.
     constexpr int SPLIT = WF_SPLIT;              // positions (of the wave's 9) with a chain per slice; the rest keep one chain
-    f32x16 acc[2][9];
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int pi = 0; pi < 9; ++pi)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[s2][pi][e] = 0.f;
+    f32x16 acc[2][9];            // never zeroed: the first MFMA of every set (round 0) takes SrcC = 0
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int a_off = (wave * 9) * (FT * 8) + (lane & 31) * 8 + (lane >> 5) * 4;     // floats inside a slice image
     const unsigned b_voff = (unsigned)lane * 16u;
     const unsigned b_pos = (unsigned)(wave * 9) * 1024u;
@@ -297,7 +292,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // hold its patch of round r + 1 after the column pass (t = B^T d):
     //   steps 0-5    row pass i of that patch -> 6 stores into image r + 1, then row i of the patch of round r + 2 is requested
     //   steps 12-17  column pass j of the patch of round r + 2 (requested >= 7 steps earlier)
-    auto round = [&](const float* vs, float* vn, const int r, const int kbase) __attribute__((always_inline)) {
+    auto round = [&](const float* vs, float* vn, const int r, const int kbase, const bool first) __attribute__((always_inline)) {
         const int r2 = r + 2 < R ? r + 2 : R - 1;                  // past the end: the last round again (never multiplied)
         f32x4 av_next = *reinterpret_cast<const f32x4*>(vs + a_off);
 #pragma unroll
@@ -310,7 +305,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             acc[pi < SPLIT ? s : 0][pi][0] += av.x * bv.x + av.y * bv.y + av.z * bv.z + av.w * bv.w;
 #else
             f32x16& ac = acc[pi < SPLIT ? s : 0][pi];
-            ac = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, ac, 0, 0, 0);
+            ac = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, (first && (s == 0 || pi < SPLIT)) ? zero : ac, 0, 0, 0);
             ac = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, ac, 0, 0, 0);
             ac = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, ac, 0, 0, 0);
             ac = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, ac, 0, 0, 0);
@@ -355,10 +350,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int j = 0; j < 6; ++j) col_pass(j);
     __syncthreads();
     static_assert(36 % BR == 0, "the ring index is static over a pair of rounds");
-    for (int r = 0; r < ((WF_SKIP & 64) ? 0 : R); r += 2) {         // Cin % 32 == 0: rounds come in pairs
-        round(st0, st1, r, 0);
+    round(st0, st1, 0, 0, true);                 // Cin % 32 == 0: rounds come in pairs; the first pair starts the accumulation chains
+    __syncthreads();
+    round(st1, st0, 1, 18, false);
+    __syncthreads();
+    for (int r = 2; r < ((WF_SKIP & 64) ? 0 : R); r += 2) {
+        round(st0, st1, r, 0, false);
         __syncthreads();
-        round(st1, st0, r + 1, 18);
+        round(st1, st0, r + 1, 18, false);
         __syncthreads();
     }
 
@@ -544,13 +543,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ---- MFMA role: positions wave * 9 .. + 8; per position 16 tiles x 4 column blocks of 16 channels ----
     // two accumulator sets, one per 16-channel slice of a round (see the 32 x 32 kernel): chains over half of K, added in the epilogue
     constexpr int SPLIT = WF_SPLIT;
-    f32x4 acc[2][9][4];
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int pi = 0; pi < 9; ++pi)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[s2][pi][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[2][9][4];          // never zeroed: the first MFMA of every set (round 0) takes SrcC = 0
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     const int a_off = (wave * 9) * (FT * 16) + (lane & 15) * 16 + (lane >> 4) * 4;     // floats inside a slice image
     const unsigned b_voff = (unsigned)lane * 16u;
     const unsigned b_pos = (unsigned)(wave * 9) * 4096u;
@@ -565,7 +559,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     // One round (32 input channels) = 18 steps: 2 slices x 9 positions, a step = 16 MFMAs (4 k-steps x 4 column blocks);
     // the shares of the other work as in the 32 x 32 kernel
-    auto round = [&](const float* vs, float* vn, const int r, const int kbase) __attribute__((always_inline)) {
+    auto round = [&](const float* vs, float* vn, const int r, const int kbase, const bool first) __attribute__((always_inline)) {
         const int r2 = r + 2 < R ? r + 2 : R - 1;
         f32x4 av_next = *reinterpret_cast<const f32x4*>(vs + a_off);
 #pragma unroll
@@ -581,7 +575,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
                     f32x4& ac = acc[pi < SPLIT ? s2 : 0][pi][nt];
-                    ac = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[nt][e], ac, 0, 0, 0);
+                    ac = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[nt][e], (first && e == 0 && (s2 == 0 || pi < SPLIT)) ? zero : ac, 0, 0, 0);
                 }
             bload((kbase + k) % BR, r, k + BR);
             if (k < 6) { row_pass(k, vn); gload_row(k, r2); }
@@ -621,10 +615,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int j = 0; j < 6; ++j) col_pass(j);
     __syncthreads();
     static_assert(36 % BR == 0, "the ring index is static over a pair of rounds");
-    for (int r = 0; r < R; r += 2) {
-        round(st0, st1, r, 0);
+    round(st0, st1, 0, 0, true);                 // the first pair of rounds starts the accumulation chains
+    __syncthreads();
+    round(st1, st0, 1, 18, false);
+    __syncthreads();
+    for (int r = 2; r < R; r += 2) {
+        round(st0, st1, r, 0, false);
         __syncthreads();
-        round(st1, st0, r + 1, 18);              // r + 1 == R (odd R): multiplied by zero filters
+        round(st1, st0, r + 1, 18, false);
         __syncthreads();
     }
 
