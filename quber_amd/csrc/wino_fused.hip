@@ -80,6 +80,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr, uns
 __device__ __forceinline__ f32x2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
 }
+__device__ __forceinline__ void buf_store4(f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voff) {
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
+}
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
@@ -161,7 +165,7 @@ struct FusedArgs {
     int relu_in;
     int Ball, boff, B;
     const float* scale; const float* shift; int ss_gs, relu;
-    float* out; int out_cs; long out_gs; int Cout;
+    float* out; int out_cs; long out_gs; int Cout; unsigned out_bytes;
     int TH, TW, d; long tiles, per_img; int NC, NB;     // 32-channel chunks, blocks = tile blocks x NC
     double* gn_sum; int gn_groups, gn_cpg;
 };
@@ -391,24 +395,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const float lo = a.relu ? 0.f : -__builtin_inff();
     const int b0 = (int)(((long)tb * FT) / a.per_img);
     double sa = 0.0, sq = 0.0;
-    float* const out = a.out + (long)g * a.out_gs + c;
+    // the 16 pixels of the tile through a buffer descriptor, as the loader's patch: row + column offsets, and the pixels outside
+    // the map (ragged last tiles, short phases, tiles past the end) are dropped by the range check instead of branches
+    const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(a.out + (long)g * a.out_gs, a.out_bytes);
+    const unsigned opix = (unsigned)a.out_cs * 4u;
+    const int oy0 = a.d * 4 * ta.ty + ta.py, ox0 = a.d * 4 * ta.tx + ta.px;
+    const unsigned obase = (unsigned)((ta.b * a.H + oy0) * a.W + ox0) * opix + (unsigned)c * 4u;
+    unsigned orow[4], ocol[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        orow[i] = (tvalid && oy0 + i * a.d < a.H) ? obase + (unsigned)(i * a.d * a.W) * opix : OOBH;
+        ocol[i] = (ox0 + i * a.d < a.W) ? (unsigned)(i * a.d) * opix : OOBH;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         PV row[4];
         at4(s[i], row);
-        const int oy = a.d * (4 * ta.ty + i) + ta.py;
-        if (!tvalid || oy >= a.H) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int ox = a.d * (4 * ta.tx + j) + ta.px;
-            if (ox >= a.W) continue;
             const f32x2 yl = pk_fma_v(row[j].lo, sc.lo, sh.lo), yh = pk_fma_v(row[j].hi, sc.hi, sh.hi);
             const f32x4 y = {fmaxf(yl.x, lo), fmaxf(yl.y, lo), fmaxf(yh.x, lo), fmaxf(yh.y, lo)};
+            const unsigned vo = orow[i] + ocol[j];
             if (a.gn_sum) {
+                if (vo < OOBH) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { sa += (double)y[e]; sq += (double)y[e] * y[e]; }
+                    for (int e = 0; e < 4; ++e) { sa += (double)y[e]; sq += (double)y[e] * y[e]; }
+                }
             }
-            *reinterpret_cast<f32x4*>(out + (((long)ta.b * a.H + oy) * a.W + ox) * a.out_cs) = y;
+            buf_store4(y, rs_out, vo);
         }
     }
     if (a.gn_sum) {
@@ -658,24 +672,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const float lo = a.relu ? 0.f : -__builtin_inff();
     const int b0 = (int)(((long)tb * FT) / a.per_img);
     double sa = 0.0, sq = 0.0;
-    float* const out = a.out + (long)g * a.out_gs + c;
+    // the 16 pixels of the tile through a buffer descriptor, as the loader's patch: row + column offsets, and the pixels outside
+    // the map (ragged last tiles, short phases, tiles past the end) are dropped by the range check instead of branches
+    const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(a.out + (long)g * a.out_gs, a.out_bytes);
+    const unsigned opix = (unsigned)a.out_cs * 4u;
+    const int oy0 = a.d * 4 * ta.ty + ta.py, ox0 = a.d * 4 * ta.tx + ta.px;
+    const unsigned obase = (unsigned)((ta.b * a.H + oy0) * a.W + ox0) * opix + (unsigned)c * 4u;
+    unsigned orow[4], ocol[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        orow[i] = (tvalid && oy0 + i * a.d < a.H) ? obase + (unsigned)(i * a.d * a.W) * opix : OOBH;
+        ocol[i] = (ox0 + i * a.d < a.W) ? (unsigned)(i * a.d) * opix : OOBH;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         PV row[4];
         at4(s[i], row);
-        const int oy = a.d * (4 * ta.ty + i) + ta.py;
-        if (!tvalid || oy >= a.H) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int ox = a.d * (4 * ta.tx + j) + ta.px;
-            if (ox >= a.W) continue;
             const f32x2 yl = pk_fma_v(row[j].lo, sc.lo, sh.lo), yh = pk_fma_v(row[j].hi, sc.hi, sh.hi);
             const f32x4 y = {fmaxf(yl.x, lo), fmaxf(yl.y, lo), fmaxf(yh.x, lo), fmaxf(yh.y, lo)};
+            const unsigned vo = orow[i] + ocol[j];
             if (a.gn_sum) {
+                if (vo < OOBH) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { sa += (double)y[e]; sq += (double)y[e] * y[e]; }
+                    for (int e = 0; e < 4; ++e) { sa += (double)y[e]; sq += (double)y[e] * y[e]; }
+                }
             }
-            *reinterpret_cast<f32x4*>(out + (((long)ta.b * a.H + oy) * a.W + ox) * a.out_cs) = y;
+            buf_store4(y, rs_out, vo);
         }
     }
     if (a.gn_sum) {
@@ -743,7 +767,8 @@ bool winograd_fused_ok(const WinoP& q, int Ball, int G) {
     if (in.p == out.p) return false;              // in place: blocks read input halos that other blocks are overwriting
     if (in.C > g_wino_fused_max_cin) return false;   // the two accumulation chains are Cin / 2 long: the accuracy class of 64-channel chains up to 128
     const double in_bytes = 4.0 * (((double)Ball * in.H * in.W - 1) * in.cs + in.C);
-    if (in_bytes > (double)0x3F000000u) return false;
+    const double out_bytes = 4.0 * (((double)Ball * in.H * in.W - 1) * out.cs + out.C);
+    if (in_bytes > (double)0x3F000000u || out_bytes > (double)0x3F000000u) return false;
     if ((long)q.dil * in.W * in.cs * 4 * 6 > (1L << 26)) return false;
     return true;
 }
@@ -771,6 +796,7 @@ int launch_conv_winograd_fused(const WinoP& q, int Ball, int G, hipStream_t st) 
     a.Ball = Ball; a.boff = 0; a.B = Ball;
     a.scale = q.scale; a.shift = q.shift; a.ss_gs = q.ss_gs; a.relu = q.relu;
     a.out = out.p; a.out_cs = out.cs; a.out_gs = out.gs; a.Cout = out.C;
+    a.out_bytes = (unsigned)(4 * (((long)Ball * H * W - 1) * out.cs + out.C));
     a.TH = tiles_1d(H, d, 4); a.TW = tiles_1d(W, d, 4); a.d = d;
     a.per_img = wino_tiles(H, W, d, 4);
     a.tiles = (long)Ball * a.per_img;
