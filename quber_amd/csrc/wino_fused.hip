@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int lt = t >> 3, q = t & 7;
     const long tile = (long)tb * FT + lt;
     const bool tvalid = tile < a.tiles;
-    const TileAt ta = locate(tvalid ? tile : 0, a.TH, a.TW, a.d);
+    const TileAt ta = locate32(tvalid ? (unsigned)tile : 0u, (unsigned)a.TH, (unsigned)a.TW, (unsigned)a.d);
     const int y0 = a.d * (4 * ta.ty - 1) + ta.py, x0 = a.d * (4 * ta.tx - 1) + ta.px;
     const unsigned pix = (unsigned)a.in_cs * 4u;
     const unsigned base = (unsigned)((ta.b * a.H + y0) * a.W + x0) * pix + (unsigned)q * 8u;      // may be "negative": wraps, fixed by the valid offsets
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int lt = t >> 4, q = t & 15;
     const long tile = (long)tb * FT + lt;
     const bool tvalid = tile < a.tiles;
-    const TileAt ta = locate(tvalid ? tile : 0, a.TH, a.TW, a.d);
+    const TileAt ta = locate32(tvalid ? (unsigned)tile : 0u, (unsigned)a.TH, (unsigned)a.TW, (unsigned)a.d);
     const int y0 = a.d * (4 * ta.ty - 1) + ta.py, x0 = a.d * (4 * ta.tx - 1) + ta.px;
     const unsigned pix = (unsigned)a.in_cs * 4u;
     const unsigned base = (unsigned)((ta.b * a.H + y0) * a.W + x0) * pix + (unsigned)q * 8u;
@@ -804,7 +804,7 @@ int launch_conv_winograd_fused(const WinoP& q, int Ball, int G, hipStream_t st) 
     const int ft = wide ? w64::FT : FT;
     a.NC = out.C / (wide ? w64::FC : FC);
     const long tblocks = (a.tiles + ft - 1) / ft;
-    if (tblocks * a.NC >= (1L << 31)) return fail("winograd (fused): too many blocks");
+    if (tblocks * a.NC >= (1L << 31) || a.tiles + 64 >= (1L << 31)) return fail("winograd (fused): too many blocks");
     a.NB = (int)(tblocks * a.NC);
     const bool gn_here = q.gn_sum && q.gn_groups > 0 && q.gn_groups <= 32 && (out.C / q.gn_groups) % 4 == 0 && a.per_img >= ft;
     a.gn_sum = gn_here ? q.gn_sum : nullptr; a.gn_groups = q.gn_groups; a.gn_cpg = q.gn_groups ? out.C / q.gn_groups : 1;

@@ -104,6 +104,21 @@ __device__ inline TileAt locate(long tile, int TH, int TW, int d) {
 }
 
 
+// the same on 32-bit indices (the single-kernel form checks tiles < 2^31: 64-bit divisions cost its prologue ~100 instructions)
+__device__ inline TileAt locate32(unsigned tile, unsigned TH, unsigned TW, unsigned d) {
+    TileAt t;
+    unsigned r = tile / TW;
+    t.tx = (int)(tile - r * TW);
+    unsigned r2 = r / TH;
+    t.ty = (int)(r - r2 * TH);
+    unsigned r3 = r2 / d;
+    t.px = (int)(r2 - r3 * d);
+    const unsigned r4 = r3 / d;
+    t.py = (int)(r3 - r4 * d);
+    t.b = (int)r4;
+    return t;
+}
+
 // tiles per image: d*d phases of ceil(ceil(H/d)/m) x ceil(ceil(W/d)/m) tiles
 inline int tiles_1d(int n, int d, int m) { return ((n + d - 1) / d + m - 1) / m; }
 inline long wino_tiles(int H, int W, int d, int m) { return (long)d * d * tiles_1d(H, d, m) * tiles_1d(W, d, m); }
