@@ -915,6 +915,59 @@ def test_conv3x3_winograd_single_kernel(case):
         assert (one[b, oy, ox].cpu().double() - ref).abs().max().item() / scale < 2e-5, (b, oy, ox)
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_conv3x3_winograd_single_kernel_random(seed):
+    """the single-kernel Winograd layer on random geometries (ragged frames, dilations, batch sizes, channel widths of both block
+    shapes) against the three-kernel pipeline on the same input - every output element - and against float64 on sampled pixels"""
+    lib = _lib.load()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    rng = np.random.default_rng(40 + seed)
+    worst = 0.0
+    for _ in range(8):
+        B, dil = int(rng.integers(1, 5)), int(rng.choice([1, 1, 1, 2, 3]))
+        H, W = int(rng.integers(5, 50)), int(rng.integers(5, 60))
+        Cin, Cout = int(rng.choice([32, 64, 96, 128, 160])), int(rng.choice([32, 64, 96, 128, 192]))
+        affine, relu = bool(rng.integers(2)), bool(rng.integers(2))
+        g = torch.Generator(device="cuda").manual_seed(int(rng.integers(1 << 30)))
+        x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
+        w = torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) / np.sqrt(Cin * 9)
+        sc = torch.rand(Cout, device="cuda", generator=g) + 0.5 if affine else None
+        sh = torch.randn(Cout, device="cuda", generator=g) if affine else None
+        tiles = B * dil * dil * ((-(-H // dil) + 3) // 4) * ((-(-W // dil) + 3) // 4)
+        u = torch.empty(36 * Cout * Cin, device="cuda")
+        ws = torch.empty(36 * tiles * (Cin + Cout) + 36 * Cout * Cin, device="cuda")
+        ys = []
+        try:
+            for fused in (0, 1):
+                lib.quber_set_tuning(25, fused)
+                y = torch.full((B, H, W, Cout), float("nan"), device="cuda")
+                _lib.check(lib.quber_op_conv3x3_winograd(p(x), B, H, W, Cin, p(w), Cout, dil, 4, p(sc), p(sh), int(relu), p(u), p(ws),
+                                                         ws.numel(), p(y), st))
+                ys.append(y)
+        finally:
+            lib.quber_set_tuning(25, 1)
+        pipe, one = ys
+        geo = (B, H, W, Cin, Cout, dil, affine, relu)
+        assert torch.isfinite(one).all(), geo
+        assert not torch.equal(pipe, one), geo
+        scale = max(1.0, pipe.abs().max().item())
+        err = (pipe - one).abs().max().item() / scale
+        worst = max(worst, err)
+        assert err < 1e-5, (geo, err)
+        xp = torch.nn.functional.pad(x.cpu().double(), (0, 0, dil, dil, dil, dil))
+        wc = w.cpu().double()
+        for _k in range(12):
+            b, oy, ox = int(rng.integers(B)), int(rng.integers(H)), int(rng.integers(W))
+            ref = torch.einsum("yxc,ocyx->o", xp[b, oy:oy + 2 * dil + 1:dil, ox:ox + 2 * dil + 1:dil, :], wc)
+            if affine:
+                ref = ref * sc.cpu().double() + sh.cpu().double()
+            if relu:
+                ref = ref.relu()
+            assert (one[b, oy, ox].cpu().double() - ref).abs().max().item() / scale < 2e-5, (geo, b, oy, ox)
+    print(f"single-kernel Winograd, seed {seed}: worst relative difference to the pipeline {worst:.2e}")
+
+
 def test_groupnorm_bilinear_maxpool_vs_torch():
     lib = _lib.load()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
