@@ -743,8 +743,11 @@ def report(a, eng, world, elapsed, ranks, center_bias, sd, host, step_ms, t, gpu
                      "fp32_pipe_launches": None if not f32p_n else {
                          "launches": f32p_n, "ms": f32p_ms, "tflops": f32p_flops / (f32p_ms * 1e-3) / 1e12,
                          "frac_of_fp32_mfma_peak": f32p_flops / (f32p_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                         "note": "launches of this mode that keep the exact fp32 MFMA kernel (HBM-bound short-K / narrow-tile "
-                                 "layers); excluded from `achieved`, `frac` and gemm_kernel_* above, which price the bf16 pipe only"},
+                         "note": "launches of this mode that keep an exact fp32 MFMA kernel (HBM-bound short-K / narrow-tile "
+                                 "layers, the single-kernel Winograd layers); excluded from `achieved`, `frac` and gemm_kernel_* above, which price the bf16 pipe only"},
+                     "conv_stages": {k: {"ms": stages[k]["ms"], "launches": stages[k]["launches"],
+                                         "executed_tflops": stages[k]["flops"] / (stages[k]["ms"] * 1e-3) / 1e12 if stages[k]["ms"] else 0.0}
+                                     for k in CONV_FAMILY if k in stages},
                      "gemm_launches_per_step": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
                      "flops_per_launch": executed / max(gemm_n, 1),
                      "conv_family_ms": {k: stages[k]["ms"] for k in CONV_FAMILY if k in stages},
