@@ -137,5 +137,44 @@ for case in range(N // 5):
         print("WINOGRAD MISMATCH", dict(B=B, H=H, W=W, Cin=Cin, Cout=Cout, dil=dil, m=m), err, flush=True)
 print(f"conv3x3_winograd: {n3} random cases against the direct kernel: {bad3} mismatches, worst relative difference "
       f"F(2x2) {worst3[2]:.1e}, F(4x4) {worst3[4]:.1e}, F(6x6) {worst3[6]:.1e}")
+
+# the single-kernel Winograd layer (wino_fused.hip: both block shapes) against the direct kernel AND the three-kernel pipeline
+worst4, worst4p, bad4, n4 = 0.0, 0.0, 0, 0
+for case in range(N // 4):
+    Cin = int(rng.choice([32, 64, 96, 128, 160]))
+    Cout = int(rng.choice([32, 64, 96, 128, 192, 256]))
+    dil = int(rng.choice([1, 1, 1, 2, 3, 5]))
+    H, W, B = int(rng.integers(3, 70)), int(rng.integers(3, 90)), int(rng.integers(1, 9))
+    tiles = B * dil * dil * ((-(-H // dil) + 3) // 4) * ((-(-W // dil) + 3) // 4)
+    g = torch.Generator(device="cuda").manual_seed(9000 + case)
+    x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) / np.sqrt(Cin * 9)
+    affine = bool(rng.integers(2))
+    sc = torch.rand(Cout, device="cuda", generator=g) + 0.5 if affine else None
+    sh = torch.randn(Cout, device="cuda", generator=g) if affine else None
+    relu = int(rng.integers(2))
+    u = torch.empty(36 * Cout * Cin, device="cuda")
+    ws = torch.empty(36 * tiles * (Cin + Cout) + 36 * Cout * Cin, device="cuda")
+    ys = []
+    for fused in (0, 1):
+        lib.quber_set_tuning(25, fused)
+        y = torch.full((B, H, W, Cout), float("nan"), device="cuda")
+        _lib.check(lib.quber_op_conv3x3_winograd(p(x), B, H, W, Cin, p(w), Cout, dil, 4, p(sc), p(sh), relu, p(u), p(ws), ws.numel(), p(y), st))
+        ys.append(y)
+    lib.quber_set_tuning(25, 1)
+    packed = torch.empty(Cout * 9 * Cin, device="cuda")
+    yd = torch.empty_like(ys[1])
+    _lib.check(lib.quber_op_conv2d(p(x), B, H, W, Cin, p(w), Cout, 3, 1, dil, dil, p(sc), p(sh), p(None), relu, p(packed), p(yd), st))
+    scale = max(1.0, float(yd.abs().max()))
+    ok = bool(torch.isfinite(ys[1]).all()) and not torch.equal(ys[0], ys[1])
+    err = float((ys[1] - yd).abs().max()) / scale if ok else float("inf")
+    errp = float((ys[1] - ys[0]).abs().max()) / scale if ok else float("inf")
+    n4 += 1
+    worst4, worst4p = max(worst4, err), max(worst4p, errp)
+    if not (err < 2e-5 and errp < 1e-5):
+        bad4 += 1
+        print("SINGLE-KERNEL WINOGRAD MISMATCH", dict(B=B, H=H, W=W, Cin=Cin, Cout=Cout, dil=dil, affine=affine, relu=relu), err, errp, flush=True)
+print(f"conv3x3_winograd, single kernel: {n4} random cases: {bad4} mismatches, worst relative difference to the direct kernel {worst4:.1e}, "
+      f"to the three-kernel pipeline {worst4p:.1e}")
 lib.quber_set_tuning(12, 0); lib.quber_set_tuning(13, 1); lib.quber_set_tuning(15, 256); lib.quber_set_tuning(2, 0)
 sys.exit(1 if bad or bad2 or bad3 else 0)
