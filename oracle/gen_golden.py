@@ -119,6 +119,56 @@ def main():
         gen_post()
     if "raster" in what or "post" in what:
         gen_group_raster()
+    if "configs" in what:
+        gen_configs()
+
+
+def gen_configs():
+    """configs.json: what quber_amd/config.py makes of EVERY refiner yaml the reference ships (configs/**/mask-refiner-*.yaml,
+    _BASE_ chains resolved against the reference tree): relative path -> {"arch": keyword arguments of arch.param_specs,
+    "post": the post-processing constants, "input": the input switches} or {"unsupported": reason}.  Data about the
+    reference's config zoo (no yaml text is stored); tests/test_oracle_golden.py asserts that the reader still derives
+    the same and that the built set covers what it claims."""
+    import glob
+    import json
+    import yaml
+    from quber_amd import config as qconfig
+    out = {}
+    root = os.path.join(REF, "configs")
+    for path in sorted(glob.glob(os.path.join(root, "**", "mask-refiner-*.yaml"), recursive=True)):
+        rel = os.path.relpath(path, root)
+        try:
+            cfg = qconfig.validate(qconfig.merge_from_file(qconfig.get_cfg(), path))
+        except qconfig.UnsupportedConfig as e:
+            out[rel] = {"unsupported": str(e)}
+            continue
+        except FileNotFoundError as e:        # a _BASE_ that does not exist in the reference tree: the reference cannot load it either
+            out[rel] = {"broken": "missing _BASE_ " + os.path.relpath(e.filename, root)}
+            continue
+        except yaml.YAMLError as e:           # not valid yaml (yacs uses the same parser)
+            out[rel] = {"broken": "yaml syntax error at line %d" % (e.problem_mark.line + 1)}
+            continue
+        kw = qconfig.arch_kwargs(cfg)
+        kw["hierarchy"] = [list(l) for l in kw["hierarchy"]]
+        kw["fusion_target"] = list(kw["fusion_target"])
+        pd = cfg.MODEL.PANOPTIC_DEEPLAB
+        out[rel] = {"arch": kw,
+                    "post": {"center_threshold": pd.CENTER_THRESHOLD, "nms_kernel": pd.NMS_KERNEL, "top_k": pd.TOP_K_INSTANCE,
+                             "stuff_area": pd.STUFF_AREA, "res5_dilation": cfg.MODEL.RESNETS.RES5_DILATION},
+                    "input": {"depth_on": bool(cfg.INPUT.DEPTH_ON), "rgb_on": bool(cfg.INPUT.RGB_ON), "format": cfg.INPUT.FORMAT,
+                              "pixel_mean": [float(v) for v in cfg.MODEL.PIXEL_MEAN], "pixel_std": [float(v) for v in cfg.MODEL.PIXEL_STD]}}
+    with open(os.path.join(OUT, "configs.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    ok = sum("arch" in v for v in out.values())
+    broken = sum("broken" in v for v in out.values())
+    print(f"wrote configs.json: {len(out)} refiner configs, {ok} load, {len(out) - ok - broken} unsupported, {broken} broken in the reference")
+    why = {}
+    for v in out.values():
+        r = v.get("unsupported") or v.get("broken")
+        if r:
+            why[r] = why.get(r, 0) + 1
+    for k, n in sorted(why.items(), key=lambda kv: -kv[1]):
+        print(f"  {n:4d}  {k}")
 
 
 def gen_group_raster():

@@ -99,3 +99,50 @@ def test_param_specs_match_oracle_module_tree():
     sd = arch.init_state_dict(seed=3)
     sd2 = arch.init_state_dict(seed=3)
     assert all(np.array_equal(sd[k], sd2[k]) for k in sd)
+
+
+def test_reference_config_zoo_fixture():
+    """tests/golden/configs.json (oracle/gen_golden.py configs): what quber_amd/config.py makes of every refiner yaml the
+    reference ships.  Asserts (a) the counts the documentation quotes, (b) where the reference tree is present (the build
+    container) that the reader still derives exactly the stored result from the reference's own files, (c) that every distinct
+    architecture the zoo asks for is one the parameter inventory AND the oracle network build, with identical state_dict keys."""
+    import json
+    import os
+    import torch
+    from oracle.network_torch import ArchCfg, MaskRefinerNet
+    here = os.path.dirname(os.path.abspath(__file__))
+    zoo = json.load(open(os.path.join(here, "golden", "configs.json")))
+    ok = {k: v for k, v in zoo.items() if "arch" in v}
+    assert len(zoo) == 622 and len(ok) == 271
+    assert sum("broken" in v for v in zoo.values()) == 223           # _BASE_ files / yaml the reference itself cannot load
+    # the evaluation default (eval/run_eval.py:15) and the canonical QuBER config load
+    for rel in ("uoais-sim/instance-segmentation/seed77/mask-refiner-rgbd-concat-l2-gn-hf-b-fco-l3-b8.yaml",):
+        if rel in zoo:
+            assert "arch" in zoo[rel], rel
+    sim = {k: v for k, v in zoo.items() if k.startswith("uoais-sim/")}
+    assert sum("arch" in v for v in sim.values()) == 132 and sum("unsupported" in v for v in sim.values()) == 2
+    root = "/root/reference/configs"
+    if os.path.isdir(root):
+        for rel, want in zoo.items():
+            path = os.path.join(root, rel)
+            try:
+                cfg = config.validate(config.merge_from_file(config.get_cfg(), path))
+            except config.UnsupportedConfig as e:
+                assert want == {"unsupported": str(e)}, rel
+                continue
+            except (FileNotFoundError, __import__("yaml").YAMLError):
+                assert "broken" in want, rel
+                continue
+            kw = config.arch_kwargs(cfg)
+            got = dict(kw, hierarchy=[list(l) for l in kw["hierarchy"]], fusion_target=list(kw["fusion_target"]))
+            assert want["arch"] == got, rel
+            assert want["post"]["center_threshold"] == cfg.MODEL.PANOPTIC_DEEPLAB.CENTER_THRESHOLD
+    distinct = {json.dumps(v["arch"], sort_keys=True) for v in ok.values()}
+    assert len(distinct) == 84
+    for s in sorted(distinct):
+        kw = json.loads(s)
+        specs = arch.param_specs(**dict(kw, hierarchy=tuple(tuple(l) for l in kw["hierarchy"]), fusion_target=tuple(kw["fusion_target"])))
+        with torch.device("meta"):
+            net = MaskRefinerNet(ArchCfg(**kw))
+        keys = {k for k in net.state_dict() if not k.endswith("num_batches_tracked")}
+        assert keys == set(specs), s

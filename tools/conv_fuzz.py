@@ -176,5 +176,5 @@ for case in range(N // 4):
         print("SINGLE-KERNEL WINOGRAD MISMATCH", dict(B=B, H=H, W=W, Cin=Cin, Cout=Cout, dil=dil, affine=affine, relu=relu), err, errp, flush=True)
 print(f"conv3x3_winograd, single kernel: {n4} random cases: {bad4} mismatches, worst relative difference to the direct kernel {worst4:.1e}, "
       f"to the three-kernel pipeline {worst4p:.1e}")
-lib.quber_set_tuning(12, 0); lib.quber_set_tuning(13, 1); lib.quber_set_tuning(15, 256); lib.quber_set_tuning(2, 0)
-sys.exit(1 if bad or bad2 or bad3 else 0)
+lib.quber_set_tuning(12, 0); lib.quber_set_tuning(13, 1); lib.quber_set_tuning(15, 256); lib.quber_set_tuning(2, 0); lib.quber_set_tuning(25, 1)
+sys.exit(1 if bad or bad2 or bad3 or bad4 else 0)
