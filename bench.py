@@ -72,7 +72,7 @@ def parse():
     ap.add_argument("--foreground-filter", action="store_true",
                     help="also run the reference adapter's LMFFNet foreground post-filter on the refined masks in every "
                          "step (eval/refiner_model.py:273-277; off for the headline metric, which is the refiner path)")
-    ap.add_argument("--tuning", default="", help="A/B knobs for quber_set_tuning, e.g. 5=0 (include/quber_hip.h)")
+    ap.add_argument("--tuning", default="", help="A/B options of the engine (quber_set_option), e.g. 5=0 (include/quber_hip.h)")
     ap.add_argument("--no-split-mode", action="store_true",
                     help="skip the extra timing of the fp32-equivalent bf16x3 mode that a default (f32, 1 GPU) run appends as "
                          "`fp32_equivalent_bf16x3` (never the headline `value`)")
@@ -176,14 +176,14 @@ def cpu_baseline(sd, h, w, n, frames, grad_frames, eng=None, batch_eng=None, bat
         # frames 0 and B-1 of the benchmarked batch through the oracle (float32 as the reference computes, and float64 as
         # the anchor) vs the batch-B HIP results already on the device: the stated tolerance "within 1e-4 (float) /
         # bit-exact (label maps)" adjudicated as tests/test_gpu_loud_parity.py::test_benchmarked_plan_float64_anchor does
-        from tests import fp64_anchor as fa
+        from oracle import fp64_anchor as fa
         lg_all, pan_all = batch["logits"].cpu(), batch["panoptic"].cpu()
-        frames = sorted({0, lg_all.shape[0] - 1})
+        chk_frames = sorted({0, lg_all.shape[0] - 1})
         anchor, flips, flip_error, iou, ks, dl = fa.AnchorErrors(), [], None, [], [], []
         image = torch.from_numpy(np.concatenate([batch["host"]["rgb"], batch["host"]["depth"]], -1)).permute(0, 3, 1, 2)
         offs = np.stack([encode_np.encode_initial_masks(batch["host"]["masks"][i]) for i in range(lg_all.shape[0])])
-        o64 = {i: fa.cat_heads(o)[0] for i, o, _ in fa.oracle64(sd, image, offs, frames=frames, want_taps=())}
-        for i in frames:
+        o64 = {i: fa.cat_heads(o)[0] for i, o, _ in fa.oracle64(sd, image, offs, frames=chk_frames, want_taps=())}
+        for i in chk_frames:
             sc = {k: batch["host"][k][i] for k in ("rgb", "depth", "masks")}
             _, out, ref = one(sc, False)
             exp = fa.cat_heads(out)
@@ -199,7 +199,7 @@ def cpu_baseline(sd, h, w, n, frames, grad_frames, eng=None, batch_eng=None, bat
             ks.append(len(ref["labels"]))
         ok, bad = anchor.verdict()
         tot = fa.summarize(flips)
-        parity = {"engine_batch": int(lg_all.shape[0]), "frames_checked": len(frames),
+        parity = {"engine_batch": int(lg_all.shape[0]), "frames_checked": len(chk_frames),
                   "within_stated_tolerance": bool(ok and flip_error is None),
                   "stated_tolerance": "1e-4 on every head output in head units (what the predictors emit; the offset planes are "
                                       "multiplied by the common stride 4 afterwards, model.py:700) against the fp32 oracle; max |HIP - "
@@ -330,9 +330,9 @@ def main():
         qc = engine.make_config(H, W, max_batch=B, max_instances=max(N, 1))
         qc.compute_dtype = {"f32": 0, "bf16": 1, "f16": 2, "f32-bf16x3": 3}[a.dtype]
         e = engine.Engine(qc, dev)
-        for kv in filter(None, a.tuning.split(",")):      # before the plan is built: some knobs act at plan time
+        for kv in filter(None, a.tuning.split(",")):      # before the plan is built: some options act at plan time
             k, v = kv.split("=")
-            e.lib.quber_set_tuning(int(k), int(v))
+            e.set_option(int(k), int(v))
         e.load_state_dict(sd)
         return e
 

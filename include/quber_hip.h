@@ -225,43 +225,56 @@ double quber_forward_flops(quber_ctx* ctx);
 /* FLOPs the matrix pipe actually executes per forward at batch 1: a layer planned as Winograd F(m x m,3x3) counts
  * (m+2)^2 / (9 m^2) of its algorithmic FLOPs, padded tiles included (transform additions not counted) */
 double quber_forward_flops_executed(quber_ctx* ctx);
-/* test-harness knobs: key 2 = give the stand-alone quber_op_conv2d a split-K workspace (value != 0) or drop it (0);
- * key 19 = 128x64 tiles for the convolutions with 33-64 output channels and no residual (1, default) or 64x64 (0);
- * key 18 = (acts at plan time) the projection block of every ResNet stage runs conv3 and its shortcut as ONE 1x1 GEMM over
- *          the concatenated inputs (1, default; reference: detectron2 BottleneckBlock as built by
- *          maskrefiner/modeling/backbone/resnet.py:37-63) or as two convolutions (0);
- * key 17 = Winograd F(4x4) transforms on channel pairs instead of quads (measured: input transform 6 % slower; default 0);
- * key 16 = diagnostics of the persistent convolution kernel (1 = its output stores are dropped by the range check);
- * key 15 = persistent launches: fewest tiles (all groups) of a launch that goes persistent (default 256; smaller launches -
- *          small batches - keep the one-tile-per-block kernel and its split-K model);
- * key 14 = persistent launches: shortest K, in 32-wide slices, whose remainder tiles are shared between blocks (default 32);
- * key 13 = persistent convolution launches (csrc/conv_persist.hip): 0 = never (one tile per block everywhere),
- *          1 = the 128x128-tile launches (default), 2 = every tile shape;
- * key 3 = force the number of K partitions of convolutions that have a workspace (0 = automatic);
- * key 12 = stand-alone conv ops only: quber_config.compute_dtype of the launch (1 = bf16 / 2 = fp16 operands, 3 = bf16x3);
- * key 11 = stand-alone conv op only: dilated 3x3 layers in tap-major K order with the zero-padding filter rows skipped;
- * key 10 = smallest output width routed to the Winograd path (default 32);
- * key 9 = Winograd output tile edge of the eligible layers (acts at plan time): 0 = automatic (default: F(4x4), or F(2x2)
- *         where its tiles fit the map better; both measure the direct kernel's error), 2, 4, or 6 = opt into F(6x6,3x3)
- *         where it executes >= 10 % fewer multiplies still (2.5x the error at tap level, +4.5 % throughput at batch 16);
- *         the algorithm of every layer is fixed at plan time from its geometry alone, never from the batch of a launch;
- * key 8 = Winograd only while its multiplies are <= value % of the direct kernel's (dilated layers; default 67);
- * key 7 = smallest input width (channels) routed to the Winograd path (default 32; below 128 channels a layer takes it only
- *         in the single-kernel form, key 25);
- * key 6 = Winograd path of the eligible 3x3 layers (acts at plan time): 0 = where it pays (default), 1 = never, 2 = always;
- * key 5 = split the ragged last round of large convolution launches into K-pieces: when the cost model
- *         favours it (1, default), never (0), whenever feasible (2);
- * key 4 = force the convolution tile shape (1 = 64x64, 2 = 128x128, 4 = 256x32; 0 = automatic);
- * key 20 = Winograd layers in passes whose V | M intermediates stay below `value` MiB (0 = the whole batch at once, default;
- *          measured slower at every size: profiles/r03c_wino_subbatch_rejected.md);
- * key 21 = K-slices per accumulation chunk of the bf16x3 mode (default 2; the exact fp32 mode folds every slice);
- * key 24 = side lanes at batches <= 2 (1, default) or everything on the caller's stream (0);
- * key 25 = (acts at plan time) Winograd F(4x4,3x3) layers as ONE kernel - input transform, the 36 position GEMMs and the output
- *          transform, no V | M intermediates in HBM (csrc/wino_fused.hip): 1 = the eligible layers (default), 0 = never;
- * key 27 = (plan time) widest input, in channels, that takes the single-kernel form (default 128: its two accumulation chains are
- *          Cin / 2 long, 64 channels being the chain class the float64-anchor test passes with margin; wider layers measured
- *          no faster than the three-kernel pipeline inside the network: profiles/r05_wino_fused_layers.md);
+/* Options.  Every knob that shapes a plan or changes the arithmetic / work distribution of a launch belongs to a CONTEXT:
+ *   quber_set_option(ctx, key, value)   this context only.  "plan" keys act when quber_finalize_weights builds the plan and
+ *                                       are refused afterwards; "launch" keys may change between forwards.
+ *   quber_get_option(ctx, key, &value)
+ *   quber_set_tuning(key, value)        the PROCESS DEFAULTS: what a context created afterwards starts from (quber_create copies
+ *                                       them) and what the stand-alone quber_op_* test ops, which have no context, use.  Contexts
+ *                                       that already exist are not affected.  Keys 2, 11, 12, 26 exist only here (test harness).
+ * Two engines with different options coexist in one process and may run on different threads.
+ * Context keys (default; when it acts):
+ * key 3  (0; launch, test harness) force the number of K partitions of convolutions that have a workspace (0 = automatic);
+ * key 4  (0; launch, test harness) force the convolution tile shape (1 = 64x64, 2 = 128x128, 3 = 128x64, 4 = 256x32);
+ * key 5  (1; launch) split the ragged last round of large convolution launches into K-pieces: when the cost model favours
+ *         it (1), never (0), whenever feasible (2);
+ * key 6  (0; plan) Winograd path of the eligible 3x3 layers: 0 = where it pays, 1 = never, 2 = always;
+ * key 7  (32; plan) smallest input width (channels) routed to the Winograd path (below 128 channels a layer takes it only in the
+ *         single-kernel form, key 25);
+ * key 8  (67; plan) Winograd only while its multiplies are <= value % of the direct kernel's (dilated layers);
+ * key 9  (0; plan) Winograd output tile edge of the eligible layers: 0 = automatic (F(4x4), or F(2x2) where its tiles fit the
+ *         map better; both measure the direct kernel's error), 2, 4, or 6 = opt into F(6x6,3x3) where it executes >= 10 % fewer
+ *         multiplies still (2.5x the error at tap level, +4.5 % throughput at batch 16); the algorithm of every layer is fixed at
+ *         plan time from its geometry alone, never from the batch of a launch;
+ * key 10 (32; plan) smallest output width routed to the Winograd path;
+ * key 13 (1; launch) persistent convolution launches (csrc/conv_persist.hip): 0 = never (one tile per block everywhere),
+ *         1 = the 128x128-tile launches, 2 = every tile shape;
+ * key 14 (32; launch) persistent launches: shortest K, in 32-wide slices, whose remainder tiles are shared between blocks;
+ * key 15 (256; launch) persistent launches: fewest tiles (all groups) of a launch that goes persistent (smaller launches - small
+ *         batches - keep the one-tile-per-block kernel and its split-K model);
+ * key 16 (0; diagnostics) 1 = the output stores of the persistent convolution kernel are dropped by the range check;
+ * key 17 (0; launch) Winograd F(4x4) transforms on channel pairs instead of quads (measured: input transform 6 % slower);
+ * key 18 (1; plan) the projection block of every ResNet stage runs conv3 and its shortcut as ONE 1x1 GEMM over the
+ *         concatenated inputs (reference: detectron2 BottleneckBlock as built by maskrefiner/modeling/backbone/resnet.py:37-63)
+ *         or as two convolutions (0);
+ * key 19 (1; launch) 128x64 tiles for the convolutions with 33-64 output channels and no residual, or 64x64 (0);
+ * key 20 (0; launch) Winograd pipeline layers in passes whose V | M intermediates stay below `value` MiB (0 = the whole batch at
+ *         once; measured slower at every size: profiles/r03c_wino_subbatch_rejected.md);
+ * key 21 (2; launch, ARITHMETIC) K-slices per chunk of the two-level fp32 accumulation of the GEMM kernels (the bf16x3 mode folds
+ *         every `value` slices, the exact fp32 mode every slice; 0 = one sequential chain over K);
+ * key 24 (1; launch) side lanes at batches <= 2, or everything on the caller's stream (0);
+ * key 25 (1; plan) Winograd F(4x4,3x3) layers as ONE kernel - input transform, the 36 position GEMMs and the output transform, no
+ *         V | M intermediates in HBM (csrc/wino_fused.hip): the eligible layers, or never (0);
+ * key 27 (160; plan, ARITHMETIC) widest input, in channels, that takes the single-kernel form.  Its two accumulation chains are
+ *         Cin / 2 long - 80 channels at the default, with which the float64-anchor ratios stay 0.64-1.11; admitting 256 / 320
+ *         channels (chains of 128-160) measures 1.20 / 1.21 and no speed-up inside the network (DESIGN.md section 4,
+ *         profiles/r05_fused_anchor.md, r05_wino_fused_layers.md).
+ * Process-only keys (quber_set_tuning): key 2 = give the stand-alone conv ops a split-K workspace (value != 0) or drop it (0);
+ * key 11 = stand-alone conv op: dilated 3x3 layers in tap-major K order with the zero-padding filter rows skipped;
+ * key 12 = stand-alone conv ops: quber_config.compute_dtype of the launch (1 = bf16 / 2 = fp16 operands, 3 = bf16x3);
  * key 26 = timing harness: quber_op_conv3x3_winograd reuses the transformed filters of its previous call (u / ws untouched) */
+int quber_set_option(quber_ctx* ctx, int32_t key, int32_t value);
+int quber_get_option(quber_ctx* ctx, int32_t key, int32_t* value);
 void quber_set_tuning(int32_t key, int32_t value);
 /* Host view of the work distribution of a persistent convolution launch (csrc/conv_persist.hip), for the CPU tests: no GPU.
  * _segments: the work list of block `block` of a launch of `blocks` blocks over `tiles` tiles of `k_slices` K-slices each
@@ -303,6 +316,16 @@ int quber_op_groupnorm(const float* dev_x, int32_t batch, int32_t h, int32_t w, 
 int quber_op_bilinear(const float* dev_x, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t oh, int32_t ow,
                       float* dev_y, void* stream);
 int quber_op_maxpool3x3s2(const float* dev_x, int32_t batch, int32_t h, int32_t w, int32_t c, float* dev_y,
+                          void* stream);
+/* a9 alone, on a caller-supplied centre list in ANY order - group_pixels(ctr, offsets) of post_processing.py:44-76
+ * (quber_postprocess derives its centres from the centre plane, i.e. always in raster order; the reference's function takes
+ * whatever list it is handed).  The grouping kernel quber_postprocess launches, unchanged.
+ *   dev_logits f32 [B][n_planes][H][W]: plane 0 foreground logit (a pixel is grouped iff sigmoid(x).round() == 1),
+ *              planes 2, 3 the (y, x) offsets; dev_centers i32 [B][cap][2] (y, x), dev_ncenters i32 [B], cap <= 254
+ *   -> dev_ids u8 [B][H][W]: 0 = background, 1..K = index of the nearest centre + 1 (first index wins ties), 255 = foreground
+ *      of a frame without centres; dev_area u32 [B][256]: pixels per id */
+int quber_op_group_pixels(const float* dev_logits, int32_t n_planes, int32_t batch, int32_t h, int32_t w, int32_t cap,
+                          const int32_t* dev_centers, const int32_t* dev_ncenters, uint8_t* dev_ids, uint32_t* dev_area,
                           void* stream);
 
 #ifdef __cplusplus

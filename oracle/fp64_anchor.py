@@ -1,6 +1,6 @@
 """Float64-anchored adjudication of the north-star tolerance ("within 1e-4 (float) / bit-exact (label maps)").
 
-Test infrastructure (imports oracle/): used by tests/test_gpu_fp64_anchor.py (the HIP path on the benchmarked plan), by
+Test infrastructure (imports oracle/): used by tests/test_gpu_loud_parity.py (the HIP path on the benchmarked plan), by
 tests/test_fp64_anchor_cpu.py (the analysis itself, on perturbed oracle logits) and by bench.py's cpu_baseline leg
 (`parity_vs_hip.within_stated_tolerance`).
 

@@ -66,6 +66,8 @@ SIGNATURES = {
     "quber_forward_flops": (C.c_double, [_P]),
     "quber_forward_flops_executed": (C.c_double, [_P]),
     "quber_set_tuning": (None, [_I, _I]),
+    "quber_set_option": (C.c_int, [_P, _I, _I]),
+    "quber_get_option": (C.c_int, [_P, _I, C.POINTER(_I)]),
     "quber_num_ops": (C.c_int, [_P]),
     "quber_op_info": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(_I), C.POINTER(C.c_double), C.POINTER(_I)]),
     "quber_debug_persistent_segments": (C.c_int32, [_I, _I, _I, _I, _I, _P, _I]),
@@ -76,6 +78,7 @@ SIGNATURES = {
     "quber_op_groupnorm": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _P, C.c_float, _I, _P, _P, _P]),
     "quber_op_bilinear": (C.c_int, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "quber_op_maxpool3x3s2": (C.c_int, [_P, _I, _I, _I, _I, _P, _P]),
+    "quber_op_group_pixels": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

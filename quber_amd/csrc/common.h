@@ -92,6 +92,9 @@ struct WinoP {
     View in, out;            // NHWC views; groups via View::gs
     const float* u;          // transformed weights [G][16][Cout][Cin]
     const float* uf;         // F(4x4) only: the same weights in the operand order of the single-kernel form (wino_fused.hip), or null
+    int algo;                // 1 = the three-kernel pipeline, 2 = the single kernel: fixed when the plan is built, for max_batch, and
+                             // honoured at every launch (a layer's algorithm never depends on the batch); 0 = decide at launch
+                             // (stand-alone op only)
     const float* scale;      // per-channel affine of the epilogue ([G][Cout], stride ss_gs) or null
     const float* shift;
     int ss_gs, relu;
@@ -123,10 +126,47 @@ void winograd_fused_pack_host(const float* u, int Cout, int Cin, float* uf);
 int launch_winograd_fused_pack(const float* u, int Cout, int Cin, float* uf, hipStream_t st);
 size_t winograd_fused_ws_floats(int B, int Cin, int G);
 int winograd_fused_prepare();
-extern int g_wino_fused, g_wino_fused_max_cin;
-extern int g_winograd, g_wino_min_cin, g_wino_max_ratio, g_wino_variant, g_wino_min_cout, g_wino_pairs, g_wino_chunk_mb;
-extern int g_tile_128x64, g_acc_chunk;
-extern int g_force_split, g_force_tile, g_tail_split, g_persist, g_persist_min_nk, g_persist_debug, g_persist_min_tiles;
+
+// Tuning state.  Every knob that shapes a plan or changes the arithmetic of a launch lives in the CONTEXT (quber_ctx::tune, set
+// with quber_set_option between quber_create and quber_finalize_weights for the plan-time keys, any time for the launch-time ones):
+// two engines with different settings coexist in one process and on several threads.  `g_tune` holds the process defaults - what
+// quber_set_tuning writes, what quber_create copies, and what the stand-alone test ops (quber_op_*), which have no context, use.
+// The launchers read tune(): the tuning of the context whose plan is being built or launched on THIS thread (TuneScope).
+struct Tuning {
+    int winograd = 0;            // key 6 (plan): Winograd path for the eligible 3x3 layers: 0 = where it pays, 1 = never, 2 = always
+    int wino_min_cin = 32;       // key 7 (plan): smallest input width routed to the Winograd path (the 32-channel stem layers take the single-kernel form)
+    int wino_max_ratio = 67;     // key 8 (plan): executed / direct multiplies (%) up to which a (dilated) layer takes the Winograd path
+    int wino_variant = 0;        // key 9 (plan): output tile edge m of the eligible layers: 0 = automatic (4 or 2), 2, 4, 6 (opt-in)
+    int wino_min_cout = 32;      // key 10 (plan): smallest output width routed to the Winograd path
+    int wino_pairs = 0;          // key 17 (launch): F(4x4) transforms on channel pairs (8-byte accesses) instead of quads
+    int wino_chunk_mb = 0;       // key 20 (launch): largest V | M footprint (MiB) of one pass over a pipeline layer; 0 = the whole batch at once
+    int wino_fused = 1;          // key 25 (plan): the eligible F(4x4) layers of the exact fp32 / bf16x3 modes as ONE kernel (wino_fused.hip); 0 = the three-kernel pipeline
+    int wino_fused_max_cin = 160;  // key 27 (plan): widest input (channels) the single-kernel form takes.  Its two accumulation chains are Cin / 2 long: 80
+                                 //   channels at the default - the float64-anchor ratios stay 0.64-1.11 (0.67-0.98 on the final plan); admitting 256 / 320
+                                 //   channels (chains of 128-160) measures 1.20 / 1.21 (profiles/r05_fused_anchor.md)
+    int acc_chunk = 2;           // key 21 (launch, arithmetic): K-slices per chunk of the two-level fp32 accumulation (2 = 64 k; 0 = one chain over K)
+    int tile_128x64 = 1;         // key 19 (launch): 128x64 tiles for the 33-64 channel layers (0: 64x64)
+    int force_tile = 0;          // key 4 (launch, test harness): force the tile shape: 1 = 64x64, 2 = 128x128, 3 = 128x64, 4 = 256x32 (0 = automatic)
+    int force_split = 0;         // key 3 (launch, test harness): force the number of K partitions of every convolution with a workspace
+    int tail_split = 1;          // key 5 (launch): split the ragged last round of large launches when the model favours it (1), never (0), whenever feasible (2)
+    int persist = 1;             // key 13 (launch): persistent convolution launches: 0 = never, 1 = 128x128 tiles, 2 = every tile shape
+    int persist_min_nk = 32;     // key 14 (launch): shortest K (in 32-wide slices) whose remainder tiles are shared between blocks
+    int persist_min_tiles = 256; // key 15 (launch): fewest tiles (all groups) of a launch that goes persistent
+    int persist_debug = 0;       // key 16 (diagnostics): 1 = every store of the persistent epilogue is dropped by the range check
+    int fuse_shortcut = 1;       // key 18 (plan): conv3 + projection shortcut of a bottleneck as one dual-input GEMM
+    int lanes = 1;               // key 24 (launch): side lanes for batches <= 2 (0 = everything on the caller's stream)
+};
+extern Tuning g_tune;
+extern thread_local const Tuning* t_tune;
+inline const Tuning& tune() { return t_tune ? *t_tune : g_tune; }
+struct TuneScope {
+    const Tuning* prev;
+    explicit TuneScope(const Tuning* t) : prev(t_tune) { t_tune = t; }
+    ~TuneScope() { t_tune = prev; }
+    TuneScope(const TuneScope&) = delete;
+    TuneScope& operator=(const TuneScope&) = delete;
+};
+bool tuning_set(Tuning& t, int key, int value);   // false: not a key of Tuning
 // persistent launch of the implicit GEMM (conv_persist.hip); p.mtiles / ntiles / vec_out filled in by the caller
 template <int BM, int BN, int WM, int WN> int launch_conv_persistent(ConvP p, int G, int bpc, hipStream_t st);
 size_t conv_persistent_ws_floats(int BM, int BN, int bpc);
@@ -202,6 +242,8 @@ int launch_postprocess(const float* logits, int nch, int B, int H, int W, const 
 size_t postprocess_ws_bytes(int B, int H, int W, int cap);
 int launch_extract_masks(const float* pan, const float* labels, int B, int H, int W, int cap, int max_inst,
                          uint8_t* out, hipStream_t st);
+int launch_group_pixels(const float* logits, int nch, int B, int H, int W, int cap, const int* centers, const int* ncenters,
+                        uint8_t* idmap, unsigned* area, hipStream_t st);
 
 }  // namespace quber
 

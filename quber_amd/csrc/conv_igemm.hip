@@ -691,11 +691,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvP p, int S
     }
 }
 
-int g_winograd = 0;       // key 6: Winograd path for the eligible 3x3 layers: 0 = where it pays, 1 = never, 2 = always
-int g_force_tile = 0;     // test-harness knobs (quber_set_tuning keys 4 / 3): force the tile shape / the number of K partitions
-int g_force_split = 0;
-int g_tile_128x64 = 1;     // key 19: 128x64 tiles for the 33-64 channel layers (0: 64x64 as before)
-int g_tail_split = 1;      // key 5: split the ragged last round of large launches when the model favours it (1), never (0), whenever feasible (2)
 
 // ---- work distribution -------------------------------------------------------------------------------------------
 // A launch is (tile shape, S = number of K partitions).  `bpc` blocks of a tile shape are resident per CU (registers /
@@ -762,7 +757,7 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
         return launch_gn_stats(o, p.B, G, p.gn_groups, gn_sum, st, false);
     };
     const int nk = p.Kpad / BK;
-    if (p.ws && g_force_split > 0) S = g_force_split;
+    if (p.ws && tune().force_split > 0) S = tune().force_split;
     if (!p.ws || S < 1 || p.es == 2) S = 1;
     if (S > nk) S = nk;
     while (S > 1 && (size_t)S * G * p.M * p.Cout > p.ws_floats) --S;
@@ -804,9 +799,9 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
     // sharing every tile's K between all resident blocks writes more partial tiles than that model's 2-8 partitions)
     // (fp16 data path: only the fused projection shortcuts - launch_conv_dual - go persistent: with 16x the matrix rate the
     // persistent kernel's per-slice tap arithmetic costs the 3x3 layers 30 %, profiles/r04a_f16_persistent_all_rejected.md)
-    if (g_persist && p.es != 2 && ((BM == 128 && BN == 128) || (g_persist == 2 && (BM == BN || BM == 256))) && BN <= 128 && !skip && p.ws && conv_persistent_ok(p) &&
-        (long)p.mtiles * p.ntiles * G >= g_persist_min_tiles &&
-        ((long)p.mtiles * p.ntiles * G >= 256L * (p.es == 2 ? 3 : BM == 64 ? 5 : 2) || nk >= g_persist_min_nk)) {      // several tiles per block, or K worth sharing
+    if (tune().persist && p.es != 2 && ((BM == 128 && BN == 128) || (tune().persist == 2 && (BM == BN || BM == 256))) && BN <= 128 && !skip && p.ws && conv_persistent_ok(p) &&
+        (long)p.mtiles * p.ntiles * G >= tune().persist_min_tiles &&
+        ((long)p.mtiles * p.ntiles * G >= 256L * (p.es == 2 ? 3 : BM == 64 ? 5 : 2) || nk >= tune().persist_min_nk)) {      // several tiles per block, or K worth sharing
         if (p.bf16 == 3 && (BM == 256 || (BM == 64 && nk <= 8))) exact_fallback();
         const int bpc = p.es == 2 ? 3 : BM == 64 ? 5 : 2;          // conv_persist.hip: pk_occupancy()
         if (p.ws_floats >= conv_persistent_ws_floats(BM, BN, bpc)) {
@@ -823,7 +818,7 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
     // together fill about one more (short) round; taken when the model prices it below the launch chosen so far.
     constexpr int BPC = igemm_occupancy(BM, BN);
     const long slots = 256L * BPC, tiles = (long)p.mtiles * p.ntiles, blocks_all = tiles * G;
-    if (p.ws && !p.bf16 && g_tail_split && g_force_split == 0 && BM == 128 && blocks_all > slots && nk >= 32) {
+    if (p.ws && !p.bf16 && tune().tail_split && tune().force_split == 0 && BM == 128 && blocks_all > slots && nk >= 32) {
         const long nfull = (blocks_all / slots) * slots / G / p.ntiles * p.ntiles;    // per group, whole tile rows
         const long rem = tiles - nfull;
         int shift = 0;
@@ -834,7 +829,7 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
             const double whole = launch_cost(blocks_all, nk, (double)G * p.M * p.Cout, S, BPC, kModel3);
             const double tail = (nk + kModel3.c) * BPC * ((double)nfull * G / slots) +
                                 launch_cost(rem * G, nk, rem_outputs, 1 << shift, BPC, kModel3);
-            if (tail < 0.995 * whole || g_tail_split == 2) {
+            if (tail < 0.995 * whole || tune().tail_split == 2) {
                 p.nfull = (int)nfull;
                 p.tail_shift = shift;
                 p.kchunk = (nk + (1 << shift) - 1) >> shift;
@@ -898,11 +893,10 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
     return gn_separate();
 }
 
-int g_acc_chunk = 2;      // key 21: K-slices per accumulation chunk (default 2 = 64 k; 0 = one chain over K)
 
 int launch_conv(const ConvP& p0, int G, hipStream_t st) {
     ConvP p = p0;
-    p.acc_chunk = g_acc_chunk;
+    p.acc_chunk = tune().acc_chunk;
     if (p.es != 2) p.es = 4;
     if (p.es == 2) {
         // fp16 data path (activations and packed weights are fp16 in HBM): the kernel moves the operands as 4-byte units, so
@@ -922,7 +916,7 @@ int launch_conv(const ConvP& p0, int G, hipStream_t st) {
     if (p.kh * p.kw > 1 && p.Cin < 8) return fail("conv: filters larger than 1x1 need at least 8 input channels (pad the input)");
     if (p.kmode && (p.Cin % BK || p.K != p.Kpad)) return fail("conv: slice-major weights need Cin % 32 == 0");
     if ((p.scale == nullptr) != (p.shift == nullptr)) return fail("conv: scale and shift go together");
-    switch (g_force_tile) {
+    switch (tune().force_tile) {
         case 1: return run<64, 64, 2, 2>(p, G, 1, st);
         case 2: return run<128, 128, 2, 2>(p, G, 1, st);
         case 4: return run<256, 32, 4, 1>(p, G, 1, st);
@@ -936,7 +930,7 @@ int launch_conv(const ConvP& p0, int G, hipStream_t st) {
     if (p.Cout <= 32) return run<256, 32, 4, 1>(p, G, choose_split(p, G, 256, 32, igemm_occupancy(256, 32)), st);
     // 33-64 output channels without a residual, at least a round of tiles: 128x64 (each wave 64x32: the weight fragments
     // are read from LDS half as often as with 64x64 tiles; +3-5 % on stem.conv3 / res2 conv1, conv2 - tools/tile_ab.py)
-    if (g_tile_128x64 && p.Cout <= 64 && p.Cout > 32 && !p.res && (long)((p.M + 127) / 128) * G >= 1024) return run<128, 64, 2, 2>(p, G, 1, st);
+    if (tune().tile_128x64 && p.Cout <= 64 && p.Cout > 32 && !p.res && (long)((p.M + 127) / 128) * G >= 1024) return run<128, 64, 2, 2>(p, G, 1, st);
     // (64 x 256 tiles for the residual 1x1 layers - input rows read once, 512-byte row segments - measured 30-50 % SLOWER than
     // 64x64 in both the fp32 and the fp16 path, profiles/r03x_tile_64x256_rejected.txt: those layers live on blocks in flight)
     if (p.Cout <= 64 || (p.res && nk <= 8 && p.Cout >= 128)) return run<64, 64, 2, 2>(p, G, choose_split(p, G, 64, 64, igemm_occupancy(64, 64)), st);

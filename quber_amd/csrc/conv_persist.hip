@@ -791,10 +791,6 @@ __global__ __launch_bounds__(256) void pk_fixup_kernel(const ConvP p, int P) {
 
 }  // namespace
 
-int g_persist_min_nk = 32; // key 14: shortest K (in 32-wide slices) whose remainder tiles are shared between blocks
-int g_persist_min_tiles = 256;   // key 15: fewest tiles (all groups) of a launch that goes persistent
-int g_persist_debug = 0;  // key 16 (diagnostics): 1 = zero-length output descriptor, every store of the epilogue is dropped by the range check
-int g_persist = 1;        // key 13: persistent launches: 0 = never, 1 = 128x128 tiles (default), 2 = every tile shape
 
 // Eligibility beyond conv_persistent_ok() is decided by the caller (conv_igemm.hip: run<>): no skipped filter rows, a
 // workspace of 2 * P tiles.  p.mtiles / p.ntiles / p.vec_out are filled in.  Returns 0 on success.
@@ -807,7 +803,7 @@ int launch_conv_persistent(ConvP p, int G, int bpc, hipStream_t st) {
     // The remainder (tiles beyond whole rounds of P) is shared out in K only when a share is long enough to pay for
     // the two partial tiles a block then writes and the fix-up pass re-reads (key 14: shortest K, default 32 slices),
     // or when the launch cannot give every block a tile; otherwise the remainder tiles are computed whole.
-    p.pk_min = (nk >= g_persist_min_nk || p.pk_T < P) ? 4 : 0;
+    p.pk_min = (nk >= tune().persist_min_nk || p.pk_T < P) ? 4 : 0;
     if (p.pk_min) {
         // never more blocks than there are shares of pk_min K-slices
         const long shares = (long)p.pk_T * nk / p.pk_min;
@@ -815,7 +811,7 @@ int launch_conv_persistent(ConvP p, int G, int bpc, hipStream_t st) {
     }
     const dim3 block(WM * WN * 64);
     p.pk_in_bytes = (int)((long)p.B * p.H * p.W * p.in_cs * 4);
-    p.pk_debug = g_persist_debug;
+    p.pk_debug = tune().persist_debug;
     const int epi = p.in2 ? 3 : p.gn_sum ? 2 : p.res ? 1 : 0;       // host: never two of them (conv_persistent_ok)
     if (p.es == 2) {
         if constexpr (BM == 128 && BN == 128) {          // the fp16 data path goes persistent on 128x128 tiles only
@@ -911,8 +907,8 @@ bool conv_persistent_ok(const ConvP& p) {
 // conv3 + projection shortcut of a bottleneck as one 1x1 GEMM over two inputs (kernel: EPI 3).  Returns 1 when the
 // launch is not covered (the caller then runs the two convolutions separately), 0 on success, -1 on a launch error.
 int launch_conv_dual(ConvP p, int G, hipStream_t st) {
-    if (!g_persist || !p.in2 || !p.ws) return 1;
-    p.acc_chunk = g_acc_chunk;
+    if (!tune().persist || !p.in2 || !p.ws) return 1;
+    p.acc_chunk = tune().acc_chunk;
     if (p.es == 2) {        // fp16 data path: K-side quantities in 4-byte units (two halfs), as launch_conv hands them over
         if (p.bf16 != 2 || p.Cin % 8 || p.in_cs % 8 || p.in2_cs % 8 || p.Kpad % 64 || p.K1 % 64 || (p.in_gs & 7) || (p.in2_gs & 7) || (p.w_gs & 1))
             return 1;
@@ -934,7 +930,7 @@ int launch_conv_dual(ConvP p, int G, hipStream_t st) {
         tag = "conv_gemm_f32pipe";                         // profiled apart: this launch runs on the fp32 matrix pipe
     }
     const long tiles128 = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * G;
-    if (tiles128 < g_persist_min_tiles) return 1;          // small batches: the two separate launches with their split-K model
+    if (tiles128 < tune().persist_min_tiles) return 1;          // small batches: the two separate launches with their split-K model
     const bool big = tiles128 >= 192 && p.Cout > 64;
     if (p.es == 2 && !big) return 1;                       // the fp16 data path has the 128x128 persistent kernel only
     const int bpc = big ? (p.es == 2 ? 3 : 2) : 5;         // pk_occupancy()

@@ -27,6 +27,42 @@
 
 namespace quber {
 
+Tuning g_tune;
+thread_local const Tuning* t_tune = nullptr;
+
+static int* tuning_field(Tuning& t, int key) {
+    switch (key) {
+        case 3: return &t.force_split;
+        case 4: return &t.force_tile;
+        case 5: return &t.tail_split;
+        case 6: return &t.winograd;
+        case 7: return &t.wino_min_cin;
+        case 8: return &t.wino_max_ratio;
+        case 9: return &t.wino_variant;
+        case 10: return &t.wino_min_cout;
+        case 13: return &t.persist;
+        case 14: return &t.persist_min_nk;
+        case 15: return &t.persist_min_tiles;
+        case 16: return &t.persist_debug;
+        case 17: return &t.wino_pairs;
+        case 18: return &t.fuse_shortcut;
+        case 19: return &t.tile_128x64;
+        case 20: return &t.wino_chunk_mb;
+        case 21: return &t.acc_chunk;
+        case 24: return &t.lanes;
+        case 25: return &t.wino_fused;
+        case 27: return &t.wino_fused_max_cin;
+        default: return nullptr;
+    }
+}
+bool tuning_set(Tuning& t, int key, int value) {
+    int* f = tuning_field(t, key);
+    if (f) *f = value;
+    return f != nullptr;
+}
+// keys that shape the plan: they act when quber_finalize_weights builds it and are refused afterwards
+bool tuning_plan_time(int key) { return key == 6 || key == 7 || key == 8 || key == 9 || key == 10 || key == 18 || key == 25 || key == 27; }
+
 static thread_local std::string g_err;
 void set_error(const std::string& m) { g_err = m; }
 int fail(const std::string& m) {
@@ -95,6 +131,7 @@ constexpr int LANE_BATCH = 2;       // side lanes are used up to this batch (the
 
 struct quber_ctx {
     quber_config cfg;
+    quber::Tuning tune;           // this context's knobs (quber_set_option); starts as a copy of the process defaults
     std::map<std::string, std::vector<float>> hostw;
     std::vector<std::pair<std::string, int64_t>> specs;
     std::vector<void*> allocs;
@@ -156,8 +193,6 @@ struct DeferredNorm {
 struct LastConv { std::shared_ptr<GnFuse> fuse; const float* out = nullptr; int G = 0, C = 0; };
 
 static int g_op_wino_reuse = 0;   // key 26
-static int g_lanes = 1;           // key 24: side lanes for batches <= LANE_BATCH (0 = everything on the caller's stream)
-static int g_fuse_shortcut = 1;   // key 18 (plan time): conv3 + projection shortcut of a bottleneck as one dual-input GEMM
 
 struct Builder {
     quber_ctx* c;
@@ -249,7 +284,7 @@ struct Builder {
         // Winograd path: tap-major K order so that blocks can skip those rows (conv_igemm.hip MODE 3 / 4)
         const bool skip_rows = k == 3 && stride == 1 && dil > 1 && Cin % KS == 0 && cin_real == Cin && 10 * 2 * pad >= 2 * 3 * OHp &&
                                !(winograd_eligible(k, stride, pad, dil, Cin, out.C) && !res && prelu.empty() &&
-                                 std::min(winograd_mac_ratio(in.H, in.W, dil, 4), winograd_mac_ratio(in.H, in.W, dil, 2)) <= g_wino_max_ratio / 100.0 && g_winograd != 1);
+                                 std::min(winograd_mac_ratio(in.H, in.W, dil, 4), winograd_mac_ratio(in.H, in.W, dil, 2)) <= tune().wino_max_ratio / 100.0 && tune().winograd != 1);
         const int kmode = (k > 1 && Cin % KS == 0 && !skip_rows) ? 1 : 0;   // slice-major K order for the 3x3 layers
         const int OH = (in.H + 2 * pad - dil * (k - 1) - 1) / stride + 1;
         const int OW = (in.W + 2 * pad - dil * (k - 1) - 1) / stride + 1;
@@ -305,30 +340,30 @@ struct Builder {
         // that a frame's logits do not change class of arithmetic with the batch it arrives in (split-K, a pure
         // re-association of the same fp32 sum, is the only per-launch choice left).
         // Ragged frames and a dilated layer's short phases are padded to whole tiles: a variant qualifies only while it
-        // still executes <= g_wino_max_ratio % of the direct multiplies.  `wq` is the best of m = 4 / 2 (F(4x4) measures the
+        // still executes <= tune().wino_max_ratio % of the direct multiplies.  `wq` is the best of m = 4 / 2 (F(4x4) measures the
         // direct kernel's error against float64, profiles/r02a_parity_report.txt).  `wq6`, the 6x6 variant, is OPT-IN
         // (quber_set_tuning key 9 = 6 / QUBER_WINOGRAD=f6): 2.5x the error at tap level, +4.5 % throughput at batch 16.
         WinoP wq{};
         // (the 16-bit operand modes keep every layer on the direct kernel: the Winograd transforms amplify the operands'
         // rounding error; the bf16x3 mode is fp32-equivalent and takes the same plan as the exact fp32 MFMA mode)
-        bool wino = winograd_eligible(k, stride, pad, dil, Cin, Cout) && cin_real == Cin && !res && prelu.empty() && g_winograd != 1 &&
+        bool wino = winograd_eligible(k, stride, pad, dil, Cin, Cout) && cin_real == Cin && !res && prelu.empty() && tune().winograd != 1 &&
                     (c->cfg.compute_dtype == 0 || c->cfg.compute_dtype == 3);
         if (wino) {
-            const double lim = (double)g_wino_max_ratio / 100.0;
+            const double lim = (double)tune().wino_max_ratio / 100.0;
             const double r6 = winograd_m6_channels_ok(Cin, Cout) ? winograd_mac_ratio(in.H, in.W, dil, 6) : 1e9;
             const double r4 = winograd_mac_ratio(in.H, in.W, dil, 4), r2 = winograd_mac_ratio(in.H, in.W, dil, 2);
             double best = lim;
             int wm = 0;
-            if (r2 <= best && g_wino_variant != 4 && g_wino_variant != 6) { best = r2; wm = 2; }
-            if (r4 <= best && g_wino_variant != 2) { best = r4; wm = 4; }
+            if (r2 <= best && tune().wino_variant != 4 && tune().wino_variant != 6) { best = r2; wm = 2; }
+            if (r4 <= best && tune().wino_variant != 2) { best = r4; wm = 4; }
             if (r2 <= lim && wm == 0) { best = r2; wm = 2; }                     // a forced larger variant does not fit: smaller tiles
-            const bool has6 = wm != 0 && g_wino_variant == 6 && r6 <= 0.9 * best;
+            const bool has6 = wm != 0 && tune().wino_variant == 6 && r6 <= 0.9 * best;
             // Maps of a handful of tiles stay on the direct kernel.  The 64-channel layers (res2.conv2) lose to it as three
             // kernels (below 128 channels only the opt-in 6x6 variant outweighs its transforms) but not as ONE: 0.25 against
             // 0.43 ms per layer (wino_fused.hip; profiles/r05_wino_fused_layers.md).
-            const bool one_kernel = wm == 4 && g_wino_fused && (c->cfg.compute_dtype == 0 || c->cfg.compute_dtype == 3) && Cout % 32 == 0 &&
-                                    Cin <= g_wino_fused_max_cin;
-            wino = wm != 0 && (g_winograd == 2 || (Cin < 128 ? (has6 || (one_kernel && (long)in.H * in.W >= 1024)) : (long)in.H * in.W >= 1024));
+            const bool one_kernel = wm == 4 && tune().wino_fused && (c->cfg.compute_dtype == 0 || c->cfg.compute_dtype == 3) && Cout % 32 == 0 &&
+                                    Cin <= tune().wino_fused_max_cin;
+            wino = wm != 0 && (tune().winograd == 2 || (Cin < 128 ? (has6 || (one_kernel && (long)in.H * in.W >= 1024)) : (long)in.H * in.W >= 1024));
             if (wino) {
                 const int m = has6 ? 6 : wm;
                 c->wino_flops += 2.0 * OH * OW * (double)cin_real * k * k * Cout * G;
@@ -337,7 +372,7 @@ struct Builder {
                 std::vector<float> u((size_t)G * P * Cout * Cin);
                 for (int g = 0; g < G; ++g) winograd_weights_host(w[g], Cout, Cin, m, &u[(size_t)g * P * Cout * Cin]);
                 wq.in = in; wq.out = out; wq.u = upload(u);
-                if (m == 4 && (c->cfg.compute_dtype == 0 || c->cfg.compute_dtype == 3) && Cout % 32 == 0 && g_wino_fused && Cin <= g_wino_fused_max_cin) {     // operand order of the single-kernel form
+                if (m == 4 && (c->cfg.compute_dtype == 0 || c->cfg.compute_dtype == 3) && Cout % 32 == 0 && tune().wino_fused && Cin <= tune().wino_fused_max_cin) {     // operand order of the single-kernel form
                     std::vector<float> uf(u.size());
                     for (int g = 0; g < G; ++g) winograd_fused_pack_host(&u[(size_t)g * P * Cout * Cin], Cout, Cin, &uf[(size_t)g * P * Cout * Cin]);
                     wq.uf = upload(uf);
@@ -356,7 +391,8 @@ struct Builder {
             WinoP probe = wq;
             if (norm) probe.in = norm->in;           // what the layer will read (in place -> the pipeline)
             const bool fusedk = wq.uf && winograd_fused_ok(probe, Bmax, G);
-            if (fusedk && winograd_fused_prepare() && err.empty()) err = "winograd (fused): cannot raise the kernels' LDS limit";
+            wq.algo = fusedk ? 2 : 1;            // decided once, here, for max_batch: every smaller launch takes the same kernels
+            if (wq.uf && winograd_fused_prepare() && err.empty()) err = "winograd (fused): cannot raise the kernels' LDS limit";
             const size_t need = fusedk ? winograd_fused_ws_floats(Bmax, Cin, G) : winograd_ws_floats(Bmax, in.H, in.W, Cin, Cout, G, dil, wq.m);
             if (need > c->wino_floats) c->wino_floats = need;
             if (cur_lane) {
@@ -436,7 +472,7 @@ struct Builder {
     // modes, views past 2 GiB) run the two original ops.
     void fuse_shortcut(const std::vector<std::string>& n3, const std::vector<std::string>& ns, const View& y, int mid,
                        const View& x, int cin, int stride, const View& out) {
-        if (dry || !g_fuse_shortcut || c->ops.size() < 2) return;
+        if (dry || !tune().fuse_shortcut || c->ops.size() < 2) return;
         const int G = (int)n3.size(), Cout = out.C, Kd = mid + cin;
         const int KS = aes == 2 ? 64 : 32;         // K-slice in elements
         if (mid % KS || cin % KS || y.C != mid || x.C != cin) return;
@@ -1107,6 +1143,7 @@ int quber_create(const quber_config* cfg, quber_ctx** out) {
     if (hipGetDevice(&device) != hipSuccess) return fail("hipGetDevice failed");
     quber_ctx* c = new quber_ctx();
     c->cfg = *cfg;
+    c->tune = quber::g_tune;          // the process defaults of this moment; quber_set_option changes this context only
     c->device = device;
     const int B = cfg->max_batch, H = cfg->height, W = cfg->width;
     // Gaussian template (predictor.py:246-251): float64 exp rounded to f32
@@ -1169,6 +1206,7 @@ int quber_finalize_weights(quber_ctx* c) {
     if (!c) return fail("null context");
     if (!c->cfg.with_network) return fail("context was created with with_network = 0");
     if (c->finalized) return fail("weights already finalized");
+    quber::TuneScope tscope(&c->tune);          // the plan is shaped by THIS context's options
     Builder b(c, false);
     c->flops = 0.0;
     c->wino_flops = 0.0;
@@ -1209,6 +1247,8 @@ double quber_forward_flops_executed(quber_ctx* c) {
     return c->flops - c->wino_saved;
 }
 void quber_set_tuning(int32_t key, int32_t value) {
+    // process defaults: copied by every context created afterwards (quber_create) and used by the stand-alone quber_op_* ops;
+    // contexts that already exist keep their own settings (quber_set_option)
     if (key == 2) {   // stand-alone conv op: allocate (value != 0) or drop the split-K workspace
         if (value && !g_op_ws) {
             if (hipMalloc((void**)&g_op_ws, sizeof(float) * g_op_ws_floats) != hipSuccess) g_op_ws = nullptr;
@@ -1216,30 +1256,27 @@ void quber_set_tuning(int32_t key, int32_t value) {
             (void)hipFree(g_op_ws);
             g_op_ws = nullptr;
         }
+        return;
     }
-    if (key == 4) g_force_tile = value;    // force the tile shape: 1 = 64x64, 2 = 128x128, 4 = 256x32 (0 = automatic)
-    if (key == 24) g_lanes = value;           // side lanes at small batches (default 1)
-    if (key == 21) g_acc_chunk = value;       // two-level fp32 accumulation: K-slices per chunk (0 = off)
-    if (key == 27) g_wino_fused_max_cin = value;  // plan time: widest input (channels) the single-kernel Winograd form takes (default 128)
-    if (key == 26) g_op_wino_reuse = value;   // timing harness: quber_op_conv3x3_winograd reuses the transformed filters its previous call left in u / ws
-    if (key == 25) g_wino_fused = value;      // plan time: the F(4x4) Winograd layers of the exact fp32 mode as ONE kernel (wino_fused.hip); 0 = the three-kernel pipeline
-    if (key == 20) g_wino_chunk_mb = value;   // Winograd layers in passes whose V | M intermediates stay below this many MiB (0 = whole batch)
-    if (key == 19) g_tile_128x64 = value;     // 128x64 tiles for the 33-64 channel convolutions (default 1)
-    if (key == 18) g_fuse_shortcut = value;   // acts at plan time: 0 = keep the projection shortcut a convolution of its own
-    if (key == 17) g_wino_pairs = value;      // F(4x4) Winograd transforms on channel pairs instead of quads
-    if (key == 16) g_persist_debug = value;   // diagnostics of the persistent kernel (1 = drop the epilogue's stores)
-    if (key == 15) g_persist_min_tiles = value;   // persistent launches: fewest tiles of a launch that goes persistent (default 256)
-    if (key == 14) g_persist_min_nk = value;  // persistent launches: shortest K (slices) whose remainder is shared between blocks
-    if (key == 13) g_persist = value;         // persistent convolution launches (conv_persist.hip): 0 = never, 1 = wherever eligible
-    if (key == 12) g_op_bf16 = value;         // stand-alone conv ops: 1 = bf16, 2 = fp16 operands, 3 = fp32 as 3 bf16 terms; fp32 accumulation
-    if (key == 11) g_op_skip_rows = value;    // stand-alone conv op: tap-major K order with padded filter rows skipped (dilated 3x3)
-    if (key == 10) g_wino_min_cout = value;   // smallest output width eligible for the Winograd path (default 32)
-    if (key == 9) g_wino_variant = value;     // Winograd output tile edge for the eligible layers: 0 = automatic (4 or 2), 2, 4, 6 (opt-in)
-    if (key == 8) g_wino_max_ratio = value;   // Winograd only while executed / direct multiplies <= value % (default 67)
-    if (key == 7) g_wino_min_cin = value;  // smallest input width eligible for the Winograd path (default 32)
-    if (key == 6) g_winograd = value;      // Winograd F(2x2,3x3) for the eligible 3x3 layers: 0 = where it pays, 1 = never, 2 = always
-    if (key == 5) g_tail_split = value;    // split the ragged last round of large convolution launches (default 1)
-    if (key == 3) g_force_split = value;   // force the number of K partitions of every convolution with a workspace (0 = automatic)
+    if (key == 26) { g_op_wino_reuse = value; return; }   // timing harness: quber_op_conv3x3_winograd reuses the transformed filters its previous call left in u / ws
+    if (key == 12) { g_op_bf16 = value; return; }         // stand-alone conv ops: 1 = bf16, 2 = fp16 operands, 3 = fp32 as 3 bf16 terms; fp32 accumulation
+    if (key == 11) { g_op_skip_rows = value; return; }    // stand-alone conv op: tap-major K order with padded filter rows skipped (dilated 3x3)
+    (void)quber::tuning_set(quber::g_tune, key, value);
+}
+
+int quber_set_option(quber_ctx* c, int32_t key, int32_t value) {
+    if (!c) return fail("null context");
+    if (quber::tuning_plan_time(key) && c->finalized) return fail("option " + std::to_string(key) + " shapes the plan: set it before quber_finalize_weights");
+    if (!quber::tuning_set(c->tune, key, value)) return fail("unknown option key " + std::to_string(key));
+    return 0;
+}
+
+int quber_get_option(quber_ctx* c, int32_t key, int32_t* value) {
+    if (!c || !value) return fail("null argument");
+    int* f = quber::tuning_field(c->tune, key);
+    if (!f) return fail("unknown option key " + std::to_string(key));
+    *value = *f;
+    return 0;
 }
 
 #ifdef PK_STAMPS
@@ -1341,6 +1378,7 @@ int quber_forward(quber_ctx* c, const uint8_t* bgr, const uint8_t* depth, const 
                   float* logits, void* stream) {
     if (check_batch(c, batch)) return -1;
     if (!c->finalized) return fail("quber_forward before quber_finalize_weights");
+    quber::TuneScope tscope(&c->tune);          // every launcher below reads this context's options (tune())
     if (c->cfg.with_network == 2) {   // LMFFNet: (bgr, depth) -> 3 class planes; `offs` is unused
         if (!bgr || !depth || !logits) return fail("null tensor");
         hipStream_t s2 = (hipStream_t)stream;
@@ -1357,7 +1395,7 @@ int quber_forward(quber_ctx* c, const uint8_t* bgr, const uint8_t* depth, const 
                                c->cfg.pixel_mean, c->cfg.pixel_std, c->cfg.streams, st);
     if (rc) return rc;
     // side lanes: at small batches the independent branches of the plan (Builder::fork / join) run on streams of the context
-    c->lanes_on = c->lanes_built && g_lanes && batch <= LANE_BATCH && c->lane_stream[1] != nullptr && quber::g_prof == nullptr;
+    c->lanes_on = c->lanes_built && tune().lanes && batch <= LANE_BATCH && c->lane_stream[1] != nullptr && quber::g_prof == nullptr;
     auto lane_used = [&](int l) { return c->lanes_on && l > 0; };
     for (auto& op : c->ops) {
         if (op.ctl == 1) {
@@ -1387,6 +1425,7 @@ int quber_forward_profiled(quber_ctx* c, const uint8_t* bgr, const uint8_t* dept
                            float* logits, void* stream, double* kind_ms, int32_t* kind_launches) {
     if (check_batch(c, batch)) return -1;
     if (!c->finalized) return fail("quber_forward_profiled before quber_finalize_weights");
+    quber::TuneScope tscope(&c->tune);
     if (!bgr || (!depth && c->cfg.streams == 2) || !offs || !logits || !kind_ms || !kind_launches) return fail("null argument");
     hipStream_t st = (hipStream_t)stream;
     c->cur_out = logits;
@@ -1584,7 +1623,7 @@ int quber_op_conv3x3_winograd(const float* x, int32_t B, int32_t h, int32_t w, i
     q.dtype = g_op_bf16;
     q.ws = ws; q.ws_floats = (size_t)ws_floats;
     // the single-kernel form where it applies and the workspace also holds its filter order (36 * cout * cin floats)
-    if (m == 4 && g_wino_fused && cout % 32 == 0 && (size_t)ws_floats >= (size_t)36 * cout * cin) {
+    if (m == 4 && tune().wino_fused && cout % 32 == 0 && (size_t)ws_floats >= (size_t)36 * cout * cin) {
         q.uf = ws;
         if (winograd_fused_ok(q, B, 1)) {
             rc = winograd_fused_prepare();
@@ -1618,6 +1657,12 @@ int quber_op_bilinear(const float* x, int32_t B, int32_t h, int32_t w, int32_t c
                       void* stream) {
     if (c % 4) return fail("bilinear: channels must be a multiple of 4");
     return launch_bilinear(mkview(x, B, h, w, c), mkview(y, B, oh, ow, c), B, (hipStream_t)stream);
+}
+
+int quber_op_group_pixels(const float* logits, int32_t n_planes, int32_t batch, int32_t h, int32_t w, int32_t cap,
+                          const int32_t* centers, const int32_t* ncenters, uint8_t* ids, uint32_t* area, void* stream) {
+    if (!logits || !centers || !ncenters || !ids || !area || batch < 1 || h < 1 || w < 1) return fail("bad argument to quber_op_group_pixels");
+    return launch_group_pixels(logits, n_planes, batch, h, w, cap, centers, ncenters, ids, area, (hipStream_t)stream);
 }
 
 int quber_op_maxpool3x3s2(const float* x, int32_t B, int32_t h, int32_t w, int32_t c, float* y, void* stream) {

@@ -436,6 +436,19 @@ int launch_postprocess(const float* logits, int nch, int B, int H, int W, const 
     return 0;
 }
 
+// test harness (quber_op_group_pixels): a9 alone on a caller-supplied centre list
+int launch_group_pixels(const float* logits, int nch, int B, int H, int W, int cap, const int* centers, const int* ncenters,
+                        uint8_t* idmap, unsigned* area, hipStream_t st) {
+    if (cap < 1 || cap > 254) return fail("group_pixels: capacity must be in 1..254");
+    if (nch < 4) return fail("group_pixels: logits need >= 4 channels (fg, centre, off_y, off_x)");
+    const long HW = (long)H * W;
+    if (int rc = launch_zero(area, (size_t)B * 256 * 4, st)) return rc;
+    hipLaunchKernelGGL(group_kernel, dim3((int)((HW + 255) / 256), B), dim3(256), 0, st, logits, nch, H, W, cap, centers, ncenters,
+                       idmap, area);
+    QB_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_extract_masks(const float* pan, const float* labels, int B, int H, int W, int cap, int max_inst,
                          uint8_t* out, hipStream_t st) {
     const long HW = (long)H * W;

@@ -31,8 +31,6 @@
 
 namespace quber {
 
-int g_wino_fused_max_cin = 160;   // key 27: widest input the single-kernel form takes (its two accumulation chains are Cin / 2 long)
-int g_wino_fused = 1;             // key 25: 1 = the eligible layers of the exact fp32 and bf16x3 modes take these kernels, 0 = never
 
 using namespace wxf;
 
@@ -269,8 +267,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
 
     // ---- MFMA role: positions wave * 9 .. + 8, all 32 tiles x 32 channels ----
-    // Two accumulator sets, one per 8-channel slice of a round: each is a chain over HALF of K (64 of the 128 input channels
-    // this kernel is used up to - the chain length class the anchor test passes with margin, profiles/r03f_anchor_chunk.md),
+    // Two accumulator sets, one per 8-channel slice of a round: each is a chain over HALF of K (at most 80 of the 160 input channels
+    // this kernel is used up to, option key 27 - float64-anchor ratios 0.64-1.11, profiles/r05_fused_anchor.md),
     // and the two are added once, in the epilogue.  No second-level addition runs inside the loop, where every vector
     // instruction would add its issue time to the MFMAs'.
     constexpr int SPLIT = WF_SPLIT;              // positions (of the wave's 9) with a chain per slice; the rest keep one chain
@@ -759,13 +757,13 @@ int launch_winograd_fused_pack(const float* u, int Cout, int Cin, float* uf, hip
 bool winograd_fused_ok(const WinoP& q, int Ball, int G) {
     const View& in = q.in;
     const View& out = q.out;
-    if (!g_wino_fused || q.m != 4 || (q.dtype != 0 && q.dtype != 3) || !q.uf || in.es != 4 || out.es != 4) return false;
+    if (!tune().wino_fused || q.m != 4 || (q.dtype != 0 && q.dtype != 3) || !q.uf || in.es != 4 || out.es != 4) return false;
     // bf16x3 mode (fp32-equivalent): this exact fp32 kernel where it beats the pipeline's bf16x3 GEMMs + transforms - not the wide
     // heads that share one input transform between their groups (profiles/r03_final_conv_layers_dtype3.md against r05t_layers.md)
     if (q.dtype == 3 && G > 1 && in.gs == 0 && out.C >= 64) return false;
     if (in.C % 32 || out.C % FC) return false;
     if (in.p == out.p) return false;              // in place: blocks read input halos that other blocks are overwriting
-    if (in.C > g_wino_fused_max_cin) return false;   // the two accumulation chains are Cin / 2 long: the accuracy class of 64-channel chains up to 128
+    if (in.C > tune().wino_fused_max_cin) return false;   // the two accumulation chains are Cin / 2 long: at most 80 channels at the default of 160 (profiles/r05_fused_anchor.md)
     const double in_bytes = 4.0 * (((double)Ball * in.H * in.W - 1) * in.cs + in.C);
     const double out_bytes = 4.0 * (((double)Ball * in.H * in.W - 1) * out.cs + out.C);
     if (in_bytes > (double)0x3F000000u || out_bytes > (double)0x3F000000u) return false;

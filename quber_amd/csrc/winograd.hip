@@ -26,11 +26,6 @@ namespace quber {
 
 using namespace wxf;
 
-int g_wino_min_cin = 32;      // key 7: smallest input width routed to this path (the 32-channel stem layers take the single-kernel form)
-int g_wino_max_ratio = 67;    // key 8: executed / direct multiplies (%) up to which a (dilated) layer takes this path
-int g_wino_variant = 0;       // key 9: output tile edge m for the eligible layers: 0 = automatic, 2, 4
-int g_wino_min_cout = 32;     // key 10: smallest output width routed to this path
-int g_wino_pairs = 0;         // key 17: F(4x4) transforms on channel pairs (8-byte accesses, half the registers per thread) instead of quads
 
 namespace {
 
@@ -288,8 +283,8 @@ bool winograd_m6_channels_ok(int Cin, int Cout) {
 }
 
 bool winograd_eligible(int k, int stride, int pad, int dil, int Cin, int Cout) {
-    return k == 3 && stride == 1 && dil >= 1 && pad == dil && Cin % 32 == 0 && Cout % 4 == 0 && Cin >= g_wino_min_cin &&
-           Cout >= g_wino_min_cout && (Cin / 4 <= 256 || (Cin / 4) % 256 == 0) && (Cout / 4 <= 256 || (Cout / 4) % 256 == 0);
+    return k == 3 && stride == 1 && dil >= 1 && pad == dil && Cin % 32 == 0 && Cout % 4 == 0 && Cin >= tune().wino_min_cin &&
+           Cout >= tune().wino_min_cout && (Cin / 4 <= 256 || (Cin / 4) % 256 == 0) && (Cout / 4 <= 256 || (Cout / 4) % 256 == 0);
 }
 
 size_t winograd_ws_floats(int B, int H, int W, int Cin, int Cout, int G, int dil, int m) {
@@ -303,7 +298,6 @@ double winograd_mac_ratio(int H, int W, int dil, int m) {
     return (double)((m + 2) * (m + 2)) * wino_tiles(H, W, dil, m) / (9.0 * H * W);
 }
 
-int g_wino_chunk_mb = 0;      // key 20: largest V | M footprint (MiB) of one pass over a layer; 0 = the whole batch at once
 
 template <int O, int V>     // V: channels per thread in the transforms
 static int run_winograd(const WinoP& q, int Ball, int G, hipStream_t st) {
@@ -317,9 +311,9 @@ static int run_winograd(const WinoP& q, int Ball, int G, hipStream_t st) {
     // Frames per pass.  The intermediates V | M of a pass are rewritten in place by the next one; kept below the Infinity
     // Cache (256 MiB) they are written and re-read on the die instead of through HBM (tools/wino_subbatch_probe.py).
     int cb = Ball;
-    if (g_wino_chunk_mb > 0) {
+    if (tune().wino_chunk_mb > 0) {
         const double per_frame = 4.0 * G * P * (double)tiles_pf * (Cin + Cout);
-        cb = (int)((double)g_wino_chunk_mb * 1048576.0 / per_frame);
+        cb = (int)((double)tune().wino_chunk_mb * 1048576.0 / per_frame);
         if (cb < 1) cb = 1;
         if (cb > Ball) cb = Ball;
         cb = (Ball + (Ball + cb - 1) / cb - 1) / ((Ball + cb - 1) / cb);     // equal passes
@@ -408,8 +402,8 @@ int launch_conv_winograd(const WinoP& q, int B, int G, hipStream_t st) {
     if (q.m == 6 && !winograd_m6_channels_ok(in.C, out.C)) return fail("winograd: channel counts unsupported by the 6x6 variant");
     if (in.cs % 4 || out.cs % 4 || ((uintptr_t)in.p & 15) || ((uintptr_t)out.p & 15) || (in.gs & 3) || (out.gs & 3))
         return fail("winograd: operands must be 16-byte aligned");
-    if (winograd_fused_ok(q, B, G)) return launch_conv_winograd_fused(q, B, G, st);
-    if (q.m == 4 && g_wino_pairs && winograd_m6_channels_ok(in.C, out.C)) return run_winograd<4, 2>(q, B, G, st);
+    if (q.algo == 2 || (q.algo == 0 && winograd_fused_ok(q, B, G))) return launch_conv_winograd_fused(q, B, G, st);
+    if (q.m == 4 && tune().wino_pairs && winograd_m6_channels_ok(in.C, out.C)) return run_winograd<4, 2>(q, B, G, st);
     return q.m == 6 ? run_winograd<6, 2>(q, B, G, st) : q.m == 4 ? run_winograd<4, 4>(q, B, G, st) : run_winograd<2, 4>(q, B, G, st);
 }
 

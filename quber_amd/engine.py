@@ -130,6 +130,16 @@ class Engine:
         except Exception:
             pass
 
+    # ---- options (include/quber_hip.h: the keys of quber_set_option) ----
+    def set_option(self, key, value):
+        """This engine only.  Plan-time keys must be set before load_state_dict(); launch-time keys any time."""
+        _lib.check(self.lib.quber_set_option(self.h, int(key), int(value)))
+
+    def get_option(self, key):
+        v = C.c_int32()
+        _lib.check(self.lib.quber_get_option(self.h, int(key), C.byref(v)))
+        return v.value
+
     # ---- weights ----
     def weight_specs(self):
         out = []

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Float64-anchor table (tests/fp64_anchor.py) of the HIP network per tuning configuration: where does the distance to
+"""Float64-anchor table (oracle/fp64_anchor.py) of the HIP network per tuning configuration: where does the distance to
 float64 come from (accumulation order, Winograd transforms), and what does a knob buy?  GPU box only; writes nothing.
 usage: tests/anchor_report.py [--frames 4] [--dtype 0] --configs "default;13=0;13=0,3=8;6=1,13=0,3=8"
 Lives under tests/ because it runs the oracle (test infrastructure)."""
@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import encode_np  # noqa: E402
 from quber_amd import _lib, arch, engine, synth  # noqa: E402
-from tests import fp64_anchor as fa  # noqa: E402
+from oracle import fp64_anchor as fa  # noqa: E402
 from tests.conftest import oracle_threads  # noqa: E402
 
 

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import encode_np, postproc_ref  # noqa: E402
 from quber_amd import arch, synth  # noqa: E402
-from tests import fp64_anchor as fa  # noqa: E402
+from oracle import fp64_anchor as fa  # noqa: E402
 
 H, W, N = 480, 640, 20
 threads = [int(t) for t in sys.argv[1].split(",")] if len(sys.argv) > 1 else [8, 16, 32, 64, 128]

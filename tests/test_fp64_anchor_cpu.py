@@ -1,4 +1,4 @@
-"""CPU: the float64-anchored adjudication itself (tests/fp64_anchor.py), exercised without a GPU.
+"""CPU: the float64-anchored adjudication itself (oracle/fp64_anchor.py), exercised without a GPU.
 
 The "candidate" here is the fp32 oracle's logits plus a perturbation: at the level of fp32 round-off every flipped label
 pixel must be explained as a float64 near-tie; a perturbation far above the stated tolerance must be refused."""
@@ -8,7 +8,7 @@ import torch
 
 from oracle import encode_np
 from quber_amd import arch, synth
-from tests import fp64_anchor as fa
+from oracle import fp64_anchor as fa
 
 
 @pytest.fixture(scope="module")

@@ -16,7 +16,7 @@ import pytest
 import torch
 
 from oracle import encode_np, postproc_ref
-from tests import fp64_anchor as fa
+from oracle import fp64_anchor as fa
 from oracle.network_torch import ArchCfg, MaskRefinerNet
 from quber_amd import arch, engine, synth
 
@@ -181,7 +181,7 @@ def test_benchmarked_plan_taps_heads_and_instances(h, w, b, n, mode):
 @pytest.mark.parametrize("h,w,b,n,mode", PLAN_CASES, ids=PLAN_IDS)
 def test_benchmarked_plan_float64_anchor(h, w, b, n, mode):
     """The stated tolerance ("within 1e-4 (float) / bit-exact (label maps)", BASELINE.json north_star) adjudicated against a
-    float64 evaluation of the oracle network on ALL frames of the benchmarked plan (tests/fp64_anchor.py):
+    float64 evaluation of the oracle network on ALL frames of the benchmarked plan (oracle/fp64_anchor.py):
       (b) per tap and per head, max |HIP - fp64| <= 1.5 x max |oracle_fp32 - fp64|: the HIP path is no further from the
           exact result than the reference's own fp32 arithmetic (taps relative to the tap's magnitude; heads in head units,
           the offset planes also in raw pixels, where the x4 of model.py:700 makes the literal 1e-4 unreachable for fp32

@@ -250,16 +250,15 @@ def test_side_lanes_equal_one_stream(dtype):
             batch = synth.make_batch(50 + b, b, h, w, n)
             bgr, dep = torch.from_numpy(batch["rgb"]).cuda(), torch.from_numpy(batch["depth"]).cuda()
             off = eng.encode(torch.from_numpy(batch["masks"]).cuda())
-            lib.quber_set_tuning(24, 0)
+            eng.set_option(24, 0)
             one = eng.forward(bgr, dep, off).clone()
             taps = {k: eng.debug_tensor(k, b).clone() for k in ("res2", "res3", "res5", "y")}
-            lib.quber_set_tuning(24, 1)
+            eng.set_option(24, 1)
             for _ in range(12):
                 assert torch.equal(eng.forward(bgr, dep, off), one)
             for k, v in taps.items():
                 assert torch.equal(eng.debug_tensor(k, b), v), k
     finally:
-        lib.quber_set_tuning(24, 1)
         eng.close()
 
 
@@ -373,9 +372,9 @@ def test_launch_structures_agree():
     outs, pans, names = {}, {}, {}
     try:
         for name, (k13, k18) in {"old": (0, 0), "new": (1, 1)}.items():
-            lib.quber_set_tuning(13, k13)
-            lib.quber_set_tuning(18, k18)
             eng = engine.Engine(engine.make_config(h, w, max_batch=b, max_instances=n), "cuda:0")
+            eng.set_option(13, k13)
+            eng.set_option(18, k18)
             eng.load_state_dict(sd)
             lg = eng.forward(bgr, dep, off)
             pans[name] = eng.postprocess(lg)["panoptic"].cpu()
@@ -383,11 +382,77 @@ def test_launch_structures_agree():
             names[name] = [p[0] for p in eng.plan() if p[1] == "conv"]
             del eng
     finally:
-        lib.quber_set_tuning(13, 1)
-        lib.quber_set_tuning(18, 1)
+        pass
     assert len(names["old"]) == len(names["new"]) + 4 and sum("+ shortcut" in s for s in names["new"]) == 4
     d = (outs["new"] - outs["old"]).abs()
     # (the oracle's own fp32 result sits 7e-5 from its float64 one on these O(1-10) logits; offset planes carry the stride factor 4)
     assert float(d[:, :2].max()) < TOL and float(d[:, 2:4].max()) < 4 * TOL and float(d[:, 4:].max()) < TOL
     assert not torch.equal(outs["new"], outs["old"])
     assert float((pans["new"] == pans["old"]).float().mean()) > 0.999
+
+
+def test_two_engines_keep_their_own_options():
+    """Options belong to a context (quber_set_option), not to the process: two engines with different plan-time and
+    arithmetic-changing settings live side by side, interleaved on one thread and concurrently on two, and each keeps producing
+    exactly its own results; a later change of the process defaults (quber_set_tuning) touches neither."""
+    import threading
+    lib = _lib.load()
+    h, w, b, n = 192, 256, 2, 6
+    sd = arch.init_state_dict(seed=4, loud_heads=True, center_bias=-1.5)
+    batch, offs = inputs(33, b, h, w, n)
+    bgr, dep, off = torch.from_numpy(batch["rgb"]).cuda(), torch.from_numpy(batch["depth"]).cuda(), torch.from_numpy(offs).cuda()
+    A = engine.Engine(engine.make_config(h, w, max_batch=b, max_instances=n), "cuda:0")
+    B = engine.Engine(engine.make_config(h, w, max_batch=b, max_instances=n), "cuda:0")
+    try:
+        B.set_option(6, 1)            # plan: no Winograd layers at all
+        B.set_option(18, 0)           # plan: projection shortcuts as convolutions of their own
+        B.set_option(21, 0)           # arithmetic: one sequential fp32 chain over K
+        B.set_option(24, 0)           # launch: no side lanes
+        assert A.get_option(6) == 0 and A.get_option(21) == 2 and B.get_option(6) == 1 and B.get_option(21) == 0
+        A.load_state_dict(sd)
+        B.load_state_dict(sd)
+        with pytest.raises(_lib.QuberError, match="before quber_finalize_weights"):
+            A.set_option(25, 0)       # a plan-time key after the plan exists
+        with pytest.raises(_lib.QuberError, match="unknown option"):
+            A.set_option(99, 1)
+        assert A.forward_flops_executed() < 0.9 * A.forward_flops() and B.forward_flops_executed() == B.forward_flops()
+        assert sum("+ shortcut" in p[0] for p in A.plan()) == 4 and sum("+ shortcut" in p[0] for p in B.plan()) == 0
+        a0, b0 = A.forward(bgr, dep, off).clone(), B.forward(bgr, dep, off).clone()
+        assert not torch.equal(a0, b0)
+        d = (a0 - b0).abs()
+        assert float(d[:, :2].max()) < 2 * TOL and float(d[:, 4:].max()) < 2 * TOL      # two plans of the same network
+        lib.quber_set_tuning(6, 1)    # process defaults: neither existing engine may notice
+        lib.quber_set_tuning(21, 0)
+        try:
+            for _ in range(3):        # interleaved on one thread
+                assert torch.equal(A.forward(bgr, dep, off), a0)
+                assert torch.equal(B.forward(bgr, dep, off), b0)
+        finally:
+            lib.quber_set_tuning(6, 0)
+            lib.quber_set_tuning(21, 2)
+        # concurrently: one thread and one stream per engine
+        bad = []
+
+        def worker(eng, want):
+            try:
+                torch.cuda.set_device(0)
+                st = torch.cuda.Stream()
+                with torch.cuda.stream(st):
+                    for _ in range(8):
+                        got = eng.forward(bgr, dep, off)
+                        st.synchronize()
+                        if not torch.equal(got, want):
+                            bad.append("mismatch")
+            except Exception as e:      # noqa: BLE001
+                bad.append(repr(e))
+
+        torch.cuda.synchronize()
+        ts = [threading.Thread(target=worker, args=(A, a0)), threading.Thread(target=worker, args=(B, b0))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not bad, bad
+    finally:
+        A.close()
+        B.close()

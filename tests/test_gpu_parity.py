@@ -219,6 +219,37 @@ def test_group_golden(path):
     np.testing.assert_array_equal(o["panoptic"], lut[ids])
 
 
+@pytest.mark.parametrize("path", golden("group"), ids=os.path.basename)
+def test_group_golden_any_centre_order(path):
+    """EVERY group_* fixture - the reference's group_pixels on centre lists in arbitrary order (group_k20 / group_k199 are
+    shuffled lists the centre-map route cannot produce) - through quber_op_group_pixels: the grouping kernel of
+    quber_postprocess on a caller-supplied list (post_processing.py:44-76).  Two frames per launch: the fixture and the same
+    offsets with the list reversed, checked against the oracle (ids are positions in the list, so the map changes)."""
+    z = np.load(path)
+    h, w = z["offsets"].shape[1:]
+    ctr = z["centers"].astype(np.int32)
+    k = len(ctr)
+    cap = 254
+    lists = [ctr, ctr[::-1].copy()]
+    lg = np.zeros((2, 4, h, w), np.float32)
+    lg[:, 0] = 4.0                                   # every pixel foreground: the ids are group_pixels' return value
+    lg[:, 2:4] = z["offsets"]
+    cbuf = np.zeros((2, cap, 2), np.int32)
+    for b, l in enumerate(lists):
+        cbuf[b, :k] = l
+    d_lg, d_c, d_n = dev(lg), dev(cbuf), dev(np.array([k, k], np.int32))
+    ids = torch.empty((2, h, w), dtype=torch.uint8, device="cuda")
+    area = torch.empty((2, 256), dtype=torch.int32, device="cuda")
+    lib = _lib.load()
+    _lib.check(lib.quber_op_group_pixels(d_lg.data_ptr(), 4, 2, h, w, cap, d_c.data_ptr(), d_n.data_ptr(), ids.data_ptr(),
+                                         area.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    got = ids.cpu().numpy().astype(np.int32)
+    np.testing.assert_array_equal(got[0], z["out"][0])                       # the reference's own output
+    want_rev = postproc_ref.group_pixels(torch.from_numpy(lists[1].astype(np.int64)), torch.from_numpy(z["offsets"])).numpy()[0]
+    np.testing.assert_array_equal(got[1], want_rev)
+    np.testing.assert_array_equal(area.cpu().numpy()[0, :k + 1], np.bincount(z["out"][0].ravel(), minlength=k + 1)[:k + 1])
+
+
 @pytest.mark.parametrize("path", golden("panoptic"), ids=os.path.basename)
 def test_panoptic_golden(path):
     z = np.load(path)
@@ -245,6 +276,60 @@ def test_postprocess_vs_oracle(h, w, n, seed):
     np.testing.assert_allclose(o["scores"][:k], ref["scores"].numpy(), rtol=2e-5, atol=1e-6)
     masks = e.extract_masks(post, k).cpu().numpy()[0]
     np.testing.assert_array_equal(masks.astype(bool), ref["masks"].numpy())
+
+
+CENTROID_CASES = [   # (rows of the block, extra pixels at (row, how many)): the exact centroid row = integer -/+ a few 1e-6
+    ("exact_integer", (40, 440), None),                 # mean y = 240 exactly
+    ("just_below_5e-6", (40, 440), (239, 1)),           # 240 - 1/200501
+    ("just_above_5e-6", (40, 440), (241, 1)),           # 240 + 1/200501
+    ("below_3e-5", (40, 440), (239, 6)),                # 240 - 6/200506: below the fp32 neighbour of 240 (spacing 1.5e-5)
+    ("below_1.2e-5", (40, 440), (238, 1)),              # 240 - 2/200501 ~ 240 - 1e-5: between 240 and its lower fp32 neighbour
+    ("tall_just_below", (0, 478), (238, 1)),            # 479 rows x 500: sums far beyond 2^24 (fp32 partial sums are inexact)
+]
+
+
+@pytest.mark.parametrize("name,rows,extra", CENTROID_CASES, ids=[c[0] for c in CENTROID_CASES])
+def test_instance_score_centroid_near_integer(name, rows, extra):
+    """a11 (model.py:340-347): the confidence is sem_score x centre[int(mean y), int(mean x)] with the means taken by an fp32
+    torch.mean over the mask's pixel indices.  When the exact centroid sits within ~1e-5 px of an integer the sampled ROW
+    depends on the rounding of that mean.  This repo's kernel divides exact integer sums in float64 and rounds ONCE to fp32
+    (csrc/postproc.hip finalize_kernel) = the correctly rounded fp32 mean; torch sums in fp32 (pairwise on the CPU, a tree on
+    a GPU), so it can land on the other side.  The test builds one instance whose centroid row is a chosen integer -/+ a few
+    1e-6, makes the centre plane a ramp over rows (the sampled row is readable from the score) and
+      * asserts the HIP side: row = int(fp32(exact mean)), always;
+      * asserts the oracle side (the reference's arithmetic on this host): its row is int() of a value within 1e-4 of the
+        exact mean - and prints which side it took, so a disagreement is visible and attributed;
+      * asserts equal scores (2e-5) whenever both sampled the same pixel, and masks / boxes bit-exact regardless."""
+    h, w = 480, 640
+    fg = np.full((h, w), -4.0, np.float32)
+    fg[rows[0]:rows[1] + 1, 100:600] = 4.0
+    if extra:
+        fg[extra[0], 50:50 + extra[1]] = 4.0
+    ramp = (0.05 + 0.0004 * np.arange(h, dtype=np.float64)).astype(np.float32)       # < 0.3: no centre on the ramp
+    ce = np.repeat(ramp[:, None], w, 1).copy()
+    ce[5, 5] = 0.9                                                                   # the one centre (outside the mask)
+    of = np.zeros((2, h, w), np.float32)
+    e, o, post = run_post(fg, ce, of)
+    ref = postproc_ref.postprocess(torch.from_numpy(fg[None]), torch.from_numpy(ce[None]), torch.from_numpy(of))
+    np.testing.assert_array_equal(o["panoptic"], ref["panoptic"].numpy())
+    assert int(o["count"]) == 1 and len(ref["labels"]) == 1
+    np.testing.assert_array_equal(o["boxes"][:1], ref["boxes"].numpy())
+    ys, xs = np.nonzero(fg > 0)
+    n, sy = len(ys), int(ys.sum())
+    exact = sy / n                                                                   # float64 of the exact rational
+    want_row = int(np.float32(exact))
+    sem = float(torch.from_numpy(fg[fg > 0]).sigmoid().double().mean())
+    def row_of(score):
+        r = (score / sem - 0.05) / 0.0004
+        assert abs(r - round(r)) < 0.05, (score, r)
+        return int(round(r))
+    hip_row, ora_row = row_of(float(o["scores"][0])), row_of(float(ref["scores"][0]))
+    print(f"\n[a11 centroid] {name}: exact mean y = {exact:.9f} (fp32 {float(np.float32(exact)):.6f}); "
+          f"HIP samples row {hip_row}, oracle (torch fp32 mean on this host) row {ora_row}")
+    assert hip_row == want_row
+    assert ora_row in (int(exact - 1e-4), int(exact + 1e-4))
+    if hip_row == ora_row:
+        np.testing.assert_allclose(o["scores"][:1], ref["scores"].numpy(), rtol=2e-5, atol=1e-6)
 
 
 def test_postprocess_batch_is_per_frame():

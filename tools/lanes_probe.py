@@ -18,7 +18,7 @@ for B in (1, 2):
     off = eng.encode(m)
     outs = {}
     for lanes in (0, LV):
-        lib.quber_set_tuning(24, lanes)
+        eng.set_option(24, lanes)
         lg = eng.forward(bgr, dep, off)
         torch.cuda.synchronize()
         taps = {n: eng.debug_tensor(n, B).clone() for n in ("res2", "res3", "res5", "y")}
@@ -33,7 +33,7 @@ for B in (1, 2):
     print("   max |lanes - one stream| on the logits:", float((outs[0][0] - outs[1][0]).abs().max()), {k: float((outs[0][1][k] - outs[1][1][k]).abs().max()) for k in outs[0][1]})
     print(f"batch {B}: forward {outs[0][2]:.3f} ms on one stream, {outs[1][2]:.3f} ms with side lanes; results identical: {same}")
     # repeated runs with lanes stay identical (no races on shared workspaces)
-    lib.quber_set_tuning(24, LV)
+    eng.set_option(24, LV)
     ok = all(torch.equal(eng.forward(bgr, dep, off), outs[1][0]) for _ in range(20))
     print("   20 repeated lane runs identical:", ok)
     eng.close()

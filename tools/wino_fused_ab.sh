@@ -1,6 +1,6 @@
 #!/bin/bash
 # End-to-end A/B of the single-kernel Winograd layers: the default bench step with the layers off (25=0), on (default: inputs
-# up to 128 channels), and with wider layers admitted (27=...), for the WF_SPLIT builds given.  usage (GPU box): tools/wino_fused_ab.sh "9 7"
+# up to 160 channels: the default of option key 27), and with wider layers admitted (27=...), for the WF_SPLIT builds given.  usage (GPU box): tools/wino_fused_ab.sh "9 7"
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R
 B="python bench.py --steps 12 --warmup 4 --cpu-frames 0 --predict-calls 0 --no-split-mode"
