@@ -1279,6 +1279,10 @@ int quber_get_option(quber_ctx* c, int32_t key, int32_t* value) {
     return 0;
 }
 
+#ifdef WF_STAMPS
+namespace quber { int wf_read_stamps(unsigned long long* dst, int n); }
+int quber_wf_read_stamps(unsigned long long* dst, int n) { return quber::wf_read_stamps(dst, n); }
+#endif
 #ifdef PK_STAMPS
 int quber_pk_read_stamps(unsigned long long* dst, int n) { return quber::pk_read_stamps(dst, n); }
 int quber_pk_read_span(unsigned long long* dst, int n) { return quber::pk_read_span(dst, n); }

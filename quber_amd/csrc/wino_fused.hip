@@ -57,6 +57,19 @@ using f32x2 = __attribute__((ext_vector_type(2))) float;
 #ifndef WF_SKIP
 #define WF_SKIP 0                               // diagnostic builds of the 32 x 32 kernel only (tools/wino_fused_ablate.sh): bit 0 no patch loads, 1 no filter loads, 2 no transforms, 4 no MFMA, 5 no epilogue, 6 no K loop
 #endif
+#ifndef WF_OPT
+#define WF_OPT 7                                // A/B switches of the round-4 diet: bit 0 = no transform work for rounds that do not exist (the last two rounds of the
+#endif                                          // K loop), bit 1 = MFMA operands swapped (filters as A): a lane's result registers are 4 consecutive CHANNELS of one tile,
+                                                // the epilogue stores them to LDS 16 bytes at a time (36 instead of 144 stores), bit 2 = GroupNorm sums of a thread's 64 outputs in
+                                                // packed fp32, converted to double once
+#ifdef WF_STAMPS
+// diagnostic build (make WFX=-DWF_STAMPS, tools/wf_stamps.py): s_memtime at the phase boundaries of the first blocks
+constexpr int WF_STAMP_BLOCKS = 512, WF_STAMP_N = 16;
+__device__ unsigned long long g_wf_stamps[WF_STAMP_BLOCKS * 4 * WF_STAMP_N];
+#define WF_STAMP(i) do { if (lane == 0 && blockIdx.x < WF_STAMP_BLOCKS && blockIdx.z == 0) g_wf_stamps[((int)blockIdx.x * 4 + wave) * WF_STAMP_N + (i)] = (i) == 15 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WF_STAMP(i) do {} while (0)
+#endif
 constexpr int FT = 32;                          // tiles per block
 constexpr int FC = 32;                          // output channels per block
 constexpr int FK = 16;                          // input channels per round: two 8-channel MFMA slices
@@ -181,6 +194,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int vb = (xcd < br ? xcd * (bq_ + 1) : br * (bq_ + 1) + (xcd - br) * bq_) + (blockIdx.x >> 3);
     const int tb = vb / a.NC, cc = vb - tb * a.NC;
     if (t < 128) gacc[t] = 0.0;                  // published by the barriers of the K loop
+    WF_STAMP(0);
+    WF_STAMP(15);
 
     // ---- loader role: tile lt of the block, channel pair q of the round ----
     const int lt = t >> 3, q = t & 7;
@@ -295,7 +310,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     //   steps 0-5    row pass i of that patch -> 6 stores into image r + 1, then row i of the patch of round r + 2 is requested
     //   steps 12-17  column pass j of the patch of round r + 2 (requested >= 7 steps earlier)
     auto round = [&](const float* vs, float* vn, const int r, const int kbase, const bool first) __attribute__((always_inline)) {
-        const int r2 = r + 2 < R ? r + 2 : R - 1;                  // past the end: the last round again (never multiplied)
+        const int r2 = r + 2 < R ? r + 2 : R - 1;
+        // what this round prepares for the rounds after it: the row pass of the next round's patch, and the request + column pass of
+        // the patch after that - nothing for rounds that do not exist (WF_OPT & 1: the last two rounds used to redo the last patch for
+        // nobody: 147 vector, 36 LDS and 36 memory instructions per round beside an MFMA pipe that shares its lanes with them)
+        const bool do_rows = !(WF_OPT & 1) || r + 1 < R, do_full = !(WF_OPT & 1) || r + 2 < R;                  // past the end: the last round again (never multiplied)
         f32x4 av_next = *reinterpret_cast<const f32x4*>(vs + a_off);
 #pragma unroll
         for (int k = 0; k < 18; ++k) {
@@ -307,16 +326,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             acc[pi < SPLIT ? s : 0][pi][0] += av.x * bv.x + av.y * bv.y + av.z * bv.z + av.w * bv.w;
 #else
             f32x16& ac = acc[pi < SPLIT ? s : 0][pi];
+#if (WF_OPT & 2)
+            ac = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.x, av.x, (first && (s == 0 || pi < SPLIT)) ? zero : ac, 0, 0, 0);      // rows = channels, columns = tiles
+            ac = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.y, av.y, ac, 0, 0, 0);
+            ac = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.z, av.z, ac, 0, 0, 0);
+            ac = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.w, av.w, ac, 0, 0, 0);
+#else
             ac = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, (first && (s == 0 || pi < SPLIT)) ? zero : ac, 0, 0, 0);
             ac = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, ac, 0, 0, 0);
             ac = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, ac, 0, 0, 0);
             ac = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, ac, 0, 0, 0);
 #endif
+#endif
             bload((kbase + k) % BR, r, k + BR);
 #if !(WF_SKIP & 4)
-            if (k < 6) { row_pass(k, vn); gload_row(k, r2); }
-            if (k == 6) gload_coef(r2);
-            if (k >= 12) col_pass(k - 12);
+            // (block-uniform branches: the accumulators are not touched inside them)
+            if (k < 6 && do_rows) row_pass(k, vn);
+            if (do_full) {
+                if (k < 6) gload_row(k, r2);
+                if (k == 6) gload_coef(r2);
+                if (k >= 12) col_pass(k - 12);
+            }
 #endif
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -352,35 +382,60 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int j = 0; j < 6; ++j) col_pass(j);
     __syncthreads();
     static_assert(36 % BR == 0, "the ring index is static over a pair of rounds");
+    WF_STAMP(1);
     round(st0, st1, 0, 0, true);                 // Cin % 32 == 0: rounds come in pairs; the first pair starts the accumulation chains
     __syncthreads();
+    WF_STAMP(2);
     round(st1, st0, 1, 18, false);
     __syncthreads();
+    WF_STAMP(3);
     for (int r = 2; r < ((WF_SKIP & 64) ? 0 : R); r += 2) {
         round(st0, st1, r, 0, false);
         __syncthreads();
         round(st1, st0, r + 1, 18, false);
         __syncthreads();
     }
+    WF_STAMP(6);
 
     // ---- epilogue: sums -> LDS [position][tile][32 channels] -> A^T . A per (tile, 4 channels) ----
 #if (WF_SKIP & 32)
     if (acc[0][0][0] != 12345.f) return;
 #endif
     const int h = lane >> 5, rr = lane & 31;
+#if (WF_OPT & 2)
+    // filters were the A operand: lane (rr, h) holds, per register quad g4, channels 8 g4 + 4 h .. + 3 of tile rr: one 16-byte store
+    // each.  The eight 16-byte chunks of a tile's 128-byte row are XOR-swizzled by tile / 2 (rows alternate between the two halves
+    // of the 64 banks): 16 lanes of a store, and the 2 tiles x 8 chunk readers below, cover all banks once.
+#pragma unroll
+    for (int pi = 0; pi < 9; ++pi)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = pi < SPLIT ? acc[0][pi][4 * g4 + e] + acc[1][pi][4 * g4 + e] : acc[0][pi][4 * g4 + e];
+            *reinterpret_cast<f32x4*>(smem + ((wave * 9 + pi) * FT + rr) * FC + (((2 * g4 + h) ^ ((rr >> 1) & 7)) << 2)) = v;
+        }
+#else
 #pragma unroll
     for (int pi = 0; pi < 9; ++pi)
 #pragma unroll
         for (int e = 0; e < 16; ++e)
             smem[((wave * 9 + pi) * FT + 8 * (e >> 2) + 4 * h + (e & 3)) * FC + rr] = pi < SPLIT ? acc[0][pi][e] + acc[1][pi][e] : acc[0][pi][e];
+#endif
     __syncthreads();
+    WF_STAMP(7);
     const int c = cc * FC + 4 * q;
+#if (WF_OPT & 2)
+    const int csw = (q ^ ((lt >> 1) & 7)) << 2;
+#else
+    const int csw = 4 * q;
+#endif
     PV s[4][6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         PV col[6], sj[4];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) col[i] = ldpv(smem + ((i * 6 + j) * FT + lt) * FC + 4 * q);
+        for (int i = 0; i < 6; ++i) col[i] = ldpv(smem + ((i * 6 + j) * FT + lt) * FC + csw);
         at4(col, sj);
 #pragma unroll
         for (int i = 0; i < 4; ++i) s[i][j] = sj[i];
@@ -393,6 +448,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const float lo = a.relu ? 0.f : -__builtin_inff();
     const int b0 = (int)(((long)tb * FT) / a.per_img);
     double sa = 0.0, sq = 0.0;
+    f32x2 psa = {0.f, 0.f}, psq = {0.f, 0.f};          // WF_OPT & 4: the thread's 64 outputs summed in packed fp32 first
     // the 16 pixels of the tile through a buffer descriptor, as the loader's patch: row + column offsets, and the pixels outside
     // the map (ragged last tiles, short phases, tiles past the end) are dropped by the range check instead of branches
     const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(a.out + (long)g * a.out_gs, a.out_bytes);
@@ -416,14 +472,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const unsigned vo = orow[i] + ocol[j];
             if (a.gn_sum) {
                 if (vo < OOBH) {
+#if (WF_OPT & 4)
+                    const f32x2 y01 = {y.x, y.y}, y23 = {y.z, y.w};
+                    psa = pk_add(pk_add(psa, y01), y23);
+                    psq = pk_fma_v(y23, y23, pk_fma_v(y01, y01, psq));
+#else
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { sa += (double)y[e]; sq += (double)y[e] * y[e]; }
+#endif
                 }
             }
             buf_store4(y, rs_out, vo);
         }
     }
+    WF_STAMP(8);
     if (a.gn_sum) {
+#if (WF_OPT & 4)
+        sa = (double)psa.x + (double)psa.y;
+        sq = (double)psq.x + (double)psq.y;
+#endif
         if (tvalid && (sa != 0.0 || sq != 0.0)) {
             const int grp = c / a.gn_cpg, o = ta.b == b0 ? 0 : 64;
             atomicAdd(&gacc[o + grp * 2], sa);
@@ -436,6 +503,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (v != 0.0 && b < a.B) atomicAdd(&a.gn_sum[(((long)g * a.Ball + a.boff + b) * a.gn_groups) * 2 + (t & 63)], v);
         }
     }
+    WF_STAMP(9);
+#ifdef WF_STAMPS
+    if (lane == 0 && blockIdx.x < WF_STAMP_BLOCKS && blockIdx.z == 0) {
+        g_wf_stamps[((int)blockIdx.x * 4 + wave) * WF_STAMP_N + 14] = __builtin_amdgcn_s_memrealtime();
+        g_wf_stamps[((int)blockIdx.x * 4 + wave) * WF_STAMP_N + 13] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);
+    }
+#endif
 }
 
 
@@ -479,6 +553,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int vb = (xcd < br ? xcd * (bq_ + 1) : br * (bq_ + 1) + (xcd - br) * bq_) + (blockIdx.x >> 3);
     const int tb = vb / a.NC, cc = vb - tb * a.NC;
     if (t < 128) gacc[t] = 0.0;
+    WF_STAMP(0);
+    WF_STAMP(15);
 
     // ---- loader role: tile lt of the block, channel pair q of the round's 32 channels ----
     const int lt = t >> 4, q = t & 15;
@@ -573,6 +649,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // the shares of the other work as in the 32 x 32 kernel
     auto round = [&](const float* vs, float* vn, const int r, const int kbase, const bool first) __attribute__((always_inline)) {
         const int r2 = r + 2 < R ? r + 2 : R - 1;
+        // what this round prepares for the rounds after it: the row pass of the next round's patch, and the request + column pass of
+        // the patch after that - nothing for rounds that do not exist (WF_OPT & 1: the last two rounds used to redo the last patch for
+        // nobody: 147 vector, 36 LDS and 36 memory instructions per round beside an MFMA pipe that shares its lanes with them)
+        const bool do_rows = !(WF_OPT & 1) || r + 1 < R, do_full = !(WF_OPT & 1) || r + 2 < R;
         f32x4 av_next = *reinterpret_cast<const f32x4*>(vs + a_off);
 #pragma unroll
         for (int k = 0; k < 18; ++k) {
@@ -587,12 +667,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
                     f32x4& ac = acc[pi < SPLIT ? s2 : 0][pi][nt];
-                    ac = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[nt][e], (first && e == 0 && (s2 == 0 || pi < SPLIT)) ? zero : ac, 0, 0, 0);
+                    const f32x4 c0 = (first && e == 0 && (s2 == 0 || pi < SPLIT)) ? zero : ac;
+#if (WF_OPT & 2)
+                    ac = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[nt][e], av[e], c0, 0, 0, 0);      // rows = channels, columns = tiles
+#else
+                    ac = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[nt][e], c0, 0, 0, 0);
+#endif
                 }
             bload((kbase + k) % BR, r, k + BR);
-            if (k < 6) { row_pass(k, vn); gload_row(k, r2); }
-            if (k == 6) gload_coef(r2);
-            if (k >= 12) col_pass(k - 12);
+            // (block-uniform branches: the accumulators are not touched inside them)
+            if (k < 6 && do_rows) row_pass(k, vn);
+            if (do_full) {
+                if (k < 6) gload_row(k, r2);
+                if (k == 6) gload_coef(r2);
+                if (k >= 12) col_pass(k - 12);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -627,21 +716,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int j = 0; j < 6; ++j) col_pass(j);
     __syncthreads();
     static_assert(36 % BR == 0, "the ring index is static over a pair of rounds");
+    WF_STAMP(1);
     round(st0, st1, 0, 0, true);                 // the first pair of rounds starts the accumulation chains
     __syncthreads();
+    WF_STAMP(2);
     round(st1, st0, 1, 18, false);
     __syncthreads();
+    WF_STAMP(3);
     for (int r = 2; r < R; r += 2) {
         round(st0, st1, r, 0, false);
         __syncthreads();
         round(st1, st0, r + 1, 18, false);
         __syncthreads();
     }
+    WF_STAMP(6);
 
     // ---- epilogue: sums -> LDS [position][tile][64 channels] -> A^T . A per (tile, 4 channels) ----
+    const int hq = lane >> 4, rr = lane & 15;
+#if (WF_OPT & 2)
+    // filters were the A operand: lane (rr, hq) holds, per column block nt, channels nt * 16 + 4 hq .. + 3 of tile rr - one 16-byte
+    // store per (position, column block).  The sixteen 16-byte chunks of a tile's row are XOR-swizzled by the tile: the 16 lanes of
+    // a store (and, below, the 16 chunk readers of a tile) cover all 64 banks once.
+#pragma unroll
+    for (int pi = 0; pi < 9; ++pi)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const f32x4 v = pi < SPLIT ? acc[0][pi][nt] + acc[1][pi][nt] : acc[0][pi][nt];
+            *reinterpret_cast<f32x4*>(smem + ((wave * 9 + pi) * FT + rr) * FC + (((nt * 4 + hq) ^ rr) << 2)) = v;
+        }
+#else
     // (the 16-channel column blocks of a row are stored XOR-swizzled by row / 4: the four lane groups of an MFMA result hold
     // rows 4 apart, which would otherwise meet in the same banks)
-    const int hq = lane >> 4, rr = lane & 15;
 #pragma unroll
     for (int pi = 0; pi < 9; ++pi)
 #pragma unroll
@@ -649,9 +754,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 smem[((wave * 9 + pi) * FT + 4 * hq + e) * FC + ((nt ^ hq) << 4) + rr] = pi < SPLIT ? acc[0][pi][nt][e] + acc[1][pi][nt][e] : acc[0][pi][nt][e];
+#endif
     __syncthreads();
+    WF_STAMP(7);
     const int c = cc * FC + 4 * q;
+#if (WF_OPT & 2)
+    const int csw = ((q ^ lt) & 15) << 2;
+#else
     const int csw = (((q >> 2) ^ ((lt >> 2) & 3)) << 4) + (q & 3) * 4;
+#endif
     PV s[4][6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -670,6 +781,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const float lo = a.relu ? 0.f : -__builtin_inff();
     const int b0 = (int)(((long)tb * FT) / a.per_img);
     double sa = 0.0, sq = 0.0;
+    f32x2 psa = {0.f, 0.f}, psq = {0.f, 0.f};          // WF_OPT & 4: the thread's 64 outputs summed in packed fp32 first
     // the 16 pixels of the tile through a buffer descriptor, as the loader's patch: row + column offsets, and the pixels outside
     // the map (ragged last tiles, short phases, tiles past the end) are dropped by the range check instead of branches
     const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(a.out + (long)g * a.out_gs, a.out_bytes);
@@ -693,14 +805,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const unsigned vo = orow[i] + ocol[j];
             if (a.gn_sum) {
                 if (vo < OOBH) {
+#if (WF_OPT & 4)
+                    const f32x2 y01 = {y.x, y.y}, y23 = {y.z, y.w};
+                    psa = pk_add(pk_add(psa, y01), y23);
+                    psq = pk_fma_v(y23, y23, pk_fma_v(y01, y01, psq));
+#else
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { sa += (double)y[e]; sq += (double)y[e] * y[e]; }
+#endif
                 }
             }
             buf_store4(y, rs_out, vo);
         }
     }
+    WF_STAMP(8);
     if (a.gn_sum) {
+#if (WF_OPT & 4)
+        sa = (double)psa.x + (double)psa.y;
+        sq = (double)psq.x + (double)psq.y;
+#endif
         if (tvalid && (sa != 0.0 || sq != 0.0)) {
             const int grp = c / a.gn_cpg, o = ta.b == b0 ? 0 : 64;
             atomicAdd(&gacc[o + grp * 2], sa);
@@ -713,6 +836,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (v != 0.0 && b < a.B) atomicAdd(&a.gn_sum[(((long)g * a.Ball + a.boff + b) * a.gn_groups) * 2 + (t & 63)], v);
         }
     }
+    WF_STAMP(9);
+#ifdef WF_STAMPS
+    if (lane == 0 && blockIdx.x < WF_STAMP_BLOCKS && blockIdx.z == 0) {
+        g_wf_stamps[((int)blockIdx.x * 4 + wave) * WF_STAMP_N + 14] = __builtin_amdgcn_s_memrealtime();
+        g_wf_stamps[((int)blockIdx.x * 4 + wave) * WF_STAMP_N + 13] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);
+    }
+#endif
 }
 
 // per-(image, channel) scale and bias of a GroupNorm whose sums are in `stats` (the arithmetic of wino_input_kernel)
@@ -782,6 +912,14 @@ int winograd_fused_prepare() {
     QB_CHECK(hipFuncSetAttribute((const void*)wino_fused64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, w64::SMEM_BYTES));
     return 0;
 }
+
+#ifdef WF_STAMPS
+int wf_read_stamps(unsigned long long* dst, int n) {
+    if (n > WF_STAMP_BLOCKS * 4 * WF_STAMP_N) n = WF_STAMP_BLOCKS * 4 * WF_STAMP_N;
+    QB_CHECK(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wf_stamps), sizeof(unsigned long long) * n));
+    return 0;
+}
+#endif
 
 int launch_conv_winograd_fused(const WinoP& q, int Ball, int G, hipStream_t st) {
     const View& in = q.in;

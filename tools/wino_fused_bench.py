@@ -23,6 +23,7 @@ st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
+flts = [f for f in flt.split(";")]           # several substrings: "head 128>128;stem"
 LAYERS = [("fusion_res2 256>256 @120x160", 1, 120, 160, 256, 256, 1),
           ("fusion_res3 512>512 @60x80", 1, 60, 80, 512, 512, 1),
           ("res3.conv2 128>128 @60x80 (2 streams)", 2, 60, 80, 128, 128, 1),
@@ -58,7 +59,7 @@ def timed(fn):  # noqa: E302
 
 
 for name, ipf, H, W, Cin, Cout, d in LAYERS:
-    if flt not in name:
+    if not any(f in name for f in flts):
         continue
     B = ipf * F
     g = torch.Generator(device="cuda").manual_seed(5)
