@@ -111,6 +111,9 @@ ProfScope::~ProfScope() {
 
 }  // namespace quber
 
+#ifdef WF_STAMPS
+namespace quber { int wf_read_stamps(unsigned long long* dst, int n); }
+#endif
 using namespace quber;
 
 constexpr int GN_SLOTS = 64;
@@ -1280,7 +1283,6 @@ int quber_get_option(quber_ctx* c, int32_t key, int32_t* value) {
 }
 
 #ifdef WF_STAMPS
-namespace quber { int wf_read_stamps(unsigned long long* dst, int n); }
 int quber_wf_read_stamps(unsigned long long* dst, int n) { return quber::wf_read_stamps(dst, n); }
 #endif
 #ifdef PK_STAMPS

@@ -26,6 +26,8 @@
 //     the affine, the ReLU, accumulates the GroupNorm sums and stores 16 pixels x 16 bytes.
 // HBM traffic of a layer: its input (re-read per channel chunk through L2: the chunks of a tile block are neighbours on one
 // XCD), its output, the filters.
+#include <algorithm>
+
 #include "common.h"
 #include "winograd_xf.h"
 
@@ -58,10 +60,10 @@ using f32x2 = __attribute__((ext_vector_type(2))) float;
 #define WF_SKIP 0                               // diagnostic builds of the 32 x 32 kernel only (tools/wino_fused_ablate.sh): bit 0 no patch loads, 1 no filter loads, 2 no transforms, 4 no MFMA, 5 no epilogue, 6 no K loop
 #endif
 #ifndef WF_OPT
-#define WF_OPT 7                                // A/B switches of the round-4 diet: bit 0 = no transform work for rounds that do not exist (the last two rounds of the
-#endif                                          // K loop), bit 1 = MFMA operands swapped (filters as A): a lane's result registers are 4 consecutive CHANNELS of one tile,
-                                                // the epilogue stores them to LDS 16 bytes at a time (36 instead of 144 stores), bit 2 = GroupNorm sums of a thread's 64 outputs in
-                                                // packed fp32, converted to double once
+#define WF_OPT 7                                // A/B switches of the round-4 diet (profiles/r09d_wino_fused_diet.md): bit 0 = no transform work for rounds that do not
+#endif                                          // exist (the last two rounds of the K loop; 16 x 64 kernel only: in the 32 x 32 kernel the branches cost 20 %), bit 1 = MFMA operands
+                                                // swapped (filters as A): a lane's result registers are 4 consecutive CHANNELS of one tile, the epilogue stores them to LDS 16 bytes
+                                                // at a time (36 instead of 144 stores), bit 2 = GroupNorm sums of a thread's 64 outputs in packed fp32, converted to double once
 #ifdef WF_STAMPS
 // diagnostic build (make WFX=-DWF_STAMPS, tools/wf_stamps.py): s_memtime at the phase boundaries of the first blocks
 constexpr int WF_STAMP_BLOCKS = 512, WF_STAMP_N = 16;
@@ -310,11 +312,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     //   steps 0-5    row pass i of that patch -> 6 stores into image r + 1, then row i of the patch of round r + 2 is requested
     //   steps 12-17  column pass j of the patch of round r + 2 (requested >= 7 steps earlier)
     auto round = [&](const float* vs, float* vn, const int r, const int kbase, const bool first) __attribute__((always_inline)) {
-        const int r2 = r + 2 < R ? r + 2 : R - 1;
-        // what this round prepares for the rounds after it: the row pass of the next round's patch, and the request + column pass of
-        // the patch after that - nothing for rounds that do not exist (WF_OPT & 1: the last two rounds used to redo the last patch for
-        // nobody: 147 vector, 36 LDS and 36 memory instructions per round beside an MFMA pipe that shares its lanes with them)
-        const bool do_rows = !(WF_OPT & 1) || r + 1 < R, do_full = !(WF_OPT & 1) || r + 2 < R;                  // past the end: the last round again (never multiplied)
+        const int r2 = r + 2 < R ? r + 2 : R - 1;                  // past the end: the last round again (never multiplied)
+        // (the last two rounds redo the last patch for nobody: skipping that work behind block-uniform branches, as the 16 x 64 kernel
+        // does, splits the 4-MFMA steps of this kernel into basic blocks and costs 20-27 %: profiles/r09d_wino_fused_diet.md)
         f32x4 av_next = *reinterpret_cast<const f32x4*>(vs + a_off);
 #pragma unroll
         for (int k = 0; k < 18; ++k) {
@@ -340,13 +340,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
             bload((kbase + k) % BR, r, k + BR);
 #if !(WF_SKIP & 4)
-            // (block-uniform branches: the accumulators are not touched inside them)
-            if (k < 6 && do_rows) row_pass(k, vn);
-            if (do_full) {
-                if (k < 6) gload_row(k, r2);
-                if (k == 6) gload_coef(r2);
-                if (k >= 12) col_pass(k - 12);
-            }
+            if (k < 6) { row_pass(k, vn); gload_row(k, r2); }
+            if (k == 6) gload_coef(r2);
+            if (k >= 12) col_pass(k - 12);
 #endif
             __builtin_amdgcn_sched_barrier(0);
         }

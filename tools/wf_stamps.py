@@ -20,6 +20,9 @@ F = int(sys.argv[5]) if len(sys.argv) > 5 else 16
 lib = _lib.load()
 raw = C.CDLL(_lib.LIB_PATH)
 lib.quber_set_tuning(2, 1)
+for kv in os.environ.get("QUBER_TUNE", "").split(","):
+    if "=" in kv:
+        lib.quber_set_tuning(*(int(v) for v in kv.split("=")))
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 B = F
