@@ -72,6 +72,7 @@ def parse():
     ap.add_argument("--foreground-filter", action="store_true",
                     help="also run the reference adapter's LMFFNet foreground post-filter on the refined masks in every "
                          "step (eval/refiner_model.py:273-277; off for the headline metric, which is the refiner path)")
+    ap.add_argument("--no-graph", action="store_true", help="N > 1 runs replay the step as one hipGraph by default (--graph); this keeps them eager")
     ap.add_argument("--tuning", default="", help="A/B options of the engine (quber_set_option), e.g. 5=0 (include/quber_hip.h)")
     ap.add_argument("--no-split-mode", action="store_true",
                     help="skip the extra timing of the fp32-equivalent bf16x3 mode that a default (f32, 1 GPU) run appends as "
@@ -230,8 +231,10 @@ def dry_main(a, world, rank):
     import torch.distributed as dist
     from quber_amd import arch, dist as qdist
     if world > 1:
+        torch.set_num_threads(1)
         dist.init_process_group(os.environ.get("QUBER_DIST_BACKEND", "gloo"))
     specs = arch.param_specs()
+    wire = qdist.label_wire_dtype()
     sd = arch.init_state_dict(seed=0) if rank == 0 else None
     if world > 1:
         sd = qdist.broadcast_state_dict(sd, specs, src=0, device="cpu")
@@ -246,7 +249,7 @@ def dry_main(a, world, rank):
             tg = time.perf_counter()
             if pending is not None:
                 got = pending.wait()
-            pending = qdist.gather_label_maps(local, [B] * world, dst=0, async_op=True)
+            pending = qdist.gather_label_maps(local, [B] * world, dst=0, async_op=True, wire_dtype=wire)
             gather_s += time.perf_counter() - tg
         else:
             got = local
@@ -259,7 +262,7 @@ def dry_main(a, world, rank):
     alone = None
     if world > 1:
         tg = time.perf_counter()
-        qdist.gather_label_maps(local, [B] * world, dst=0)
+        qdist.gather_label_maps(local, [B] * world, dst=0, wire_dtype=wire)
         alone = (time.perf_counter() - tg) * 1e3
     ranks = [{"rank": rank, "world_size": world, "device": "cpu", "device_name": "cpu (dry)", "backend": dist.get_backend() if world > 1 else None,
               "weights": digest, "step_ms_median": float(np.median(step_ms)), "step_ms_max": float(np.max(step_ms)),
@@ -283,7 +286,7 @@ def dry_main(a, world, rank):
                           "gather": None if world == 1 else {
                               "ms_per_step_max_over_ranks": max(r["gather_ms_per_step"] for r in ranks),
                               "alone_ms_max_over_ranks": max((r["gather_alone_ms"] or 0.0) for r in ranks),
-                              "bytes_per_rank_per_step": B * H * W * 4},
+                              "bytes_per_rank_per_step": B * H * W * 2, "wire_dtype": "int16"},
                           "roofline": None, "cpu_baseline": None}), flush=True)
     if world > 1:
         dist.barrier()
@@ -306,7 +309,19 @@ def main():
     import torch
     from quber_amd import arch, dist as qdist, engine, synth
     dist = None
+    cpu_share = None
     if world > 1:
+        # one rank per GPU on ONE node: give every rank its own slice of the host's CPUs and one OpenMP thread - eight ranks each
+        # forking a 128-thread OpenMP team for a torch CPU op cost 90 ms per occurrence (profiles/r03q_predict_profile.txt)
+        try:
+            cpus = sorted(os.sched_getaffinity(0))
+            share = len(cpus) // world
+            if share >= 1:
+                os.sched_setaffinity(0, cpus[local * share:(local + 1) * share])
+                cpu_share = share
+        except (AttributeError, OSError):
+            pass
+        torch.set_num_threads(1)
         import torch.distributed as dist
         backend = os.environ.get("QUBER_DIST_BACKEND", "nccl")     # "gloo": rehearsal of the N > 1 path on one GPU
         ndev = torch.cuda.device_count()                           # (counting devices does not initialise the GPU)
@@ -385,7 +400,8 @@ def main():
             lmff.foreground(b_, d_, om)
 
     graph = None
-    if a.graph:
+    use_graph = a.graph or (world > 1 and not a.no_graph)      # N > 1: one launch per step keeps eight host processes out of each other's way
+    if use_graph:
         # every launch of the step goes to torch's current stream and nothing allocates or synchronises,
         # so the whole step is capturable (include/quber_hip.h contract)
         side = torch.cuda.Stream()
@@ -393,10 +409,18 @@ def main():
         with torch.cuda.stream(side):
             gpu_step()
         torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            gpu_step()
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                gpu_step()
+        except RuntimeError as e:                 # a node that cannot capture must still produce the line: eager steps
+            if a.graph:
+                raise
+            print(f"[bench rank {rank}] hipGraph capture failed ({e}); running eager steps", file=sys.stderr, flush=True)
+            graph = None
+            torch.cuda.synchronize()
 
+    wire = qdist.label_wire_dtype(top_k=eng.cap)     # int16 label maps on the wire (values -1, 1000 ... 1200): half the f32 bytes
     pending = [None]      # the label-map gather of the previous step: it travels over xGMI while this step computes
     gather_host_s = [0.0]  # host time inside the gather calls (issue + wait) - what the gather costs the step loop
 
@@ -409,7 +433,7 @@ def main():
             t_g = time.perf_counter()
             if pending[0] is not None:
                 pending[0].wait()
-            pending[0] = qdist.gather_label_maps(post["panoptic"], counts, dst=0, async_op=True)
+            pending[0] = qdist.gather_label_maps(post["panoptic"], counts, dst=0, async_op=True, wire_dtype=wire)
             gather_host_s[0] += time.perf_counter() - t_g
 
     def drain():
@@ -446,7 +470,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
             t_g = time.perf_counter()
-            qdist.gather_label_maps(post["panoptic"], counts, dst=0)
+            qdist.gather_label_maps(post["panoptic"], counts, dst=0, wire_dtype=wire)
             torch.cuda.synchronize()
             ts.append((time.perf_counter() - t_g) * 1e3)
         gather_alone_ms = float(np.median(ts[1:]))
@@ -457,7 +481,7 @@ def main():
                  "elapsed_ms_per_step": elapsed / a.steps * 1e3,
                  "gather_ms_per_step": gather_host_s[0] / a.steps * 1e3 if dist is not None else 0.0,
                  "gather_alone_ms": gather_alone_ms,
-                 "instances_out": int(cnt_host.sum()), "frames": int(B)}
+                 "instances_out": int(cnt_host.sum()), "frames": int(B), "cpus": cpu_share, "hipgraph": graph is not None}
     ranks = [rank_info]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
@@ -478,6 +502,8 @@ def main():
             line["host_io"] = host_io
         if world == 1 and a.predict_calls > 0 and a.dtype == "f32":
             line["predict_api"] = predict_api_run(a, sd, host, dev)
+            if H == 480 and W == 640:        # the adapter resizes every frame to 640x480 (eval/refiner_model.py:246)
+                line["predict_api"]["streamed"] = predict_stream_run(a, sd, host, dev)
         if a.dtype == "f32" and world == 1 and not a.no_split_mode:
             line["fp32_equivalent_bf16x3"] = split_mode_run(a, make_engine, sd, gpu_step_args=(masks, bgr, depth, offsets, max_inst),
                                                             exact_logits=logits, exact_pan=post["panoptic"])
@@ -589,6 +615,45 @@ def predict_api_run(a, sd, host, dev):
             "note": "MaskRefinerPredictor.predict(rgb, depth, masks) + output['instances'].to('cpu').pred_masks.numpy(), numpy in / "
                     "numpy out, one frame per call (the reference's timed region, eval/refiner_model.py:265-271); "
                     "engine_batch1_step = the same frame on resident device buffers, no host side"}
+
+
+def predict_stream_run(a, sd, host, dev, frames=64):
+    """The reference's evaluation loop (eval/eval_utils.py:235-286: MaskRefiner.predict(rgb_path, depth_path, masks) per frame) through
+    this repo's drop-in adapter in its streamed, batched form: files on disk in, numpy masks out.  Host work (PNG decoding, resize,
+    depth normalisation, TELEA in-painting of the depth holes, upload) on worker threads, `batch` frames per engine call, one batch in
+    flight while the previous one is copied out (quber_amd/eval/refiner_model.py:predict_stream)."""
+    import tempfile
+    from PIL import Image
+    from quber_amd.eval.refiner_model import MaskRefiner
+    B, N = a.batch, a.instances
+    workers = max(2, min(12, (os.cpu_count() or 4) - 2))
+    with tempfile.TemporaryDirectory() as d:
+        items = []
+        rng = np.random.default_rng(0)
+        for i in range(min(B, 8)):
+            Image.fromarray(host["rgb"][i][:, :, ::-1].copy()).save(os.path.join(d, f"rgb{i}.png"))
+            mm = host["depth"][i][:, :, 0].astype(np.uint16) * 5 + 300
+            for _ in range(12):                                            # ~8 000 zero-depth pixels in a dozen holes: work for the in-painting
+                y, x = int(rng.integers(0, mm.shape[0] - 40)), int(rng.integers(0, mm.shape[1] - 40))
+                mm[y:y + 22, x:x + 30] = 0
+            Image.fromarray(mm).save(os.path.join(d, f"depth{i}.png"))
+            items.append((os.path.join(d, f"rgb{i}.png"), os.path.join(d, f"depth{i}.png"), host["masks"][i] != 0, None))
+        ref = MaskRefiner(None, None, dataset="OSD", device=str(dev))
+        ref.refiner_predictor.model.state_dict = sd
+        ref.refiner_predictor.model._engines.clear()
+        work = [items[i % len(items)] for i in range(frames)]
+        out = {}
+        for name, kw in (("batch1_2workers", dict(workers=2, batch=1)), (f"batch{B}_{workers}workers", dict(workers=workers, batch=B))):
+            list(ref.predict_stream(work[:max(2 * B, 8)], **kw))           # warm-up: engine for this batch size, worker streams
+            t0 = time.perf_counter()
+            res = list(ref.predict_stream(work, **kw))
+            dt = time.perf_counter() - t0
+            out[name] = {"frames_per_s": frames / dt, "masks_per_s": N * frames / dt, "ms_per_frame": dt / frames * 1e3,
+                         "instances_out_mean": float(np.mean([len(r[0]) for r in res]))}
+        out["note"] = ("files -> refined numpy masks through MaskRefiner.predict_stream (PNG decode, resize, normalize_depth, TELEA in-painting, "
+                       "upload on worker threads; eval/eval_utils.py:235-286 drives the reference's adapter frame after frame)")
+        out["frames"] = frames
+        return out
 
 
 def host_io_run(a, eng, host, offsets, logits, post, max_inst, dev):
@@ -712,7 +777,7 @@ def report(a, eng, world, elapsed, ranks, center_bias, sd, host, step_ms, t, gpu
         "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": f"batch={B} {W}x{H} RGB-D, {N} initial instances/frame, ResNet-50 RGB-D refiner "
                                f"(boundary-error -> fg/centre/offset), encode+network+grouping+mask extraction",
-                   "frames_per_step_per_gpu": B, "parallelism": f"dp{world}", "hipgraph": bool(a.graph),
+                   "frames_per_step_per_gpu": B, "parallelism": f"dp{world}", "hipgraph": bool(ranks[0].get("hipgraph", a.graph)),
                    "foreground_filter": bool(a.foreground_filter),
                    "weights": ("seeded synthetic, loud predictors N(0, %.2f), centre bias %.4f calibrated for ~N peaks per frame"
                                % (arch_sigma(), center_bias)) if a.heads == "loud"
@@ -723,7 +788,7 @@ def report(a, eng, world, elapsed, ranks, center_bias, sd, host, step_ms, t, gpu
         "gather": None if world == 1 else {
             "ms_per_step_max_over_ranks": max(r["gather_ms_per_step"] for r in ranks),
             "alone_ms_max_over_ranks": max((r["gather_alone_ms"] or 0.0) for r in ranks),
-            "bytes_per_rank_per_step": B * H * W * 4,
+            "bytes_per_rank_per_step": B * H * W * 2, "wire_dtype": "int16 (labels -1, 1000 ... 1200; f32 again on rank 0)",
             "note": "ms_per_step = host time inside the asynchronous gather's issue + wait calls per step (what the overlapped "
                     "gather costs the step loop); alone = one synchronous gather with nothing beside it (what it would cost "
                     "un-overlapped); per-rank values and step medians in rccl_ranks"},

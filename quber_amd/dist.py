@@ -41,18 +41,35 @@ def broadcast_state_dict(sd, specs, src=0, device="cpu"):
     return out
 
 
-def gather_label_maps(local, counts, dst=0, async_op=False):
+def label_wire_dtype(label_divisor=1000, n_thing_classes=1, top_k=200):
+    """Smallest integer type that carries every value a panoptic map can hold (-1, class * divisor [+ instance id <= top_k]):
+    int16 for the refiner's one thing class (labels <= 1200) - half the bytes of the f32 maps on the wire."""
+    return torch.int16 if (n_thing_classes + 1) * label_divisor + top_k < 32768 else torch.int32
+
+
+def gather_label_maps(local, counts, dst=0, async_op=False, wire_dtype=None):
     """local: [b_r, H, W] label maps of this rank (b_r may differ by one between ranks); counts: frames per rank.
     Returns the concatenated [sum(b_r), H, W] tensor on `dst`, None elsewhere.
+    wire_dtype (e.g. label_wire_dtype()): the maps travel in that integer type (the values are integers: lossless) and come back in
+    `local`'s own dtype on `dst`.
     async_op=True: returns a handle instead, `h.wait()` -> that result.  The collective then runs on the backend's
     own stream beside whatever the caller enqueues next (the next step's kernels); `local` is copied first, so the
     caller may overwrite it at once."""
     world, rank = dist.get_world_size(), dist.get_rank()
     bmax = max(counts)
-    if local.shape[0] < bmax:
-        pad = torch.cat([local, local.new_full((bmax - local.shape[0],) + tuple(local.shape[1:]), -1)])
+    out_dtype = local.dtype
+    wired = wire_dtype is not None and wire_dtype != local.dtype
+    if wired:
+        # a fresh tensor (no further copy needed for the asynchronous form), handed to the backend as bytes: neither gloo nor
+        # RCCL has a 16-bit integer type, and a gather only moves bytes
+        local = local.to(wire_dtype).contiguous().view(torch.uint8)
+        async_copy = False
     else:
-        pad = local.clone() if async_op else local
+        async_copy = async_op
+    if local.shape[0] < bmax:
+        pad = torch.cat([local, local.new_full((bmax - local.shape[0],) + tuple(local.shape[1:]), 255 if wired else -1)])
+    else:
+        pad = local.clone() if async_copy else local
     pad = pad.contiguous().to(_comm_device(pad.device))
     bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
     work = dist.gather(pad, bufs, dst=dst, async_op=async_op)
@@ -60,7 +77,8 @@ def gather_label_maps(local, counts, dst=0, async_op=False):
     def finish():
         if rank != dst:
             return None
-        return torch.cat([b[:c] for b, c in zip(bufs, counts)])
+        got = torch.cat([b[:c] for b, c in zip(bufs, counts)])
+        return got.view(wire_dtype).to(out_dtype) if wired else got
 
     if not async_op:
         return finish()

@@ -130,18 +130,20 @@ class MaskRefiner:
 
     def _refine(self, fr):
         """The reference's timed region and what follows it (eval/refiner_model.py:265-297) on a loaded frame."""
+        start = time.time()
         if self.dataset == "armbench":
-            start = time.time()
             output = self.refiner_predictor.predict(fr["rgb"], None, fr["masks"])[0]
-            refined = output["instances"].to("cpu").pred_masks.numpy() if "instances" in output else []
+        else:
+            output = self.refiner_predictor.predict(fr["rgb"], fr["depth"], fr["masks"])[0]
+        refined = output["instances"].to("cpu").pred_masks.numpy() if "instances" in output else []
+        return self._finish(fr, output, refined, start)
+
+    def _finish(self, fr, output, refined, start):
+        """What follows the refiner call inside and after the reference's timed region (eval/refiner_model.py:273-297): the
+        LMFFNet foreground filter, the elapsed time, the OCID zero-depth masking."""
+        if self.dataset == "armbench":
             return refined, output, time.time() - start, None
         rgb, depth, zero_depth = fr["rgb"], fr["depth"], fr["zero_depth"]
-        start = time.time()
-        output = self.refiner_predictor.predict(rgb, depth, fr["masks"])[0]
-        if "instances" not in output:
-            refined = []
-        else:
-            refined = output["instances"].to("cpu").pred_masks.numpy()
         fg, filt = None, refined
         if self.lmffnet is not None:
             from ..foreground.predictor import filter_masks
@@ -164,33 +166,101 @@ class MaskRefiner:
     def predict(self, rgb_path, depth_path, initial_masks, fg_mask=None):
         return self._refine(self._load(rgb_path, depth_path, initial_masks))
 
-    def predict_stream(self, items, workers=2):
+    def predict_stream(self, items, workers=2, batch=1):
         """items: iterable of (rgb_path, depth_path, initial_masks[, fg_mask]) -> yields predict()'s tuple per item, in order.
-        The reference's evaluation loop (eval/eval_utils.py:277) calls predict() frame after frame; the host side of a frame -
+        The reference's evaluation loop (eval/eval_utils.py:235-286) calls predict() frame after frame; the host side of a frame -
         file decoding and, above all, the TELEA depth in-painting (9-14 ms, two to three times the refiner's GPU time) - is
         independent of the previous frame's refinement, so it runs ahead on `workers` threads (the in-painting is a ctypes call
-        and releases the GIL; the workers' device work - resize, depth normalisation - goes to their own HIP stream)."""
+        and releases the GIL; the workers' device work - resize, depth normalisation, and with batch > 1 the upload of the frame -
+        goes to their own HIP stream).
+
+        batch = k > 1: k consecutive frames of one size are refined by ONE engine call (the batched form of a1 ... a11 the
+        reference lacks: it always runs batch 1, predictor.py:358), with the next batch already enqueued while the results of the
+        current one are copied out - the GPU's batched throughput through the reference's own adapter API.  The per-frame tuples
+        are the ones predict() returns (`seconds` = the batch's device time / k); a frame's logits may differ from its batch-1
+        logits in the last bits (split-K partitions follow the launch size), which tests/test_gpu_network.py bounds and explains."""
         from collections import deque
         from concurrent.futures import ThreadPoolExecutor
+        import threading
         dev = self.refiner_predictor.device
         sides = {}
+        k = max(1, int(batch))
 
         def load(item):
-            import threading
-            side = sides.setdefault(threading.get_ident(), torch.cuda.Stream(device=dev))
+            tid = threading.get_ident()
+            if tid not in sides:
+                sides[tid] = torch.cuda.Stream(device=dev)
+            side = sides[tid]
             with torch.cuda.stream(side):
-                return self._load(item[0], item[1], item[2])
+                fr = self._load(item[0], item[1], item[2])
+                if k > 1:                        # the frame goes to the device here, off the main thread
+                    m = fr["masks"]
+                    fr["d_rgb"] = torch.from_numpy(fr["rgb"]).to(dev, non_blocking=True)
+                    fr["d_depth"] = None if fr["depth"] is None else torch.from_numpy(np.ascontiguousarray(fr["depth"])).to(dev, non_blocking=True)
+                    fr["d_masks"] = torch.from_numpy(np.ascontiguousarray(m.view(np.uint8) if m.dtype == np.bool_ else (m != 0).view(np.uint8))).to(dev, non_blocking=True)
+                    fr["ready"] = torch.cuda.Event()
+                    fr["ready"].record(side)
+                    side.synchronize()           # (pageable sources: the copies are complete when this returns)
+                return fr
+
+        def enqueue(frs):
+            model = self.refiner_predictor.model
+            n = max(f["d_masks"].shape[0] for f in frs)
+            H_, W_ = frs[0]["d_rgb"].shape[:2]
+            for f in frs:
+                torch.cuda.current_stream().wait_event(f["ready"])
+            d_masks = torch.zeros((len(frs), n, H_, W_), dtype=torch.uint8, device=dev)
+            for b, f in enumerate(frs):
+                if f["d_masks"].shape[0]:
+                    d_masks[b, :f["d_masks"].shape[0]] = f["d_masks"]
+            d_rgb = torch.stack([f["d_rgb"] for f in frs])
+            two = self.refiner_predictor.depth_on and self.refiner_predictor.rgb_on
+            if not self.refiner_predictor.rgb_on:                 # depth-only: the image IS the depth map (predictor.py:296-298)
+                d_rgb = torch.stack([f["d_depth"] for f in frs])
+            d_depth = torch.stack([f["d_depth"] for f in frs]) if two else None
+            return model.enqueue_batch(d_rgb, d_depth, d_masks, slots=max(32, n + 12), capacity=k)
+
+        def collect(frs, hd):
+            outs, ms = self.refiner_predictor.model.collect_batch(hd)
+            for fr, output in zip(frs, outs):
+                refined = output["instances"].pred_masks.cpu().numpy() if "instances" in output else []
+                # `seconds` of a streamed frame = its share of the batch's device time (+ the post-filter, if any, inside _finish)
+                yield self._finish(fr, output, refined, time.time() - ms * 1e-3 / len(frs))
 
         with ThreadPoolExecutor(max_workers=max(1, workers)) as pool:
             it = iter(items)
             ahead = deque()
+            depth = max(workers, 2 * k if k > 1 else 0)
             for item in it:
                 ahead.append(pool.submit(load, item))
-                if len(ahead) > workers:
+                if len(ahead) > depth:
                     break
-            while ahead:
+
+            def next_frame():
                 fr = ahead.popleft().result()
                 nxt = next(it, None)
                 if nxt is not None:
                     ahead.append(pool.submit(load, nxt))
-                yield self._refine(fr)
+                return fr
+
+            if k == 1:
+                while ahead:
+                    yield self._refine(next_frame())
+                return
+            pending = None                        # (frames, handle) of the batch in flight
+            carry = None                          # a loaded frame that did not fit the current group (other size)
+            while ahead or carry is not None:
+                group = [carry] if carry is not None else []
+                carry = None
+                while len(group) < k and ahead:
+                    fr = next_frame()
+                    if group and fr["d_rgb"].shape != group[0]["d_rgb"].shape:
+                        carry = fr
+                        break
+                    group.append(fr)
+                hd = enqueue(group)
+                if pending is not None:
+                    yield from collect(*pending)
+                pending = (group, hd)
+            if pending is not None:
+                yield from collect(*pending)

@@ -173,6 +173,38 @@ class RefinerModel:
         # prefetch into a pinned buffer plus the copy out of it does not beat - tools/predict_profile.py)
         return self.frame_dict(eng, logits[0], post_out, 0, k, masks_b)
 
+    # -- batched form on device-resident frames, split into "enqueue" and "collect" so that a caller can keep one batch in flight --
+    def enqueue_batch(self, d_bgr, d_depth, d_masks, slots=32, capacity=0):
+        """d_bgr / d_depth: u8 [B,H,W,3] (depth None for single-stream configs), d_masks: u8 [B,N,H,W] on the device.  Enqueues a1 ...
+        a11 and the extraction of the first `slots` instance masks of every frame on the current stream WITHOUT synchronising;
+        returns a handle for collect_batch()."""
+        B, H, W = d_bgr.shape[:3]
+        eng = self.engine_for(H, W, max(B, capacity), d_masks.shape[1])      # (`capacity`: the caller's batch size - a short last batch must not rebuild)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        if d_masks.shape[1]:
+            offsets = eng.encode(d_masks)
+        else:
+            offsets = torch.zeros((B, 3, H, W), dtype=torch.float32, device=self.device)
+        logits = eng.forward(d_bgr, d_depth, offsets)
+        post = eng.postprocess(logits)
+        slots = min(max(1, slots), eng.cap)
+        masks = eng.extract_masks(post, slots)
+        count = torch.empty((B,), dtype=torch.int32).pin_memory()
+        count.copy_(post["count"], non_blocking=True)
+        e1.record()
+        return {"eng": eng, "logits": logits, "post": post, "masks": masks, "slots": slots, "count": count, "e0": e0, "e1": e1}
+
+    def collect_batch(self, hd):
+        """-> (list of the reference's per-frame output dicts, device milliseconds of the whole batch)."""
+        hd["e1"].synchronize()
+        eng, post, count = hd["eng"], hd["post"], hd["count"].numpy()
+        kmax = int(count.max()) if len(count) else 0
+        masks = hd["masks"] if kmax <= hd["slots"] else eng.extract_masks(post, kmax)      # rare: more instances than pre-extracted slots
+        outs = [self.frame_dict(eng, hd["logits"][b], post, b, int(count[b]), masks[b, :int(count[b])].view(torch.bool) if count[b] > 0 else None)
+                for b in range(len(count))]
+        return outs, hd["e0"].elapsed_time(hd["e1"])
+
     def __call__(self, batched_inputs):
         dev = self.device
         imgs = torch.stack([x["image"] for x in batched_inputs]).to(dev)

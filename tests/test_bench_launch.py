@@ -33,11 +33,26 @@ def test_self_launch_two_ranks_dry():
             assert k in x, k
         assert x["backend"] == "gloo" and x["frames"] == 3 and x["gather_alone_ms"] > 0
     g = j["gather"]
-    assert g["bytes_per_rank_per_step"] == 3 * 32 * 48 * 4
+    assert g["bytes_per_rank_per_step"] == 3 * 32 * 48 * 2        # int16 label maps on the wire
     assert g["ms_per_step_max_over_ranks"] == max(x["gather_ms_per_step"] for x in j["rccl_ranks"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in j, k
+
+
+def test_self_launch_eight_ranks_dry():
+    """The N = 8 line of the driver's scaling run, rehearsed on the CPU: eight ranks rendezvous over gloo, receive rank 0's weights,
+    gather their (asynchronous) label maps in rank order, and rank 0 prints ONE line that carries all eight."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry", "--steps", "2", "--batch", "2"],
+                       env=_env(QUBER_DIST_BACKEND="gloo", OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["dry"] is True and j["scaling"] == "weak"
+    assert [x["rank"] for x in j["rccl_ranks"]] == list(range(8)) and all(x["world_size"] == 8 for x in j["rccl_ranks"])
+    assert len({x["weights"] for x in j["rccl_ranks"]}) == 1
+    assert j["gather"]["bytes_per_rank_per_step"] == 2 * 32 * 48 * 2          # int16 label maps on the wire
 
 
 def test_nccl_preflight_needs_enough_gpus():

@@ -40,9 +40,11 @@ def _worker(rank, world, port, n_frames, q):
         handle = qdist.gather_label_maps(mine, counts, dst=0, async_op=True)
         mine.fill_(-7.0)
         later = handle.wait()
+        # int16 on the wire (bench.py: label values are integers <= 1200), f32 again on the destination
+        wired = qdist.gather_label_maps(local, counts, dst=0, async_op=True, wire_dtype=qdist.label_wire_dtype()).wait()
         if rank == 0:
             ok_g = allmaps.shape == (n_frames, 4, 6) and all(float(allmaps[i, 0, 0]) == i for i in range(n_frames))
-            ok_g = ok_g and torch.equal(later, allmaps)
+            ok_g = ok_g and torch.equal(later, allmaps) and torch.equal(wired, allmaps) and wired.dtype == allmaps.dtype
         else:
             ok_g = allmaps is None and later is None
         q.put((rank, ok_w, ok_g, (s, e)))

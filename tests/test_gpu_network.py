@@ -200,6 +200,64 @@ def test_adapter_stream_equals_sequential(tmp_path):
         assert torch.equal(o0["sem_seg"], o1["sem_seg"]) and torch.equal(o0["panoptic_seg"][0], o1["panoptic_seg"][0])
 
 
+def test_adapter_stream_batched(tmp_path):
+    """MaskRefiner.predict_stream(items, workers, batch=k): k frames per engine call, one batch in flight while the previous one is
+    copied out - the tuples of predict() called frame after frame, in order.  With loud heads (real instances).  A frame's logits
+    in a batch-k launch may differ from its batch-1 logits in the last bits (the split-K partition follows the launch size; same
+    plan, same arithmetic class): the label maps must agree on >= 99.999 % of the pixels and every differing pixel must be a
+    float64 near-tie of the decision that produced it (oracle/fp64_anchor.py: explain_label_flips)."""
+    from PIL import Image
+    from oracle import fp64_anchor as fa
+    from quber_amd.eval.refiner_model import MaskRefiner
+    n_frames, n = 10, 6
+    items = []
+    for i in range(n_frames):
+        sc = synth.make_scene(40 + i, 480, 640, n)
+        Image.fromarray(sc["rgb"][:, :, ::-1].copy()).save(tmp_path / f"rgb{i}.png")
+        depth_mm = (sc["depth"][:, :, 0].astype(np.uint16) * 5 + 300)
+        depth_mm[40 + 10 * i:70 + 10 * i, 100:180] = 0                      # a hole to in-paint
+        Image.fromarray(depth_mm).save(tmp_path / f"depth{i}.png")
+        items.append((str(tmp_path / f"rgb{i}.png"), str(tmp_path / f"depth{i}.png"), sc["masks"] != 0, None))
+    sd = arch.init_state_dict(seed=0, loud_heads=True, center_bias=-1.68)
+    ref = MaskRefiner(None, None, dataset="OSD")
+    model = ref.refiner_predictor.model
+    model.state_dict = sd
+    model._engines.clear()
+    seq = [ref.predict(*it) for it in items]
+    got = list(ref.predict_stream(items, workers=4, batch=4))              # 4 + 4 + 2 frames
+    assert len(got) == n_frames and sum(len(r[0]) for r in seq) >= n_frames       # real instances
+    differing = []
+    px = 0
+    for i, ((m0, o0, s0, _), (m1, o1, s1, _)) in enumerate(zip(seq, got)):
+        assert s0 > 0 and s1 > 0
+        assert float((o0["sem_seg"] - o1["sem_seg"]).abs().max()) < TOL and float((o0["eee_boundary"] - o1["eee_boundary"]).abs().max()) < TOL
+        p0, p1 = o0["panoptic_seg"][0], o1["panoptic_seg"][0]
+        nd = int((p0 != p1).sum())
+        px += nd
+        if nd:
+            differing.append(i)
+        else:
+            np.testing.assert_array_equal(np.asarray(m0), np.asarray(m1))
+            assert torch.equal(o0["instances"].pred_boxes.tensor, o1["instances"].pred_boxes.tensor) if "instances" in o0 else "instances" not in o1
+    assert px <= 1e-5 * n_frames * 480 * 640, f"{px} pixels differ"
+    # every differing pixel: a float64 near-tie.  The logits of both launch sizes, from the engine the adapter used.
+    if differing:
+        frs = [ref._load(*items[i][:3]) for i in differing]
+        eng = model.engine_for(480, 640, 4, n)
+        image = torch.from_numpy(np.stack([np.concatenate([f["rgb"], f["depth"]], -1) for f in frs])).permute(0, 3, 1, 2)
+        offs = np.stack([encode_np.encode_initial_masks((f["masks"] != 0).astype(np.uint8)) for f in frs])
+        o64 = {j: fa.cat_heads(o)[0] for j, o, _ in fa.oracle64(sd, image, offs, want_taps=())}
+        for j, (i, f) in enumerate(zip(differing, frs)):
+            a0 = (i // 4) * 4                                               # the batch the stream put the frame in
+            grp = [ref._load(*items[q][:3]) for q in range(a0, min(a0 + 4, n_frames))]
+            d = lambda key: torch.from_numpy(np.stack([np.ascontiguousarray(g[key]) for g in grp])).cuda()
+            mk = torch.from_numpy(np.stack([(g["masks"] != 0).astype(np.uint8) for g in grp])).cuda()
+            lg_b = eng.forward(d("rgb"), d("depth"), eng.encode(mk))[i - a0].cpu()
+            lg_1 = eng.forward(d("rgb")[i - a0:i - a0 + 1], d("depth")[i - a0:i - a0 + 1], eng.encode(mk[i - a0:i - a0 + 1]))[0].cpu()
+            rep = fa.explain_label_flips(lg_b, lg_1, o64[j], pan_hip=got[i][1]["panoptic_seg"][0].cpu())
+            print(f"\n[stream batch 4] frame {i}: {rep}")
+
+
 def test_adapter_armbench_branch(tmp_path):
     """eval/refiner_model.py:226-244: RGB only, image resized to shortest edge 800 / longest 1333 with cv2.resize, the
     initial masks with INTER_NEAREST, refined masks returned at THAT size, fg_mask None."""

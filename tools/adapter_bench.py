@@ -42,6 +42,15 @@ with tempfile.TemporaryDirectory() as d:
     t0 = time.perf_counter()
     out = list(ref.predict_stream(work))
     stream = time.perf_counter() - t0
+    batched = {}
+    ncpu = os.cpu_count() or 4
+    for wk, bt in ((4, 4), (8, 8), (min(12, ncpu), 16), (min(16, ncpu), 16)):
+        work_b = [items[i % 8] for i in range(max(F, 6 * bt))]
+        list(ref.predict_stream(work_b[:2 * bt], workers=wk, batch=bt))            # engine of this capacity, worker streams
+        t0 = time.perf_counter()
+        res = list(ref.predict_stream(work_b, workers=wk, batch=bt))
+        dtb = time.perf_counter() - t0
+        batched[(wk, bt)] = (len(work_b) / dtb, float(np.mean([len(r[0]) for r in res])))
     t0 = time.perf_counter()
     for it in work[:8]:
         ref._load(*it[:3])
@@ -62,3 +71,5 @@ with tempfile.TemporaryDirectory() as d:
     print(f"{F} frames 640x480, N = {N}: predict() frame after frame {F / seq:.1f} frames/s ({seq / F * 1e3:.2f} ms/frame; reference-timed region "
           f"median {np.median(refined) * 1e3:.2f} ms); predict_stream() {F / stream:.1f} frames/s ({stream / F * 1e3:.2f} ms/frame); "
           f"host pre-processing alone (file decode + resize + normalise + TELEA) {load * 1e3:.2f} ms/frame")
+    for (wk, bt), (fps, k) in batched.items():
+        print(f"  predict_stream(workers={wk}, batch={bt}): {fps:.1f} frames/s = {fps * N:.0f} refined masks/s file-to-masks ({k:.1f} instances out per frame; {ncpu} host CPUs visible)")
