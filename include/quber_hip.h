@@ -214,6 +214,10 @@ int quber_resize_u8(const uint8_t* dev_src, int32_t src_h, int32_t src_w, int32_
  *   host_img u8 [h][w], host_mask u8 [h][w] (non-zero = to be filled)  ->  host_out u8 [h][w] */
 int quber_inpaint_telea_u8(const uint8_t* host_img, const uint8_t* host_mask, int32_t h, int32_t w, int32_t radius,
                            uint8_t* host_out);
+/* inpaint_depth(depth, kernel_size) of eval/preprocess_utils.py:44-64 (factor 1) in one host call: mask = pixels whose three channels
+ * are 0, dilated by a kernel x kernel square; TELEA in-painting (radius = kernel) per channel; only the zero pixels are replaced.
+ *   host_depth3 u8 [h][w][3]  ->  host_out3 u8 [h][w][3] */
+int quber_inpaint_depth_u8(const uint8_t* host_depth3, int32_t h, int32_t w, int32_t kernel, uint8_t* host_out3);
 
 /* ---- introspection / kernel-level entry points used by the parity tests and the benchmark ---- */
 /* device pointer + NHWC geometry of a named intermediate of the last quber_forward ("res2", "res3", "res5", "y", ...) */

@@ -198,7 +198,8 @@ int launch_upsample_logits(const float* q, float* out, int B, int nch, int h, in
 int launch_normalize_depth(const void* depth, int is_float, long n, double lo, double hi, uint8_t* out3, uint8_t* zero,
                            hipStream_t st);
 
-int inpaint_telea_u8_host(const uint8_t* img, const uint8_t* mask, int H, int W, int radius, uint8_t* out);   // HOST pointers
+int inpaint_telea_u8_host(const uint8_t* img, const uint8_t* mask, int H, int W, int radius, uint8_t* out);
+int inpaint_depth_u8_host(const uint8_t* depth3, int H, int W, int kernel, uint8_t* out3);   // HOST pointers
 int launch_resize_u8(const uint8_t* src, int sh, int sw, int ch, uint8_t* dst, int dh, int dw, int linear, hipStream_t st);
 
 // LMFFNet foreground network + post-filter (lmff.hip)

@@ -177,4 +177,46 @@ int inpaint_telea_u8_host(const uint8_t* img, const uint8_t* mask, int H, int W,
     return 0;
 }
 
+// inpaint_depth of eval/preprocess_utils.py:44-64 (factor 1) on one 3-channel 8-bit depth image, whole: mask = pixels whose three
+// channels are all 0, dilated by a kernel x kernel square; cv2.inpaint(..., kernel, INPAINT_TELEA) per channel; only the pixels that
+// were 0 take the filled value.  One call = one GIL-free stretch for the Python adapter's worker threads (the numpy form of the
+// mask preparation held the interpreter lock for ~2 ms per frame: tools/stream_probe.py).
+int inpaint_depth_u8_host(const uint8_t* depth3, int H, int W, int kernel, uint8_t* out3) {
+    if (!depth3 || !out3 || H < 1 || W < 1 || kernel < 1 || !(kernel & 1)) return fail("inpaint_depth: bad argument");
+    const size_t n = (size_t)H * W;
+    std::vector<uint8_t> zero(n), mask(n, 0), src(n), dst(n);
+    bool any = false, same = true;
+    for (size_t i = 0; i < n; ++i) {
+        const uint8_t a = depth3[3 * i], b = depth3[3 * i + 1], c = depth3[3 * i + 2];
+        zero[i] = (a | b | c) == 0;
+        any |= zero[i] != 0;
+        same &= a == b && a == c;
+        out3[3 * i] = a; out3[3 * i + 1] = b; out3[3 * i + 2] = c;
+    }
+    if (!any) return 0;
+    const int r = kernel / 2;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            if (!zero[(size_t)y * W + x]) continue;
+            for (int dy = -r; dy <= r; ++dy)
+                for (int dx = -r; dx <= r; ++dx) {
+                    const int yy = y + dy, xx = x + dx;
+                    if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) mask[(size_t)yy * W + xx] = 1;
+                }
+        }
+    for (int c = 0; c < (same ? 1 : 3); ++c) {           // normalize_depth replicates one channel: in-paint it once
+        for (size_t i = 0; i < n; ++i) src[i] = depth3[3 * i + c];
+        if (int rc = inpaint_telea_u8_host(src.data(), mask.data(), H, W, kernel, dst.data())) return rc;
+        for (size_t i = 0; i < n; ++i) {
+            // np.where(depth == 0, filled, depth), element-wise per channel
+            if (same) {
+                if (depth3[3 * i] == 0) out3[3 * i] = out3[3 * i + 1] = out3[3 * i + 2] = dst[i];
+            } else if (depth3[3 * i + c] == 0) {
+                out3[3 * i + c] = dst[i];
+            }
+        }
+    }
+    return 0;
+}
+
 }  // namespace quber

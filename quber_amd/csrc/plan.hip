@@ -1522,6 +1522,10 @@ int quber_inpaint_telea_u8(const uint8_t* host_img, const uint8_t* host_mask, in
     return inpaint_telea_u8_host(host_img, host_mask, h, w, radius, host_out);
 }
 
+int quber_inpaint_depth_u8(const uint8_t* host_depth3, int32_t h, int32_t w, int32_t kernel, uint8_t* host_out3) {
+    return inpaint_depth_u8_host(host_depth3, h, w, kernel, host_out3);
+}
+
 int quber_resize_u8(const uint8_t* src, int32_t src_h, int32_t src_w, int32_t channels, uint8_t* dst, int32_t dst_h,
                     int32_t dst_w, int32_t linear, void* stream) {
     if (!src || !dst) return fail("bad argument to quber_resize_u8");

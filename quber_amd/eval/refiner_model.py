@@ -44,33 +44,19 @@ def normalize_depth(depth, min_val=250.0, max_val=1500.0):
 
 def inpaint_depth(depth, kernel_size=3):
     """eval/preprocess_utils.py:44-64 with factor = 1: mask = pixels whose three channels are 0, dilated by a 3x3 square;
-    TELEA in-painting with radius 3; only the zero pixels of the input are replaced."""
+    TELEA in-painting with radius 3; only the zero pixels of the input are replaced.  One host call (csrc/inpaint.hip:
+    inpaint_depth_u8_host) that releases the GIL from the mask preparation to the merge: predict_stream's worker threads run it
+    side by side (the numpy form of the mask preparation held the interpreter lock for ~2 ms per frame)."""
     import ctypes as C
     from .. import _lib
     lib = _lib.load()
     depth = np.ascontiguousarray(depth, dtype=np.uint8)
+    if depth.ndim != 3 or depth.shape[2] != 3:
+        raise ValueError("inpaint_depth expects a [H, W, 3] uint8 depth image")
     h, w = depth.shape[:2]
-    mask = np.all(depth == 0, axis=2)
-    if not mask.any():
-        return depth
-    r = kernel_size // 2
-    pad = np.pad(mask, r)
-    dil = np.zeros_like(mask)
-    for dy in range(kernel_size):
-        for dx in range(kernel_size):
-            dil |= pad[dy:dy + h, dx:dx + w]
-    m8 = np.ascontiguousarray(dil, dtype=np.uint8)
-    filled = np.empty_like(depth)
-    same = bool((depth[..., 0] == depth[..., 1]).all() and (depth[..., 0] == depth[..., 2]).all())
-    for c in range(1 if same else depth.shape[2]):      # normalize_depth replicates one channel: in-paint it once
-        src = np.ascontiguousarray(depth[..., c])
-        dst = np.empty_like(src)
-        _lib.check(lib.quber_inpaint_telea_u8(C.c_void_p(src.ctypes.data), C.c_void_p(m8.ctypes.data), h, w, kernel_size,
-                                              C.c_void_p(dst.ctypes.data)))
-        filled[..., c] = dst
-    if same:
-        filled[..., 1] = filled[..., 2] = filled[..., 0]
-    return np.where(depth == 0, filled, depth)
+    out = np.empty_like(depth)
+    _lib.check(lib.quber_inpaint_depth_u8(C.c_void_p(depth.ctypes.data), h, w, kernel_size, C.c_void_p(out.ctypes.data)))
+    return out
 
 
 def resize_shortest_edge_shape(oldh, oldw, short_edge_length=800, max_size=1333):
@@ -197,7 +183,8 @@ class MaskRefiner:
                     m = fr["masks"]
                     fr["d_rgb"] = torch.from_numpy(fr["rgb"]).to(dev, non_blocking=True)
                     fr["d_depth"] = None if fr["depth"] is None else torch.from_numpy(np.ascontiguousarray(fr["depth"])).to(dev, non_blocking=True)
-                    fr["d_masks"] = torch.from_numpy(np.ascontiguousarray(m.view(np.uint8) if m.dtype == np.bool_ else (m != 0).view(np.uint8))).to(dev, non_blocking=True)
+                    # (the encoder tests the mask bytes for non-zero, csrc/encode.hip: bool / 0-255 masks upload as they are)
+                    fr["d_masks"] = torch.from_numpy(np.ascontiguousarray(m.view(np.uint8) if m.dtype == np.bool_ else m.astype(np.uint8, copy=False))).to(dev, non_blocking=True)
                     fr["ready"] = torch.cuda.Event()
                     fr["ready"].record(side)
                     side.synchronize()           # (pageable sources: the copies are complete when this returns)

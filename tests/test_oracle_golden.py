@@ -232,3 +232,12 @@ def test_inpaint_telea_restatement():
     np.testing.assert_array_equal(out, inpaint_np.inpaint_depth(d3))
     assert (out[d3 != 0] == d3[d3 != 0]).all() and (out[12:20, 30:41] > 0).all()
     assert np.abs(out[12:20, 30:41, 0].astype(int) - d[12:20, 30:41]).max() <= 8
+    # three DIFFERENT channels (not what normalize_depth produces, but what the function accepts): a pixel is masked only where all
+    # three are 0, yet every zero ELEMENT takes its channel's filled value (np.where(depth == 0, ...), element-wise)
+    d3b = d3.copy()
+    d3b[..., 1] = np.clip(d3b[..., 1].astype(int) + 7, 0, 255)
+    d3b[12:20, 30:41] = 0
+    d3b[25:27, 50:60, 2] = 0                                           # zero in one channel only: not part of the mask
+    np.testing.assert_array_equal(inpaint_depth(d3b), inpaint_np.inpaint_depth(d3b))
+    no_holes = np.repeat(d[:, :, None], 3, 2)
+    np.testing.assert_array_equal(inpaint_depth(no_holes), no_holes)
