@@ -626,7 +626,7 @@ def predict_stream_run(a, sd, host, dev, frames=64):
     from PIL import Image
     from quber_amd.eval.refiner_model import MaskRefiner
     B, N = a.batch, a.instances
-    workers = max(2, min(12, (os.cpu_count() or 4) - 2))
+    workers = max(2, min(16, (os.cpu_count() or 4) - 2))
     with tempfile.TemporaryDirectory() as d:
         items = []
         rng = np.random.default_rng(0)

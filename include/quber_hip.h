@@ -218,6 +218,14 @@ int quber_inpaint_telea_u8(const uint8_t* host_img, const uint8_t* host_mask, in
  * are 0, dilated by a kernel x kernel square; TELEA in-painting (radius = kernel) per channel; only the zero pixels are replaced.
  *   host_depth3 u8 [h][w][3]  ->  host_out3 u8 [h][w][3] */
 int quber_inpaint_depth_u8(const uint8_t* host_depth3, int32_t h, int32_t w, int32_t kernel, uint8_t* host_out3);
+/* The same on the DEVICE, asynchronous on `stream`, for a batch of frames, bit-equal to the host function above (csrc/inpaint_dev.hip):
+ * the hole regions that can influence each other (connected components of the mask dilated by radius + 2) are marched one wave each
+ * with the host's queue order; a pixel's (2 r + 1)^2 neighbours are evaluated one per lane and summed in the host's order.
+ * kernel <= 3 (the reference calls it with 3: eval/refiner_model.py:255).
+ *   dev_depth3 u8 [batch][h][w][3] -> dev_out3 u8 [batch][h][w][3]; dev_workspace: quber_inpaint_depth_workspace_bytes(batch, h, w) bytes */
+int64_t quber_inpaint_depth_workspace_bytes(int32_t batch, int32_t h, int32_t w);
+int quber_inpaint_depth_device(const uint8_t* dev_depth3, int32_t batch, int32_t h, int32_t w, int32_t kernel, void* dev_workspace,
+                               int64_t workspace_bytes, uint8_t* dev_out3, void* stream);
 
 /* ---- introspection / kernel-level entry points used by the parity tests and the benchmark ---- */
 /* device pointer + NHWC geometry of a named intermediate of the last quber_forward ("res2", "res3", "res5", "y", ...) */

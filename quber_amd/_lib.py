@@ -61,6 +61,8 @@ SIGNATURES = {
     "quber_normalize_depth": (C.c_int, [_P, _I, C.c_int64, C.c_double, C.c_double, _P, _P, _P]),
     "quber_inpaint_telea_u8": (C.c_int, [_P, _P, _I, _I, _I, _P]),
     "quber_inpaint_depth_u8": (C.c_int, [_P, _I, _I, _I, _P]),
+    "quber_inpaint_depth_workspace_bytes": (C.c_int64, [_I, _I, _I]),
+    "quber_inpaint_depth_device": (C.c_int, [_P, _I, _I, _I, _I, _P, C.c_int64, _P, _P]),
     "quber_resize_u8": (C.c_int, [_P, _I, _I, _I, _P, _I, _I, _I, _P]),
     "quber_debug_tensor": (C.c_int, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(_I * 4), C.POINTER(_I)]),
     "quber_debug_tensor_elem_size": (C.c_int32, [_P, C.c_char_p]),

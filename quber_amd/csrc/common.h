@@ -199,7 +199,9 @@ int launch_normalize_depth(const void* depth, int is_float, long n, double lo, d
                            hipStream_t st);
 
 int inpaint_telea_u8_host(const uint8_t* img, const uint8_t* mask, int H, int W, int radius, uint8_t* out);
-int inpaint_depth_u8_host(const uint8_t* depth3, int H, int W, int kernel, uint8_t* out3);   // HOST pointers
+int inpaint_depth_u8_host(const uint8_t* depth3, int H, int W, int kernel, uint8_t* out3);
+size_t inpaint_depth_ws_bytes(int B, int H, int W);
+int launch_inpaint_depth(const uint8_t* depth3, int B, int H, int W, int kernel, void* ws, size_t ws_bytes, uint8_t* out3, hipStream_t st);   // HOST pointers
 int launch_resize_u8(const uint8_t* src, int sh, int sw, int ch, uint8_t* dst, int dh, int dw, int linear, hipStream_t st);
 
 // LMFFNet foreground network + post-filter (lmff.hip)

@@ -1526,6 +1526,13 @@ int quber_inpaint_depth_u8(const uint8_t* host_depth3, int32_t h, int32_t w, int
     return inpaint_depth_u8_host(host_depth3, h, w, kernel, host_out3);
 }
 
+int64_t quber_inpaint_depth_workspace_bytes(int32_t batch, int32_t h, int32_t w) { return (int64_t)inpaint_depth_ws_bytes(batch, h, w); }
+
+int quber_inpaint_depth_device(const uint8_t* dev_depth3, int32_t batch, int32_t h, int32_t w, int32_t kernel, void* dev_workspace,
+                               int64_t workspace_bytes, uint8_t* dev_out3, void* stream) {
+    return launch_inpaint_depth(dev_depth3, batch, h, w, kernel, dev_workspace, (size_t)workspace_bytes, dev_out3, (hipStream_t)stream);
+}
+
 int quber_resize_u8(const uint8_t* src, int32_t src_h, int32_t src_w, int32_t channels, uint8_t* dst, int32_t dst_h,
                     int32_t dst_w, int32_t linear, void* stream) {
     if (!src || !dst) return fail("bad argument to quber_resize_u8");

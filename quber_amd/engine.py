@@ -100,6 +100,27 @@ def resize_u8(img, dh, dw, linear=True):
     return out
 
 
+_INPAINT_WS = {}
+
+
+def inpaint_depth(depth3, kernel_size=3):
+    """inpaint_depth of eval/preprocess_utils.py:44-64 on the device (csrc/inpaint_dev.hip; bit-equal to the host restatement
+    quber_inpaint_depth_u8): depth3 u8 [H,W,3] or [B,H,W,3] device tensor -> the same shape.  Asynchronous on the current stream."""
+    lib = _lib.load()
+    assert depth3.is_cuda and depth3.dtype == torch.uint8 and depth3.is_contiguous() and depth3.shape[-1] == 3 and depth3.dim() in (3, 4)
+    B = 1 if depth3.dim() == 3 else depth3.shape[0]
+    H, W = depth3.shape[-3], depth3.shape[-2]
+    need = lib.quber_inpaint_depth_workspace_bytes(B, H, W)
+    key = (depth3.device, torch.cuda.current_stream().cuda_stream)      # one workspace per stream: calls on one stream are ordered
+    ws = _INPAINT_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=depth3.device)
+        _INPAINT_WS[key] = ws
+    out = torch.empty_like(depth3)
+    _lib.check(lib.quber_inpaint_depth_device(_ptr(depth3), B, H, W, int(kernel_size), _ptr(ws), ws.numel(), _ptr(out), _stream()))
+    return out
+
+
 class Engine:
     """One context on the current device.  All methods are asynchronous on torch's current stream."""
 

@@ -15,9 +15,10 @@ is opt-in (``foreground_filter=True``) because the reference's ``rgbd_lmffnet.pt
 a meaningless foreground - with it off, ``fg_mask`` is None and the OCID branch masks zero depth on the unfiltered masks.
 
 ``inpaint_depth`` (eval/preprocess_utils.py:44-64: the pixels whose NORMALISED depth is 0 - holes and everything nearer than
-``min_val`` - are filled with ``cv2.inpaint(..., 3, cv2.INPAINT_TELEA)``) runs on the host, as in the reference:
-``quber_inpaint_telea_u8`` restates Telea's fast-marching method in the form OpenCV implements it (csrc/inpaint.hip; parity
-unpinned, own tolerance - OpenCV is not in the image).  ``MaskRefiner(inpaint=False)`` skips it.
+``min_val`` - are filled with ``cv2.inpaint(..., 3, cv2.INPAINT_TELEA)``) runs on the device too (``inpaint="device"``, the
+default: csrc/inpaint_dev.hip marches the independent hole regions one wave each) - bit-equal to the host function
+(``inpaint="host"``: ``quber_inpaint_depth_u8``, csrc/inpaint.hip), which restates Telea's fast-marching method in the form OpenCV
+implements it (parity with cv2 unpinned, own tolerance - OpenCV is not in the image).  ``MaskRefiner(inpaint=False)`` skips it.
 cv2 / imageio are absent from the image, so files are read with PIL.
 """
 import time
@@ -71,11 +72,12 @@ def resize_shortest_edge_shape(oldh, oldw, short_edge_length=800, max_size=1333)
 
 class MaskRefiner:
     def __init__(self, config_file=None, weights_file=None, dataset="OSD", device="cuda:0", foreground_filter=False,
-                 lmffnet_weights="./foreground_segmentation/rgbd_lmffnet.pth", inpaint=True):
+                 lmffnet_weights="./foreground_segmentation/rgbd_lmffnet.pth", inpaint="device"):
         self.refiner_predictor = MaskRefinerPredictor(config_file, weights_file=weights_file, device=device)
         self.dataset = dataset
         self.lmffnet = None
-        self.inpaint = inpaint
+        # "device" (default): csrc/inpaint_dev.hip; "host" / True: the host function it equals bit for bit; False: none
+        self.inpaint = "host" if inpaint is True else inpaint
         if foreground_filter:
             from ..foreground.predictor import lmffNet
             self.lmffnet = lmffNet(lmffnet_weights, device=device)
@@ -105,14 +107,23 @@ class MaskRefiner:
         rgb = self._resize(rgb, H, W, linear=True)                               # cv2.resize(rgb_img, (W, H))
         zero_depth = np.where(depth == 0)
         lo, hi = (0.25, 1.5) if "npy" in depth_path else (250.0, 1500.0)
+        # normalise -> nearest resize -> in-paint: on the device from end to end (refiner_model.py:250-255), one copy back for the
+        # numpy-in API of the predictor (the batched stream keeps the device tensor)
         if depth.ndim == 2 and depth.dtype in (np.uint16, np.float32):
-            depth = qengine.normalize_depth(self._dev(np.array(depth)), lo, hi)[0].cpu().numpy()
+            d_dev = qengine.normalize_depth(self._dev(np.array(depth)), lo, hi)[0]
         else:
-            depth = normalize_depth(depth, lo, hi)
-        depth = self._resize(depth, H, W, linear=False)                          # cv2.resize(..., INTER_NEAREST)
-        if self.inpaint:
-            depth = inpaint_depth(depth)                                         # refiner_model.py:255
-        return {"rgb": np.ascontiguousarray(rgb), "depth": depth, "masks": initial_masks, "zero_depth": zero_depth}
+            d_dev = self._dev(normalize_depth(depth, lo, hi))
+        if tuple(d_dev.shape[:2]) != (H, W):
+            d_dev = qengine.resize_u8(d_dev, H, W, linear=False)                 # cv2.resize(..., INTER_NEAREST)
+        if self.inpaint == "device":
+            d_dev = qengine.inpaint_depth(d_dev)                                 # refiner_model.py:255, csrc/inpaint_dev.hip
+            depth = d_dev.cpu().numpy()
+        elif self.inpaint:
+            depth = inpaint_depth(d_dev.cpu().numpy())                           # the host function (bit-equal; csrc/inpaint.hip)
+            d_dev = None
+        else:
+            depth = d_dev.cpu().numpy()
+        return {"rgb": np.ascontiguousarray(rgb), "depth": depth, "masks": initial_masks, "zero_depth": zero_depth, "depth_dev": d_dev}
 
     def _refine(self, fr):
         """The reference's timed region and what follows it (eval/refiner_model.py:265-297) on a loaded frame."""
@@ -182,7 +193,10 @@ class MaskRefiner:
                 if k > 1:                        # the frame goes to the device here, off the main thread
                     m = fr["masks"]
                     fr["d_rgb"] = torch.from_numpy(fr["rgb"]).to(dev, non_blocking=True)
-                    fr["d_depth"] = None if fr["depth"] is None else torch.from_numpy(np.ascontiguousarray(fr["depth"])).to(dev, non_blocking=True)
+                    if fr.get("depth_dev") is not None:
+                        fr["d_depth"] = fr["depth_dev"]          # already there (normalised, resized, in-painted on the device)
+                    else:
+                        fr["d_depth"] = None if fr["depth"] is None else torch.from_numpy(np.ascontiguousarray(fr["depth"])).to(dev, non_blocking=True)
                     # (the encoder tests the mask bytes for non-zero, csrc/encode.hip: bool / 0-255 masks upload as they are)
                     fr["d_masks"] = torch.from_numpy(np.ascontiguousarray(m.view(np.uint8) if m.dtype == np.bool_ else m.astype(np.uint8, copy=False))).to(dev, non_blocking=True)
                     fr["ready"] = torch.cuda.Event()
@@ -208,9 +222,8 @@ class MaskRefiner:
             return model.enqueue_batch(d_rgb, d_depth, d_masks, slots=max(32, n + 12), capacity=k)
 
         def collect(frs, hd):
-            outs, ms = self.refiner_predictor.model.collect_batch(hd)
-            for fr, output in zip(frs, outs):
-                refined = output["instances"].pred_masks.cpu().numpy() if "instances" in output else []
+            outs, ms, host = self.refiner_predictor.model.collect_batch(hd, host_masks=True)
+            for fr, output, refined in zip(frs, outs, host):
                 # `seconds` of a streamed frame = its share of the batch's device time (+ the post-filter, if any, inside _finish)
                 yield self._finish(fr, output, refined, time.time() - ms * 1e-3 / len(frs))
 

@@ -195,15 +195,24 @@ class RefinerModel:
         e1.record()
         return {"eng": eng, "logits": logits, "post": post, "masks": masks, "slots": slots, "count": count, "e0": e0, "e1": e1}
 
-    def collect_batch(self, hd):
-        """-> (list of the reference's per-frame output dicts, device milliseconds of the whole batch)."""
+    def collect_batch(self, hd, host_masks=False):
+        """-> (list of the reference's per-frame output dicts, device milliseconds of the whole batch[, per-frame numpy masks]).
+        host_masks: also the refined masks of every frame as numpy bool [K_b, H, W] - what the reference's caller takes with
+        output['instances'].to('cpu').pred_masks.numpy() - through ONE device-to-host copy for the whole batch (the arrays of a
+        batch are views of one host block)."""
         hd["e1"].synchronize()
         eng, post, count = hd["eng"], hd["post"], hd["count"].numpy()
         kmax = int(count.max()) if len(count) else 0
         masks = hd["masks"] if kmax <= hd["slots"] else eng.extract_masks(post, kmax)      # rare: more instances than pre-extracted slots
         outs = [self.frame_dict(eng, hd["logits"][b], post, b, int(count[b]), masks[b, :int(count[b])].view(torch.bool) if count[b] > 0 else None)
                 for b in range(len(count))]
-        return outs, hd["e0"].elapsed_time(hd["e1"])
+        ms = hd["e0"].elapsed_time(hd["e1"])
+        if not host_masks:
+            return outs, ms
+        if kmax == 0:
+            return outs, ms, [[] for _ in count]
+        host = masks[:, :kmax].contiguous().cpu().numpy().view(np.bool_)
+        return outs, ms, [host[b, :int(count[b])] if count[b] > 0 else [] for b in range(len(count))]
 
     def __call__(self, batched_inputs):
         dev = self.device
