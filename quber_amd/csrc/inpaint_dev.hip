@@ -25,7 +25,7 @@ namespace {
 
 enum : uint8_t { KNOWN = 0, BAND = 1, INSIDE = 2, CHANGE = 3 };
 constexpr int MAXR = 3;                      // radius of the fill neighbourhood: (2 r + 1)^2 <= 49 lanes
-constexpr int MAXCOMP_BLOCKS = 2048;
+constexpr int MAXCOMP_BLOCKS = 256;          // blocks of the march launch (each loops over components; a block without work exits at once)
 
 struct DNode { float t; uint32_t seq; int i, j; };
 
@@ -55,8 +55,8 @@ __device__ __forceinline__ bool heap_less(const DNode& a, const DNode& b) { retu
 // The march is a chain of dependent accesses (a pop walks ~log2 n levels), and one wave has nothing to hide their latency behind:
 // the first HCAP entries - the top levels, which every operation touches - live in LDS (64-cycle accesses), deeper ones in the
 // component's range of global memory (an L2 round trip each).  The narrow band of a hole holds about its perimeter: thousands of
-// pixels fit the LDS part entirely.
-constexpr int HCAP = 3072;
+// pixels fit the LDS part entirely (16 KB: the march must not crowd the refiner's kernels off the CUs it shares with them).
+constexpr int HCAP = 1024;
 struct Heap {
     DNode* lds;
     DNode* glob;
@@ -230,7 +230,7 @@ constexpr int WIN_BYTES = WCAP * 7;
 __global__ __launch_bounds__(64) void tel_march_kernel(const Tel a, int ch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     __shared__ float4 sv[64];                    // per neighbour: (w I, w gix rx, w giy ry, w); zeros for the neighbours that do not count
-    __shared__ DNode hl[HCAP];                   // the top of the active heap (48 KB)
+    __shared__ DNode hl[HCAP];                   // the top of the active heap (16 KB)
     const int lane = threadIdx.x;
     if (ch > 0 && !a.counters[3]) return;        // the three channels are alike (what normalize_depth produces): channel 0's fill serves all
     const int R = a.R, C = a.C, range = a.range;

@@ -111,7 +111,10 @@ def inpaint_depth(depth3, kernel_size=3):
     B = 1 if depth3.dim() == 3 else depth3.shape[0]
     H, W = depth3.shape[-3], depth3.shape[-2]
     need = lib.quber_inpaint_depth_workspace_bytes(B, H, W)
-    key = (depth3.device, torch.cuda.current_stream().cuda_stream)      # one workspace per stream: calls on one stream are ordered
+    import threading
+    # one workspace per (stream, calling thread): the launches of one call are ordered on their stream, but two threads that share
+    # a stream interleave theirs
+    key = (depth3.device, torch.cuda.current_stream().cuda_stream, threading.get_ident())
     ws = _INPAINT_WS.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=depth3.device)

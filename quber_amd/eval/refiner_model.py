@@ -15,10 +15,11 @@ is opt-in (``foreground_filter=True``) because the reference's ``rgbd_lmffnet.pt
 a meaningless foreground - with it off, ``fg_mask`` is None and the OCID branch masks zero depth on the unfiltered masks.
 
 ``inpaint_depth`` (eval/preprocess_utils.py:44-64: the pixels whose NORMALISED depth is 0 - holes and everything nearer than
-``min_val`` - are filled with ``cv2.inpaint(..., 3, cv2.INPAINT_TELEA)``) runs on the device too (``inpaint="device"``, the
-default: csrc/inpaint_dev.hip marches the independent hole regions one wave each) - bit-equal to the host function
-(``inpaint="host"``: ``quber_inpaint_depth_u8``, csrc/inpaint.hip), which restates Telea's fast-marching method in the form OpenCV
-implements it (parity with cv2 unpinned, own tolerance - OpenCV is not in the image).  ``MaskRefiner(inpaint=False)`` skips it.
+``min_val`` - are filled with ``cv2.inpaint(..., 3, cv2.INPAINT_TELEA)``): ``inpaint="host"`` (default) runs
+``quber_inpaint_depth_u8`` (csrc/inpaint.hip: Telea's fast-marching method restated in the form OpenCV implements it; parity with cv2
+unpinned, own tolerance - OpenCV is not in the image) on the calling thread, as the reference does; ``inpaint="device"`` runs
+csrc/inpaint_dev.hip, which marches the independent hole regions one wave each and equals the host function bit for bit
+(tests/test_gpu_inpaint.py).  ``MaskRefiner(inpaint=False)`` skips it.
 cv2 / imageio are absent from the image, so files are read with PIL.
 """
 import time
@@ -72,11 +73,14 @@ def resize_shortest_edge_shape(oldh, oldw, short_edge_length=800, max_size=1333)
 
 class MaskRefiner:
     def __init__(self, config_file=None, weights_file=None, dataset="OSD", device="cuda:0", foreground_filter=False,
-                 lmffnet_weights="./foreground_segmentation/rgbd_lmffnet.pth", inpaint="device"):
+                 lmffnet_weights="./foreground_segmentation/rgbd_lmffnet.pth", inpaint="host"):
         self.refiner_predictor = MaskRefinerPredictor(config_file, weights_file=weights_file, device=device)
         self.dataset = dataset
         self.lmffnet = None
-        # "device" (default): csrc/inpaint_dev.hip; "host" / True: the host function it equals bit for bit; False: none
+        # "host" / True (default): csrc/inpaint.hip on the calling (worker) thread; "device": csrc/inpaint_dev.hip, bit-equal, for hosts
+        # short of CPU cores - a march occupies one wave per hole region for milliseconds and, streamed beside the refiner's batches,
+        # costs more GPU time than the host cores it frees are worth on this box: 193 against 278 frames/s (profiles/r09f_adapter_stream.txt);
+        # False: none
         self.inpaint = "host" if inpaint is True else inpaint
         if foreground_filter:
             from ..foreground.predictor import lmffNet

@@ -81,7 +81,7 @@ def test_device_inpaint_batch_and_channels():
 
 
 def test_adapter_paths_agree(tmp_path):
-    """MaskRefiner's pre-processing (eval/refiner_model.py:246-263) with inpaint="device" (default) and inpaint="host": the frames
+    """MaskRefiner's pre-processing (eval/refiner_model.py:246-263) with inpaint="device" and inpaint="host" (default): the frames
     handed to the predictor are identical."""
     from PIL import Image
     from quber_amd import synth
@@ -95,8 +95,8 @@ def test_adapter_paths_agree(tmp_path):
         mm[y:y + int(rng.integers(2, 30)), x:x + int(rng.integers(2, 40))] = 0
     mm[:6, 200:260] = 0                                    # a hole through the frame
     Image.fromarray(mm).save(tmp_path / "depth.png")
-    dev_ref = MaskRefiner(None, None, dataset="OSD")
-    host_ref = MaskRefiner(None, None, dataset="OSD", inpaint="host")
+    dev_ref = MaskRefiner(None, None, dataset="OSD", inpaint="device")
+    host_ref = MaskRefiner(None, None, dataset="OSD")
     assert dev_ref.inpaint == "device" and host_ref.inpaint == "host"
     a = dev_ref._load(str(tmp_path / "rgb.png"), str(tmp_path / "depth.png"), sc["masks"] != 0)
     b = host_ref._load(str(tmp_path / "rgb.png"), str(tmp_path / "depth.png"), sc["masks"] != 0)

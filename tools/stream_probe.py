@@ -17,11 +17,12 @@ with tempfile.TemporaryDirectory() as d:
             y,x=int(rng.integers(0,440)),int(rng.integers(0,600)); mm[y:y+22,x:x+30]=0
         Image.fromarray(mm).save(os.path.join(d,f"depth{i}.png"))
         items.append((os.path.join(d,f"rgb{i}.png"),os.path.join(d,f"depth{i}.png"),sc["masks"]!=0,None))
-    ref=MaskRefiner(None,None,dataset="OSD")
+    ref=MaskRefiner(None,None,dataset="OSD",inpaint=os.environ.get("INPAINT","host"))
+    print("inpaint =", ref.inpaint)
     ref.refiner_predictor.model.state_dict=arch.init_state_dict(seed=0,loud_heads=True,center_bias=-1.68)
     ref.refiner_predictor.model._engines.clear()
     work=[items[i%8] for i in range(128)]
-    for wk,bt in ((16,16),(24,16),(32,16),(48,16),(32,32)):
+    for wk,bt in ((16,16),(32,16)):
         list(ref.predict_stream(work[:2*bt],workers=wk,batch=bt))
         t0=time.perf_counter(); res=list(ref.predict_stream(work,workers=wk,batch=bt)); dt=time.perf_counter()-t0
         print(f"workers={wk} batch={bt}: {len(work)/dt:.1f} frames/s", flush=True)
@@ -38,7 +39,7 @@ with tempfile.TemporaryDirectory() as d:
     print(f"instrumented: {len(work)/dt:.1f} frames/s; per batch: total {dt/tt['n']*1e3:.1f} ms, enqueue_batch {tt['enq']/tt['n']*1e3:.1f} ms, collect_batch (sync + dicts) {tt['col']/tt['n']*1e3:.1f} ms")
     # load alone with 32 threads
     from concurrent.futures import ThreadPoolExecutor
-    for wk in (8,16,32,64):
+    for wk in (16,):
         with ThreadPoolExecutor(wk) as pool:
             t0=time.perf_counter(); list(pool.map(lambda it: ref._load(*it[:3]), work)); dt=time.perf_counter()-t0
         print(f"_load alone on {wk} threads: {len(work)/dt:.1f} frames/s", flush=True)
