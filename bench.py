@@ -503,7 +503,10 @@ def main():
         if world == 1 and a.predict_calls > 0 and a.dtype == "f32":
             line["predict_api"] = predict_api_run(a, sd, host, dev)
             if H == 480 and W == 640:        # the adapter resizes every frame to 640x480 (eval/refiner_model.py:246)
-                line["predict_api"]["streamed"] = predict_stream_run(a, sd, host, dev)
+                try:
+                    line["predict_api"]["streamed"] = predict_stream_run(a, sd, host, dev)
+                except Exception as e:           # an auxiliary figure must never cost the line its headline
+                    line["predict_api"]["streamed"] = {"error": repr(e)}
         if a.dtype == "f32" and world == 1 and not a.no_split_mode:
             line["fp32_equivalent_bf16x3"] = split_mode_run(a, make_engine, sd, gpu_step_args=(masks, bgr, depth, offsets, max_inst),
                                                             exact_logits=logits, exact_pan=post["panoptic"])
@@ -804,6 +807,10 @@ def report(a, eng, world, elapsed, ranks, center_bias, sd, host, step_ms, t, gpu
                      "algorithmic_note": "2 x MAC of the direct convolutions (SURVEY 8d: 375.6 GFLOP per 640x480 frame) over the "
                                          "same time; exceeds `achieved` because Winograd F(m x m,3x3) executes (m+2)^2 / 9m^2 of them",
                      "executed_over_algorithmic": nominal / algorithmic if algorithmic else None,
+                     # `achieved` counts what the matrix pipe multiplies, the padding of ragged Winograd tiles included (a 30x40 map under
+                     # 4x4 tiles carries 6.7 % of it): the share of it, and `frac` with it taken out
+                     "tile_padding_share_of_executed": (eng.forward_flops_padding() * B / nominal) if nominal else None,
+                     "frac_without_tile_padding": (ex_tf / peak) * (1.0 - eng.forward_flops_padding() * B / nominal) if nominal else None,
                      "fp32_equivalent_tflops": nominal / (fam_ms * 1e-3) / 1e12 if fam_ms else 0.0,
                      "fp32_pipe_launches": None if not f32p_n else {
                          "launches": f32p_n, "ms": f32p_ms, "tflops": f32p_flops / (f32p_ms * 1e-3) / 1e12,

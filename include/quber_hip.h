@@ -237,6 +237,9 @@ double quber_forward_flops(quber_ctx* ctx);
 /* FLOPs the matrix pipe actually executes per forward at batch 1: a layer planned as Winograd F(m x m,3x3) counts
  * (m+2)^2 / (9 m^2) of its algorithmic FLOPs, padded tiles included (transform additions not counted) */
 double quber_forward_flops_executed(quber_ctx* ctx);
+/* ... and the part of those executed FLOPs that is tile padding (ragged maps, short phases of dilated layers): a 30x40 map under 4x4 tiles
+ * carries 6.7 % of it */
+double quber_forward_flops_padding(quber_ctx* ctx);
 /* Options.  Every knob that shapes a plan or changes the arithmetic / work distribution of a launch belongs to a CONTEXT:
  *   quber_set_option(ctx, key, value)   this context only.  "plan" keys act when quber_finalize_weights builds the plan and
  *                                       are refused afterwards; "launch" keys may change between forwards.

@@ -68,6 +68,7 @@ SIGNATURES = {
     "quber_debug_tensor_elem_size": (C.c_int32, [_P, C.c_char_p]),
     "quber_forward_flops": (C.c_double, [_P]),
     "quber_forward_flops_executed": (C.c_double, [_P]),
+    "quber_forward_flops_padding": (C.c_double, [_P]),
     "quber_set_tuning": (None, [_I, _I]),
     "quber_set_option": (C.c_int, [_P, _I, _I]),
     "quber_get_option": (C.c_int, [_P, _I, C.POINTER(_I)]),

@@ -171,6 +171,7 @@ struct quber_ctx {
     double flops = 0.0;
     double wino_flops = 0.0;      // algorithmic FLOPs (batch 1) of the layers that take the Winograd path
     double wino_saved = 0.0;      // ... and the part of them the path does not execute
+    double wino_pad = 0.0;        // executed FLOPs (batch 1) spent on the padding of ragged / short-phase Winograd tiles
     std::vector<hipEvent_t> prof_events;
     std::unique_ptr<quber::Profiler> prof;
     bool finalized = false;
@@ -371,6 +372,8 @@ struct Builder {
                 const int m = has6 ? 6 : wm;
                 c->wino_flops += 2.0 * OH * OW * (double)cin_real * k * k * Cout * G;
                 c->wino_saved += 2.0 * OH * OW * (double)cin_real * k * k * Cout * G * (1.0 - (has6 ? r6 : best));
+                // exactly tiled, F(m x m) executes (m + 2)^2 / (9 m^2) of the direct multiplies: what it executes beyond that is tile padding
+                c->wino_pad += 2.0 * OH * OW * (double)cin_real * k * k * Cout * G * ((has6 ? r6 : best) - (double)((m + 2) * (m + 2)) / (9.0 * m * m));
                 const int P = (m + 2) * (m + 2);
                 std::vector<float> u((size_t)G * P * Cout * Cin);
                 for (int g = 0; g < G; ++g) winograd_weights_host(w[g], Cout, Cin, m, &u[(size_t)g * P * Cout * Cin]);
@@ -1214,6 +1217,7 @@ int quber_finalize_weights(quber_ctx* c) {
     c->flops = 0.0;
     c->wino_flops = 0.0;
     c->wino_saved = 0.0;
+    c->wino_pad = 0.0;
     if (c->cfg.with_network == 2) {
         c->splitk_floats = (size_t)4 << 20;
         c->splitk_ws = (float*)b.dalloc_bytes(sizeof(float) * c->splitk_floats);
@@ -1249,6 +1253,7 @@ double quber_forward_flops_executed(quber_ctx* c) {
     // included) instead of 9 m^2
     return c->flops - c->wino_saved;
 }
+double quber_forward_flops_padding(quber_ctx* c) { return c ? c->wino_pad : 0.0; }
 void quber_set_tuning(int32_t key, int32_t value) {
     // process defaults: copied by every context created afterwards (quber_create) and used by the stand-alone quber_op_* ops;
     // contexts that already exist keep their own settings (quber_set_option)

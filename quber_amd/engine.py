@@ -203,6 +203,10 @@ class Engine:
     def forward_flops_executed(self):
         return self.lib.quber_forward_flops_executed(self.h)
 
+    def forward_flops_padding(self):
+        """The part of forward_flops_executed() spent on the padding of Winograd tiles."""
+        return self.lib.quber_forward_flops_padding(self.h)
+
     # ---- hot path ----
     def encode(self, masks, out=None):
         """masks u8 [B,N,H,W] (device) -> f32 [B,3,H,W]."""
