@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Where MaskRefiner.predict_stream(batch=k) spends a batch: frames/s per (workers, batch), the main thread's enqueue / collect phases,
+and the worker side (_load) alone.  INPAINT=host|device selects where inpaint_depth runs.  GPU box only.
+usage: [INPAINT=device] tools/stream_probe.py        (results: profiles/r09f_adapter_stream.txt)"""
 import os, sys, time, tempfile
 import numpy as np
 from PIL import Image
