@@ -288,6 +288,19 @@ def test_adapter_armbench_branch(tmp_path):
     exp_masks = np.stack([adapter_np.cv2_resize_nearest(m, 1067, 800) for m in m255])
     got_off = eng.encode(torch.from_numpy(exp_masks[None]).cuda()).cpu().numpy()[0]
     np.testing.assert_array_equal(got_off, encode_np.encode_initial_masks(exp_masks))
+    # the batched stream on this branch: RGB only (no depth tensor), frames of TWO sizes -> a group never mixes sizes, order kept
+    from PIL import Image as _I
+    sc2 = synth.make_scene(4, 240, 400, 3)
+    _I.fromarray(sc2["rgb"][:, :, ::-1].copy()).save(tmp_path / "rgb2.png")
+    a_item = (str(tmp_path / "rgb.png"), None, sc["masks"] != 0, None)
+    b_item = (str(tmp_path / "rgb2.png"), None, sc2["masks"] != 0, None)
+    seq = [ref.predict(*it) for it in (a_item, a_item, b_item, a_item)]
+    got = list(ref.predict_stream([a_item, a_item, b_item, a_item], workers=2, batch=2))
+    assert [g[1]["sem_seg"].shape for g in got] == [q[1]["sem_seg"].shape for q in seq]
+    for (m0, o0, _, f0), (m1, o1, _, f1) in zip(seq, got):
+        assert f0 is None and f1 is None
+        assert float((o0["sem_seg"] - o1["sem_seg"]).abs().max()) < TOL
+        assert (o0["panoptic_seg"][0] != o1["panoptic_seg"][0]).float().mean() < 1e-5
 
 
 @pytest.mark.parametrize("dtype", [0, 3], ids=["f32", "bf16x3"])
