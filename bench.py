@@ -620,7 +620,7 @@ def predict_api_run(a, sd, host, dev):
                     "engine_batch1_step = the same frame on resident device buffers, no host side"}
 
 
-def predict_stream_run(a, sd, host, dev, frames=64):
+def predict_stream_run(a, sd, host, dev, frames=128):
     """The reference's evaluation loop (eval/eval_utils.py:235-286: MaskRefiner.predict(rgb_path, depth_path, masks) per frame) through
     this repo's drop-in adapter in its streamed, batched form: files on disk in, numpy masks out.  Host work (PNG decoding, resize,
     depth normalisation, TELEA in-painting of the depth holes, upload) on worker threads, `batch` frames per engine call, one batch in
