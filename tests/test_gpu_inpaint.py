@@ -104,3 +104,31 @@ def test_adapter_paths_agree(tmp_path):
     np.testing.assert_array_equal(a["rgb"], b["rgb"])
     assert (a["depth"] > 0).all()                          # every hole was filled
     np.testing.assert_array_equal(a["depth_dev"].cpu().numpy(), a["depth"])
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_device_inpaint_fuzz(seed):
+    """Random frame sizes (odd ones included), hole counts and hole sizes - single pixels, stripes one pixel wide, holes that merge,
+    holes that leave the frame, whole rows missing - device against host, bit for bit."""
+    rng = np.random.default_rng(1000 + seed)
+    h, w = int(rng.integers(12, 150)), int(rng.integers(12, 200))
+    d = depth_image(seed, 160, 200)[:h, :w].copy()
+    kind = seed % 4
+    if kind == 0:
+        d = punch(d, rng, int(rng.integers(1, 30)), int(rng.integers(2, 25)))
+    elif kind == 1:                                       # specks and one-pixel-wide stripes
+        d[rng.random((h, w)) < 0.03] = 0
+        d[int(rng.integers(0, h)), :] = 0
+        d[:, int(rng.integers(0, w))] = 0
+    elif kind == 2:                                       # few pixels known
+        keep = rng.random((h, w)) < 0.15
+        d = np.where(keep, d, 0).astype(np.uint8)
+    else:
+        d = punch(d, rng, 3, max(3, min(h, w) // 2))
+    if not (d == 0).any():
+        d[h // 2, w // 2] = 0
+    if (d == 0).all():
+        d[0, 0] = 77
+    d3 = np.ascontiguousarray(np.repeat(d[:, :, None], 3, 2))
+    got = engine.inpaint_depth(torch.from_numpy(d3).cuda()).cpu().numpy()
+    np.testing.assert_array_equal(got, host_inpaint(d3))
