@@ -35,8 +35,8 @@ HBM_PEAK_GBPS = 8000.0          # same guide, "HBM3E peak BW" (spec; 6.29 TB/s m
 # stage tags (quber_profile_stage) of the convolution family and of the HBM-bound stages reported in `hbm_stages`
 CONV_GEMM = ("conv_gemm", "wino_gemm", "wino_fused")   # wino_fused: a Winograd layer as ONE kernel (transforms inside), priced on what it multiplies
 CONV_GEMM_F32PIPE = ("conv_gemm_f32pipe",)   # launches of the bf16x3 mode that keep the exact fp32 MFMA kernel (short K, narrow tiles)
-CONV_FAMILY = CONV_GEMM + CONV_GEMM_F32PIPE + ("splitk_reduce", "wino_input", "wino_output")
-HBM_STAGES = ("encode_reduce", "encode_paint", "errmaps_pack", "errmaps_erode", "errmaps_quadruple", "preprocess", "wino_input",
+CONV_FAMILY = CONV_GEMM + CONV_GEMM_F32PIPE + ("splitk_reduce", "wino_input", "wino_output", "stem_fused")   # stem_fused: a3 + stem.conv1, vector FMAs (csrc/stem.hip)
+HBM_STAGES = ("encode_reduce", "encode_paint", "errmaps_pack", "errmaps_erode", "errmaps_quadruple", "preprocess", "stem_fused", "wino_input",
               "wino_output", "splitk_reduce", "gn_stats", "gn_apply", "maxpool", "bilinear", "predictor", "upsample_logits",
               "post_nms", "post_select", "post_group", "post_paint_stats", "extract_masks")
 

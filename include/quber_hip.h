@@ -284,6 +284,8 @@ double quber_forward_flops_padding(quber_ctx* ctx);
  *         Cin / 2 long - 80 channels at the default, with which the float64-anchor ratios stay 0.64-1.11; admitting 256 / 320
  *         channels (chains of 128-160) measures 1.20 / 1.21 and no speed-up inside the network (DESIGN.md section 4,
  *         profiles/r05_fused_anchor.md, r05_wino_fused_layers.md).
+ * key 29 (1; plan) the input normalisation + concatenation (a3, model.py:137-153) inside the first stem convolution's kernel
+ *         (csrc/stem.hip: same fmaf chains as the implicit GEMM, no normalised input tensor in HBM), or as a kernel of its own (0).
  * Process-only keys (quber_set_tuning): key 2 = give the stand-alone conv ops a split-K workspace (value != 0) or drop it (0);
  * key 11 = stand-alone conv op: dilated 3x3 layers in tap-major K order with the zero-padding filter rows skipped;
  * key 12 = stand-alone conv ops: quber_config.compute_dtype of the launch (1 = bf16 / 2 = fp16 operands, 3 = bf16x3);

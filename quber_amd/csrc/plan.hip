@@ -52,6 +52,7 @@ static int* tuning_field(Tuning& t, int key) {
         case 24: return &t.lanes;
         case 25: return &t.wino_fused;
         case 27: return &t.wino_fused_max_cin;
+        case 29: return &t.stem_fused;
         default: return nullptr;
     }
 }
@@ -61,7 +62,7 @@ bool tuning_set(Tuning& t, int key, int value) {
     return f != nullptr;
 }
 // keys that shape the plan: they act when quber_finalize_weights builds it and are refused afterwards
-bool tuning_plan_time(int key) { return key == 6 || key == 7 || key == 8 || key == 9 || key == 10 || key == 18 || key == 25 || key == 27; }
+bool tuning_plan_time(int key) { return key == 6 || key == 7 || key == 8 || key == 9 || key == 10 || key == 18 || key == 25 || key == 27 || key == 29; }
 
 static thread_local std::string g_err;
 void set_error(const std::string& m) { g_err = m; }
@@ -174,6 +175,7 @@ struct quber_ctx {
     double wino_pad = 0.0;        // executed FLOPs (batch 1) spent on the padding of ragged / short-phase Winograd tiles
     std::vector<hipEvent_t> prof_events;
     std::unique_ptr<quber::Profiler> prof;
+    bool stem_fused = false;      // the plan's first op reads the u8 images and the encoding itself: quber_forward launches no preprocess kernel
     bool finalized = false;
     int device = 0;
 };
@@ -611,6 +613,46 @@ struct Builder {
         gn_relu({n + ".norm"}, tmp, out, single_consumer);
     }
 
+    // a3 + stem.conv1 as one kernel (csrc/stem.hip): names = the conv's key prefix per stream; out = [NS][Bmax][h2][w2][32]
+    void emit_stem_fused(const std::vector<std::string>& names, const View& out) {
+        const int G = (int)names.size();
+        std::vector<float> packed((size_t)G * 9 * 6 * 32), scale((size_t)G * 32, 1.f), shift((size_t)G * 32, 0.f);
+        bool ok = true;
+        for (int g = 0; g < G; ++g) {
+            const std::string& n = names[g];
+            const float* w = hw(n + ".weight", (int64_t)32 * 6 * 9);
+            const float* bw = hw(n + ".norm.weight", 32);
+            const float* bb = hw(n + ".norm.bias", 32);
+            const float* bm = hw(n + ".norm.running_mean", 32);
+            const float* bv = hw(n + ".norm.running_var", 32);
+            if (dry) continue;
+            if (!w || !bw || !bb || !bm || !bv) { ok = false; continue; }
+            for (int o = 0; o < 32; ++o) {
+                for (int ci = 0; ci < 6; ++ci)
+                    for (int t = 0; t < 9; ++t) packed[(((size_t)g * 9 + t) * 6 + ci) * 32 + o] = w[((size_t)o * 6 + ci) * 9 + t];
+                // the same per-channel affine as conv() derives (FrozenBN, [d2]: scale = weight * rsqrt(var + eps))
+                const float sc = bw[o] * (1.0f / sqrtf(bv[o] + 1e-5f));
+                scale[(size_t)g * 32 + o] = sc;
+                shift[(size_t)g * 32 + o] = bb[o] - bm[o] * sc;
+            }
+        }
+        if (dry || !ok) return;
+        const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+        if (out.C != 32 || out.cs != 32 || out.H != OH || out.W != OW || out.es != 4) { if (err.empty()) err = "internal: fused stem output geometry"; return; }
+        const double fl = 2.0 * OH * OW * 6.0 * 9.0 * 32.0 * G;
+        c->flops += fl;
+        const float *dw = upload(packed), *ds = upload(scale), *dh = upload(shift);
+        quber_ctx* ctx = c;
+        const View o = out;
+        c->stem_fused = true;
+        c->ops.push_back({[=](int B, hipStream_t st) {
+            return launch_stem_conv1(ctx->cur_bgr, ctx->cur_depth, ctx->cur_off, B, ctx->cfg.height, ctx->cfg.width, G, ctx->cfg.pixel_mean,
+                                     ctx->cfg.pixel_std, dw, ds, dh, o.p, o.gs, st);
+        }, OP_CONV, names[0], fl, 1});
+        last_conv = {nullptr, nullptr, 0, 0};
+        pending_norm.reset();
+    }
+
     void build() {
         const quber_config& cf = c->cfg;
         const int* nb = cf.resnet_depth == 50 ? BLOCKS50 : cf.resnet_depth == 101 ? BLOCKS101 : BLOCKS152;
@@ -637,10 +679,17 @@ struct Builder {
 
         // ---------------- input + stems (both streams as G = 2) ----------------
         // (fp16 data path: 16 channels - the loader steps through a filter tap in units of 8 four-byte words)
-        View X = make(aes == 2 ? 16 : 8, H, W, NS);
-        if (!dry) c->X = X;
+        // fp32 tensors (exact fp32 and bf16x3 modes): a3 runs inside the first convolution's kernel - the normalised 8-channel input
+        // (315 MB per 16-frame step) is neither written nor read back (option key 29)
+        const bool stem_one = aes == 4 && tune().stem_fused;
         View s1 = make(32, h2, w2, NS), s2 = make(32, h2, w2, NS), s3 = make(64, h2, w2, NS);
-        conv(two("stem.conv1", false), X, 6, s1, 3, 2, 1, 1, AF_FROZEN_BN, nullptr, true);
+        if (stem_one) {
+            emit_stem_fused(two("stem.conv1", false), s1);
+        } else {
+            View X = make(aes == 2 ? 16 : 8, H, W, NS);
+            if (!dry) c->X = X;
+            conv(two("stem.conv1", false), X, 6, s1, 3, 2, 1, 1, AF_FROZEN_BN, nullptr, true);
+        }
         conv(two("stem.conv2", false), s1, 32, s2, 3, 1, 1, 1, AF_FROZEN_BN, nullptr, true);
         conv(two("stem.conv3", false), s2, 32, s3, 3, 1, 1, 1, AF_FROZEN_BN, nullptr, true);
         View x = make(64, h4, w4, NS);
@@ -1402,8 +1451,9 @@ int quber_forward(quber_ctx* c, const uint8_t* bgr, const uint8_t* depth, const 
     if (!bgr || (!depth && c->cfg.streams == 2) || !offs || !logits) return fail("null tensor");
     hipStream_t st = (hipStream_t)stream;
     c->cur_out = logits;
-    int rc = launch_preprocess(bgr, depth, offs, c->X, batch, c->cfg.max_batch, c->cfg.height, c->cfg.width,
-                               c->cfg.pixel_mean, c->cfg.pixel_std, c->cfg.streams, st);
+    c->cur_bgr = bgr; c->cur_depth = depth; c->cur_off = offs;
+    int rc = c->stem_fused ? 0 : launch_preprocess(bgr, depth, offs, c->X, batch, c->cfg.max_batch, c->cfg.height, c->cfg.width,
+                                                   c->cfg.pixel_mean, c->cfg.pixel_std, c->cfg.streams, st);
     if (rc) return rc;
     // side lanes: at small batches the independent branches of the plan (Builder::fork / join) run on streams of the context
     c->lanes_on = c->lanes_built && tune().lanes && batch <= LANE_BATCH && c->lane_stream[1] != nullptr && quber::g_prof == nullptr;
@@ -1446,8 +1496,9 @@ int quber_forward_profiled(quber_ctx* c, const uint8_t* bgr, const uint8_t* dept
         c->prof_events.resize(2 * n);
         for (size_t i = old; i < 2 * n; ++i) QB_CHECK(hipEventCreate(&c->prof_events[i]));
     }
-    int rc = launch_preprocess(bgr, depth, offs, c->X, batch, c->cfg.max_batch, c->cfg.height, c->cfg.width,
-                               c->cfg.pixel_mean, c->cfg.pixel_std, c->cfg.streams, st);
+    c->cur_bgr = bgr; c->cur_depth = depth; c->cur_off = offs;
+    int rc = c->stem_fused ? 0 : launch_preprocess(bgr, depth, offs, c->X, batch, c->cfg.max_batch, c->cfg.height, c->cfg.width,
+                                                   c->cfg.pixel_mean, c->cfg.pixel_std, c->cfg.streams, st);
     if (rc) return rc;
     c->lanes_on = false;          // one stream: every op in plan order
     for (size_t i = 0; i < n; ++i) {

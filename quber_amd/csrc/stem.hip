@@ -1,0 +1,124 @@
+// a3 + the first stem convolution as ONE kernel ("a3 ... or 0 if fused into the stem loader").
+//   reference: model.py:137-153 (normalise, concatenate image | initial-mask encoding) -> resnet.py:37-44 stem.conv1 (3x3, stride 2,
+//   6 -> 32 channels, FrozenBN, ReLU), one per stream (rgb, depth).
+// The two-kernel form writes the normalised 8-channel fp32 input of both streams (315 MB per 16-frame step) only for the convolution
+// to read it back; here a block stages the u8 pixels and the three encoding planes of its input window in LDS (normalised on the
+// way, the zero padding as zeros) and every thread computes one output pixel x 32 channels for BOTH streams (they share the
+// encoding planes).  HBM traffic: 88 MB of inputs + 315 MB of outputs per step.
+// Arithmetic: exactly the MFMA path's.  v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain; the implicit GEMM packs k = tap * 8 +
+// channel, cuts it into K-slices of 32 (taps 0-3 | 4-7 | 8) that start from zero, and adds the slice sums in order (two-level
+// accumulation); inside a group of 8 k the kernel's four MFMAs multiply the pairs (0, 4), (1, 5), (2, 6), (3, 7) - lane half h supplies
+// k = 4 h + e - so a tap's channels enter the chain in the order 0, 4, 1, 5, 2, 3 (6 and 7 are the zero channels of the padded input);
+// the epilogue is fmaf(acc, scale, shift), max(., 0).  The same chains here, in vector FMAs (54 per output channel: the multiply-add
+// count of this layer is 0.1 % of the network's), as packed fp32 FMAs (v_pk_fma_f32: two output channels per instruction, the pixel value broadcast, the filter pair a scalar-register
+// operand fetched by scalar loads - the filter pointer is a `const __restrict__` kernel parameter for exactly that).
+#include "common.h"
+
+namespace quber {
+namespace {
+
+constexpr int TY = 8, TX = 32;                   // output pixels per block: one per thread
+constexpr int IY = 2 * TY + 1, IX = 2 * TX + 1;  // input window (stride 2, 3x3, pad 1)
+
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+struct StemP {
+    const uint8_t* bgr; const uint8_t* depth; const float* offs;
+    float* out; long out_gs;                     // [streams][B][OH][OW][32]
+    int B, H, W, OH, OW, streams;
+    float mean[6], stdv[6];
+};
+
+// wq: filters [streams][9 taps][6 channels][32] (output channel fastest); scq / shq: [streams][32]
+__global__ __launch_bounds__(256) void stem_conv1_kernel(const StemP p, const float* __restrict__ wq, const float* __restrict__ scq,
+                                                         const float* __restrict__ shq) {
+    __shared__ float sx[9][IY][IX + 1];          // planes: image 0 (3), image 1 (3), heat, off_y, off_x
+    const int t = threadIdx.x;
+    const int b = blockIdx.z;
+    const int oy0 = blockIdx.y * TY, ox0 = blockIdx.x * TX;
+    const int iy0 = 2 * oy0 - 1, ix0 = 2 * ox0 - 1;
+    const long HW = (long)p.H * p.W;
+    // ---- stage the window: u8 pixels normalised as model.py:138 does ((x - mean) / std, IEEE division), encoding planes as they are ----
+    for (int i = t; i < IY * IX; i += 256) {
+        const int r = i / IX, c = i - r * IX;
+        const int y = iy0 + r, x = ix0 + c;
+        const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        const long pix = (long)b * HW + (long)y * p.W + x;
+        float v[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            const uint8_t* q = p.bgr + pix * 3;
+            v[0] = ((float)q[0] - p.mean[0]) / p.stdv[0];
+            v[1] = ((float)q[1] - p.mean[1]) / p.stdv[1];
+            v[2] = ((float)q[2] - p.mean[2]) / p.stdv[2];
+            if (p.streams == 2) {
+                const uint8_t* d = p.depth + pix * 3;
+                v[3] = ((float)d[0] - p.mean[3]) / p.stdv[3];
+                v[4] = ((float)d[1] - p.mean[4]) / p.stdv[4];
+                v[5] = ((float)d[2] - p.mean[5]) / p.stdv[5];
+            }
+            const float* o = p.offs + (long)b * 3 * HW + (long)y * p.W + x;
+            v[6] = o[0]; v[7] = o[HW]; v[8] = o[2 * HW];
+        }
+#pragma unroll
+        for (int e = 0; e < 9; ++e) sx[e][r][c] = v[e];
+    }
+    __syncthreads();
+    const int ty = t >> 5, tx = t & 31;
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    if (oy >= p.OH || ox >= p.OW) return;
+    for (int g = 0; g < p.streams; ++g) {
+        const float* __restrict__ w = wq + g * (9 * 6 * 32);
+        f32x2 top[16], acc[16];
+        // K-slices of the packed GEMM: taps 0-3, taps 4-7, tap 8 - each chain starts from zero (SrcC = 0), the sums are added in order
+#pragma unroll
+        for (int slice = 0; slice < 3; ++slice) {
+#pragma unroll
+            for (int tap = slice * 4; tap < (slice == 2 ? 9 : slice * 4 + 4); ++tap) {
+                const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    const int ci = q == 0 ? 0 : q == 1 ? 4 : q == 2 ? 1 : q == 3 ? 5 : q == 4 ? 2 : 3;      // the MFMA's order inside a group of 8 k
+                    const float x = sx[ci < 3 ? 3 * g + ci : 3 + ci][2 * ty + ky][2 * tx + kx];
+                    const float* wr = w + (tap * 6 + ci) * 32;
+                    const bool first = tap == slice * 4 && q == 0;
+#pragma unroll
+                    for (int o = 0; o < 16; ++o)
+                        acc[o] = __builtin_elementwise_fma(f32x2{x, x}, f32x2{wr[2 * o], wr[2 * o + 1]}, first ? f32x2{0.f, 0.f} : acc[o]);
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < 16; ++o) top[o] = slice == 0 ? f32x2{0.f, 0.f} + acc[o] : top[o] + acc[o];
+        }
+        float* dst = p.out + (long)g * p.out_gs + (((long)b * p.OH + oy) * p.OW + ox) * 32;
+        const float* __restrict__ sc = scq + g * 32;
+        const float* __restrict__ sh = shq + g * 32;
+#pragma unroll
+        for (int o = 0; o < 16; o += 2) {
+            float4 y;
+            y.x = fmaxf(fmaf(top[o].x, sc[2 * o], sh[2 * o]), 0.f);
+            y.y = fmaxf(fmaf(top[o].y, sc[2 * o + 1], sh[2 * o + 1]), 0.f);
+            y.z = fmaxf(fmaf(top[o + 1].x, sc[2 * o + 2], sh[2 * o + 2]), 0.f);
+            y.w = fmaxf(fmaf(top[o + 1].y, sc[2 * o + 3], sh[2 * o + 3]), 0.f);
+            *reinterpret_cast<float4*>(dst + 2 * o) = y;
+        }
+    }
+}
+
+}  // namespace
+
+// w: [streams][9][6][32] device floats; out: NHWC [streams][Bcap][OH][OW][32] (group stride out_gs elements)
+int launch_stem_conv1(const uint8_t* bgr, const uint8_t* depth, const float* offs, int B, int H, int W, int streams, const float* mean6,
+                      const float* std6, const float* w, const float* scale, const float* shift, float* out, long out_gs, hipStream_t st) {
+    if (!bgr || !offs || !w || !scale || !shift || !out || (streams == 2 && !depth)) return fail("stem: null argument");
+    StemP p{};
+    p.bgr = bgr; p.depth = depth; p.offs = offs; p.out = out; p.out_gs = out_gs;
+    p.B = B; p.H = H; p.W = W; p.OH = (H + 1) / 2; p.OW = (W + 1) / 2; p.streams = streams;
+    for (int i = 0; i < 6; ++i) { p.mean[i] = mean6[i]; p.stdv[i] = std6[i]; }
+    const double px = (double)B * H * W, opx = (double)B * p.OH * p.OW;
+    ProfScope prof("stem_fused", px * (3.0 * streams + 12.0) + opx * 32.0 * 4.0 * streams, 2.0 * opx * 54.0 * 32.0 * streams, st);
+    hipLaunchKernelGGL(stem_conv1_kernel, dim3((p.OW + TX - 1) / TX, (p.OH + TY - 1) / TY, B), dim3(256), 0, st, p, w, scale, shift);
+    QB_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace quber

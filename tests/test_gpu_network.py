@@ -527,3 +527,24 @@ def test_two_engines_keep_their_own_options():
     finally:
         A.close()
         B.close()
+
+
+@pytest.mark.parametrize("h,w,b", [(480, 640, 2), (70, 102, 3), (53, 75, 1)])
+def test_stem_fused_equals_preprocess_plus_gemm(h, w, b):
+    """a3 inside the first stem convolution's kernel (csrc/stem.hip, option key 29, default) against the preprocess kernel + implicit
+    GEMM it replaces: the same fmaf chains in the same order (K-slices of the packed GEMM, two-level sums, fmaf epilogue), so the
+    whole network's output is bit-identical - odd frame sizes (ragged last tiles, borders) included."""
+    sd = arch.init_state_dict(seed=7, loud_heads=True, center_bias=-1.5)
+    batch, offs = inputs(61, b, h, w, 4)
+    bgr, dep, off = torch.from_numpy(batch["rgb"]).cuda(), torch.from_numpy(batch["depth"]).cuda(), torch.from_numpy(offs).cuda()
+    outs, plans = [], []
+    for fused in (1, 0):
+        eng = engine.Engine(engine.make_config(h, w, max_batch=b), "cuda:0")
+        eng.set_option(29, fused)
+        eng.load_state_dict(sd)
+        outs.append((eng.forward(bgr, dep, off).clone(), eng.debug_tensor("res2", b).clone()))
+        plans.append(eng.plan())
+        eng.close()
+    assert len(plans[0]) == len(plans[1]) and plans[0][1][0] == plans[1][1][0] == "backbone.rgb_backbone.stem.conv1"
+    assert torch.equal(outs[0][1], outs[1][1]), "res2 differs"
+    assert torch.equal(outs[0][0], outs[1][0]), "logits differ"

@@ -56,6 +56,9 @@ def report(a):
         elif "wino_fused" in n_:                  # a Winograd layer as ONE kernel (wino_fused.hip)
             groups.append(("winograd single-kernel", [allk[i]]))
             i += 1
+        elif "stem_conv1" in n_:                  # a3 + stem.conv1 as one kernel (stem.hip)
+            groups.append(("fused with a3", [allk[i]]))
+            i += 1
         elif "conv_igemm" in n_:
             j = i + 1
             while j < len(allk) and any(t in name(allk[j]) for t in ("splitk_reduce", "pk_fixup")):
@@ -71,9 +74,11 @@ def report(a):
            "|---|---|---|---|---|---|"]
     for i, (c, (path, ks)) in enumerate(zip(convs, groups[-n:])):
         ms = sum(dur(r) for r in ks)
-        r = next(k for k in ks if "conv_igemm" in name(k) or "wino_fused" in name(k))
+        r = next(k for k in ks if "conv_igemm" in name(k) or "wino_fused" in name(k) or "stem_conv1" in name(k))
         fl = c[2] * B
-        if "wino_fused" in name(r):
+        if "stem_conv1" in name(r):
+            tile = "vector FMA, 8 x 32 pixels x 32 ch per block"
+        elif "wino_fused" in name(r):
             tile = "16 tiles x 64 ch" if "fused64" in name(r) else "32 tiles x 32 ch"
         else:
             tile = ("persistent " if "conv_igemm_pk" in name(r) else "") + name(r).split("<")[1].split(">")[0].replace(" ", "")

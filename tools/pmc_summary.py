@@ -26,7 +26,7 @@ while i < len(disp):
             j += 1
         groups.append([v for v in disp[i:j + 1] if "conv_igemm" in v["name"]])
         i = j + 1
-    elif "wino_fused" in n_:
+    elif "wino_fused" in n_ or "stem_conv1" in n_:
         groups.append([disp[i]])
         i += 1
     elif "conv_igemm" in n_:
