@@ -411,7 +411,9 @@ def main():
         torch.cuda.current_stream().wait_stream(side)
         try:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # with a process group alive its watchdog thread queries events while this thread captures: "thread_local" keeps those
+            # calls from invalidating the capture (the default "global" mode treats them as errors)
+            with torch.cuda.graph(graph, capture_error_mode="thread_local" if world > 1 else "global"):
                 gpu_step()
         except RuntimeError as e:                 # a node that cannot capture must still produce the line: eager steps
             if a.graph:
