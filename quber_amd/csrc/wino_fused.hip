@@ -526,8 +526,8 @@ constexpr int SMEM_BYTES = 2 * STAGE * 4 + 2 * 32 * 2 * 8;
 // element i of [Cout/64][Cin/16][36][4 column blocks][64 lanes][4] <- index into U [36][Cout][Cin]: lane l of the MFMA on
 // column block nt supplies output channel nt * 16 + l % 16 and input channels 4 * (l / 16) + e of the 16-channel slice
 // which kernel a layer takes: 16 tiles x 64 channels needs 64 | Cout and an even number of 32-channel rounds (an odd count would
-// run one round on zero filters; the 32 x 32 kernel's rounds are 16 channels)
-__host__ __device__ inline bool fused_wide(int Cout, int Cin) { return Cout % 64 == 0 && (Cin / 32) % 2 == 0; }
+// run one round on zero filters; the 32 x 32 kernel's rounds are 16 channels) - or exactly one round (the ONE instance: stem.conv3)
+__host__ __device__ inline bool fused_wide(int Cout, int Cin) { return Cout % 64 == 0 && ((Cin / 32) % 2 == 0 || (Cin == 32 && (WF_OPT & 1))); }
 __host__ __device__ inline long fused64_src(long i, int Cout, int Cin) {
     const int e = (int)(i & 3), l = (int)((i >> 2) & 63), nt = (int)((i >> 8) & 3);
     long r = i >> 10;
@@ -537,7 +537,9 @@ __host__ __device__ inline long fused64_src(long i, int Cout, int Cin) {
     return ((long)p * Cout + cc * 64 + nt * 16 + (l & 15)) * Cin + ks * 16 + 4 * (l >> 4) + e;
 }
 
-template <bool NORM>
+// ONE: the layer has a single 32-channel round (32 input channels: stem.conv3): one patch, one round, no second image - a template
+// instance, because a branch around the second round of the pair costs the register allocation its balance (2.5x slower)
+template <bool NORM, bool ONE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_fused64_kernel(const FusedArgs a) {
     constexpr int FT = w64::FT, FC = w64::FC, FK = w64::FK, SLICE = w64::SLICE, STAGE = w64::STAGE;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -686,6 +688,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float* const st1 = smem + STAGE;
     // prologue: the patches of rounds 0 and 1 are requested together (one exposure to the memory latency, not two)
     const int r1 = R > 1 ? 1 : 0;
+    static_assert(36 % BR == 0, "the ring index is static over a pair of rounds");
+    if constexpr (ONE) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) gload_row(i, 0);
+        gload_coef(0);
+#pragma unroll
+        for (int g0 = 0; g0 < BR; ++g0) bload(g0, 0, g0);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) col_pass(j);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) row_pass(i, st0);
+        __syncthreads();
+        WF_STAMP(1);
+        round(st0, st1, 0, 0, true);             // R == 1: nothing to prepare (do_rows, do_full are false), both slices start their chains
+        __syncthreads();
+    } else {
     {
         f32x2 d1[6][6];
         const unsigned so1 = (unsigned)r1 * (FK * 4u);
@@ -711,7 +729,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int j = 0; j < 6; ++j) col_pass(j);
     __syncthreads();
-    static_assert(36 % BR == 0, "the ring index is static over a pair of rounds");
     WF_STAMP(1);
     round(st0, st1, 0, 0, true);                 // the first pair of rounds starts the accumulation chains
     __syncthreads();
@@ -724,6 +741,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __syncthreads();
         round(st1, st0, r + 1, 18, false);
         __syncthreads();
+    }
     }
     WF_STAMP(6);
 
@@ -906,6 +924,8 @@ int winograd_fused_prepare() {
     QB_CHECK(hipFuncSetAttribute((const void*)wino_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
     QB_CHECK(hipFuncSetAttribute((const void*)wino_fused64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, w64::SMEM_BYTES));
     QB_CHECK(hipFuncSetAttribute((const void*)wino_fused64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, w64::SMEM_BYTES));
+    QB_CHECK(hipFuncSetAttribute((const void*)wino_fused64_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, w64::SMEM_BYTES));
+    QB_CHECK(hipFuncSetAttribute((const void*)wino_fused64_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, w64::SMEM_BYTES));
     return 0;
 }
 
@@ -956,7 +976,8 @@ int launch_conv_winograd_fused(const WinoP& q, int Ball, int G, hipStream_t st) 
         ProfScope prof(q.dtype == 3 ? "conv_gemm_f32pipe" : "wino_fused", 4.0 * G * ((double)Ball * H * W * (in.C + out.C) + (double)FP * in.C * out.C),
                        2.0 * G * FP * (double)a.tiles * in.C * out.C, st);
         const void* fn32 = norm ? (const void*)wino_fused_kernel<true> : (const void*)wino_fused_kernel<false>;
-        const void* fn64 = norm ? (const void*)wino_fused64_kernel<true> : (const void*)wino_fused64_kernel<false>;
+        const void* fn64 = in.C == 32 ? (norm ? (const void*)wino_fused64_kernel<true, true> : (const void*)wino_fused64_kernel<false, true>)
+                                      : (norm ? (const void*)wino_fused64_kernel<true> : (const void*)wino_fused64_kernel<false>);
         const void* fn = wide ? fn64 : fn32;
         const int smem_bytes = wide ? w64::SMEM_BYTES : SMEM_BYTES;
         void* args[] = {(void*)&a};
