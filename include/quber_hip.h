@@ -312,6 +312,12 @@ int quber_op_conv2d(const float* dev_x, int32_t batch, int32_t h, int32_t w, int
                     int32_t cout, int32_t ksize, int32_t stride, int32_t pad, int32_t dil, const float* dev_scale,
                     const float* dev_shift, const float* dev_residual, int32_t relu, float* dev_packed_scratch,
                     float* dev_y, void* stream);
+/* the 1x1 / stride 1 convolution of the fp16 data path (compute_dtype 2 with fp16 tensors in HBM): x [batch][h][w][cin],
+ * w [cout][cin], residual and y [batch][h][w][cout] are fp16, scale / shift fp32; cin a multiple of 64 (test hook: the
+ * network reaches this kernel only through quber_forward). */
+int quber_op_conv1x1_f16(const void* dev_x, int32_t batch, int32_t h, int32_t w, int32_t cin, const void* dev_w_oi,
+                         int32_t cout, const float* dev_scale, const float* dev_shift, const void* dev_residual,
+                         int32_t relu, void* dev_y, void* stream);
 /* one 1x1 GEMM over two inputs: out = relu?(y . w[:, :mid] + x[::stride, ::stride] . w[:, mid:] + shift), NHWC;
  * y [batch][oh][ow][mid], x [batch][h2][w2][cin], w [cout][mid + cin], `dev_ones` = cout ones (the kernel's affine scale).
  * Needs the op workspace (key 2) and fp32 / bf16x3 arithmetic (key 12 = 0 / 3). */

@@ -76,6 +76,7 @@ SIGNATURES = {
     "quber_op_info": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(_I), C.POINTER(C.c_double), C.POINTER(_I)]),
     "quber_debug_persistent_segments": (C.c_int32, [_I, _I, _I, _I, _I, _P, _I]),
     "quber_debug_persistent_fixup": (C.c_int32, [_I, _I, _I, _I, _I, _I, _P, _P, _I]),
+    "quber_op_conv1x1_f16": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P]),
     "quber_op_conv1x1_dual": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P]),
     "quber_op_conv2d": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P]),
     "quber_op_conv3x3_winograd": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _I, _P, _P, C.c_int64, _P, _P]),

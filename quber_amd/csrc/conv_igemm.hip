@@ -69,6 +69,7 @@ constexpr int NPL(int dt) { return dt == 3 ? 3 : 1; }     // bf16 planes per ope
 // waves per SIMD the kernel is compiled for: two accumulator sets (the MFMA chain and the chunk sums, below) cost the
 // 128-row tiles their third resident block; the 64x64 tiles keep five
 constexpr int igemm_occupancy(int BM, int BN, int DT = 0) {
+    if (DT == 4 && BM * BN > 128 * 128) return 2;         // 128x256 (wave tiles of 64x128: 128 accumulator registers)
     if (DT == 4 && BM * BN >= 128 * 128) return QB_H16_OCC;
     if (DT == 4 && BM == 64 && BN == 64) return 7;        // HBM-bound residual layers: blocks in flight are what they live on
     if (BM * BN >= 128 * 128 || (BM == 256 && DT == 3)) return 2;
@@ -793,6 +794,16 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
             hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(blocks, G), dim3(256), 0, st, p, parts, G, chunk);
     };
     const bool skip = BM != 256 && p.skip_rows && p.kmode == 0 && p.kh > 1 && p.Cin % BK == 0 && p.K == p.Kpad && p.ohw > 0;
+    if (p.es == 2) {        // fp16 data path: one K pass (the loop is 16x shorter than the fp32 one), padded filter rows skipped; never
+                            // persistent (below), split or on the fp32 pipe
+        ProfScope prof(tag, conv_bytes, conv_flops, st);
+        if (skip) hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 3, 4>), dim3(p.mtiles * p.ntiles, 1, G), block, 0, st, p);
+        else hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 0, 4>), dim3(p.mtiles * p.ntiles, 1, G), block, 0, st, p);
+        QB_CHECK(hipGetLastError());
+        return gn_separate();
+    }
+    if constexpr (BN > 128) return fail("conv: 128x256 tiles exist for the fp16 data path only");
+    else {
     // Persistent launch (conv_persist.hip): one block per resident slot walks whole tiles and an equal share of the
     // K-slices of the remainder
     // (launches of a few dozen tiles - small batches - keep the one-tile-per-block kernel and its fitted split-K model:
@@ -851,13 +862,6 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
     // residual) and the 32-column head layers on 256x32 tiles lose occupancy to its three LDS planes and gain nothing
     // (profiles/r02j_conv_layers_dtype{0,3}.md): they keep the exact fp32 MFMA kernel, which is at least as accurate.
     if (p.bf16 == 3 && (BM == 256 || (BM == 64 && nk <= 8))) exact_fallback();
-    if (p.es == 2) {        // fp16 data path: one K pass (the loop is 16x shorter than the fp32 one), padded filter rows skipped
-        ProfScope prof(tag, conv_bytes, conv_flops, st);
-        if (skip) hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 3, 4>), dim3(p.mtiles * p.ntiles, 1, G), block, 0, st, p);
-        else hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 0, 4>), dim3(p.mtiles * p.ntiles, 1, G), block, 0, st, p);
-        QB_CHECK(hipGetLastError());
-        return gn_separate();
-    }
     if (p.bf16) {
         {
             ProfScope prof(tag, conv_bytes, conv_flops, st);
@@ -891,6 +895,7 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
     }
     QB_CHECK(hipGetLastError());
     return gn_separate();
+    }
 }
 
 
@@ -921,6 +926,7 @@ int launch_conv(const ConvP& p0, int G, hipStream_t st) {
         case 2: return run<128, 128, 2, 2>(p, G, 1, st);
         case 4: return run<256, 32, 4, 1>(p, G, 1, st);
         case 3: return run<128, 64, 2, 2>(p, G, 1, st);
+        case 5: if (p.es == 2) return run<128, 256, 2, 2>(p, G, 1, st); break;
         default: break;
     }
     // Tile shape (sweep: profiles/r01i_conv_sweep_*.md).  <= 32 output channels: 256x32.  <= 64 channels, and the
@@ -934,6 +940,10 @@ int launch_conv(const ConvP& p0, int G, hipStream_t st) {
     // (64 x 256 tiles for the residual 1x1 layers - input rows read once, 512-byte row segments - measured 30-50 % SLOWER than
     // 64x64 in both the fp32 and the fp16 path, profiles/r03x_tile_64x256_rejected.txt: those layers live on blocks in flight)
     if (p.Cout <= 64 || (p.res && nk <= 8 && p.Cout >= 128)) return run<64, 64, 2, 2>(p, G, choose_split(p, G, 64, 64, igemm_occupancy(64, 64)), st);
+    // fp16 data path, Cout a multiple of 256, at least two rounds of tiles: 128x256 tiles (wave tiles of 64x128 - the K-slice
+    // fragments are read from LDS 25 % less often per MFMA than with 64x64 wave tiles, and that kernel is LDS-bound)
+    if (p.es == 2 && tune().h16_wide && p.Cout % 256 == 0 && (long)((p.M + 127) / 128) * (p.Cout / 256) * G >= tune().h16_wide_min_tiles)
+        return run<128, 256, 2, 2>(p, G, 1, st);
     const long tiles128 = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * G;
     const int s128 = choose_split(p, G, 128, 128, igemm_occupancy(128, 128));
     if (tiles128 < 64 || (tiles128 < 384 && s128 == 1)) return run<64, 64, 2, 2>(p, G, choose_split(p, G, 64, 64, igemm_occupancy(64, 64)), st);

@@ -53,6 +53,8 @@ static int* tuning_field(Tuning& t, int key) {
         case 25: return &t.wino_fused;
         case 27: return &t.wino_fused_max_cin;
         case 29: return &t.stem_fused;
+        case 31: return &t.h16_wide;
+        case 32: return &t.h16_wide_min_tiles;
         default: return nullptr;
     }
 }
@@ -1658,6 +1660,20 @@ int quber_op_conv2d(const float* x, int32_t B, int32_t h, int32_t w, int32_t cin
     p.ws = g_op_ws;
     p.ws_floats = g_op_ws ? g_op_ws_floats : 0;
     return launch_conv(p, 1, st);
+}
+
+// the fp16 data path's 1x1 convolution on fp16 tensors (x, w [cout][cin], residual, y: fp16 in HBM; scale / shift fp32)
+int quber_op_conv1x1_f16(const void* x, int32_t B, int32_t h, int32_t w, int32_t cin, const void* w_oi, int32_t cout,
+                         const float* scale, const float* shift, const void* residual, int32_t relu, void* y, void* stream) {
+    if (cin % 64) return fail("conv1x1_f16: cin must be a multiple of 64");
+    ConvP p{};
+    p.in = (const float*)x; p.w = (const float*)w_oi; p.scale = scale; p.shift = shift; p.res = (const float*)residual; p.out = (float*)y;
+    p.B = B; p.H = h; p.W = w; p.Cin = cin; p.in_cs = cin; p.OH = h; p.OW = w;
+    p.Cout = cout; p.out_cs = cout; p.res_cs = cout; p.K = cin; p.Kpad = cin;
+    p.kh = 1; p.kw = 1; p.stride = 1; p.pad = 0; p.dil = 1; p.relu = relu;
+    p.bf16 = 2; p.es = 2;
+    p.M = B * h * w; p.ohw = h * w;
+    return launch_conv(p, 1, (hipStream_t)stream);
 }
 
 // y: [B][oh][ow][mid], x: [B][h2][w2][cin] (sampled at `stride`), w: [cout][mid + cin] (BN scales already folded in),

@@ -17,11 +17,19 @@ namespace quber {
 constexpr int NT = 32;  // NMS tile
 
 // ---- P1: threshold + (2r+1)^2 max-pool NMS -> candidate map (value or -1) ----
+// The window maximum is separable (rows, then columns: 2 (2r + 1) LDS reads per pixel instead of (2r + 1)^2; a maximum does not depend
+// on the order it is taken in).  Surviving candidates are also appended - value and pixel index - to a short per-frame list
+// (LCAND slots): a frame has a few dozen of them, and P2 then never walks the 300 000-pixel map; a frame with more candidates than
+// slots (plateaus: every pixel of a constant region is its window's maximum) keeps the map path.
+constexpr int LCAND = 2048;
+struct CandList { unsigned n; unsigned pad; float val[LCAND]; int idx[LCAND]; };
+
 __global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ logits, int nch, int H, int W, float thr,
-                                                  int r, float* __restrict__ cand) {
-    extern __shared__ float sv[];  // (NT+2r)^2
+                                                  int r, float* __restrict__ cand, CandList* __restrict__ lists) {
+    extern __shared__ float sv[];  // (NT+2r)^2 thresholded values, then (NT+2r) x NT row maxima
     const int b = blockIdx.z;
     const int P = NT + 2 * r;
+    float* const rowmax = sv + P * P;
     const float* c = logits + ((long)b * nch + 1) * H * W;
     const int ty0 = blockIdx.y * NT, tx0 = blockIdx.x * NT;
     for (int i = threadIdx.x; i < P * P; i += 256) {
@@ -35,26 +43,92 @@ __global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ logi
         sv[i] = v;
     }
     __syncthreads();
+    for (int i = threadIdx.x; i < P * NT; i += 256) {
+        const int ly = i / NT, lx = i - ly * NT;
+        float m = -INFINITY;
+        for (int dx = 0; dx <= 2 * r; ++dx) m = fmaxf(m, sv[ly * P + lx + dx]);
+        rowmax[i] = m;
+    }
+    __syncthreads();
     for (int i = threadIdx.x; i < NT * NT; i += 256) {
         const int ly = i / NT, lx = i - ly * NT;
         const int gy = ty0 + ly, gx = tx0 + lx;
         if (gy >= H || gx >= W) continue;
         const float v = sv[(ly + r) * P + lx + r];
         float m = -INFINITY;
-        for (int dy = 0; dy <= 2 * r; ++dy)
-            for (int dx = 0; dx <= 2 * r; ++dx) m = fmaxf(m, sv[(ly + dy) * P + lx + dx]);
-        cand[(long)b * H * W + (long)gy * W + gx] = (v == m) ? v : -1.f;
+        for (int dy = 0; dy <= 2 * r; ++dy) m = fmaxf(m, rowmax[(ly + dy) * NT + lx]);
+        const bool keep = v == m;
+        cand[(long)b * H * W + (long)gy * W + gx] = keep ? v : -1.f;
+        if (keep && v > 0.f) {                     // (P2 counts strictly positive candidates only)
+            const unsigned slot = atomicAdd(&lists[b].n, 1u);
+            if (slot < (unsigned)LCAND) { lists[b].val[slot] = v; lists[b].idx[slot] = gy * W + gx; }
+        }
     }
 }
 
 // ---- P2: exact k-th largest (radix select on the float bits) + raster-order compaction; one block per frame ----
 __global__ __launch_bounds__(1024) void select_kernel(const float* __restrict__ cand, int HW, int W, int top_k, int cap,
-                                                      int* __restrict__ centers, int* __restrict__ ncenters) {
+                                                      int* __restrict__ centers, int* __restrict__ ncenters,
+                                                      const CandList* __restrict__ lists) {
     __shared__ unsigned hist[256];
     __shared__ unsigned s_prefix, s_mask, s_remaining, s_npos;
     __shared__ unsigned scan[1024];
     const int b = blockIdx.x, t = threadIdx.x;
     const float* c = cand + (long)b * HW;
+    // ---- the short list (P1): the same selection on a few dozen (value, pixel) pairs instead of the whole map ----
+    const unsigned nl = lists[b].n;
+    if (nl <= (unsigned)LCAND) {
+        __shared__ float lv[LCAND];
+        __shared__ int li[LCAND];
+        for (unsigned i = t; i < nl; i += 1024) { lv[i] = lists[b].val[i]; li[i] = lists[b].idx[i]; }
+        __syncthreads();
+        float cut = 0.f;                           // max(k-th largest, 0); fewer than k positives: 0
+        if ((int)nl >= top_k) {
+            if (t == 0) { s_prefix = 0; s_mask = 0; s_remaining = (unsigned)top_k; }
+            __syncthreads();
+            for (int shift = 24; shift >= 0; shift -= 8) {
+                if (t < 256) hist[t] = 0;
+                __syncthreads();
+                const unsigned prefix = s_prefix, mask = s_mask;
+                for (unsigned i = t; i < nl; i += 1024) {
+                    const unsigned u = __float_as_uint(lv[i]);
+                    if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+                }
+                __syncthreads();
+                if (t == 0) {
+                    unsigned rem = s_remaining;
+                    int d = 255;
+                    for (; d > 0; --d) {
+                        if (hist[d] >= rem) break;
+                        rem -= hist[d];
+                    }
+                    s_prefix = prefix | ((unsigned)d << shift);
+                    s_mask = mask | (255u << shift);
+                    s_remaining = rem;
+                }
+                __syncthreads();
+            }
+            cut = __uint_as_float(s_prefix);
+        }
+        // survivors (strictly above the cut: at most top_k - 1, or all nl < top_k) in raster order: a survivor's slot is the number
+        // of survivors with a smaller pixel index
+        if (t == 0) s_npos = 0;
+        __syncthreads();
+        for (unsigned i = t; i < nl; i += 1024) {
+            if (!(lv[i] > cut)) continue;
+            const int me = li[i];
+            unsigned at = 0;
+            for (unsigned j = 0; j < nl; ++j) at += (lv[j] > cut && li[j] < me) ? 1u : 0u;
+            atomicAdd(&s_npos, 1u);
+            if ((int)at < cap) {
+                centers[((long)b * cap + at) * 2] = me / W;
+                centers[((long)b * cap + at) * 2 + 1] = me % W;
+            }
+        }
+        __syncthreads();
+        if (t == 0) ncenters[b] = min((int)s_npos, cap);
+        return;
+    }
     // count strictly positive candidates
     unsigned local = 0;
     if ((HW & 3) == 0) {
@@ -380,7 +454,7 @@ __global__ void extract_masks_generic_kernel(const float* __restrict__ pan, cons
 static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 size_t postprocess_ws_bytes(int B, int H, int W, int cap) {
     const size_t HW = (size_t)H * W;
-    return al(B * HW * 4) + al(B * HW) + al((size_t)B * 256 * 4) * 2 + al((size_t)B * cap * sizeof(InstStat));
+    return al(B * HW * 4) + al(B * HW) + al((size_t)B * 256 * 4) * 2 + al((size_t)B * cap * sizeof(InstStat)) + al((size_t)B * sizeof(CandList));
 }
 
 int launch_postprocess(const float* logits, int nch, int B, int H, int W, const PostCfg& c, void* ws, float* pan,
@@ -396,19 +470,21 @@ int launch_postprocess(const float* logits, int nch, int B, int H, int W, const 
     uint8_t* idmap = reinterpret_cast<uint8_t*>(w); w += al(B * HW);
     unsigned* area = reinterpret_cast<unsigned*>(w); w += al((size_t)B * 256 * 4);
     float* lut = reinterpret_cast<float*>(w); w += al((size_t)B * 256 * 4);
-    InstStat* stats = reinterpret_cast<InstStat*>(w);
+    InstStat* stats = reinterpret_cast<InstStat*>(w); w += al((size_t)B * c.cap * sizeof(InstStat));
+    CandList* lists = reinterpret_cast<CandList*>(w);
 
     const int r = (c.nms_kernel - 1) / 2;
     const int P = NT + 2 * r;
     const double px = (double)B * HW;
+    if (int rc = launch_zero(lists, (size_t)B * sizeof(CandList), st)) return rc;      // (the counts; the slots behind them ride along)
     {   // a8: centre plane in, candidate map out
         ProfScope prof("post_nms", 8.0 * px, 0.0, st);
-        hipLaunchKernelGGL(nms_kernel, dim3((W + NT - 1) / NT, (H + NT - 1) / NT, B), dim3(256), sizeof(float) * P * P, st,
-                           logits, nch, H, W, c.threshold, r, cand);
+        hipLaunchKernelGGL(nms_kernel, dim3((W + NT - 1) / NT, (H + NT - 1) / NT, B), dim3(256), sizeof(float) * (P * P + P * NT), st,
+                           logits, nch, H, W, c.threshold, r, cand, lists);
     }
     {   // a8: k-th largest candidate + ordered compaction (one block per frame; reads the candidate map)
         ProfScope prof("post_select", 4.0 * px, 0.0, st);
-        hipLaunchKernelGGL(select_kernel, dim3(B), dim3(1024), 0, st, cand, (int)HW, W, c.top_k, c.cap, centers, ncenters);
+        hipLaunchKernelGGL(select_kernel, dim3(B), dim3(1024), 0, st, cand, (int)HW, W, c.top_k, c.cap, centers, ncenters, lists);
     }
     if (int rc = launch_zero(area, (size_t)B * 256 * 4, st)) return rc;
     const int pblocks = (int)((HW + 255) / 256);

@@ -193,6 +193,40 @@ def test_centers_golden(path):
     np.testing.assert_array_equal(o["centers"][:k], z["out"])
 
 
+CENTRE_LIST_CASES = [   # (name, peaks, distinct values, plateau): the candidate list of P1 (2048 slots) and the map path behind it
+    ("few", 37, 0, None),
+    ("exactly_top_k", 200, 0, None),
+    ("above_top_k", 900, 0, None),
+    ("ties_at_the_cut", 600, 5, None),                  # five distinct values: the k-th largest is shared by ~120 peaks
+    ("list_full", 2048, 0, None),
+    ("list_overflows_by_one", 2049, 0, None),
+    ("plateau", 150, 0, (100, 200, 300, 420)),          # a constant region: every pixel of it is a candidate (24 000 of them)
+    ("plateau_below_the_cut", 400, 0, (10, 50, 30, 90)),
+]
+
+
+@pytest.mark.parametrize("name,peaks,levels,plateau", CENTRE_LIST_CASES, ids=[c[0] for c in CENTRE_LIST_CASES])
+def test_centres_list_and_map_paths(name, peaks, levels, plateau):
+    """a8 (post_processing.py:9-44 find_instance_center): the short candidate list and the full-map walk select the same centres."""
+    h, w = 480, 640
+    rng = np.random.default_rng(len(name) * 131 + peaks)
+    c = rng.uniform(0.0, 0.25, (h, w)).astype(np.float32)           # below the 0.3 threshold
+    ys, xs = np.meshgrid(np.arange(3, h - 3, 8), np.arange(3, w - 3, 8), indexing="ij")   # 8-pixel lattice: no peak suppresses another
+    at = rng.permutation(ys.size)[:peaks]
+    vals = rng.uniform(0.35, 0.99, peaks).astype(np.float32)
+    if levels:
+        vals = np.float32(0.4) + np.float32(0.1) * rng.integers(0, levels, peaks).astype(np.float32)
+    c[ys.ravel()[at], xs.ravel()[at]] = vals
+    if plateau:
+        y0, y1, x0, x1 = plateau
+        c[y0:y1, x0:x1] = np.float32(0.36 if "below" in name else 0.97)
+    _, o, _ = run_post(np.full((h, w), -4.0, np.float32), c, np.zeros((2, h, w), np.float32))
+    ref = postproc_ref.find_centers(torch.from_numpy(c)[None]).numpy()
+    k = int(o["ncenters"])
+    assert k == min(len(ref), 200)
+    np.testing.assert_array_equal(o["centers"][:k], ref[:k])
+
+
 @pytest.mark.parametrize("path", [p for p in golden("group") if "k20" not in p and "k199" not in p], ids=os.path.basename)
 def test_group_golden(path):
     # fixtures whose centre list is in raster order can be reproduced through a centre map with peaks there
@@ -676,6 +710,48 @@ def test_conv_refuses_narrow_inputs_for_3x3():
     rc = lib.quber_op_conv2d(p(x), 1, 8, 8, 4, p(w), 32, 3, 1, 1, 1, C.c_void_p(0), C.c_void_p(0), C.c_void_p(0), 0, p(packed), p(y),
                              C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc != 0 and b"8 input channels" in lib.quber_last_error()
+
+
+POINTWISE16_CASES = [
+    # B, H, W, Cin, Cout, affine, residual, relu      (the fp16 data path's 1x1 layers: ResNet bottleneck conv1 / conv3)
+    (2, 64, 64, 64, 256, True, True, True),           # res2 conv3
+    (2, 64, 64, 256, 64, True, False, True),          # res2 conv1
+    (2, 32, 32, 128, 512, True, True, True),          # res3 conv3
+    (1, 16, 16, 512, 2048, True, True, True),         # res5 conv3
+    (1, 16, 16, 192, 384, False, False, False),       # no affine
+    (3, 17, 23, 64, 192, True, True, False),          # ragged M (1173 pixels), no ReLU
+    (1, 1, 1, 64, 64, True, True, True),              # M = 1
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", POINTWISE16_CASES, ids=[f"{c[3]}to{c[4]}@{c[0]}x{c[1]}x{c[2]}" for c in POINTWISE16_CASES])
+def test_pointwise_fp16_tensors_vs_float64(case):
+    """the implicit GEMM on fp16 tensors (fp16 data path, compute_dtype 2) through the stand-alone op: within fp16 output rounding
+    of a float64 evaluation of the same fp16 operands (detectron2 BottleneckBlock conv1 / conv3, maskrefiner/modeling/backbone/resnet.py:37-63)."""
+    B, H, W, Cin, Cout, affine, residual, relu = case
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(Cin * 7 + Cout)
+    x = torch.randn(B, H, W, Cin, device="cuda", generator=g).half()
+    w = (torch.randn(Cout, Cin, device="cuda", generator=g) / np.sqrt(Cin)).half()
+    sc = (torch.rand(Cout, device="cuda", generator=g) + 0.5) if affine else None
+    sh = torch.randn(Cout, device="cuda", generator=g) if affine else None
+    res = torch.randn(B, H, W, Cout, device="cuda", generator=g).half() if residual else None
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    y = torch.full((B, H, W, Cout), float("nan"), device="cuda", dtype=torch.float16)
+    rc = lib.quber_op_conv1x1_f16(p(x), B, H, W, Cin, p(w), Cout, p(sc), p(sh), p(res), int(relu), p(y), st)
+    assert rc == 0, lib.quber_last_error()
+    torch.cuda.synchronize()
+    ref = x.double().reshape(-1, Cin) @ w.double().T
+    if affine:
+        ref = ref * sc.double() + sh.double()
+    if residual:
+        ref = ref + res.double().reshape(-1, Cout)
+    if relu:
+        ref = ref.clamp(min=0)
+    err = (y.double().reshape(-1, Cout) - ref).abs()
+    assert float((err / (ref.abs() + 1.0)).max()) < 2e-3       # fp16 output rounding 2^-11 + fp32 accumulation
 
 
 PERSISTENT_CASES = [

@@ -74,7 +74,7 @@ def report(a):
            "|---|---|---|---|---|---|"]
     for i, (c, (path, ks)) in enumerate(zip(convs, groups[-n:])):
         ms = sum(dur(r) for r in ks)
-        r = next(k for k in ks if "conv_igemm" in name(k) or "wino_fused" in name(k) or "stem_conv1" in name(k))
+        r = next(k for k in ks if any(t in name(k) for t in ("conv_igemm", "wino_fused", "stem_conv1")))
         fl = c[2] * B
         if "stem_conv1" in name(r):
             tile = "vector FMA, 8 x 32 pixels x 32 ch per block"
