@@ -58,6 +58,7 @@ struct ConvP {
     int es;              // element size of the activations (in / in2 / res / out): 4 = fp32, 2 = fp16 in HBM (conv_igemm_f32 DT 4)
     int acc_chunk;       // K-slices per accumulation chunk (two-level fp32 accumulation: the MFMA accumulator is folded into a
                          // second register set every acc_chunk slices); 0 = one sequential chain over K
+    int lean_in_bytes;   // LEAN loader (conv_igemm.hip): bytes of one group's input view (buffer descriptor range)
     int bf16;            // quber_config.compute_dtype: 0 = fp32 MFMA, 1 = bf16 / 2 = fp16 operands, 3 = fp32 operands split into 3 bf16 terms
 };
 
@@ -154,6 +155,7 @@ struct Tuning {
     int persist_min_tiles = 256; // key 15 (launch): fewest tiles (all groups) of a launch that goes persistent
     int persist_debug = 0;       // key 16 (diagnostics): 1 = every store of the persistent epilogue is dropped by the range check
     int stem_fused = 1;          // key 29 (plan): input normalisation + concat (a3) inside the first stem convolution's kernel (csrc/stem.hip); 0 = preprocess kernel + implicit GEMM
+    int lean_loader = 1;         // key 30 (launch): implicit GEMM with block-uniform filter taps and buffer loads where the layer allows it (conv_igemm.hip LEAN); 0 = per-thread tap arithmetic
     int h16_wide = 0;            // key 31 (launch): fp16 data path - 128x256 tiles for layers with Cout % 256 == 0
     int h16_wide_min_tiles = 1024; // key 32 (launch): fewest 128x256 tiles of a launch that takes them
     int fuse_shortcut = 1;       // key 18 (plan): conv3 + projection shortcut of a bottleneck as one dual-input GEMM
@@ -185,7 +187,7 @@ int launch_preprocess(const uint8_t* rgb, const uint8_t* depth, const float* off
                       int H, int W, const float* mean6, const float* std6, int streams, hipStream_t st);
 int launch_maxpool3x3s2(const View& in, const View& out, int B, int G, hipStream_t st);
 int launch_stem_conv1(const uint8_t* bgr, const uint8_t* depth, const float* offs, int B, int H, int W, int streams, const float* mean6,
-                      const float* std6, const float* w, const float* scale, const float* shift, float* out, long out_gs, hipStream_t st);
+                      const float* std6, const float* w, const float* scale, const float* shift, float* out, long out_gs, int es, hipStream_t st);
 int launch_zero(void* p, size_t bytes, hipStream_t st);
 int launch_gn_stats(const View& in, int B, int G, int groups, double* stats, hipStream_t st, bool zero = true);
 int launch_gn_apply(const View& in, const View& out, int B, int G, int groups, const double* stats,

@@ -68,16 +68,28 @@ constexpr int NPL(int dt) { return dt == 3 ? 3 : 1; }     // bf16 planes per ope
 #endif
 // waves per SIMD the kernel is compiled for: two accumulator sets (the MFMA chain and the chunk sums, below) cost the
 // 128-row tiles their third resident block; the 64x64 tiles keep five
-constexpr int igemm_occupancy(int BM, int BN, int DT = 0) {
-    if (DT == 4 && BM * BN > 128 * 128) return 2;         // 128x256 (wave tiles of 64x128: 128 accumulator registers)
+#ifndef QB_H16_LEAN_OCC
+#define QB_H16_LEAN_OCC 4  // LEAN loader (no 64-bit addresses, no bounds state): the 128x128 fp16 kernel fits 128 registers - four resident blocks
+#endif
+constexpr int igemm_occupancy(int BM, int BN, int DT = 0, bool LEAN = false) {
+    if (DT == 4 && BM * BN > 128 * 128) return 2;
+    if (DT == 4 && LEAN && BM == 128 && BN == 128) return QB_H16_LEAN_OCC;         // 128x256 (wave tiles of 64x128: 128 accumulator registers)
     if (DT == 4 && BM * BN >= 128 * 128) return QB_H16_OCC;
     if (DT == 4 && BM == 64 && BN == 64) return 7;        // HBM-bound residual layers: blocks in flight are what they live on
     if (BM * BN >= 128 * 128 || (BM == 256 && DT == 3)) return 2;
     return BM == 64 ? (DT == 0 ? 6 : 5) : 3;
 }
 
-template <int BM, int BN, int WM, int WN, int MODE, int DT = 0>
-__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(igemm_occupancy(BM, BN, DT)))) void conv_igemm_f32(const ConvP p) {
+// LEAN (host: Cin a multiple of the K-slice, tensors below 2 GiB, at most 32 filter taps): every K-slice lies inside one filter
+// tap, so the tap position is block-uniform and lives in scalar registers; a thread keeps one 32-bit byte offset and one
+// tap-validity bit mask per A row, and the loads are buffer loads whose out-of-range offset (a padding tap) returns zeros -
+// 4 vector instructions per A row and K-slice instead of ~20 (64-bit address arithmetic, four bounds compares, four selects
+// when the slice is written to LDS).  The fp16 kernel issues 16 MFMAs of 32 cycles per K-slice and the matrix pipe does not
+// run beside vector instructions of the same SIMD: the loader's ~95 vector instructions cost it as much time as the MFMAs
+// (SQ_INSTS_VALU / SQ_INSTS_MFMA = 8.3, MFMA busy 0.39: profiles/r10b_h16_loader.md).
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+template <int BM, int BN, int WM, int WN, int MODE, int DT = 0, bool LEAN = false>
+__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(igemm_occupancy(BM, BN, DT, LEAN)))) void conv_igemm_f32(const ConvP p) {
     constexpr int NTH = WM * WN * 64;
     constexpr int RPP = NTH / 8;      // tile rows covered by one pass of the loader
     constexpr int TM = BM / WM / 32;
@@ -215,9 +227,91 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(ig
         kx = tap - ky * p.kw;
     }
 
+    // LEAN loader state: byte offset of (pixel of row i at tap (0, 0), channel kq) and the taps of row i that fall inside the image
+    int aoff[AL], boff[BL];
+    unsigned amask[AL];
+    int skc = 0, skx = 0, sky = 0;        // block-uniform tap position of the next K-slice
+    __amdgpu_buffer_rsrc_t rsa, rsb;
+    if constexpr (LEAN) {
+#pragma unroll
+        for (int i = 0; i < AL; ++i) {
+            const int m = m0 + lrow + RPP * i;
+            aoff[i] = 0;
+            amask[i] = 0;
+            if (m < p.M && p.kh == 1 && p.stride == 1 && p.pad == 0) {
+                aoff[i] = (m * p.in_cs + kq) * 4;
+                amask[i] = 1;
+            } else if (m < p.M) {
+                const int ohw = p.OH * p.OW;
+                const int b = m / ohw;
+                const int rem = m - b * ohw;
+                const int oy = rem / p.OW;
+                const int ox = rem - oy * p.OW;
+                const int y0 = oy * p.stride - p.pad, x0 = ox * p.stride - p.pad;
+                aoff[i] = (((b * p.H + y0) * p.W + x0) * p.in_cs + kq) * 4;
+                unsigned mk = 0;
+                for (int ty = 0; ty < p.kh; ++ty)
+                    for (int tx = 0; tx < p.kw; ++tx)
+                        if ((unsigned)(y0 + ty * p.dil) < (unsigned)p.H && (unsigned)(x0 + tx * p.dil) < (unsigned)p.W) mk |= 1u << (ty * p.kw + tx);
+                amask[i] = mk;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BL; ++i) {
+            const int n = n0 + lrow + RPP * i;
+            boff[i] = ((n < p.Cout ? n : 0) * p.Kpad + kq) * 4;
+        }
+        {
+            const int kb = __builtin_amdgcn_readfirstlane(k_begin);
+            if (p.kmode) {
+                const int taps = p.kh * p.kw;
+                const int cb = kb / taps, tap = kb - cb * taps;
+                skc = cb * BK;
+                sky = tap / p.kw;
+                skx = tap - sky * p.kw;
+            } else {
+                const int k = kb * BK;
+                const int tap = k / p.Cin;
+                skc = k - tap * p.Cin;
+                sky = tap / p.kw;
+                skx = tap - sky * p.kw;
+            }
+            skc = __builtin_amdgcn_readfirstlane(skc); skx = __builtin_amdgcn_readfirstlane(skx); sky = __builtin_amdgcn_readfirstlane(sky);
+        }
+        rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, p.lean_in_bytes, 0x00020000);
+        rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wt), 0, 0x7ffffff0, 0x00020000);
+    }
+
     f32x4 ra[AL], rb[BL];
     bool aok[AL];
     auto gload = [&](int kt) __attribute__((always_inline)) {
+        if constexpr (LEAN) {
+            const int tap = sky * p.kw + skx;
+            const int soff = (((sky * p.dil) * p.W + skx * p.dil) * p.in_cs + skc) * 4;
+#pragma unroll
+            for (int i = 0; i < AL; ++i) {
+                const bool ok = (amask[i] >> tap) & 1u;
+                aok[i] = true;
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsa, ok ? aoff[i] + soff : (int)0x80000000, 0, 0);
+                ra[i] = __builtin_bit_cast(f32x4, v);
+            }
+            const int wso = kt * BK * 4;
+#pragma unroll
+            for (int i = 0; i < BL; ++i) rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsb, boff[i], wso, 0));
+            if (p.kmode) {
+                if (++skx == p.kw) {
+                    skx = 0;
+                    if (++sky == p.kh) { sky = 0; skc += BK; }
+                }
+            } else {
+                skc += BK;
+                if (skc >= p.Cin) {
+                    skc = 0;
+                    if (++skx == p.kw) { skx = 0; ++sky; }
+                }
+            }
+            return;
+        }
         const bool kok = p.kmode || ky < p.kh;
         const int dy = ky * p.dil, dx = kx * p.dil;
         const long off = ((long)dy * p.W + dx) * p.in_cs + kc;
@@ -267,7 +361,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(ig
             };
 #pragma unroll
             for (int i = 0; i < AL; ++i)
-                split(aok[i] ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f}, &Ah[(lrow + RPP * i) * PITCH_H + kq], BM * PITCH_H);
+                split((LEAN || aok[i]) ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f}, &Ah[(lrow + RPP * i) * PITCH_H + kq], BM * PITCH_H);
 #pragma unroll
             for (int i = 0; i < BL; ++i) split(rb[i], &Bh[(lrow + RPP * i) * PITCH_H + kq], BN * PITCH_H);
             return;
@@ -275,7 +369,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(ig
         if constexpr (!RAW) {
 #pragma unroll
             for (int i = 0; i < AL; ++i) {
-                const f32x4 v = aok[i] ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 v = (LEAN || aok[i]) ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f};
                 *reinterpret_cast<h16x4*>(&Ah[buf * BM * PITCH_H + (lrow + RPP * i) * PITCH_H + kq]) =
                     h16x4{(H16)v.x, (H16)v.y, (H16)v.z, (H16)v.w};
             }
@@ -288,7 +382,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(ig
 #pragma unroll
         for (int i = 0; i < AL; ++i)
             *reinterpret_cast<f32x4*>(&As[buf * BM * PITCH + (lrow + RPP * i) * PITCH + kq]) =
-                aok[i] ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+                (LEAN || aok[i]) ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < BL; ++i)
             *reinterpret_cast<f32x4*>(&Bs[buf * BN * PITCH + (lrow + RPP * i) * PITCH + kq]) = rb[i];
@@ -735,6 +829,18 @@ static int choose_split(const ConvP& p, int G, int BM, int BN, int bpc) {
     return best;
 }
 
+// the LEAN loader of conv_igemm_f32: block-uniform filter taps (every K-slice inside one tap), 32-bit byte offsets, <= 32 taps;
+// fills p.lean_in_bytes (the extent of one group's input view, the buffer descriptor's range)
+static bool lean_loader(ConvP& p) {
+    if (!tune().lean_loader || p.in2) return false;
+    if (p.Cin % BK || p.K != p.Kpad || p.kh * p.kw > 32) return false;
+    const long in_bytes = ((long)p.B * p.H * p.W * p.in_cs) * 4, w_bytes = (long)p.Cout * p.Kpad * 4;
+    if (in_bytes >= 0x7fffff00L || w_bytes >= 0x7fffff00L) return false;
+    // a padding tap of the first pixel reaches at most (pad rows + pad columns) before the view: offsets stay inside int32
+    p.lean_in_bytes = (int)in_bytes;
+    return true;
+}
+
 template <int BM, int BN, int WM, int WN>
 static int run(ConvP p, int G, int S, hipStream_t st) {
     p.mtiles = (p.M + BM - 1) / BM;
@@ -797,8 +903,12 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
     if (p.es == 2) {        // fp16 data path: one K pass (the loop is 16x shorter than the fp32 one), padded filter rows skipped; never
                             // persistent (below), split or on the fp32 pipe
         ProfScope prof(tag, conv_bytes, conv_flops, st);
-        if (skip) hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 3, 4>), dim3(p.mtiles * p.ntiles, 1, G), block, 0, st, p);
-        else hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 0, 4>), dim3(p.mtiles * p.ntiles, 1, G), block, 0, st, p);
+        const dim3 grid(p.mtiles * p.ntiles, 1, G);
+        if (lean_loader(p)) {
+            if (skip) hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 3, 4, true>), grid, block, 0, st, p);
+            else hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 0, 4, true>), grid, block, 0, st, p);
+        } else if (skip) hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 3, 4>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 0, 4>), grid, block, 0, st, p);
         QB_CHECK(hipGetLastError());
         return gn_separate();
     }

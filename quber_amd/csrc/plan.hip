@@ -53,6 +53,7 @@ static int* tuning_field(Tuning& t, int key) {
         case 25: return &t.wino_fused;
         case 27: return &t.wino_fused_max_cin;
         case 29: return &t.stem_fused;
+        case 30: return &t.lean_loader;
         case 31: return &t.h16_wide;
         case 32: return &t.h16_wide_min_tiles;
         default: return nullptr;
@@ -631,7 +632,10 @@ struct Builder {
             if (!w || !bw || !bb || !bm || !bv) { ok = false; continue; }
             for (int o = 0; o < 32; ++o) {
                 for (int ci = 0; ci < 6; ++ci)
-                    for (int t = 0; t < 9; ++t) packed[(((size_t)g * 9 + t) * 6 + ci) * 32 + o] = w[((size_t)o * 6 + ci) * 9 + t];
+                    for (int t = 0; t < 9; ++t) {
+                        const float v = w[((size_t)o * 6 + ci) * 9 + t];
+                        packed[(((size_t)g * 9 + t) * 6 + ci) * 32 + o] = out.es == 2 ? (float)(_Float16)v : v;      // fp16 data path: the operand the MFMA kernel multiplies
+                    }
                 // the same per-channel affine as conv() derives (FrozenBN, [d2]: scale = weight * rsqrt(var + eps))
                 const float sc = bw[o] * (1.0f / sqrtf(bv[o] + 1e-5f));
                 scale[(size_t)g * 32 + o] = sc;
@@ -640,7 +644,7 @@ struct Builder {
         }
         if (dry || !ok) return;
         const int OH = (H + 1) / 2, OW = (W + 1) / 2;
-        if (out.C != 32 || out.cs != 32 || out.H != OH || out.W != OW || out.es != 4) { if (err.empty()) err = "internal: fused stem output geometry"; return; }
+        if (out.C != 32 || out.cs != 32 || out.H != OH || out.W != OW || (out.es != 4 && out.es != 2)) { if (err.empty()) err = "internal: fused stem output geometry"; return; }
         const double fl = 2.0 * OH * OW * 6.0 * 9.0 * 32.0 * G;
         c->flops += fl;
         const float *dw = upload(packed), *ds = upload(scale), *dh = upload(shift);
@@ -649,7 +653,7 @@ struct Builder {
         c->stem_fused = true;
         c->ops.push_back({[=](int B, hipStream_t st) {
             return launch_stem_conv1(ctx->cur_bgr, ctx->cur_depth, ctx->cur_off, B, ctx->cfg.height, ctx->cfg.width, G, ctx->cfg.pixel_mean,
-                                     ctx->cfg.pixel_std, dw, ds, dh, o.p, o.gs, st);
+                                     ctx->cfg.pixel_std, dw, ds, dh, o.p, o.gs, o.es, st);
         }, OP_CONV, names[0], fl, 1});
         last_conv = {nullptr, nullptr, 0, 0};
         pending_norm.reset();
@@ -683,7 +687,8 @@ struct Builder {
         // (fp16 data path: 16 channels - the loader steps through a filter tap in units of 8 four-byte words)
         // fp32 tensors (exact fp32 and bf16x3 modes): a3 runs inside the first convolution's kernel - the normalised 8-channel input
         // (315 MB per 16-frame step) is neither written nor read back (option key 29)
-        const bool stem_one = aes == 4 && tune().stem_fused;
+        // fp16 tensors: the same kernel on the fp16-rounded operands (no 16-channel fp16 input tensor, no zero channels multiplied)
+        const bool stem_one = tune().stem_fused != 0;
         View s1 = make(32, h2, w2, NS), s2 = make(32, h2, w2, NS), s3 = make(64, h2, w2, NS);
         if (stem_one) {
             emit_stem_fused(two("stem.conv1", false), s1);
@@ -692,6 +697,7 @@ struct Builder {
             if (!dry) c->X = X;
             conv(two("stem.conv1", false), X, 6, s1, 3, 2, 1, 1, AF_FROZEN_BN, nullptr, true);
         }
+        if (!dry) c->taps["stem1"] = s1;
         conv(two("stem.conv2", false), s1, 32, s2, 3, 1, 1, 1, AF_FROZEN_BN, nullptr, true);
         conv(two("stem.conv3", false), s2, 32, s3, 3, 1, 1, 1, AF_FROZEN_BN, nullptr, true);
         View x = make(64, h4, w4, NS);

@@ -249,28 +249,51 @@ __global__ __launch_bounds__(256) void group_kernel(const float* __restrict__ lo
     __syncthreads();
     const long HW = (long)H * W;
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned id = 0;
+    bool fg = false;
     if (p < HW) {
         const float* base = logits + (long)b * nch * HW;
-        const bool fg = base[p] > 0x1.8p-24f;  // sigmoid(x).round() == 1
-        unsigned id = 0;
+        // (the three planes are requested together: a foreground pixel does not wait twice)
+        const float l0 = base[p], oy = base[2 * HW + p], ox = base[3 * HW + p];
+        fg = l0 > 0x1.8p-24f;  // sigmoid(x).round() == 1
         if (fg) {
             if (K == 0) {
                 id = 255;
             } else {
                 const int y = (int)(p / W), x = (int)(p - (long)y * W);
-                const float ly = __fadd_rn((float)y, base[2 * HW + p]);
-                const float lx = __fadd_rn((float)x, base[3 * HW + p]);
-                float best = INFINITY;
+                const float ly = __fadd_rn((float)y, oy);
+                const float lx = __fadd_rn((float)x, ox);
+                // argmin over k of sqrt(dx^2 + dy^2), first index on ties (torch.norm + argmin).  The square root is monotone, so a
+                // smaller d^2 can only tie - never lose - after it; the root (a quarter-rate instruction) is taken just for the
+                // pairs whose squares are within a few ulp of each other, where two different squares may round to one root
+                float best2 = INFINITY;
                 for (int k = 0; k < K; ++k) {
                     const float dy = __fsub_rn(cy[k], ly), dx = __fsub_rn(cx[k], lx);
-                    const float d = __fsqrt_rn(__fmaf_rn(dx, dx, __fmul_rn(dy, dy)));
-                    if (d < best) { best = d; id = k + 1; }
+                    const float d2 = __fmaf_rn(dx, dx, __fmul_rn(dy, dy));
+                    if (d2 < best2) {
+                        // (the root through fp64, correctly rounded to fp32: HIP's __fsqrt_rn is the NATIVE square-root instruction - 1 ulp -
+                        // unless OCML_BASIC_ROUNDED_OPERATIONS is defined; with it the grouping of near-equidistant pixels left the
+                        // reference's, tests/test_gpu_parity.py::test_group_near_ties_follow_the_rounded_norm)
+                        if (d2 > best2 * 0.999999f && !((float)sqrt((double)d2) < (float)sqrt((double)best2))) continue;    // the roots tie: the earlier centre stays
+                        best2 = d2;
+                        id = k + 1;
+                    }
                 }
                 if (id == 0) id = 1;  // all-NaN distances: argmin returns index 0
             }
-            atomicAdd(&harea[id], 1u);
         }
         idmap[(long)b * HW + p] = (uint8_t)id;
+    }
+    {   // areas: one LDS atomic per wave when its foreground lanes agree on the instance (inside an object: nearly always)
+        const unsigned long long m = __ballot(fg);
+        if (m) {
+            const unsigned first = __shfl(id, __ffsll((long long)m) - 1);
+            if (__all(!fg || id == first)) {
+                if ((threadIdx.x & 63) == 0) atomicAdd(&harea[first], (unsigned)__popcll(m));
+            } else if (fg) {
+                atomicAdd(&harea[id], 1u);
+            }
+        }
     }
     __syncthreads();
     if (harea[threadIdx.x]) atomicAdd(&area[(long)b * 256 + threadIdx.x], harea[threadIdx.x]);
@@ -342,20 +365,30 @@ __global__ __launch_bounds__(256) void paint_stats_kernel(const float* __restric
     __syncthreads();
     const long HW = (long)H * W;
     const long base = (long)blockIdx.x * PS_PIX;
+    // the block's instance ids and foreground logits are requested up front (16 + 16 loads in flight per thread): 2048 blocks
+    // walking 16 dependent load pairs each left the launch latency-bound at 6 % of the HBM rate
+    uint8_t ids[PS_PIX / 256];
+    float lgs[PS_PIX / 256];
+#pragma unroll
+    for (int it = 0; it < PS_PIX / 256; ++it) {
+        const long p = base + it * 256 + t;
+        ids[it] = p < HW ? idmap[(long)b * HW + p] : 0;
+        lgs[it] = p < HW ? logits[(long)b * nch * HW + p] : 0.f;
+    }
+#pragma unroll
     for (int it = 0; it < PS_PIX / 256; ++it) {
         const long p = base + it * 256 + t;
         int slot = -1, y = 0, x = 0;
         double pr = 0.0;
         if (p < HW) {
-            const float lab = slut[idmap[(long)b * HW + p]];
+            const float lab = slut[ids[it]];
             pan[(long)b * HW + p] = lab;
             if (lab >= 0.f) {
                 slot = (int)lab - label_divisor;     // 1000 -> 0 (centre-less blob), 1001.. -> 0..
                 if (slot > 0) slot -= 1;
                 y = (int)(p / W);
                 x = (int)(p - (long)y * W);
-                const float lg = logits[(long)b * nch * HW + p];
-                pr = (double)(1.f / (1.f + expf(-lg)));
+                pr = (double)(1.f / (1.f + expf(-lgs[it])));
             }
         }
         const int first = __shfl(slot, 0);

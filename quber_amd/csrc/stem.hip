@@ -30,6 +30,12 @@ struct StemP {
 };
 
 // wq: filters [streams][9 taps][6 channels][32] (output channel fastest); scq / shq: [streams][32]
+// H16 (fp16 data path, compute_dtype 2 with fp16 tensors): the operands the MFMA kernel would see - the normalised input rounded to
+// fp16, filters rounded to fp16 by the host - multiplied exactly and summed in fp32, the output rounded to fp16.  The fp16 MFMA sums
+// the 16 products of a step in an order of its own, so this form agrees with the preprocess kernel + implicit GEMM to fp32
+// summation order (a last-place difference of a few fp16 outputs), not bit for bit; it replaces a 16-channel fp16 input tensor
+// (537 MB per 8-frame step at 1024x1024) and a GEMM that multiplies 10 zero channels per tap.
+template <bool H16>
 __global__ __launch_bounds__(256) void stem_conv1_kernel(const StemP p, const float* __restrict__ wq, const float* __restrict__ scq,
                                                          const float* __restrict__ shq) {
     __shared__ float sx[9][IY][IX + 1];          // planes: image 0 (3), image 1 (3), heat, off_y, off_x
@@ -60,7 +66,7 @@ __global__ __launch_bounds__(256) void stem_conv1_kernel(const StemP p, const fl
             v[6] = o[0]; v[7] = o[HW]; v[8] = o[2 * HW];
         }
 #pragma unroll
-        for (int e = 0; e < 9; ++e) sx[e][r][c] = v[e];
+        for (int e = 0; e < 9; ++e) sx[e][r][c] = H16 ? (float)(_Float16)v[e] : v[e];
     }
     __syncthreads();
     const int ty = t >> 5, tx = t & 31;
@@ -89,9 +95,24 @@ __global__ __launch_bounds__(256) void stem_conv1_kernel(const StemP p, const fl
 #pragma unroll
             for (int o = 0; o < 16; ++o) top[o] = slice == 0 ? f32x2{0.f, 0.f} + acc[o] : top[o] + acc[o];
         }
-        float* dst = p.out + (long)g * p.out_gs + (((long)b * p.OH + oy) * p.OW + ox) * 32;
         const float* __restrict__ sc = scq + g * 32;
         const float* __restrict__ sh = shq + g * 32;
+        if constexpr (H16) {
+            using h16x8 = __attribute__((ext_vector_type(8))) _Float16;
+            _Float16* dst = reinterpret_cast<_Float16*>(p.out) + (long)g * p.out_gs + (((long)b * p.OH + oy) * p.OW + ox) * 32;
+#pragma unroll
+            for (int o = 0; o < 16; o += 4) {
+                h16x8 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    y[2 * e] = (_Float16)fmaxf(fmaf(top[o + e].x, sc[2 * (o + e)], sh[2 * (o + e)]), 0.f);
+                    y[2 * e + 1] = (_Float16)fmaxf(fmaf(top[o + e].y, sc[2 * (o + e) + 1], sh[2 * (o + e) + 1]), 0.f);
+                }
+                *reinterpret_cast<h16x8*>(dst + 2 * o) = y;
+            }
+            continue;
+        }
+        float* dst = p.out + (long)g * p.out_gs + (((long)b * p.OH + oy) * p.OW + ox) * 32;
 #pragma unroll
         for (int o = 0; o < 16; o += 2) {
             float4 y;
@@ -106,17 +127,19 @@ __global__ __launch_bounds__(256) void stem_conv1_kernel(const StemP p, const fl
 
 }  // namespace
 
-// w: [streams][9][6][32] device floats; out: NHWC [streams][Bcap][OH][OW][32] (group stride out_gs elements)
+// w: [streams][9][6][32] device floats; out: NHWC [streams][Bcap][OH][OW][32] (group stride out_gs elements) of fp32 (es 4) or fp16 (es 2)
 int launch_stem_conv1(const uint8_t* bgr, const uint8_t* depth, const float* offs, int B, int H, int W, int streams, const float* mean6,
-                      const float* std6, const float* w, const float* scale, const float* shift, float* out, long out_gs, hipStream_t st) {
+                      const float* std6, const float* w, const float* scale, const float* shift, float* out, long out_gs, int es, hipStream_t st) {
     if (!bgr || !offs || !w || !scale || !shift || !out || (streams == 2 && !depth)) return fail("stem: null argument");
     StemP p{};
     p.bgr = bgr; p.depth = depth; p.offs = offs; p.out = out; p.out_gs = out_gs;
     p.B = B; p.H = H; p.W = W; p.OH = (H + 1) / 2; p.OW = (W + 1) / 2; p.streams = streams;
     for (int i = 0; i < 6; ++i) { p.mean[i] = mean6[i]; p.stdv[i] = std6[i]; }
     const double px = (double)B * H * W, opx = (double)B * p.OH * p.OW;
-    ProfScope prof("stem_fused", px * (3.0 * streams + 12.0) + opx * 32.0 * 4.0 * streams, 2.0 * opx * 54.0 * 32.0 * streams, st);
-    hipLaunchKernelGGL(stem_conv1_kernel, dim3((p.OW + TX - 1) / TX, (p.OH + TY - 1) / TY, B), dim3(256), 0, st, p, w, scale, shift);
+    ProfScope prof("stem_fused", px * (3.0 * streams + 12.0) + opx * 32.0 * es * streams, 2.0 * opx * 54.0 * 32.0 * streams, st);
+    const dim3 grid((p.OW + TX - 1) / TX, (p.OH + TY - 1) / TY, B);
+    if (es == 2) hipLaunchKernelGGL(stem_conv1_kernel<true>, grid, dim3(256), 0, st, p, w, scale, shift);
+    else hipLaunchKernelGGL(stem_conv1_kernel<false>, grid, dim3(256), 0, st, p, w, scale, shift);
     QB_CHECK(hipGetLastError());
     return 0;
 }

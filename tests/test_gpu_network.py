@@ -462,6 +462,58 @@ def test_launch_structures_agree():
     assert float((pans["new"] == pans["old"]).float().mean()) > 0.999
 
 
+@pytest.mark.parametrize("h,w,b", [(256, 320, 2), (70, 102, 3)])
+def test_stem_fused_fp16_data_path(h, w, b):
+    """fp16 data path: a3 + stem.conv1 as one kernel on the fp16-rounded operands (csrc/stem.hip H16, key 29 = 1, default) against the
+    preprocess kernel + fp16 implicit GEMM (key 29 = 0).  Both multiply the same fp16 operands exactly and sum in fp32 - in
+    different orders (the MFMA's internal tree) - so the stem output agrees to the last place of fp16 and the logits to the path's
+    tolerance; the fused plan holds no 16-channel input tensor."""
+    sd = arch.init_state_dict(seed=7, loud_heads=True, center_bias=-1.5)
+    batch, offs = inputs(61, b, h, w, 4)
+    bgr, dep, off = torch.from_numpy(batch["rgb"]).cuda(), torch.from_numpy(batch["depth"]).cuda(), torch.from_numpy(offs).cuda()
+    outs = []
+    for fused, dt in ((1, 2), (0, 2), (1, 0)):                          # the last: exact fp32, the yardstick for the logits
+        qc = engine.make_config(h, w, max_batch=b)
+        qc.compute_dtype = dt
+        eng = engine.Engine(qc, "cuda:0")
+        eng.set_option(29, fused)
+        eng.load_state_dict(sd)
+        outs.append((eng.forward(bgr, dep, off).clone(), eng.debug_tensor("stem1", b).float().clone()))
+        eng.close()
+    s1, s0 = outs[0][1], outs[1][1]
+    assert s1.shape == s0.shape and float(s0.abs().max()) > 0.1
+    d = (s1 - s0).abs()
+    assert float((d / (s0.abs() + 1e-2)).max()) < 2e-3                 # one fp16 place (2^-10 relative)
+    assert float((d > 0).float().mean()) < 0.02                          # and rarely that
+    # a last-place flip in the stem travels through 80 fp16 layers: the two forms are equally far from the fp32 network
+    e1, e0 = float((outs[0][0] - outs[2][0]).abs().max()), float((outs[1][0] - outs[2][0]).abs().max())
+    assert e0 > 0 and e1 < 1.5 * e0 + 1e-3, (e1, e0)
+
+
+@pytest.mark.parametrize("h,w,b,name", [(150, 203, 3, None), (96, 128, 2, "single-stream"), (256, 320, 2, "m-b-f-c-o-e2")],
+                         ids=["ragged-default", "single-stream", "run_eval-default-yaml"])
+def test_fp16_lean_loader_equals_tap_arithmetic(h, w, b, name):
+    """fp16 data path (compute_dtype 2, configs[4] stand-in): the implicit GEMM with block-uniform filter taps, tap-validity masks and
+    buffer loads (conv_igemm.hip LEAN, key 30 = 1) against the per-thread tap arithmetic (key 30 = 0): every convolution of the
+    network (1x1, 3x3 with stride / dilation, 5x5 heads, padded borders) gives the same bits, so the logits do."""
+    kw = VARIANTS[name] if name else {}
+    qc = engine.set_arch(engine.make_config(h, w, max_batch=b), **kw)
+    qc.compute_dtype = 2
+    e = engine.Engine(qc, "cuda:0")
+    e.load_state_dict(arch.init_state_dict(seed=11, loud_heads=True, **kw))
+    batch, offs = inputs(5, b, h, w, 6)
+    bgr, dep, off = torch.from_numpy(batch["rgb"]).cuda(), torch.from_numpy(batch["depth"]).cuda(), torch.from_numpy(offs).cuda()
+    single = kw.get("streams", 2) == 1
+    outs = {}
+    for mode in (0, 1):
+        e.set_option(30, mode)
+        outs[mode] = e.forward(bgr, None if single else dep, off).clone()
+    assert e.get_option(30) == 1
+    assert torch.isfinite(outs[1]).all() and float(outs[1].abs().max()) > 0
+    assert torch.equal(outs[0], outs[1])
+    e.close()
+
+
 def test_two_engines_keep_their_own_options():
     """Options belong to a context (quber_set_option), not to the process: two engines with different plan-time and
     arithmetic-changing settings live side by side, interleaved on one thread and concurrently on two, and each keeps producing

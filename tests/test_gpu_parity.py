@@ -284,6 +284,51 @@ def test_group_golden_any_centre_order(path):
     np.testing.assert_array_equal(area.cpu().numpy()[0, :k + 1], np.bincount(z["out"][0].ravel(), minlength=k + 1)[:k + 1])
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_group_near_ties_follow_the_rounded_norm(seed):
+    """a9 (post_processing.py:44-76): torch.norm + argmin compares ROUNDED roots, first index on ties.  The kernel compares squared
+    distances and takes the root only for near-equal squares; here every pixel is steered to (almost) the same distance from several
+    centres - squares a few ulp apart that round to one root, exact ties, and the order of the list decides - and the oracle's
+    ids must come out, for the list and for its reverse."""
+    rng = np.random.default_rng(100 + seed)
+    h, w, k = 120, 160, 12
+    cy, cx = h // 2, w // 2
+    # twelve lattice points at EXACTLY the same distance from the frame centre (300 = |(180, 240)|, 37 = |(12, 35)|), shuffled; every
+    # pixel's offset sends it to that centre plus a few 1e-5, so its squared distances to the twelve differ by a few ulp
+    a, bq, rad = (180, 240, 300) if seed % 2 else (12, 35, 37)
+    pts = [(a, bq), (a, -bq), (-a, bq), (-a, -bq), (bq, a), (bq, -a), (-bq, a), (-bq, -a), (rad, 0), (-rad, 0), (0, rad), (0, -rad)]
+    ctr = (np.array(pts, np.int32) + [cy, cx])[rng.permutation(k)]
+    if seed == 3:
+        ctr[1] = ctr[0]                                                  # a duplicated centre: exact ties everywhere
+    yy, xx = np.meshgrid(np.arange(h, dtype=np.float32), np.arange(w, dtype=np.float32), indexing="ij")
+    off = np.stack([cy - yy, cx - xx]).astype(np.float32) + rng.uniform(-3e-5, 3e-5, (2, h, w)).astype(np.float32)
+    cap = 254
+    lists = [ctr, ctr[::-1].copy()]
+    lg = np.zeros((2, 4, h, w), np.float32)
+    lg[:, 0] = 4.0
+    lg[:, 2:4] = off
+    cbuf = np.zeros((2, cap, 2), np.int32)
+    for b, l in enumerate(lists):
+        cbuf[b, :k] = l
+    d_lg, d_c, d_n = dev(lg), dev(cbuf), dev(np.array([k, k], np.int32))
+    ids = torch.empty((2, h, w), dtype=torch.uint8, device="cuda")
+    area = torch.empty((2, 256), dtype=torch.int32, device="cuda")
+    lib = _lib.load()
+    _lib.check(lib.quber_op_group_pixels(d_lg.data_ptr(), 4, 2, h, w, cap, d_c.data_ptr(), d_n.data_ptr(), ids.data_ptr(),
+                                         area.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    got = ids.cpu().numpy().astype(np.int32)
+    for b, l in enumerate(lists):
+        want = postproc_ref.group_pixels(torch.from_numpy(l.astype(np.int64)), torch.from_numpy(off)).numpy()[0]
+        np.testing.assert_array_equal(got[b], want)
+        assert len(np.unique(want)) >= 2                                  # the steering left a real choice
+    # the case exists: somewhere two different squared distances share their rounded root
+    loc = np.stack([yy + off[0], xx + off[1]])
+    d2 = ((ctr[:, 0, None, None].astype(np.float32) - loc[0]) ** 2 + (ctr[:, 1, None, None].astype(np.float32) - loc[1]) ** 2).astype(np.float32)
+    srt = np.sort(d2, 0)
+    tie = (srt[0] != srt[1]) & (np.sqrt(srt[0]) == np.sqrt(srt[1]))
+    assert tie.any()
+
+
 @pytest.mark.parametrize("path", golden("panoptic"), ids=os.path.basename)
 def test_panoptic_golden(path):
     z = np.load(path)
