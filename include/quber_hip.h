@@ -285,7 +285,11 @@ double quber_forward_flops_padding(quber_ctx* ctx);
  *         channels (chains of 128-160) measures 1.20 / 1.21 and no speed-up inside the network (DESIGN.md section 4,
  *         profiles/r05_fused_anchor.md, r05_wino_fused_layers.md).
  * key 29 (1; plan) the input normalisation + concatenation (a3, model.py:137-153) inside the first stem convolution's kernel
- *         (csrc/stem.hip: same fmaf chains as the implicit GEMM, no normalised input tensor in HBM), or as a kernel of its own (0).
+ *         (csrc/stem.hip: same fmaf chains as the implicit GEMM, no normalised input tensor in HBM; fp16 data path: the same kernel
+ *         on the fp16-rounded operands, equal to the MFMA form up to fp32 summation order), or as a kernel of its own (0).
+ * key 30 (1; launch) implicit GEMM loader: block-uniform filter taps in scalar registers, a tap-validity bit mask and a 32-bit byte
+ *         offset per row, buffer loads whose out-of-range offset returns the zero padding (conv_igemm.hip LEAN; layers with
+ *         Cin % 32 == 0 - fp16 data path: % 64 - and tensors below 2 GiB), or per-thread tap arithmetic everywhere (0).  Same bits.
  * Process-only keys (quber_set_tuning): key 2 = give the stand-alone conv ops a split-K workspace (value != 0) or drop it (0);
  * key 11 = stand-alone conv op: dilated 3x3 layers in tap-major K order with the zero-padding filter rows skipped;
  * key 12 = stand-alone conv ops: quber_config.compute_dtype of the launch (1 = bf16 / 2 = fp16 operands, 3 = bf16x3);

@@ -156,8 +156,6 @@ struct Tuning {
     int persist_debug = 0;       // key 16 (diagnostics): 1 = every store of the persistent epilogue is dropped by the range check
     int stem_fused = 1;          // key 29 (plan): input normalisation + concat (a3) inside the first stem convolution's kernel (csrc/stem.hip); 0 = preprocess kernel + implicit GEMM
     int lean_loader = 1;         // key 30 (launch): implicit GEMM with block-uniform filter taps and buffer loads where the layer allows it (conv_igemm.hip LEAN); 0 = per-thread tap arithmetic
-    int h16_wide = 0;            // key 31 (launch): fp16 data path - 128x256 tiles for layers with Cout % 256 == 0
-    int h16_wide_min_tiles = 1024; // key 32 (launch): fewest 128x256 tiles of a launch that takes them
     int fuse_shortcut = 1;       // key 18 (plan): conv3 + projection shortcut of a bottleneck as one dual-input GEMM
     int lanes = 1;               // key 24 (launch): side lanes for batches <= 2 (0 = everything on the caller's stream)
 };

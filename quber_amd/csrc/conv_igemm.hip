@@ -72,8 +72,7 @@ constexpr int NPL(int dt) { return dt == 3 ? 3 : 1; }     // bf16 planes per ope
 #define QB_H16_LEAN_OCC 4  // LEAN loader (no 64-bit addresses, no bounds state): the 128x128 fp16 kernel fits 128 registers - four resident blocks
 #endif
 constexpr int igemm_occupancy(int BM, int BN, int DT = 0, bool LEAN = false) {
-    if (DT == 4 && BM * BN > 128 * 128) return 2;
-    if (DT == 4 && LEAN && BM == 128 && BN == 128) return QB_H16_LEAN_OCC;         // 128x256 (wave tiles of 64x128: 128 accumulator registers)
+    if (DT == 4 && LEAN && BM == 128 && BN == 128) return QB_H16_LEAN_OCC;
     if (DT == 4 && BM * BN >= 128 * 128) return QB_H16_OCC;
     if (DT == 4 && BM == 64 && BN == 64) return 7;        // HBM-bound residual layers: blocks in flight are what they live on
     if (BM * BN >= 128 * 128 || (BM == 256 && DT == 3)) return 2;
@@ -829,6 +828,13 @@ static int choose_split(const ConvP& p, int G, int BM, int BN, int bpc) {
     return best;
 }
 
+// one launch site for both loaders of an instantiation
+template <int BM, int BN, int WM, int WN, int MODE, int DT>
+static void launch_igemm(bool lean, dim3 grid, dim3 block, hipStream_t st, const ConvP& p) {
+    if (lean) hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, MODE, DT, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, MODE, DT, false>), grid, block, 0, st, p);
+}
+
 // the LEAN loader of conv_igemm_f32: block-uniform filter taps (every K-slice inside one tap), 32-bit byte offsets, <= 32 taps;
 // fills p.lean_in_bytes (the extent of one group's input view, the buffer descriptor's range)
 static bool lean_loader(ConvP& p) {
@@ -902,18 +908,17 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
     const bool skip = BM != 256 && p.skip_rows && p.kmode == 0 && p.kh > 1 && p.Cin % BK == 0 && p.K == p.Kpad && p.ohw > 0;
     if (p.es == 2) {        // fp16 data path: one K pass (the loop is 16x shorter than the fp32 one), padded filter rows skipped; never
                             // persistent (below), split or on the fp32 pipe
+                            // (128x256 tiles - wave tiles of 64x128, 25 % fewer LDS fragment reads per MFMA - measured level with
+                            // 128x128: 15.84 against 15.79 ms of convolutions, profiles/r10b_h16_loader.md)
         ProfScope prof(tag, conv_bytes, conv_flops, st);
         const dim3 grid(p.mtiles * p.ntiles, 1, G);
-        if (lean_loader(p)) {
-            if (skip) hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 3, 4, true>), grid, block, 0, st, p);
-            else hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 0, 4, true>), grid, block, 0, st, p);
-        } else if (skip) hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 3, 4>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 0, 4>), grid, block, 0, st, p);
+        const bool lean = lean_loader(p);
+        if (skip) launch_igemm<BM, BN, WM, WN, 3, 4>(lean, grid, block, st, p);
+        else launch_igemm<BM, BN, WM, WN, 0, 4>(lean, grid, block, st, p);
         QB_CHECK(hipGetLastError());
         return gn_separate();
     }
-    if constexpr (BN > 128) return fail("conv: 128x256 tiles exist for the fp16 data path only");
-    else {
+    const bool lean = lean_loader(p);
     // Persistent launch (conv_persist.hip): one block per resident slot walks whole tiles and an equal share of the
     // K-slices of the remainder
     // (launches of a few dozen tiles - small batches - keep the one-tile-per-block kernel and its fitted split-K model:
@@ -959,8 +964,7 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
                 // every piece owns at least one K-slice: (2^shift - 1) * kchunk < nk because nk >= 8 * 2^shift
                 {
                     ProfScope prof(tag, conv_bytes, conv_flops, st);
-                    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 2>), dim3((unsigned)(nfull + (rem << shift)), 1, G), block, 0,
-                                       st, p);
+                    launch_igemm<BM, BN, WM, WN, 2, 0>(lean, dim3((unsigned)(nfull + (rem << shift)), 1, G), block, st, p);
                 }
                 reduce(1 << shift);
                 QB_CHECK(hipGetLastError());
@@ -977,14 +981,14 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
             ProfScope prof(tag, conv_bytes, conv_flops, st);
             const dim3 grid(p.mtiles * p.ntiles, S, G);
             if (p.bf16 == 3) {
-                if (S > 1) hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 1, 3>), grid, block, 0, st, p);
-                else hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 0, 3>), grid, block, 0, st, p);
+                if (S > 1) launch_igemm<BM, BN, WM, WN, 1, 3>(lean, grid, block, st, p);
+                else launch_igemm<BM, BN, WM, WN, 0, 3>(lean, grid, block, st, p);
             } else if (p.bf16 == 2) {
-                if (S > 1) hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 1, 2>), grid, block, 0, st, p);
-                else hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 0, 2>), grid, block, 0, st, p);
+                if (S > 1) launch_igemm<BM, BN, WM, WN, 1, 2>(lean, grid, block, st, p);
+                else launch_igemm<BM, BN, WM, WN, 0, 2>(lean, grid, block, st, p);
             } else {
-                if (S > 1) hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 1, 1>), grid, block, 0, st, p);
-                else hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 0, 1>), grid, block, 0, st, p);
+                if (S > 1) launch_igemm<BM, BN, WM, WN, 1, 1>(lean, grid, block, st, p);
+                else launch_igemm<BM, BN, WM, WN, 0, 1>(lean, grid, block, st, p);
             }
         }
         if (S > 1) reduce(S);
@@ -994,18 +998,17 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
     if (S > 1) {
         {
             ProfScope prof(tag, conv_bytes, conv_flops, st);
-            if (skip) hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 4>), dim3(p.mtiles * p.ntiles, S, G), block, 0, st, p);
-            else hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 1>), dim3(p.mtiles * p.ntiles, S, G), block, 0, st, p);
+            if (skip) launch_igemm<BM, BN, WM, WN, 4, 0>(lean, dim3(p.mtiles * p.ntiles, S, G), block, st, p);
+            else launch_igemm<BM, BN, WM, WN, 1, 0>(lean, dim3(p.mtiles * p.ntiles, S, G), block, st, p);
         }
         reduce(S);
     } else {
         ProfScope prof(tag, conv_bytes, conv_flops, st);
-        if (skip) hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 3>), dim3(p.mtiles * p.ntiles, 1, G), block, 0, st, p);
-        else hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, 0>), dim3(p.mtiles * p.ntiles, 1, G), block, 0, st, p);
+        if (skip) launch_igemm<BM, BN, WM, WN, 3, 0>(lean, dim3(p.mtiles * p.ntiles, 1, G), block, st, p);
+        else launch_igemm<BM, BN, WM, WN, 0, 0>(lean, dim3(p.mtiles * p.ntiles, 1, G), block, st, p);
     }
     QB_CHECK(hipGetLastError());
     return gn_separate();
-    }
 }
 
 
@@ -1036,7 +1039,6 @@ int launch_conv(const ConvP& p0, int G, hipStream_t st) {
         case 2: return run<128, 128, 2, 2>(p, G, 1, st);
         case 4: return run<256, 32, 4, 1>(p, G, 1, st);
         case 3: return run<128, 64, 2, 2>(p, G, 1, st);
-        case 5: if (p.es == 2) return run<128, 256, 2, 2>(p, G, 1, st); break;
         default: break;
     }
     // Tile shape (sweep: profiles/r01i_conv_sweep_*.md).  <= 32 output channels: 256x32.  <= 64 channels, and the
@@ -1050,10 +1052,6 @@ int launch_conv(const ConvP& p0, int G, hipStream_t st) {
     // (64 x 256 tiles for the residual 1x1 layers - input rows read once, 512-byte row segments - measured 30-50 % SLOWER than
     // 64x64 in both the fp32 and the fp16 path, profiles/r03x_tile_64x256_rejected.txt: those layers live on blocks in flight)
     if (p.Cout <= 64 || (p.res && nk <= 8 && p.Cout >= 128)) return run<64, 64, 2, 2>(p, G, choose_split(p, G, 64, 64, igemm_occupancy(64, 64)), st);
-    // fp16 data path, Cout a multiple of 256, at least two rounds of tiles: 128x256 tiles (wave tiles of 64x128 - the K-slice
-    // fragments are read from LDS 25 % less often per MFMA than with 64x64 wave tiles, and that kernel is LDS-bound)
-    if (p.es == 2 && tune().h16_wide && p.Cout % 256 == 0 && (long)((p.M + 127) / 128) * (p.Cout / 256) * G >= tune().h16_wide_min_tiles)
-        return run<128, 256, 2, 2>(p, G, 1, st);
     const long tiles128 = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * G;
     const int s128 = choose_split(p, G, 128, 128, igemm_occupancy(128, 128));
     if (tiles128 < 64 || (tiles128 < 384 && s128 == 1)) return run<64, 64, 2, 2>(p, G, choose_split(p, G, 64, 64, igemm_occupancy(64, 64)), st);

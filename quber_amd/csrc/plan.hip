@@ -54,8 +54,6 @@ static int* tuning_field(Tuning& t, int key) {
         case 27: return &t.wino_fused_max_cin;
         case 29: return &t.stem_fused;
         case 30: return &t.lean_loader;
-        case 31: return &t.h16_wide;
-        case 32: return &t.h16_wide_min_tiles;
         default: return nullptr;
     }
 }

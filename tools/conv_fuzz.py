@@ -21,7 +21,7 @@ st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 lib.quber_set_tuning(2, 1)
 lib.quber_set_tuning(15, 0)
-worst, bad, worst64, n64 = 0.0, 0, 0.0, 0
+worst, bad, worst64, n64, bad5, n_lean = 0.0, 0, 0.0, 0, 0, 0
 for case in range(N):
     k = int(rng.choice([1, 1, 3]))
     Cin = int(rng.choice([4, 8, 32, 36, 64, 96, 128, 164, 256, 512, 1024]))
@@ -50,7 +50,19 @@ for case in range(N):
         y = torch.full((B, OH, OW, Cout), float("nan"), device="cuda")
         _lib.check(lib.quber_op_conv2d(p(x), B, H, W, Cin, p(w), Cout, k, stride, pad, dil, p(sc), p(sh), p(r), relu, p(packed), p(y), st))
         outs.append(y)
+    # the one-tile-per-block kernel again with per-thread tap arithmetic (key 30 = 0): the LEAN loader (block-uniform taps, buffer
+    # loads; taken when Cin % 32 == 0) must give the same bits
+    lib.quber_set_tuning(13, 0)
+    lib.quber_set_tuning(30, 0)
+    y0 = torch.full((B, OH, OW, Cout), float("nan"), device="cuda")
+    _lib.check(lib.quber_op_conv2d(p(x), B, H, W, Cin, p(w), Cout, k, stride, pad, dil, p(sc), p(sh), p(r), relu, p(packed), p(y0), st))
+    lib.quber_set_tuning(30, 1)
     torch.cuda.synchronize()
+    n_lean += int(Cin % 32 == 0)
+    if not torch.equal(y0, outs[0]):
+        bad5 += 1
+        print("LEAN LOADER MISMATCH", dict(B=B, H=H, W=W, Cin=Cin, Cout=Cout, k=k, stride=stride, dil=dil, res=res, relu=relu, dt=dt),
+              float((y0 - outs[0]).abs().max()), flush=True)
     if 2.0 * B * OH * OW * Cout * Cin * k * k < 4.0e9:          # small enough for a float64 reference on the device
         ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, stride, pad, dil).permute(0, 2, 3, 1)
         ref = ref * sc.double() + sh.double()
@@ -71,7 +83,8 @@ for case in range(N):
         bad += 1
         print("MISMATCH", dict(B=B, H=H, W=W, Cin=Cin, Cout=Cout, k=k, stride=stride, dil=dil, res=res, relu=relu, dt=dt), err, flush=True)
 print(f"conv2d: {N} random cases, persistent vs one-tile-per-block: {bad} mismatches, worst relative difference {worst:.2e}; "
-      f"{n64} of them also against a float64 convolution: worst relative error {worst64:.2e}")
+      f"{n64} of them also against a float64 convolution: worst relative error {worst64:.2e}; "
+      f"LEAN loader vs per-thread tap arithmetic ({n_lean} eligible cases): {bad5} bit mismatches")
 
 # dual-input 1x1 against float64
 worst2, bad2 = 0.0, 0
@@ -177,4 +190,4 @@ for case in range(N // 4):
 print(f"conv3x3_winograd, single kernel: {n4} random cases: {bad4} mismatches, worst relative difference to the direct kernel {worst4:.1e}, "
       f"to the three-kernel pipeline {worst4p:.1e}")
 lib.quber_set_tuning(12, 0); lib.quber_set_tuning(13, 1); lib.quber_set_tuning(15, 256); lib.quber_set_tuning(2, 0); lib.quber_set_tuning(25, 1)
-sys.exit(1 if bad or bad2 or bad3 or bad4 else 0)
+sys.exit(1 if bad or bad2 or bad3 or bad4 or bad5 else 0)
