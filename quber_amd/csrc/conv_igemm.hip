@@ -68,12 +68,22 @@ constexpr int NPL(int dt) { return dt == 3 ? 3 : 1; }     // bf16 planes per ope
 #endif
 // waves per SIMD the kernel is compiled for: two accumulator sets (the MFMA chain and the chunk sums, below) cost the
 // 128-row tiles their third resident block; the 64x64 tiles keep five
+#ifndef QB_F32_LEAN64_OCC
+#define QB_F32_LEAN64_OCC 7  // LEAN loader on 64x64 fp32 tiles (the HBM-bound residual 1x1 layers): 72 registers, no spills (the per-thread
+                           // tap loader needs 80 + 6-14 spilled at six waves); seven resident blocks: res2 / res3 / res4 conv3 0.326 / 0.231 /
+                           // 0.189 -> 0.315 / 0.220 / 0.183 ms; eight would spill 8.  (128x64 tiles at four blocks instead of three: no change)
+#endif
+#ifndef QB_H16_LEAN64_OCC
+#define QB_H16_LEAN64_OCC 8  // fp16 64x64 tiles with the LEAN loader: 58 registers, eight resident blocks (res3 conv3 0.170 -> 0.160 ms at 1024x1024 x 8)
+#endif
 #ifndef QB_H16_LEAN_OCC
 #define QB_H16_LEAN_OCC 4  // LEAN loader (no 64-bit addresses, no bounds state): the 128x128 fp16 kernel fits 128 registers - four resident blocks
 #endif
 constexpr int igemm_occupancy(int BM, int BN, int DT = 0, bool LEAN = false) {
     if (DT == 4 && LEAN && BM == 128 && BN == 128) return QB_H16_LEAN_OCC;
+    if (DT == 0 && LEAN && BM == 64 && BN == 64) return QB_F32_LEAN64_OCC;
     if (DT == 4 && BM * BN >= 128 * 128) return QB_H16_OCC;
+    if (DT == 4 && LEAN && BM == 64 && BN == 64) return QB_H16_LEAN64_OCC;
     if (DT == 4 && BM == 64 && BN == 64) return 7;        // HBM-bound residual layers: blocks in flight are what they live on
     if (BM * BN >= 128 * 128 || (BM == 256 && DT == 3)) return 2;
     return BM == 64 ? (DT == 0 ? 6 : 5) : 3;
@@ -1052,6 +1062,10 @@ int launch_conv(const ConvP& p0, int G, hipStream_t st) {
     // (64 x 256 tiles for the residual 1x1 layers - input rows read once, 512-byte row segments - measured 30-50 % SLOWER than
     // 64x64 in both the fp32 and the fp16 path, profiles/r03x_tile_64x256_rejected.txt: those layers live on blocks in flight)
     if (p.Cout <= 64 || (p.res && nk <= 8 && p.Cout >= 128)) return run<64, 64, 2, 2>(p, G, choose_split(p, G, 64, 64, igemm_occupancy(64, 64)), st);
+    // dilated layers that skip the filter rows lying in the padding (ASPP d = 18 on a 30-row map): 64-row tiles span 2-3 map rows
+    // instead of 4-5, so more of them see a filter row entirely in the padding - 1.28 -> 1.07 ms on that layer (tools/aspp_d18_ab.py)
+    if (p.skip_rows && p.es != 2 && p.kmode == 0 && p.kh > 1 && p.dil * 5 >= p.H * 2)
+        return run<64, 64, 2, 2>(p, G, choose_split(p, G, 64, 64, igemm_occupancy(64, 64)), st);
     const long tiles128 = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * G;
     const int s128 = choose_split(p, G, 128, 128, igemm_occupancy(128, 128));
     if (tiles128 < 64 || (tiles128 < 384 && s128 == 1)) return run<64, 64, 2, 2>(p, G, choose_split(p, G, 64, 64, igemm_occupancy(64, 64)), st);
