@@ -40,19 +40,33 @@ __device__ inline void stat_merge(SetStat* stat, unsigned any_or, unsigned any_n
 }
 
 // ---- 1. pack ---------------------------------------------------------------------------------------------------------
-// grid (ceil(H * wpr * 4 / 256), n masks, B); thread = one 16-pixel group of the row-padded group grid (wpr * 4 per row)
+// grid (ceil(H * wpr * 4 / (256 * PACK_IT)), n masks, B); a thread packs PACK_IT 16-pixel groups of the row-padded group grid
+// (wpr * 4 per row), 256 groups apart, their 16-byte loads requested together (one load per thread and block left the launch at a
+// quarter of the HBM rate: 48 000 blocks per 16-frame step)
+constexpr int PACK_IT = 4;
+
 __global__ __launch_bounds__(256) void errmaps_pack_kernel(const uint8_t* __restrict__ masks, int N, int H, int W, int wpr,
                                                            u64* __restrict__ mbits, int n0, int Ntot,
                                                            SetStat* __restrict__ stat) {
     const int n = blockIdx.y, b = blockIdx.z;
     const long HW = (long)H * W;
     const int gpr = wpr * 4;
-    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-    const int y = (int)(gid / gpr), gx = (int)(gid - (long)y * gpr);
-    unsigned piece = 0, any_or = 0, any_nand = 0;
-    if (y < H && gx * 16 < W) {
-        const uint4 v = *reinterpret_cast<const uint4*>(masks + ((long)b * N + n) * HW + (long)y * W + gx * 16);
-        const unsigned wds[4] = {v.x, v.y, v.z, v.w};
+    uint4 v[PACK_IT];
+    int ys[PACK_IT], gxs[PACK_IT];
+#pragma unroll
+    for (int it = 0; it < PACK_IT; ++it) {
+        const long gid = ((long)blockIdx.x * PACK_IT + it) * 256 + threadIdx.x;
+        const int y = (int)(gid / gpr), gx = (int)(gid - (long)y * gpr);
+        ys[it] = y; gxs[it] = gx;
+        v[it] = make_uint4(0u, 0u, 0u, 0u);
+        if (y < H && gx * 16 < W) v[it] = *reinterpret_cast<const uint4*>(masks + ((long)b * N + n) * HW + (long)y * W + gx * 16);
+    }
+    unsigned any_or = 0, any_nand = 0;
+#pragma unroll
+    for (int it = 0; it < PACK_IT; ++it) {
+        const int y = ys[it], gx = gxs[it];
+        unsigned piece = 0;
+        const unsigned wds[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const unsigned wd = wds[j];
@@ -66,12 +80,12 @@ __global__ __launch_bounds__(256) void errmaps_pack_kernel(const uint8_t* __rest
                 }
             }
         }
+        // four consecutive lanes hold the four 16-bit pieces of one word
+        unsigned pair = piece | (__shfl_down(piece, 1) << 16);
+        const unsigned hi = __shfl_down(pair, 2);
+        if ((threadIdx.x & 3) == 0 && y < H)
+            mbits[(((long)b * Ntot + n0 + n) * H + y) * wpr + (gx >> 2)] = (u64)pair | ((u64)hi << 32);
     }
-    // four consecutive lanes hold the four 16-bit pieces of one word
-    unsigned pair = piece | (__shfl_down(piece, 1) << 16);
-    const unsigned hi = __shfl_down(pair, 2);
-    if ((threadIdx.x & 3) == 0 && y < H)
-        mbits[(((long)b * Ntot + n0 + n) * H + y) * wpr + (gx >> 2)] = (u64)pair | ((u64)hi << 32);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         any_or |= __shfl_down(any_or, o);
@@ -339,7 +353,7 @@ int launch_errmaps(const uint8_t* init, int N, const uint8_t* gt, int Ng, int B,
             const int n = s ? Ng : N, n0 = s ? N : 0;
             if (n == 0) continue;
             if (fast)
-                hipLaunchKernelGGL(errmaps_pack_kernel, dim3((unsigned)(((long)H * wpr * 4 + 255) / 256), n, B), dim3(256), 0, st,
+                hipLaunchKernelGGL(errmaps_pack_kernel, dim3((unsigned)(((long)H * wpr * 4 + 256 * PACK_IT - 1) / (256 * PACK_IT)), n, B), dim3(256), 0, st,
                                    src, n, H, W, wpr, mbits, n0, Ntot, stat + s);
             else
                 hipLaunchKernelGGL(errmaps_pack_ballot_kernel, dim3((unsigned)(((long)H * wpr + 3) / 4), n, B), dim3(256), 0, st,

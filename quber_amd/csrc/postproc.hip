@@ -234,6 +234,10 @@ __global__ __launch_bounds__(1024) void select_kernel(const float* __restrict__ 
 
 // ---- P3: nearest-centre grouping + instance areas ----
 // idmap: 0 = background, 1..K = instance id on foreground, 255 = foreground with no centre at all
+// A block owns GP_PIX consecutive pixels (8 per thread, their three planes requested up front): a block per 256 pixels spent its
+// life on the prologue - K centres into LDS, a barrier, 256 area counters to flush - 32 768 times per 8-frame 1024x1024 step.
+constexpr int GP_PIX = 2048;
+
 __global__ __launch_bounds__(256) void group_kernel(const float* __restrict__ logits, int nch, int H, int W, int cap,
                                                     const int* __restrict__ centers, const int* __restrict__ ncenters,
                                                     uint8_t* __restrict__ idmap, unsigned* __restrict__ area) {
@@ -246,23 +250,32 @@ __global__ __launch_bounds__(256) void group_kernel(const float* __restrict__ lo
         cy[threadIdx.x] = (float)centers[((long)b * cap + threadIdx.x) * 2];
         cx[threadIdx.x] = (float)centers[((long)b * cap + threadIdx.x) * 2 + 1];
     }
-    __syncthreads();
     const long HW = (long)H * W;
-    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned id = 0;
-    bool fg = false;
-    if (p < HW) {
-        const float* base = logits + (long)b * nch * HW;
-        // (the three planes are requested together: a foreground pixel does not wait twice)
-        const float l0 = base[p], oy = base[2 * HW + p], ox = base[3 * HW + p];
-        fg = l0 > 0x1.8p-24f;  // sigmoid(x).round() == 1
+    const float* base = logits + (long)b * nch * HW;
+    const long p0 = (long)blockIdx.x * GP_PIX + threadIdx.x;
+    constexpr int NP = GP_PIX / 256;
+    float l0[NP], oy[NP], ox[NP];
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+        const long p = p0 + it * 256;
+        const bool in = p < HW;
+        l0[it] = in ? base[p] : -1.f;
+        oy[it] = in ? base[2 * HW + p] : 0.f;
+        ox[it] = in ? base[3 * HW + p] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+        const long p = p0 + it * 256;
+        unsigned id = 0;
+        const bool fg = p < HW && l0[it] > 0x1.8p-24f;  // sigmoid(x).round() == 1
         if (fg) {
             if (K == 0) {
                 id = 255;
             } else {
                 const int y = (int)(p / W), x = (int)(p - (long)y * W);
-                const float ly = __fadd_rn((float)y, oy);
-                const float lx = __fadd_rn((float)x, ox);
+                const float ly = __fadd_rn((float)y, oy[it]);
+                const float lx = __fadd_rn((float)x, ox[it]);
                 // argmin over k of sqrt(dx^2 + dy^2), first index on ties (torch.norm + argmin).  The square root is monotone, so a
                 // smaller d^2 can only tie - never lose - after it; the root (a quarter-rate instruction) is taken just for the
                 // pairs whose squares are within a few ulp of each other, where two different squares may round to one root
@@ -282,9 +295,8 @@ __global__ __launch_bounds__(256) void group_kernel(const float* __restrict__ lo
                 if (id == 0) id = 1;  // all-NaN distances: argmin returns index 0
             }
         }
-        idmap[(long)b * HW + p] = (uint8_t)id;
-    }
-    {   // areas: one LDS atomic per wave when its foreground lanes agree on the instance (inside an object: nearly always)
+        if (p < HW) idmap[(long)b * HW + p] = (uint8_t)id;
+        // areas: one LDS atomic per wave when its foreground lanes agree on the instance (inside an object: nearly always)
         const unsigned long long m = __ballot(fg);
         if (m) {
             const unsigned first = __shfl(id, __ffsll((long long)m) - 1);
@@ -520,10 +532,9 @@ int launch_postprocess(const float* logits, int nch, int B, int H, int W, const 
         hipLaunchKernelGGL(select_kernel, dim3(B), dim3(1024), 0, st, cand, (int)HW, W, c.top_k, c.cap, centers, ncenters, lists);
     }
     if (int rc = launch_zero(area, (size_t)B * 256 * 4, st)) return rc;
-    const int pblocks = (int)((HW + 255) / 256);
     {   // a9: fg + 2 offset planes in, id map out
         ProfScope prof("post_group", 13.0 * px, 0.0, st);
-        hipLaunchKernelGGL(group_kernel, dim3(pblocks, B), dim3(256), 0, st, logits, nch, H, W, c.cap, centers, ncenters,
+        hipLaunchKernelGGL(group_kernel, dim3((int)((HW + GP_PIX - 1) / GP_PIX), B), dim3(256), 0, st, logits, nch, H, W, c.cap, centers, ncenters,
                            idmap, area);
     }
     {
@@ -552,7 +563,7 @@ int launch_group_pixels(const float* logits, int nch, int B, int H, int W, int c
     if (nch < 4) return fail("group_pixels: logits need >= 4 channels (fg, centre, off_y, off_x)");
     const long HW = (long)H * W;
     if (int rc = launch_zero(area, (size_t)B * 256 * 4, st)) return rc;
-    hipLaunchKernelGGL(group_kernel, dim3((int)((HW + 255) / 256), B), dim3(256), 0, st, logits, nch, H, W, cap, centers, ncenters,
+    hipLaunchKernelGGL(group_kernel, dim3((int)((HW + GP_PIX - 1) / GP_PIX), B), dim3(256), 0, st, logits, nch, H, W, cap, centers, ncenters,
                        idmap, area);
     QB_CHECK(hipGetLastError());
     return 0;
