@@ -203,7 +203,12 @@ class RefinerModel:
         hd["e1"].synchronize()
         eng, post, count = hd["eng"], hd["post"], hd["count"].numpy()
         kmax = int(count.max()) if len(count) else 0
-        masks = hd["masks"] if kmax <= hd["slots"] else eng.extract_masks(post, kmax)      # rare: more instances than pre-extracted slots
+        ready = hd["e1"]
+        masks = hd["masks"]
+        if kmax > hd["slots"]:                       # rare: more instances than pre-extracted slots - extracted now, on the caller's stream
+            masks = eng.extract_masks(post, kmax)
+            ready = torch.cuda.Event()
+            ready.record()
         outs = [self.frame_dict(eng, hd["logits"][b], post, b, int(count[b]), masks[b, :int(count[b])].view(torch.bool) if count[b] > 0 else None)
                 for b in range(len(count))]
         ms = hd["e0"].elapsed_time(hd["e1"])
@@ -211,8 +216,19 @@ class RefinerModel:
             return outs, ms
         if kmax == 0:
             return outs, ms, [[] for _ in count]
-        host = masks[:, :kmax].contiguous().cpu().numpy().view(np.bool_)
+        # The copy runs on a stream of its own, behind this batch's end event only: on the caller's stream it would queue behind
+        # the NEXT batch, which predict_stream has already enqueued - and the host would wait 33 ms for masks that are ready.
+        side = self._copy_stream()
+        side.wait_event(ready)
+        with torch.cuda.stream(side):
+            host = masks[:, :kmax].contiguous().cpu().numpy().view(np.bool_)
         return outs, ms, [host[b, :int(count[b])] if count[b] > 0 else [] for b in range(len(count))]
+
+    def _copy_stream(self):
+        st = getattr(self, "_d2h_stream", None)
+        if st is None:
+            st = self._d2h_stream = torch.cuda.Stream(device=self.device)
+        return st
 
     def __call__(self, batched_inputs):
         dev = self.device
