@@ -757,6 +757,59 @@ def test_conv_refuses_narrow_inputs_for_3x3():
     assert rc != 0 and b"8 input channels" in lib.quber_last_error()
 
 
+LEAN_CASES = [
+    # B, H, W, Cin, Cout, k, stride, dil, residual, arithmetic mode, skip padded filter rows, split-K workspace
+    (2, 33, 47, 64, 64, 3, 1, 1, False, 0, 0, 0),        # 3x3, ragged map: padding taps on every border, 64x64 tiles
+    (2, 33, 47, 64, 96, 3, 2, 1, False, 0, 0, 0),        # stride 2 (tap-major... slice-major K order), ragged N
+    (1, 30, 40, 256, 128, 3, 1, 18, False, 0, 1, 1),     # ASPP-like: dilation 18 on 30 rows, padded filter rows skipped, split-K
+    (1, 30, 40, 128, 128, 3, 1, 6, True, 0, 1, 0),       # dilation 6, rows skipped, residual
+    (3, 17, 23, 128, 256, 1, 1, 1, True, 0, 0, 0),       # residual 1x1 (the prologue's division-free path)
+    (2, 30, 40, 256, 64, 1, 2, 1, False, 0, 0, 0),       # strided 1x1
+    (2, 24, 32, 96, 32, 3, 1, 2, False, 3, 0, 0),        # bf16x3, 256x32 tiles, dilation 2
+    (1, 60, 80, 32, 128, 3, 1, 1, False, 3, 0, 1),       # bf16x3, 128-wide tiles, Cin = one K-slice per tap
+    (4, 9, 11, 512, 512, 3, 1, 1, False, 0, 0, 1),       # K = 4608 on a small map: split-K partitions start mid-filter
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", LEAN_CASES, ids=[f"{c[3]}to{c[4]}k{c[5]}s{c[6]}d{c[7]}m{c[9]}" for c in LEAN_CASES])
+def test_conv_lean_loader_equals_tap_arithmetic(case):
+    """The implicit GEMM's LEAN loader (block-uniform taps in scalar registers, tap-validity masks, buffer loads whose range check
+    supplies the zero padding; option key 30) against per-thread tap arithmetic on the stand-alone op: the same bits - strides,
+    dilations, skipped filter rows, split-K partitions that start in the middle of the filter, exact fp32 and bf16x3."""
+    B, H, W, Cin, Cout, k, stride, dil, residual, mode, skip, ws = case
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(Cin + 3 * Cout + dil)
+    pad = dil * (k // 2)
+    OH, OW = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1, (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
+    w = torch.randn(Cout, Cin, k, k, device="cuda", generator=g) / np.sqrt(Cin * k * k)
+    sc, sh = torch.rand(Cout, device="cuda", generator=g) + 0.5, torch.randn(Cout, device="cuda", generator=g)
+    r = torch.randn(B, OH, OW, Cout, device="cuda", generator=g) if residual else None
+    packed = torch.empty(Cout * k * k * Cin, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    outs = {}
+    try:
+        lib.quber_set_tuning(12, mode); lib.quber_set_tuning(11, skip); lib.quber_set_tuning(2, ws); lib.quber_set_tuning(13, 0)
+        for lean in (0, 1):
+            lib.quber_set_tuning(30, lean)
+            y = torch.full((B, OH, OW, Cout), float("nan"), device="cuda")
+            _lib.check(lib.quber_op_conv2d(p(x), B, H, W, Cin, p(w), Cout, k, stride, pad, dil, p(sc), p(sh), p(r), 1, p(packed), p(y), st))
+            torch.cuda.synchronize()
+            outs[lean] = y
+    finally:
+        lib.quber_set_tuning(30, 1); lib.quber_set_tuning(12, 0); lib.quber_set_tuning(11, 0); lib.quber_set_tuning(2, 0); lib.quber_set_tuning(13, 1)
+    assert torch.isfinite(outs[1]).all()
+    assert torch.equal(outs[0], outs[1])
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, stride, pad, dil).permute(0, 2, 3, 1)
+    ref = ref * sc.double() + sh.double()
+    if residual:
+        ref = ref + r.double()
+    ref = ref.relu()
+    assert float((outs[1].double() - ref).abs().max()) / max(1.0, float(ref.abs().max())) < 4e-6
+
+
 POINTWISE16_CASES = [
     # B, H, W, Cin, Cout, affine, residual, relu      (the fp16 data path's 1x1 layers: ResNet bottleneck conv1 / conv3)
     (2, 64, 64, 64, 256, True, True, True),           # res2 conv3
