@@ -27,6 +27,29 @@ template <> __device__ inline void stv4<half_t>(half_t* p, float4 v) {
     *reinterpret_cast<h4*>(p) = h4{(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
 }
 template <class T> static inline const T* cptr(const View& v) { return reinterpret_cast<const T*>(v.p); }
+// 16 bytes per lane whatever the storage type: 4 floats, or 8 halfs (the fp16 data path's pooling / resizing kernels)
+template <class T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    static __device__ inline void load(const float* p, float* v) { *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(p); }
+    static __device__ inline void store(float* p, const float* v) { *reinterpret_cast<float4*>(p) = *reinterpret_cast<const float4*>(v); }
+};
+template <> struct Vec16<half_t> {
+    static constexpr int N = 8;
+    using h8 = __attribute__((ext_vector_type(8))) half_t;
+    static __device__ inline void load(const half_t* p, float* v) {
+        const h8 x = *reinterpret_cast<const h8*>(p);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)x[e];
+    }
+    static __device__ inline void store(half_t* p, const float* v) {
+        h8 x;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = (half_t)v[e];
+        *reinterpret_cast<h8*>(p) = x;
+    }
+};
+
 
 static inline int cap_grid(long work, int per_block) {
     long g = (work + per_block - 1) / per_block;
@@ -91,46 +114,60 @@ int launch_preprocess(const uint8_t* rgb, const uint8_t* depth, const float* off
 }
 
 // ------------------------------------------------------------------------------------------------
-template <class T>
-__global__ void maxpool_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int H, int W, int C4,
-                               int in_cs, int OH, int OW, int out_cs, long in_gs, long out_gs) {
-    in += blockIdx.y * in_gs;
-    out += blockIdx.y * out_gs;
-    const long total = (long)B * OH * OW * C4;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c4 = i % C4;
-        long pix = i / C4;
-        const int ox = pix % OW;
-        pix /= OW;
-        const int oy = pix % OH;
-        const int b = pix / OH;
-        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+// grid (ceil(OW * CV / 256), OH, G * B): a block row is one output row - one 32-bit division per thread (the grid-stride form took four
+// 64-bit divisions per element); V = 16 bytes of channels per lane (4 floats / 8 halfs), falling back to 4 channels when C % 8 != 0
+template <class T, int V>
+__global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int H, int W, int CV,
+                                                      int in_cs, int OH, int OW, int out_cs, long in_gs, long out_gs) {
+    const int g = blockIdx.z / B, b = blockIdx.z - g * B;
+    in += g * in_gs;
+    out += g * out_gs;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= OW * CV) return;
+    const int ox = idx / CV, cv = idx - ox * CV;
+    const int oy = blockIdx.y;
+    float m[V];
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const int iy = oy * 2 - 1 + dy;
-            if ((unsigned)iy >= (unsigned)H) continue;
+    for (int e = 0; e < V; ++e) m[e] = -INFINITY;
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int ix = ox * 2 - 1 + dx;
-                if ((unsigned)ix >= (unsigned)W) continue;
-                const float4 v = ldv4(in + ((long)(b * H + iy) * W + ix) * in_cs + c4 * 4);
-                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
-            }
+    for (int dy = 0; dy < 3; ++dy) {
+        const int iy = oy * 2 - 1 + dy;
+        if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int ix = ox * 2 - 1 + dx;
+            if ((unsigned)ix >= (unsigned)W) continue;
+            float v[V];
+            const T* src = in + ((long)(b * H + iy) * W + ix) * in_cs + cv * V;
+            if constexpr (V == Vec16<T>::N) Vec16<T>::load(src, v);
+            else { const float4 q = ldv4(src); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+#pragma unroll
+            for (int e = 0; e < V; ++e) m[e] = fmaxf(m[e], v[e]);
         }
-        stv4(out + ((long)(b * OH + oy) * OW + ox) * out_cs + c4 * 4, m);
     }
+    T* dst = out + ((long)(b * OH + oy) * OW + ox) * out_cs + cv * V;
+    if constexpr (V == Vec16<T>::N) Vec16<T>::store(dst, m);
+    else stv4(dst, make_float4(m[0], m[1], m[2], m[3]));
 }
 
 int launch_maxpool3x3s2(const View& in, const View& out, int B, int G, hipStream_t st) {
-    const long total = (long)B * out.H * out.W * (in.C / 4);
     ProfScope prof("maxpool", (double)in.es * G * B * in.C * ((double)in.H * in.W + (double)out.H * out.W), 0.0, st);
     if (in.es != out.es) return fail("maxpool: mixed element types");
-    if (in.es == 2)
-        hipLaunchKernelGGL(maxpool_kernel<half_t>, dim3(cap_grid(total, 256), G), dim3(256), 0, st, cptr<half_t>(in), (half_t*)out.p, B,
-                           in.H, in.W, in.C / 4, in.cs, out.H, out.W, out.cs, in.gs, out.gs);
-    else
-        hipLaunchKernelGGL(maxpool_kernel<float>, dim3(cap_grid(total, 256), G), dim3(256), 0, st, in.p, out.p, B, in.H, in.W,
-                           in.C / 4, in.cs, out.H, out.W, out.cs, in.gs, out.gs);
+    if (in.es == 2) {
+        const bool wide = in.C % 8 == 0 && in.cs % 8 == 0 && out.cs % 8 == 0 && (in.gs & 7) == 0 && (out.gs & 7) == 0;
+        const int V = wide ? 8 : 4, CV = in.C / V;
+        const dim3 grid((out.W * CV + 255) / 256, out.H, G * B);
+        if (wide)
+            hipLaunchKernelGGL((maxpool_kernel<half_t, 8>), grid, dim3(256), 0, st, cptr<half_t>(in), (half_t*)out.p, B, in.H, in.W, CV, in.cs,
+                               out.H, out.W, out.cs, in.gs, out.gs);
+        else
+            hipLaunchKernelGGL((maxpool_kernel<half_t, 4>), grid, dim3(256), 0, st, cptr<half_t>(in), (half_t*)out.p, B, in.H, in.W, CV, in.cs,
+                               out.H, out.W, out.cs, in.gs, out.gs);
+    } else {
+        const int CV = in.C / 4;
+        hipLaunchKernelGGL((maxpool_kernel<float, 4>), dim3((out.W * CV + 255) / 256, out.H, G * B), dim3(256), 0, st, in.p, out.p, B, in.H,
+                           in.W, CV, in.cs, out.H, out.W, out.cs, in.gs, out.gs);
+    }
     QB_CHECK(hipGetLastError());
     return 0;
 }
@@ -245,7 +282,8 @@ int launch_gn_stats(const View& in, int B, int G, int groups, double* stats, hip
 // y = relu(x*scale + bias), scale = rstd*gamma, bias = beta - mean*scale  (torch's GroupNorm CPU form).
 // mean / rstd come from the fp64 sums of gn_stats_kernel.  A thread keeps one 16-byte channel column: its four
 // (scale, bias) pairs are computed once, the pixel loop is load - fma - store with no index arithmetic beyond an add.
-template <class T>
+// V channels = 16 bytes per lane (4 floats / 8 halfs; 4 halfs when C % 8 != 0); four pixels of a thread's column in flight per step
+template <class T, int V>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int HW,
                                                        int C, int in_cs, int out_cs, long in_gs, long out_gs, int groups,
                                                        const double* __restrict__ stats, const float* __restrict__ gamma,
@@ -258,40 +296,58 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ in,
     gamma += g * param_gs;
     beta += g * param_gs;
     const double* sbase = stats + ((long)(g * B + b) * groups) * 2;
-    const int C4 = C >> 2, cpg = C / groups;
+    const int CV = C / V, cpg = C / groups;
     const int p0 = blockIdx.x * ppb;
     const int p1 = min(HW, p0 + ppb);
-    const int colsper = min(C4, 256);
+    const int colsper = min(CV, 256);
     const int rows = 256 / colsper;
     const int col = t % colsper, row = t / colsper;
-    for (int cp = 0; cp < C4; cp += colsper) {
-        const int c4 = cp + col;
-        if (row >= rows || c4 >= C4) continue;
-        const float4 ga = *reinterpret_cast<const float4*>(gamma + c4 * 4);
-        const float4 be = *reinterpret_cast<const float4*>(beta + c4 * 4);
-        const float gm[4] = {ga.x, ga.y, ga.z, ga.w}, bt[4] = {be.x, be.y, be.z, be.w};
-        float sc[4], bi[4];
+    auto ld = [&](const T* p, float* v) __attribute__((always_inline)) {
+        if constexpr (V == Vec16<T>::N) Vec16<T>::load(p, v);
+        else { const float4 q = ldv4(p); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+    };
+    auto stt = [&](T* p, const float* v) __attribute__((always_inline)) {
+        if constexpr (V == Vec16<T>::N) Vec16<T>::store(p, v);
+        else stv4(p, make_float4(v[0], v[1], v[2], v[3]));
+    };
+    for (int cp = 0; cp < CV; cp += colsper) {
+        const int cv = cp + col;
+        if (row >= rows || cv >= CV) continue;
+        float sc[V], bi[V];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int grp = (c4 * 4 + j) / cpg;
+        for (int j = 0; j < V; ++j) {
+            const int ch = cv * V + j;
+            const int grp = ch / cpg;
             const double mean = sbase[2 * grp] / n;
             double var = sbase[2 * grp + 1] / n - mean * mean;
             if (var < 0.0) var = 0.0;
             const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-            sc[j] = rstd * gm[j];
-            bi[j] = bt[j] - (float)mean * sc[j];
+            sc[j] = rstd * gamma[ch];
+            bi[j] = beta[ch] - (float)mean * sc[j];
         }
-        for (int pix = p0 + row; pix < p1; pix += rows) {
-            const float4 v = ldv4(in + (long)pix * in_cs + c4 * 4);
-            float4 o;
-            o.x = fmaf(v.x, sc[0], bi[0]);
-            o.y = fmaf(v.y, sc[1], bi[1]);
-            o.z = fmaf(v.z, sc[2], bi[2]);
-            o.w = fmaf(v.w, sc[3], bi[3]);
-            if (relu) {
-                o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+        auto norm = [&](float* v) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                v[j] = fmaf(v[j], sc[j], bi[j]);
+                if (relu) v[j] = fmaxf(v[j], 0.f);
             }
-            stv4(out + (long)pix * out_cs + c4 * 4, o);
+        };
+        int pix = p0 + row;
+        for (; pix + 3 * rows < p1; pix += 4 * rows) {
+            float v[4][V];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ld(in + (long)(pix + u * rows) * in_cs + cv * V, v[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                norm(v[u]);
+                stt(out + (long)(pix + u * rows) * out_cs + cv * V, v[u]);
+            }
+        }
+        for (; pix < p1; pix += rows) {
+            float v[V];
+            ld(in + (long)pix * in_cs + cv * V, v);
+            norm(v);
+            stt(out + (long)pix * out_cs + cv * V, v);
         }
     }
 }
@@ -302,12 +358,18 @@ int launch_gn_apply(const View& in, const View& out, int B, int G, int groups, c
     const int ppb = gn_pixels_per_block(HW, in.C, B, G);
     ProfScope prof("gn_apply", 2.0 * in.es * G * B * (double)HW * in.C, 0.0, st);
     if (in.es != out.es) return fail("groupnorm: mixed element types");
-    if (in.es == 2)
-        hipLaunchKernelGGL(gn_apply_kernel<half_t>, dim3((HW + ppb - 1) / ppb, B, G), dim3(256), 0, st, cptr<half_t>(in), (half_t*)out.p,
-                           B, HW, in.C, in.cs, out.cs, in.gs, out.gs, groups, stats, gamma, beta, param_gs, relu, ppb,
-                           (double)HW * (in.C / groups), eps);
-    else
-        hipLaunchKernelGGL(gn_apply_kernel<float>, dim3((HW + ppb - 1) / ppb, B, G), dim3(256), 0, st, in.p, out.p, B, HW, in.C,
+    const dim3 grid((HW + ppb - 1) / ppb, B, G);
+    if (in.es == 2) {
+        const bool wide = in.C % 8 == 0 && in.cs % 8 == 0 && out.cs % 8 == 0 && (in.gs & 7) == 0 && (out.gs & 7) == 0 &&
+                          (((uintptr_t)in.p | (uintptr_t)out.p) & 15) == 0;
+        if (wide)
+            hipLaunchKernelGGL((gn_apply_kernel<half_t, 8>), grid, dim3(256), 0, st, cptr<half_t>(in), (half_t*)out.p, B, HW, in.C, in.cs, out.cs,
+                               in.gs, out.gs, groups, stats, gamma, beta, param_gs, relu, ppb, (double)HW * (in.C / groups), eps);
+        else
+            hipLaunchKernelGGL((gn_apply_kernel<half_t, 4>), grid, dim3(256), 0, st, cptr<half_t>(in), (half_t*)out.p, B, HW, in.C, in.cs, out.cs,
+                               in.gs, out.gs, groups, stats, gamma, beta, param_gs, relu, ppb, (double)HW * (in.C / groups), eps);
+    } else
+        hipLaunchKernelGGL((gn_apply_kernel<float, 4>), grid, dim3(256), 0, st, in.p, out.p, B, HW, in.C,
                            in.cs, out.cs, in.gs, out.gs, groups, stats, gamma, beta, param_gs, relu, ppb,
                            (double)HW * (in.C / groups), eps);
     QB_CHECK(hipGetLastError());
@@ -325,46 +387,55 @@ __device__ inline void bilin_src(int o, float scale, int in_size, int& i0, int& 
     l1 = s - (float)i0;
 }
 
-template <class T>
-__global__ void bilinear_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int H, int W, int C4,
-                                int in_cs, int OH, int OW, int out_cs, float sy, float sx) {
-    const long total = (long)B * OH * OW * C4;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c4 = i % C4;
-        long pix = i / C4;
-        const int ox = pix % OW;
-        pix /= OW;
-        const int oy = pix % OH;
-        const int b = pix / OH;
-        int y0, y1, x0, x1;
-        float ly, lx;
-        bilin_src(oy, sy, H, y0, y1, ly);
-        bilin_src(ox, sx, W, x0, x1, lx);
-        const float hy = 1.f - ly, hx = 1.f - lx;
-        const T* base = in + (long)b * H * W * in_cs + c4 * 4;
-        const float4 v00 = ldv4(base + ((long)y0 * W + x0) * in_cs);
-        const float4 v01 = ldv4(base + ((long)y0 * W + x1) * in_cs);
-        const float4 v10 = ldv4(base + ((long)y1 * W + x0) * in_cs);
-        const float4 v11 = ldv4(base + ((long)y1 * W + x1) * in_cs);
-        float4 r;
-        r.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
-        r.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
-        r.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
-        r.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
-        stv4(out + ((long)(b * OH + oy) * OW + ox) * out_cs + c4 * 4, r);
-    }
+// grid (ceil(OW * CV / 256), OH, B): as maxpool above - one output row per block row, 16 bytes of channels per lane
+template <class T, int V>
+__global__ __launch_bounds__(256) void bilinear_kernel(const T* __restrict__ in, T* __restrict__ out, int H, int W, int CV,
+                                                       int in_cs, int OH, int OW, int out_cs, float sy, float sx) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= OW * CV) return;
+    const int ox = idx / CV, cv = idx - ox * CV;
+    const int oy = blockIdx.y, b = blockIdx.z;
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bilin_src(oy, sy, H, y0, y1, ly);
+    bilin_src(ox, sx, W, x0, x1, lx);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const T* base = in + (long)b * H * W * in_cs + cv * V;
+    float v00[V], v01[V], v10[V], v11[V], r[V];
+    auto ld = [&](const T* p, float* v) __attribute__((always_inline)) {
+        if constexpr (V == Vec16<T>::N) Vec16<T>::load(p, v);
+        else { const float4 q = ldv4(p); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+    };
+    ld(base + ((long)y0 * W + x0) * in_cs, v00);
+    ld(base + ((long)y0 * W + x1) * in_cs, v01);
+    ld(base + ((long)y1 * W + x0) * in_cs, v10);
+    ld(base + ((long)y1 * W + x1) * in_cs, v11);
+#pragma unroll
+    for (int e = 0; e < V; ++e) r[e] = hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e]);
+    T* dst = out + ((long)(b * OH + oy) * OW + ox) * out_cs + cv * V;
+    if constexpr (V == Vec16<T>::N) Vec16<T>::store(dst, r);
+    else stv4(dst, make_float4(r[0], r[1], r[2], r[3]));
 }
 
 int launch_bilinear(const View& in, const View& out, int B, hipStream_t st) {
-    const long total = (long)B * out.H * out.W * (in.C / 4);
     ProfScope prof("bilinear", (double)in.es * B * in.C * ((double)in.H * in.W + (double)out.H * out.W), 0.0, st);
     if (in.es != out.es) return fail("bilinear: mixed element types");
-    if (in.es == 2)
-        hipLaunchKernelGGL(bilinear_kernel<half_t>, dim3(cap_grid(total, 256)), dim3(256), 0, st, cptr<half_t>(in), (half_t*)out.p, B, in.H,
-                           in.W, in.C / 4, in.cs, out.H, out.W, out.cs, (float)in.H / (float)out.H, (float)in.W / (float)out.W);
-    else
-        hipLaunchKernelGGL(bilinear_kernel<float>, dim3(cap_grid(total, 256)), dim3(256), 0, st, in.p, out.p, B, in.H, in.W,
-                           in.C / 4, in.cs, out.H, out.W, out.cs, (float)in.H / (float)out.H, (float)in.W / (float)out.W);
+    const float sy = (float)in.H / (float)out.H, sx = (float)in.W / (float)out.W;
+    if (in.es == 2) {
+        const bool wide = in.C % 8 == 0 && in.cs % 8 == 0 && out.cs % 8 == 0;
+        const int V = wide ? 8 : 4, CV = in.C / V;
+        const dim3 grid((out.W * CV + 255) / 256, out.H, B);
+        if (wide)
+            hipLaunchKernelGGL((bilinear_kernel<half_t, 8>), grid, dim3(256), 0, st, cptr<half_t>(in), (half_t*)out.p, in.H, in.W, CV, in.cs,
+                               out.H, out.W, out.cs, sy, sx);
+        else
+            hipLaunchKernelGGL((bilinear_kernel<half_t, 4>), grid, dim3(256), 0, st, cptr<half_t>(in), (half_t*)out.p, in.H, in.W, CV, in.cs,
+                               out.H, out.W, out.cs, sy, sx);
+    } else {
+        const int CV = in.C / 4;
+        hipLaunchKernelGGL((bilinear_kernel<float, 4>), dim3((out.W * CV + 255) / 256, out.H, B), dim3(256), 0, st, in.p, out.p, in.H, in.W,
+                           CV, in.cs, out.H, out.W, out.cs, sy, sx);
+    }
     QB_CHECK(hipGetLastError());
     return 0;
 }
