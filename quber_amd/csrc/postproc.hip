@@ -403,31 +403,31 @@ __global__ __launch_bounds__(256) void paint_stats_kernel(const float* __restric
                 pr = (double)(1.f / (1.f + expf(-lgs[it])));
             }
         }
-        const int first = __shfl(slot, 0);
-        if (__all(slot == first)) {
-            if (first < 0) continue;                 // whole wave is background
-            unsigned cnt = 1, sy = (unsigned)y, sx = (unsigned)x;
-            int x0 = x, y0 = y, x1 = x, y1 = y;
+        // one wave reduction per DISTINCT instance among the 64 lanes (one inside an object, two or three on a boundary): per-lane LDS
+        // atomics on a boundary wave were 512 operations on two or three addresses
+        unsigned long long remaining = __ballot(slot >= 0);
+        while (remaining) {
+            const int s = __shfl(slot, __ffsll((long long)remaining) - 1);
+            const bool mine = slot == s;
+            unsigned cnt = mine ? 1u : 0u, sy = mine ? (unsigned)y : 0u, sx = mine ? (unsigned)x : 0u;
+            double pw = mine ? pr : 0.0;
+            int x0 = mine ? x : 1 << 30, y0 = mine ? y : 1 << 30, x1 = mine ? x : -1, y1 = mine ? y : -1;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 cnt += __shfl_down(cnt, o);
                 sy += __shfl_down(sy, o);
                 sx += __shfl_down(sx, o);
-                pr += __shfl_down(pr, o);
+                pw += __shfl_down(pw, o);
                 x0 = min(x0, __shfl_down(x0, o)); y0 = min(y0, __shfl_down(y0, o));
                 x1 = max(x1, __shfl_down(x1, o)); y1 = max(y1, __shfl_down(y1, o));
             }
             if ((t & 63) == 0) {
-                atomicAdd(&s_prob[first], pr); atomicAdd(&s_cnt[first], cnt);
-                atomicAdd(&s_sy[first], sy); atomicAdd(&s_sx[first], sx);
-                atomicMin(&s_x0[first], x0); atomicMin(&s_y0[first], y0);
-                atomicMax(&s_x1[first], x1); atomicMax(&s_y1[first], y1);
+                atomicAdd(&s_prob[s], pw); atomicAdd(&s_cnt[s], cnt);
+                atomicAdd(&s_sy[s], sy); atomicAdd(&s_sx[s], sx);
+                atomicMin(&s_x0[s], x0); atomicMin(&s_y0[s], y0);
+                atomicMax(&s_x1[s], x1); atomicMax(&s_y1[s], y1);
             }
-        } else if (slot >= 0) {
-            atomicAdd(&s_prob[slot], pr); atomicAdd(&s_cnt[slot], 1u);
-            atomicAdd(&s_sy[slot], (unsigned)y); atomicAdd(&s_sx[slot], (unsigned)x);
-            atomicMin(&s_x0[slot], x); atomicMin(&s_y0[slot], y);
-            atomicMax(&s_x1[slot], x); atomicMax(&s_y1[slot], y);
+            remaining &= ~__ballot(mine);
         }
     }
     __syncthreads();
