@@ -322,6 +322,15 @@ int quber_op_conv2d(const float* dev_x, int32_t batch, int32_t h, int32_t w, int
 int quber_op_conv1x1_f16(const void* dev_x, int32_t batch, int32_t h, int32_t w, int32_t cin, const void* dev_w_oi,
                          int32_t cout, const float* dev_scale, const float* dev_shift, const void* dev_residual,
                          int32_t relu, void* dev_y, void* stream);
+/* a convolution of the fp16 data path on fp16 tensors: x [batch][h][w][cin] (cin a multiple of 64), w_packed [cout][k*k*cin] in the
+ * kernels' K order - kmode 0: k = (tap, channel); kmode 1: k = (channel / 64, tap, channel % 64) - residual and y fp16, scale /
+ * shift fp32; gn_sums (or null): f64 [batch][gn_groups][2], the sums and sums of squares of the stored outputs per norm group
+ * are ADDED to it (the GroupNorm statistics the network's convolutions gather in their epilogue).  Test hook: the layers of
+ * maskrefiner/modeling/backbone/resnet.py:395-449, 472-485 reach these kernels through quber_forward. */
+int quber_op_conv2d_f16(const void* dev_x, int32_t batch, int32_t h, int32_t w, int32_t cin, const void* dev_w_packed,
+                        int32_t cout, int32_t ksize, int32_t stride, int32_t pad, int32_t dil, int32_t kmode,
+                        const float* dev_scale, const float* dev_shift, const void* dev_residual, int32_t relu,
+                        double* dev_gn_sums, int32_t gn_groups, void* dev_y, void* stream);
 /* one 1x1 GEMM over two inputs: out = relu?(y . w[:, :mid] + x[::stride, ::stride] . w[:, mid:] + shift), NHWC;
  * y [batch][oh][ow][mid], x [batch][h2][w2][cin], w [cout][mid + cin], `dev_ones` = cout ones (the kernel's affine scale).
  * Needs the op workspace (key 2) and fp32 / bf16x3 arithmetic (key 12 = 0 / 3). */

@@ -77,6 +77,7 @@ SIGNATURES = {
     "quber_debug_persistent_segments": (C.c_int32, [_I, _I, _I, _I, _I, _P, _I]),
     "quber_debug_persistent_fixup": (C.c_int32, [_I, _I, _I, _I, _I, _I, _P, _P, _I]),
     "quber_op_conv1x1_f16": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P]),
+    "quber_op_conv2d_f16": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _P]),
     "quber_op_conv1x1_dual": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P]),
     "quber_op_conv2d": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P]),
     "quber_op_conv3x3_winograd": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _I, _P, _P, C.c_int64, _P, _P]),

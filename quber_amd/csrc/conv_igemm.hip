@@ -1047,6 +1047,10 @@ int launch_conv(const ConvP& p0, int G, hipStream_t st) {
     if (p.kh * p.kw > 1 && p.Cin < 8) return fail("conv: filters larger than 1x1 need at least 8 input channels (pad the input)");
     if (p.kmode && (p.Cin % BK || p.K != p.Kpad)) return fail("conv: slice-major weights need Cin % 32 == 0");
     if ((p.scale == nullptr) != (p.shift == nullptr)) return fail("conv: scale and shift go together");
+    if (p.es == 2 && tune().force_tile == 0) {      // the wide layers of the fp16 data path: 256 x 256 tiles, LDS-DMA pipeline (conv_h8.hip)
+        const int rc = launch_conv_h8(p, G, st);
+        if (rc != 1) return rc;
+    }
     switch (tune().force_tile) {
         case 1: return run<64, 64, 2, 2>(p, G, 1, st);
         case 2: return run<128, 128, 2, 2>(p, G, 1, st);

@@ -54,6 +54,8 @@ static int* tuning_field(Tuning& t, int key) {
         case 27: return &t.wino_fused_max_cin;
         case 29: return &t.stem_fused;
         case 30: return &t.lean_loader;
+        case 31: return &t.h8;
+        case 32: return &t.h8_min_tiles;
         default: return nullptr;
     }
 }
@@ -1677,6 +1679,29 @@ int quber_op_conv1x1_f16(const void* x, int32_t B, int32_t h, int32_t w, int32_t
     p.kh = 1; p.kw = 1; p.stride = 1; p.pad = 0; p.dil = 1; p.relu = relu;
     p.bf16 = 2; p.es = 2;
     p.M = B * h * w; p.ohw = h * w;
+    return launch_conv(p, 1, (hipStream_t)stream);
+}
+
+int quber_op_conv2d_f16(const void* x, int32_t B, int32_t h, int32_t w, int32_t cin, const void* w_packed, int32_t cout, int32_t ksize,
+                        int32_t stride, int32_t pad, int32_t dil, int32_t kmode, const float* scale, const float* shift,
+                        const void* residual, int32_t relu, double* gn_sums, int32_t gn_groups, void* y, void* stream) {
+    if (cin % 64) return fail("conv2d_f16: cin must be a multiple of 64");
+    if (ksize < 1 || stride < 1 || dil < 1 || pad < 0) return fail("conv2d_f16: bad geometry");
+    ConvP p{};
+    p.in = (const float*)x; p.w = (const float*)w_packed; p.scale = scale; p.shift = shift; p.res = (const float*)residual; p.out = (float*)y;
+    p.B = B; p.H = h; p.W = w; p.Cin = cin; p.in_cs = cin;
+    p.OH = (h + 2 * pad - dil * (ksize - 1) - 1) / stride + 1; p.OW = (w + 2 * pad - dil * (ksize - 1) - 1) / stride + 1;
+    if (p.OH < 1 || p.OW < 1) return fail("conv2d_f16: empty output");
+    p.Cout = cout; p.out_cs = cout; p.res_cs = cout; p.K = ksize * ksize * cin; p.Kpad = p.K;
+    p.kh = ksize; p.kw = ksize; p.stride = stride; p.pad = pad; p.dil = dil; p.relu = relu;
+    p.kmode = kmode;
+    p.bf16 = 2; p.es = 2;
+    p.M = B * p.OH * p.OW; p.ohw = p.OH * p.OW;
+    p.w_gs = (long)cout * p.Kpad; p.ss_gs = cout;
+    if (gn_sums) {
+        if (gn_groups < 1 || cout % gn_groups) return fail("conv2d_f16: channels must divide into the norm groups");
+        p.gn_sum = gn_sums; p.gn_groups = gn_groups; p.gn_cpg = cout / gn_groups;
+    }
     return launch_conv(p, 1, (hipStream_t)stream);
 }
 

@@ -1,0 +1,126 @@
+"""GPU: the 256 x 256-tile LDS-DMA convolution kernel of the fp16 data path (csrc/conv_h8.hip) through the C ABI
+(quber_op_conv2d_f16), against a float32 CPU convolution of the same fp16 operands (torch, the oracle's arithmetic for
+one layer: oracle/network_torch.py runs the reference's F.conv2d) and against the 128 x 128 kernel it replaces
+(conv_igemm.hip, option key 31 = 0).
+
+Layers this kernel runs in the network: maskrefiner/modeling/backbone/resnet.py:395-449 (res4 / res5 bottlenecks),
+:472-485 (fusion convolutions, bias + GroupNorm).  Tolerance: the result is rounded to fp16 once (2^-11 relative) after an
+fp32 accumulation over K <= 4608 fp16 products; 3e-3 of the layer's output scale covers both."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from quber_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def pack(w, kmode):
+    """OIHW -> [cout][K] in the kernels' K order (csrc/plan.hip emit_conv)."""
+    co, ci, kh, kw = w.shape
+    t = w.permute(0, 2, 3, 1).reshape(co, kh * kw, ci)               # [co][tap][ci]
+    if kmode == 0:
+        return t.reshape(co, kh * kw * ci).contiguous()
+    return t.reshape(co, kh * kw, ci // 64, 64).permute(0, 2, 1, 3).reshape(co, kh * kw * ci).contiguous()
+
+
+def run(lib, x, wp, cout, k, stride, pad, dil, kmode, scale, shift, res, relu, groups):
+    B, H, W, cin = x.shape
+    oh = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    ow = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    y = torch.full((B, oh, ow, cout), float("nan"), dtype=torch.float16, device="cuda")
+    sums = torch.zeros((B, groups, 2), dtype=torch.float64, device="cuda") if groups else None
+    p = lambda t_: C.c_void_p(t_.data_ptr()) if t_ is not None else None
+    _lib.check(lib.quber_op_conv2d_f16(p(x), B, H, W, cin, p(wp), cout, k, stride, pad, dil, kmode, p(scale), p(shift), p(res),
+                                       int(relu), p(sums), groups, p(y), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    return y, sums
+
+
+CASES = [
+    # B, H, W, cin, cout, k, stride, pad, dil, kmode, affine, residual, relu, norm groups, key 31
+    (2, 40, 52, 64, 256, 3, 1, 1, 1, 1, True, False, True, 0, 1),        # ragged last pixel tile, padded borders
+    (3, 40, 52, 128, 256, 3, 1, 2, 2, 1, True, False, False, 32, 1),     # dilated; GroupNorm sums, tiles across image boundaries
+    (2, 33, 47, 128, 512, 1, 1, 0, 1, 0, True, True, True, 0, 1),        # 1x1 + residual + ReLU (bottleneck conv3)
+    (2, 48, 64, 256, 256, 1, 2, 0, 1, 0, True, False, True, 0, 1),       # strided 1x1 (first block of a stage)
+    (1, 36, 44, 64, 320, 3, 1, 1, 1, 0, False, False, False, 0, 1),      # tap-major K order, ragged channel tile, no affine
+    (2, 32, 40, 128, 128, 3, 1, 1, 1, 1, False, False, False, 32, 2),    # 128 channels (key 31 = 2): 4 channels per norm group
+    (1, 64, 64, 512, 512, 3, 1, 4, 4, 1, True, False, True, 0, 1),       # res5-like: K = 4608
+    (1, 20, 24, 2048, 256, 1, 1, 0, 1, 0, True, False, True, 32, 1),     # long 1x1 (ASPP convs.0 / fusion_res5-like)
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(str(v) for v in c[:10]))
+def test_h8_conv_matches_float32_convolution_and_the_128_tile_kernel(case):
+    B, H, W, cin, cout, k, stride, pad, dil, kmode, affine, residual, relu, groups, key31 = case
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(1234 + cin + cout + k)
+    x = torch.randn((B, H, W, cin), generator=g).half()
+    w = (torch.randn((cout, cin, k, k), generator=g) / (cin * k * k) ** 0.5).half()
+    scale = (0.5 + torch.rand(cout, generator=g)) if affine else None
+    shift = torch.randn(cout, generator=g) * 0.3 if affine else None
+    oh = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    ow = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    res = torch.randn((B, oh, ow, cout), generator=g).half() if residual else None
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), None, stride, pad, dil).permute(0, 2, 3, 1)
+    if affine:
+        ref = ref * scale + shift
+    if residual:
+        ref = ref + res.float()
+    if relu:
+        ref = ref.clamp_min(0)
+    dev = lambda t_: t_.cuda() if t_ is not None else None
+    args = (dev(x), dev(pack(w, kmode)), cout, k, stride, pad, dil, kmode, dev(scale), dev(shift), dev(res), relu, groups)
+    try:
+        lib.quber_set_tuning(32, 1)            # these launches are a handful of tiles
+        lib.quber_set_tuning(31, key31)
+        y, sums = run(lib, *args)
+        lib.quber_set_tuning(31, 0)
+        y0, sums0 = run(lib, *args)
+    finally:
+        lib.quber_set_tuning(31, 1)
+        lib.quber_set_tuning(32, 224)
+    assert torch.isfinite(y).all()
+    tol = 3e-3 * max(1.0, float(ref.abs().max()))
+    assert float((y.cpu().float() - ref).abs().max()) < tol
+    assert float((y0.cpu().float() - ref).abs().max()) < tol
+    # the two kernels differ by the order of the fp32 sum inside a K-tile only: a few fp16 roundings apart at most
+    assert float((y.float() - y0.float()).abs().max()) < tol
+    if groups:
+        yd = y.double().reshape(B, oh * ow, groups, cout // groups)
+        exp = torch.stack([yd.sum((1, 3)), (yd * yd).sum((1, 3))], -1)
+        assert torch.allclose(sums, exp, rtol=1e-11, atol=1e-9)
+        yd0 = y0.double().reshape(B, oh * ow, groups, cout // groups)
+        assert torch.allclose(sums0, torch.stack([yd0.sum((1, 3)), (yd0 * yd0).sum((1, 3))], -1), rtol=1e-11, atol=1e-9)
+
+
+def test_h8_takes_the_wide_layers_of_the_network():
+    """The fp16 network with the kernel on and off: same plan, logits within the fp16 path's own noise of each other."""
+    from quber_amd import arch, engine, synth
+    from oracle import encode_np
+    h, w, b = 256, 320, 4
+    qc = engine.make_config(h, w, max_batch=b)
+    qc.compute_dtype = 2
+    e = engine.Engine(qc, "cuda:0")
+    e.load_state_dict(arch.init_state_dict(seed=11, loud_heads=True))
+    batch = synth.make_batch(5, b, h, w, 6)
+    offs = np.stack([encode_np.encode_initial_masks(m) for m in batch["masks"]])
+    bgr, dep, off = torch.from_numpy(batch["rgb"]).cuda(), torch.from_numpy(batch["depth"]).cuda(), torch.from_numpy(offs).cuda()
+    outs, stages = {}, {}
+    for mode in (0, 1):
+        e.set_option(31, mode)
+        e.set_option(32, 16)
+        e.profile_begin()
+        outs[mode] = e.forward(bgr, dep, off).clone()
+        stages[mode] = e.profile_end()
+    e.close()
+    assert torch.isfinite(outs[1]).all()
+    # the kernel is on the path: the stage profile shows its launches (fusion convolutions, res4 / res5 bottlenecks), none with key 31 = 0
+    assert "conv_gemm_h8" not in stages[0] and stages[1]["conv_gemm_h8"]["launches"] >= 10
+    assert stages[1]["conv_gemm"]["launches"] + stages[1]["conv_gemm_h8"]["launches"] == stages[0]["conv_gemm"]["launches"]
+    d = (outs[0] - outs[1]).abs()
+    scale = max(1.0, float(outs[0].abs().max()))
+    assert float(d.max()) < 2e-2 * scale, float(d.max())
