@@ -21,6 +21,8 @@
 //   * v_mfma_f32_16x16x32_f16 with the WEIGHTS as the row operand: a lane's four accumulator values are four consecutive
 //     output channels of one pixel, and with the channel rows of a tile pair interleaved a lane owns 8 consecutive channels -
 //     the epilogue stores 16 bytes per lane straight from the accumulators, no transpose through LDS.
+#include <algorithm>
+
 #include "common.h"
 
 namespace quber {
@@ -30,11 +32,14 @@ namespace {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using h16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using h16x4 = __attribute__((ext_vector_type(4))) _Float16;
+using h16x2 = __attribute__((ext_vector_type(2))) _Float16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int H8_BM = 256;                  // pixels per tile
 constexpr int H8_KB = 128;                  // bytes of one K-tile row (64 halfs)
 constexpr int H8_HALF = 128 * H8_KB;        // one half-tile image: 128 rows
+constexpr int H8_SS = 2048;                 // bytes of one tile's [scale | shift] image in LDS
 constexpr int H8_OOB = (int)0x80000000;     // a buffer offset past every descriptor range: the DMA writes zeros
 
 // QT = 16-channel tiles per wave: 8 (256-channel tile: waves 4 (pixels) x 2 (channels), 64 x 128 each)
@@ -46,110 +51,140 @@ struct H8Geo {
     static constexpr int QBASE = 2 * H8_HALF;            // channel rows start here inside a slot
 };
 
-template <int QT>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_h8_kernel(const ConvP p) {
-    using G = H8Geo<QT>;
-    constexpr int BN = G::BN, SLOT = G::SLOT;
-    constexpr int QPW = QT * 16 / 8 / 8;          // DMA pieces (8 rows) of a channel half-tile per wave: 2 (QT 8)
-    static_assert(QT == 8, "geometry");
-    // ONE shared object: a second one beside a DMA target makes hipcc wait vmcnt(0) before the fragment reads
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * SLOT];
+#ifdef H8_STAMPS
+// diagnostic build (make H8X=-DH8_STAMPS, tools/h8_stamps.py): s_memtime of wave 0 at the tile boundaries of every block
+constexpr int H8_STAMP_TILES = 16, H8_STAMP_N = 8;
+__device__ unsigned long long g_h8_stamps[256 * H8_STAMP_TILES * H8_STAMP_N];
+#define H8_STAMP(i) do { if (t == 0 && blockIdx.x < 256 && stamp_tile < H8_STAMP_TILES) g_h8_stamps[((int)blockIdx.x * H8_STAMP_TILES + stamp_tile) * H8_STAMP_N + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define H8_STAMP(i) do {} while (0)
+#endif
 
-    const int t = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
-    const int wp = wave & 3, wq = wave >> 2;      // pixel quarter, channel half of this wave; waves w and w + 4 share a SIMD
-    const int fr = lane & 15, fq = lane >> 4;
-    const int g = blockIdx.z;
+// n / d for every 32-bit n by one multiply (Granlund-Montgomery, round-up method): host side h8_magic()
+__device__ __forceinline__ unsigned h8_div(unsigned n, unsigned m, unsigned s) {
+    const unsigned t = __umulhi(n, m);
+    return (t + ((n - t) >> (s & 1u))) >> (s >> 1);
+}
 
-    // XCD-aware tile order (as conv_igemm.hip): blocks b and b + 8 share an XCD; every XCD takes a contiguous run of tiles
-    int tile;
-    {
-        const int bid = blockIdx.x, nblk = gridDim.x;
-        const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int nt = tile % p.ntiles, mt = tile / p.ntiles;
-    const int m0 = mt * H8_BM, n0 = nt * BN;
-    const int nk = p.Kpad / 32;                   // K-tiles (ConvP of the fp16 path counts K in 4-byte units)
-
-    // ---- DMA source state: 4 pixel rows and 4 channel rows per thread ----
-    // piece u (8 rows x 128 B) of a half-tile goes to wave u / 2; lane l fills row l >> 3, physical chunk l & 7 of it and
-    // fetches the LOGICAL chunk (l & 7) ^ swizzle(row)
-    int aoff[4], boff[4];
-    unsigned amask[4];
+// per-tile DMA source state of a thread: 4 pixel rows and 4 channel rows
+// piece u (8 rows x 128 B) of a half-tile goes to wave u / 2; lane l fills row l >> 3, physical chunk l & 7 of it and fetches
+// the LOGICAL chunk (l & 7) ^ swizzle(row).  Offsets are bytes from the first group's base (one descriptor for all groups).
+template <int BN, bool K3>
+__device__ __forceinline__ void h8_tile_state(const ConvP& p, int tile, int wave, int lane, int (&aoff)[4], unsigned (&amask)[4], int (&boff)[4],
+                                              int& m0, int& n0, int& g) {
+    g = (int)h8_div((unsigned)tile, p.dv_m[2], p.dv_s[2]);          // tile / tiles per group
+    const int rem = tile - g * p.pk_tpg;
+    const int mt = (int)h8_div((unsigned)rem, p.dv_m[3], p.dv_s[3]);   // rem / ntiles
+    const int nt = rem - mt * p.ntiles;
+    m0 = mt * H8_BM;
+    n0 = nt * BN;
     const int prow = lane >> 3, pc = lane & 7;
+    const int gin = g * (int)p.in_gs * 4, gw = g * (int)p.w_gs * 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int R = 128 * (i >> 1) + 8 * (2 * wave + (i & 1)) + prow;         // pixel row of the tile
         const int m = m0 + R;
         const int chunk = pc ^ ((R >> 1) & 7);
-        aoff[i] = 0;
-        amask[i] = 0;
-        if (m < p.M && p.kh == 1 && p.stride == 1 && p.pad == 0) {
-            aoff[i] = (m * p.in_cs) * 4 + chunk * 16;
-            amask[i] = 1;
-        } else if (m < p.M) {
-            const int b = m / p.ohw;
-            const int rem = m - b * p.ohw;
-            const int oy = rem / p.OW;
-            const int ox = rem - oy * p.OW;
-            const int y0 = oy * p.stride - p.pad, x0 = ox * p.stride - p.pad;
-            aoff[i] = (((b * p.H + y0) * p.W + x0) * p.in_cs) * 4 + chunk * 16;
-            unsigned xbits = 0, mk = 0;
-            for (int tx = 0; tx < p.kw; ++tx)
-                if ((unsigned)(x0 + tx * p.dil) < (unsigned)p.W) xbits |= 1u << tx;
-            for (int ty = 0; ty < p.kh; ++ty)
-                if ((unsigned)(y0 + ty * p.dil) < (unsigned)p.H) mk |= xbits << (ty * p.kw);
-            amask[i] = mk;
+        const int b = (int)h8_div((unsigned)m, p.dv_m[0], p.dv_s[0]);           // m / ohw
+        const int r2 = m - b * p.ohw;
+        const int oy = (int)h8_div((unsigned)r2, p.dv_m[1], p.dv_s[1]);         // r2 / OW
+        const int ox = r2 - oy * p.OW;
+        const int y0 = oy * p.stride - p.pad, x0 = ox * p.stride - p.pad;
+        aoff[i] = gin + (((b * p.H + y0) * p.W + x0) * p.in_cs) * 4 + chunk * 16;
+        unsigned mk = 1;
+        if constexpr (K3) {          // bit 3 ky + kx: tap (ky, kx) of this pixel lies inside the image
+            const unsigned W = (unsigned)p.W, H = (unsigned)p.H;
+            const unsigned xb = ((unsigned)x0 < W ? 1u : 0u) | ((unsigned)(x0 + p.dil) < W ? 2u : 0u) | ((unsigned)(x0 + 2 * p.dil) < W ? 4u : 0u);
+            mk = ((unsigned)y0 < H ? xb : 0u) | ((unsigned)(y0 + p.dil) < H ? xb << 3 : 0u) | ((unsigned)(y0 + 2 * p.dil) < H ? xb << 6 : 0u);
         }
+        amask[i] = m < p.M ? mk : 0u;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int R = (BN / 2) * (i >> 1) + 8 * (QPW * wave + (i & 1)) + prow;  // channel row of the tile
+        const int R = (BN / 2) * (i >> 1) + 8 * (2 * wave + (i & 1)) + prow;    // channel row of the tile
         const int n = n0 + R;
         const int chunk = pc ^ (((R >> 1) & 1) | (((R >> 3) & 3) << 1));
-        boff[i] = n < p.Cout ? (n * p.Kpad) * 4 + chunk * 16 : H8_OOB;          // rows past Cout: zeros
+        boff[i] = n < p.Cout ? gw + (n * p.Kpad) * 4 + chunk * 16 : H8_OOB;     // rows past Cout: zeros
     }
-    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(p.in) + (long)g * p.in_gs * 4), 0, p.lean_in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(p.w) + (long)g * p.w_gs * 4), 0, p.Cout * p.Kpad * 4, 0x00020000);
+}
 
-    // block-uniform position of the next pixel K-tile to issue: tap (ky, kx), channel block
+// Persistent: a block walks the tiles start + j, start + j + nb, ... of its XCD's contiguous run, and the operand pipeline runs
+// across the tile boundaries - while a tile's last K-tiles are multiplied the first K-tiles of the block's next tile are already
+// on their way, and its epilogue (stores, GroupNorm sums) runs under those loads.  With one tile per block launch the epilogue
+// stores and the next prologue's cold loads of all 256 CUs fell into the same moments: 54 k of a 36-K-tile layer's 149 k cycles
+// per tile (profiles/r11_h8_kernel.md).
+template <int QT, bool K3>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_h8_kernel(const ConvP p) {
+    using G = H8Geo<QT>;
+    constexpr int BN = G::BN, SLOT = G::SLOT;
+    static_assert(QT == 8, "geometry");
+    // ONE shared object: a second one beside a DMA target makes hipcc wait vmcnt(0) before the fragment reads
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * SLOT + 1024 + 2 * H8_SS];
+    double* const gacc = reinterpret_cast<double*>(smem + 2 * SLOT);       // [image b0 / b0 + 1][group][sum, sum of squares]
+    constexpr int SSBASE = 2 * SLOT + 1024;       // two images of [scale (256 floats) | shift (256 floats)]: this tile's and the next one's
+
+    const int t = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+    const int wp = wave & 3, wq = wave >> 2;      // pixel quarter, channel half of this wave; waves w and w + 4 share a SIMD
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nk = p.Kpad / 32;                   // K-tiles (ConvP of the fp16 path counts K in 4-byte units)
+
+    // this block's tiles (XCD-aware as conv_igemm.hip: blocks b and b + 8 share an XCD, every XCD owns one contiguous run)
+    int tile, tile_step, tile_end;
+    {
+        const int bid = blockIdx.x, nblk = gridDim.x, T = p.pk_T;
+        const int xcd = bid & 7, q = T >> 3, r = T & 7;
+        const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        tile_end = start + q + (xcd < r ? 1 : 0);
+        tile_step = (nblk >> 3) + (xcd < (nblk & 7) ? 1 : 0);
+        tile = start + (bid >> 3);
+    }
+
+    int aoff[4], boff[4], aoffN[4], boffN[4];
+    unsigned amask[4], amaskN[4];
+    int m0, n0, g, m0N = 0, n0N = 0, gN = 0;
+    h8_tile_state<BN, K3>(p, tile, wave, lane, aoff, amask, boff, m0, n0, g);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { aoffN[i] = 0; amaskN[i] = 0; boffN[i] = H8_OOB; }
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.lean_in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.pk_in_bytes, 0x00020000);
+
+    // block-uniform position of the next pixel K-tile to issue: K-tile sk of (pnext ? the next : this) tile, tap (ky, kx), channel block
     int sk = 0, skc = 0, skx = 0, sky = 0;
+    bool pnext = false, has_next = false;
     auto issue_p = [&](int half, int slot) __attribute__((always_inline)) {
-        const int tap = sk < nk ? sky * p.kw + skx : 31;          // past the end of K: every lane out of range (no traffic)
-        const int soff = (((sky * p.dil) * p.W + skx * p.dil) * p.in_cs + skc) * 4;
+        const bool live = !pnext || has_next;
+        const int tap = live ? (K3 ? sky * 3 + skx : 0) : 31;     // past the last tile: every lane out of range (no traffic)
+        const int soff = K3 ? (((sky * p.dil) * p.W + skx * p.dil) * p.in_cs + skc) * 4 : skc * 4;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int i = 2 * half + j;
-            const bool ok = (amask[i] >> tap) & 1u;
-            const int voff = ok ? aoff[i] + soff : H8_OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr_t)(smem + slot * SLOT + half * H8_HALF + (2 * wave + j) * 1024), 16, voff, 0, 0, 0);
+            const unsigned mk = pnext ? amaskN[i] : amask[i];
+            const int ao = pnext ? aoffN[i] : aoff[i];
+            const bool ok = (mk >> tap) & 1u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr_t)(smem + slot * SLOT + half * H8_HALF + (2 * wave + j) * 1024), 16,
+                                                     ok ? ao + soff : H8_OOB, 0, 0, 0);
         }
     };
     auto advance_p = [&]() __attribute__((always_inline)) {
-        ++sk;
-        if (p.kmode) {                    // k = (channel block, tap, channel): the taps of one 64-channel block are consecutive K-tiles
-            if (++skx == p.kw) {
+        if constexpr (K3) {               // k = (channel block, tap, channel): the nine taps of one 64-channel block are consecutive K-tiles
+            if (++skx == 3) {
                 skx = 0;
-                if (++sky == p.kh) { sky = 0; skc += 32; }
+                if (++sky == 3) { sky = 0; skc += 32; }
             }
-        } else {                          // k = (tap, channel)
+        } else {
             skc += 32;
-            if (skc >= p.Cin) {
-                skc = 0;
-                if (++skx == p.kw) { skx = 0; ++sky; }
-            }
         }
+        if (++sk == nk) { sk = 0; skc = 0; skx = 0; sky = 0; pnext = true; }
     };
-    auto issue_q = [&](int half, int slot, int kt) __attribute__((always_inline)) {
-        const bool live = kt < nk;
+    auto issue_q = [&](int half, int slot, int kq) __attribute__((always_inline)) {      // channel half of K-tile kq (== nk: K-tile 0 of the next tile)
+        const bool nxt = kq >= nk;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int i = 2 * half + j;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lds_ptr_t)(smem + slot * SLOT + G::QBASE + half * G::QHALF + (QPW * wave + j) * 1024), 16,
-                                                     live ? boff[i] : H8_OOB, kt * H8_KB, 0, 0);
+            const int bo = nxt ? boffN[i] : boff[i];             // (past the last tile boffN is out of range)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lds_ptr_t)(smem + slot * SLOT + G::QBASE + half * G::QHALF + (2 * wave + j) * 1024), 16,
+                                                     bo, nxt ? 0 : kq * H8_KB, 0, 0);
         }
     };
 
@@ -166,19 +201,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 
     f32x4 acc[QT][4];
-#pragma unroll
-    for (int c = 0; c < QT; ++c)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[c][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     h16x8 pf[2][4], qf[4];
 
+    // the affine vectors of a tile's 256 channels: one DMA each (wave 0; 64 lanes x 16 bytes), issued a whole tile ahead, so that
+    // the epilogue loads nothing from global memory (a plain load there waits for the DMAs of the next tile queued before it)
+    const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.scale), 0, p.scale ? p.h8_ss_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.shift), 0, p.scale ? p.h8_ss_bytes : 0, 0x00020000);
+    auto issue_ss = [&](int buf, int tg, int tn0) __attribute__((always_inline)) {
+        if (wave == 0 && p.scale) {
+            const int off = (tg * p.ss_gs + tn0) * 4 + lane * 16;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rss, (lds_ptr_t)(smem + SSBASE + buf * H8_SS), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsh, (lds_ptr_t)(smem + SSBASE + buf * H8_SS + 1024), 16, off, 0, 0, 0);
+        }
+    };
+    int ssb = 0;                          // image of this tile's scale / shift
+
     // ---- prologue: K-tile 0 whole, the pixel halves of K-tile 1 ----
+    issue_ss(0, g, n0);
     issue_p(0, 0); issue_p(1, 0); advance_p();
     issue_q(0, 0, 0); issue_q(1, 0, 0);
     issue_p(0, 1); issue_p(1, 1); advance_p();
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (wq == 1) __builtin_amdgcn_s_barrier();      // stagger: waves 4-7 run half a phase behind their SIMD partners
+    int gk = 0;                           // K-tiles consumed so far: K-tile gk lives in image gk & 1
 
 #define H8_READ_Q(JH, KS)                                                                                              \
     _Pragma("unroll") for (int c4 = 0; c4 < 4; ++c4) {                                                                  \
@@ -195,129 +240,209 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __builtin_amdgcn_s_setprio(0);                                                                                      \
     __builtin_amdgcn_s_barrier();
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int s = kt & 1;
-        const int sbase = s * SLOT;
-        // phase 0: every pixel fragment of the K-tile + channel tiles 0-3, k-step 0; DMA: channel half 0 of K-tile kt + 1
-        H8_READ_Q(0, 0)
-        __builtin_amdgcn_sched_barrier(0);
+#ifdef H8_STAMPS
+    int stamp_tile = 0;
+#endif
+    for (;;) {
+        H8_STAMP(0);
+        // the block's next tile: its source state is needed from the last two K-tiles of this one on
+        has_next = tile + tile_step < tile_end;
+        if (has_next) {
+            h8_tile_state<BN, K3>(p, tile + tile_step, wave, lane, aoffN, amaskN, boffN, m0N, n0N, gN);
+            issue_ss(ssb ^ 1, gN, n0N);
+        }
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int c = 0; c < QT; ++c)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) pf[ks][i] = *reinterpret_cast<const h16x8*>(smem + sbase + paddr[ks] + i * 16 * H8_KB);
-        issue_q(0, s ^ 1, kt + 1);
-        H8_MMA(0, 0)
-        // phase 1: channel tiles 4-7, k-step 0; DMA: channel half 1 of K-tile kt + 1
-        H8_READ_Q(1, 0)
-        issue_q(1, s ^ 1, kt + 1);
-        H8_MMA(1, 0)
-        // phase 2: channel tiles 4-7, k-step 1; DMA: pixel half 0 of K-tile kt + 2 (this image's pixel rows were read in phase 0)
-        H8_READ_Q(1, 1)
-        issue_p(0, s);
-        H8_MMA(1, 1)
-        // phase 3: channel tiles 0-3, k-step 1; DMA: pixel half 1 of K-tile kt + 2; everything older than the two pixel halves
-        // just issued has landed after this wait + the next barrier pair
-        H8_READ_Q(0, 1)
-        issue_p(1, s);
-        advance_p();
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        H8_MMA(0, 1)
+            for (int i = 0; i < 4; ++i) acc[c][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (wq == 1) __builtin_amdgcn_s_barrier();      // stagger: waves 4-7 run half a phase behind their SIMD partners
+        H8_STAMP(1);
+
+        for (int kt = 0; kt < nk; ++kt, ++gk) {
+            const int s = gk & 1;
+            const int sbase = s * SLOT;
+#ifdef H8_STAMPS
+            if (kt == 4) H8_STAMP(4);
+            if (kt == nk - 4) H8_STAMP(5);
+#endif
+            // phase 0: every pixel fragment of the K-tile + channel tiles 0-3, k-step 0; DMA: channel half 0 of K-tile kt + 1
+            H8_READ_Q(0, 0)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pf[ks][i] = *reinterpret_cast<const h16x8*>(smem + sbase + paddr[ks] + i * 16 * H8_KB);
+            issue_q(0, s ^ 1, kt + 1);
+            H8_MMA(0, 0)
+            // phase 1: channel tiles 4-7, k-step 0; DMA: channel half 1 of K-tile kt + 1
+            H8_READ_Q(1, 0)
+            issue_q(1, s ^ 1, kt + 1);
+            H8_MMA(1, 0)
+            // phase 2: channel tiles 4-7, k-step 1; DMA: pixel half 0 of K-tile kt + 2 (this image's pixel rows were read in phase 0)
+            H8_READ_Q(1, 1)
+            issue_p(0, s);
+            H8_MMA(1, 1)
+            // phase 3: channel tiles 0-3, k-step 1; DMA: pixel half 1 of K-tile kt + 2; everything older than the two pixel halves
+            // just issued has landed after this wait + the next barrier pair
+            H8_READ_Q(0, 1)
+            issue_p(1, s);
+            advance_p();
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            H8_MMA(0, 1)
+        }
+        H8_STAMP(2);
+        if (wq == 0) __builtin_amdgcn_s_barrier();      // the two halves level again: the epilogue's barriers are ordinary ones
+
+        // ---- epilogue: y = acc * scale + shift (+ residual) (ReLU), 8 channels = 16 bytes per lane ----
+        // Buffer stores through a descriptor of this tile's rows: a row past M is past its range and dropped; raw barriers and
+        // explicit LDS waits (a __syncthreads() here would drain the next tile's DMAs); the affine vectors come from the LDS image
+        // the DMA of a tile ago filled, by ds_read in asm (hipcc orders a plain read of DMA-written LDS behind vmcnt(0)).
+        {
+            const int rows = min(p.M - m0, H8_BM);
+            const long org = (long)g * p.out_gs + (long)m0 * p.out_cs + n0;
+            const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<_Float16*>(p.out) + org, 0, ((rows - 1) * p.out_cs + min(p.Cout - n0, BN)) * 2, 0x00020000);
+            const long rorg = (long)g * p.res_gs + (long)m0 * p.res_cs + n0;
+            const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<_Float16*>(reinterpret_cast<const _Float16*>(p.res)) + (p.res ? rorg : 0), 0,
+                p.res ? ((rows - 1) * p.res_cs + min(p.Cout - n0, BN)) * 2 : 0, 0x00020000);
+            const bool affine = p.scale != nullptr, has_res = p.res != nullptr;
+            const float lo = p.relu ? 0.f : -__builtin_inff();
+            const bool gn = p.gn_sum != nullptr;
+            const int b0 = gn ? (int)h8_div((unsigned)m0, p.dv_m[0], p.dv_s[0]) : 0;
+            const int m_next = (b0 + 1) * p.ohw;
+            // one image and whole rows (the common case): every lane adds into the same pair of sums
+            const bool plain = m0 + H8_BM <= p.M && m0 + H8_BM <= m_next;
+            if (gn) {
+                if (t < 128) gacc[t] = 0.0;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            // (opaque copies: the offsets derived from them are recomputed per tile instead of living in registers across the K loop)
+            int fr_e = fr, fq_e = fq;
+            asm volatile("" : "+v"(fr_e), "+v"(fq_e));
+            const int prow0 = 64 * wp + fr_e;
+#pragma unroll
+            for (int gg = 0; gg < QT / 2; ++gg) {
+                const int nl = QT * 16 * wq + 32 * gg + 8 * fq_e;    // first of this lane's 8 channels inside the tile
+                const bool colok = n0 + nl < p.Cout;                 // (Cout is a multiple of 8)
+                f32x4 sc0, sc1, sh0, sh1;
+                if (affine) {
+                    const unsigned ad = SSBASE + ssb * H8_SS + nl * 4;
+                    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:1024\n\tds_read_b128 %3, %4 offset:1040\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(sc0), "=&v"(sc1), "=&v"(sh0), "=&v"(sh1) : "v"(ad) : "memory");
+                }
+                float s0[2] = {0.f, 0.f}, q0[2] = {0.f, 0.f}, s1[2] = {0.f, 0.f}, q1[2] = {0.f, 0.f};   // [channel half] of image b0 / b0 + 1
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = prow0 + 16 * i;
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = acc[2 * gg][i][e]; v[4 + e] = acc[2 * gg + 1][i][e]; }
+                    if (affine) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] = fmaf(v[e], sc0[e], sh0[e]); v[4 + e] = fmaf(v[4 + e], sc1[e], sh1[e]); }
+                    }
+                    if (has_res) {
+                        const h16x8 rh = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rsr, colok ? (r * p.res_cs + nl) * 2 : H8_OOB, 0, 0));
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += (float)rh[e];
+                    }
+                    h16x2 h[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x0 = __builtin_amdgcn_fmed3f(v[2 * e], lo, __builtin_inff()), x1 = __builtin_amdgcn_fmed3f(v[2 * e + 1], lo, __builtin_inff());
+                        h[e] = h16x2{(_Float16)x0, (_Float16)x1};
+                    }
+                    u32x4 pk = {__builtin_bit_cast(unsigned, h[0]), __builtin_bit_cast(unsigned, h[1]), __builtin_bit_cast(unsigned, h[2]), __builtin_bit_cast(unsigned, h[3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(pk, rso, colok ? (r * p.out_cs + nl) * 2 : H8_OOB, 0, 0);
+                    if (gn) {       // sums of the stored (rounded) values: two fp16 products per v_dot2, fp32 accumulation
+                        const h16x2 one = {(_Float16)1.f, (_Float16)1.f};
+                        const float a = __builtin_amdgcn_fdot2(h[1], one, __builtin_amdgcn_fdot2(h[0], one, 0.f, false), false);
+                        const float b = __builtin_amdgcn_fdot2(h[1], h[1], __builtin_amdgcn_fdot2(h[0], h[0], 0.f, false), false);
+                        const float a2 = __builtin_amdgcn_fdot2(h[3], one, __builtin_amdgcn_fdot2(h[2], one, 0.f, false), false);
+                        const float b2 = __builtin_amdgcn_fdot2(h[3], h[3], __builtin_amdgcn_fdot2(h[2], h[2], 0.f, false), false);
+                        if (plain) {
+                            s0[0] += a; q0[0] += b; s0[1] += a2; q0[1] += b2;
+                        } else {
+                            const int m = m0 + r;
+                            if (m < p.M) {
+                                if (m < m_next) { s0[0] += a; q0[0] += b; s0[1] += a2; q0[1] += b2; } else { s1[0] += a; q1[0] += b; s1[1] += a2; q1[1] += b2; }
+                            }
+                        }
+                    }
+                }
+                if (gn && colok) {
+                    // the 16 lanes fr = 0..15 of a DPP row hold the same channels: four row_shr adds leave the row's sum in lane fr = 15;
+                    // fp32 inside a wave (at most 256 values per sum), fp64 from there on
+                    const int n = n0 + nl;
+                    const int grp0 = n / p.gn_cpg, grp1 = (n + 4) / p.gn_cpg;
+                    float d[8] = {s0[0], q0[0], s1[0], q1[0], s0[1], q0[1], s1[1], q1[1]};
+                    if (grp0 == grp1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) d[e] += d[4 + e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        d[e] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d[e]), 0x111, 0xf, 0xf, true));
+                        d[e] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d[e]), 0x112, 0xf, 0xf, true));
+                        d[e] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d[e]), 0x114, 0xf, 0xf, true));
+                        d[e] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d[e]), 0x118, 0xf, 0xf, true));
+                    }
+                    if (fr_e == 15) {
+                        atomicAdd(&gacc[grp0 * 2], (double)d[0]); atomicAdd(&gacc[grp0 * 2 + 1], (double)d[1]);
+                        if (d[2] != 0.f || d[3] != 0.f) { atomicAdd(&gacc[64 + grp0 * 2], (double)d[2]); atomicAdd(&gacc[64 + grp0 * 2 + 1], (double)d[3]); }
+                        if (grp0 != grp1) {
+                            atomicAdd(&gacc[grp1 * 2], (double)d[4]); atomicAdd(&gacc[grp1 * 2 + 1], (double)d[5]);
+                            if (d[6] != 0.f || d[7] != 0.f) { atomicAdd(&gacc[64 + grp1 * 2], (double)d[6]); atomicAdd(&gacc[64 + grp1 * 2 + 1], (double)d[7]); }
+                        }
+                    }
+                }
+            }
+            if (gn) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (t < 128) {
+                    const double v = gacc[t];
+                    const int b = b0 + (t >> 6);
+                    if (v != 0.0 && b < p.B) atomicAdd(&p.gn_sum[(((long)g * p.B + b) * p.gn_groups) * 2 + (t & 63)], v);
+                }
+            }
+        }
+        H8_STAMP(3);
+#ifdef H8_STAMPS
+        ++stamp_tile;
+#endif
+        if (!has_next) break;
+        // the next tile becomes this one; its K-tiles 0 and 1 are already issued (sk == 2)
+        tile += tile_step;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { aoff[i] = aoffN[i]; amask[i] = amaskN[i]; boff[i] = boffN[i]; }
+        m0 = m0N; n0 = n0N; g = gN;
+        pnext = false;
+        ssb ^= 1;
     }
 #undef H8_READ_Q
 #undef H8_MMA
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the out-of-range tail DMAs still write (zeros) into the images
-    if (wq == 0) __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_s_barrier();
-
-    // ---- epilogue: y = acc * scale + shift (+ residual) (ReLU), 8 channels = 16 bytes per lane ----
-    _Float16* __restrict__ out = reinterpret_cast<_Float16*>(p.out) + (long)g * p.out_gs;
-    const _Float16* __restrict__ res = p.res ? reinterpret_cast<const _Float16*>(p.res) + (long)g * p.res_gs : nullptr;
-    const float* __restrict__ scale = p.scale ? p.scale + g * p.ss_gs : nullptr;
-    const float* __restrict__ shift = p.shift ? p.shift + g * p.ss_gs : nullptr;
-    double* const gacc = reinterpret_cast<double*>(smem);       // [image b0 / b0 + 1][group][sum, sum of squares]
-    const bool gn = p.gn_sum != nullptr;
-    int b0 = 0, m_next = 0;
-    if (gn) {
-        if (t < 128) gacc[t] = 0.0;
-        b0 = m0 / p.ohw;
-        m_next = (b0 + 1) * p.ohw;
-        __syncthreads();
-    }
-#pragma unroll
-    for (int gg = 0; gg < QT / 2; ++gg) {
-        const int n = n0 + QT * 16 * wq + 32 * gg + 8 * fq;
-        if (n >= p.Cout) continue;
-        float sc[8], sh[8];
-        if (scale) {
-            *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(scale + n);
-            *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(scale + n + 4);
-            *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(shift + n);
-            *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(shift + n + 4);
-        }
-        double s0[2] = {0.0, 0.0}, q0[2] = {0.0, 0.0}, s1[2] = {0.0, 0.0}, q1[2] = {0.0, 0.0};   // [channel half] of image b0 / b0 + 1
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + 64 * wp + 16 * i + fr;
-            if (m >= p.M) continue;
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = acc[2 * gg][i][e]; v[4 + e] = acc[2 * gg + 1][i][e]; }
-            if (scale) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
-            }
-            if (res) {
-                const h16x8 rh = *reinterpret_cast<const h16x8*>(res + (long)m * p.res_cs + n);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += (float)rh[e];
-            }
-            h16x8 hv;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if (p.relu) v[e] = fmaxf(v[e], 0.f);
-                hv[e] = (_Float16)v[e];
-                v[e] = (float)hv[e];
-            }
-            *reinterpret_cast<h16x8*>(out + (long)m * p.out_cs + n) = hv;
-            if (gn) {       // sums of the stored (rounded) values, as conv_igemm.hip
-                const double a = (double)v[0] + (double)v[1] + (double)v[2] + (double)v[3];
-                const double b = (double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2] + (double)v[3] * v[3];
-                const double a2 = (double)v[4] + (double)v[5] + (double)v[6] + (double)v[7];
-                const double b2 = (double)v[4] * v[4] + (double)v[5] * v[5] + (double)v[6] * v[6] + (double)v[7] * v[7];
-                if (m < m_next) { s0[0] += a; q0[0] += b; s0[1] += a2; q0[1] += b2; } else { s1[0] += a; q1[0] += b; s1[1] += a2; q1[1] += b2; }
-            }
-        }
-        if (gn) {
-            // the 16 lanes fr = 0..15 of a row hold the same channels: reduce over them, one lane adds to the block's sums
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-#pragma unroll
-                for (int d = 1; d < 16; d <<= 1) {
-                    s0[h] += __shfl_xor(s0[h], d); q0[h] += __shfl_xor(q0[h], d);
-                    s1[h] += __shfl_xor(s1[h], d); q1[h] += __shfl_xor(q1[h], d);
-                }
-            }
-            if (fr == 0) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int grp = (n + 4 * h) / p.gn_cpg;
-                    atomicAdd(&gacc[grp * 2], s0[h]); atomicAdd(&gacc[grp * 2 + 1], q0[h]);
-                    if (s1[h] != 0.0 || q1[h] != 0.0) { atomicAdd(&gacc[64 + grp * 2], s1[h]); atomicAdd(&gacc[64 + grp * 2 + 1], q1[h]); }
-                }
-            }
-        }
-    }
-    if (gn) {
-        __syncthreads();
-        if (t < 128) {
-            const double v = gacc[t];
-            const int b = b0 + (t >> 6);
-            if (v != 0.0 && b < p.B) atomicAdd(&p.gn_sum[(((long)g * p.B + b) * p.gn_groups) * 2 + (t & 63)], v);
-        }
-    }
 }
 
 }  // namespace
+
+#ifdef H8_STAMPS
+int h8_read_stamps(unsigned long long* dst, int n) {
+    if (n > 256 * H8_STAMP_TILES * H8_STAMP_N) n = 256 * H8_STAMP_TILES * H8_STAMP_N;
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_h8_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
+#endif
+
+// magic number of n / d for every 32-bit n (device side: h8_div)
+static void h8_magic(unsigned d, unsigned& m, unsigned& s) {
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    m = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+    s = ((l > 0 ? l - 1 : 0) << 1) | (l > 0 ? 1u : 0u);
+}
 
 // The launches this kernel takes: fp16 tensors, every K-tile inside one filter tap (Cin a multiple of 64 halfs), at most 31 taps,
 // views below 2 GiB, 16-byte epilogue accesses, no second input, and enough tiles to fill the chip.
@@ -325,7 +450,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 int launch_conv_h8(ConvP p, int G, hipStream_t st) {
     if (!tune().h8 || p.es != 2 || p.in2 || p.prelu || p.skip_rows) return 1;
     // (ConvP of the fp16 path: Cin / in_cs / K / Kpad / in_gs / w_gs are in 4-byte units)
-    if (p.Cin % 32 || p.K != p.Kpad || p.kh * p.kw > 31 || p.Kpad / 32 < 2) return 1;
+    if (p.Cin % 32 || p.K != p.Kpad || p.Kpad / 32 < 3) return 1;
+    const bool k3 = p.kh == 3 && p.kw == 3 && p.kmode == 1;
+    if (!k3 && !(p.kh == 1 && p.kw == 1 && p.pad == 0)) return 1;
     if (p.Cout < 256 && tune().h8 < 2) return 1;
     const long in_bytes = ((long)p.B * p.H * p.W * p.in_cs) * 4, w_bytes = (long)p.Cout * p.Kpad * 4;
     if (in_bytes >= 0x7fffff00L || w_bytes >= 0x7fffff00L) return 1;
@@ -336,19 +463,39 @@ int launch_conv_h8(ConvP p, int G, hipStream_t st) {
     p.mtiles = (p.M + H8_BM - 1) / H8_BM;
     p.ntiles = (p.Cout + 255) / 256;
     const long tiles = (long)p.mtiles * p.ntiles * G;
-    if (tiles < tune().h8_min_tiles) return 1;
-    p.lean_in_bytes = (int)in_bytes;
+    if (tiles < tune().h8_min_tiles || tiles > 0x3fffffff) return 1;
+    // one descriptor per operand over all groups: 31-bit byte offsets
+    const long in_all = in_bytes + (long)(G - 1) * p.in_gs * 4, w_all = w_bytes + (long)(G - 1) * p.w_gs * 4;
+    if (in_all >= 0x7fffff00L || w_all >= 0x7fffff00L) return 1;
+    p.lean_in_bytes = (int)in_all;
+    p.pk_in_bytes = (int)w_all;
+    p.pk_T = (int)tiles;
+    p.pk_tpg = p.mtiles * p.ntiles;
+    h8_magic((unsigned)p.ohw, p.dv_m[0], p.dv_s[0]);
+    h8_magic((unsigned)p.OW, p.dv_m[1], p.dv_s[1]);
+    h8_magic((unsigned)p.pk_tpg, p.dv_m[2], p.dv_s[2]);
+    h8_magic((unsigned)p.ntiles, p.dv_m[3], p.dv_s[3]);
+    p.h8_ss_bytes = ((G - 1) * p.ss_gs + p.Cout) * 4;
     // GroupNorm sums in the epilogue: whole 4-channel halves inside one norm group, at most 32 groups, images of at least one
     // tile of rows (a tile then meets at most two images); otherwise a separate pass over the output
     const bool gn_sep = p.gn_sum && !(p.gn_cpg % 4 == 0 && p.gn_groups <= 32 && p.ohw >= H8_BM);
     double* const gn_sum = p.gn_sum;
     if (gn_sep) p.gn_sum = nullptr;
     {
+        static int cus = 0;
+        if (!cus) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail("conv_h8: cannot query the device");
+            cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        }
         const double out_bytes = 2.0 * G * (double)p.M * p.Cout;
         const double conv_bytes = 4.0 * G * ((double)p.B * p.H * p.W * p.Cin + (double)p.Cout * p.K) + out_bytes * (p.res ? 2.0 : 1.0);
         const double conv_flops = 2.0 * G * (double)p.M * p.K * p.Cout * 2.0;
         ProfScope prof(p.tag ? p.tag : "conv_gemm_h8", conv_bytes, conv_flops, st);
-        hipLaunchKernelGGL((conv_h8_kernel<8>), dim3(p.mtiles * p.ntiles, 1, G), dim3(512), 0, st, p);
+        const int blocks = (int)std::min<long>(tiles, cus);        // one block per CU (128 KB of LDS), each walks its share of the tiles
+        if (k3) hipLaunchKernelGGL((conv_h8_kernel<8, true>), dim3(blocks), dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((conv_h8_kernel<8, false>), dim3(blocks), dim3(512), 0, st, p);
     }
     QB_CHECK(hipGetLastError());
     if (gn_sep) {

@@ -118,6 +118,9 @@ ProfScope::~ProfScope() {
 #ifdef WF_STAMPS
 namespace quber { int wf_read_stamps(unsigned long long* dst, int n); }
 #endif
+#ifdef H8_STAMPS
+namespace quber { int h8_read_stamps(unsigned long long* dst, int n); }
+#endif
 using namespace quber;
 
 constexpr int GN_SLOTS = 64;
@@ -1346,6 +1349,9 @@ int quber_get_option(quber_ctx* c, int32_t key, int32_t* value) {
 
 #ifdef WF_STAMPS
 int quber_wf_read_stamps(unsigned long long* dst, int n) { return quber::wf_read_stamps(dst, n); }
+#endif
+#ifdef H8_STAMPS
+int quber_h8_read_stamps(unsigned long long* dst, int n) { return quber::h8_read_stamps(dst, n); }
 #endif
 #ifdef PK_STAMPS
 int quber_pk_read_stamps(unsigned long long* dst, int n) { return quber::pk_read_stamps(dst, n); }
