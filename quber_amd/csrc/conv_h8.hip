@@ -308,7 +308,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 p.res ? ((rows - 1) * p.res_cs + min(p.Cout - n0, BN)) * 2 : 0, 0x00020000);
             const bool affine = p.scale != nullptr, has_res = p.res != nullptr;
             const float lo = p.relu ? 0.f : -__builtin_inff();
+#if defined(H8_EXP) && H8_EXP == 2
+            const bool gn = false;
+#else
             const bool gn = p.gn_sum != nullptr;
+#endif
             const int b0 = gn ? (int)h8_div((unsigned)m0, p.dv_m[0], p.dv_s[0]) : 0;
             const int m_next = (b0 + 1) * p.ohw;
             // one image and whole rows (the common case): every lane adds into the same pair of sums
@@ -355,7 +359,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         h[e] = h16x2{(_Float16)x0, (_Float16)x1};
                     }
                     u32x4 pk = {__builtin_bit_cast(unsigned, h[0]), __builtin_bit_cast(unsigned, h[1]), __builtin_bit_cast(unsigned, h[2]), __builtin_bit_cast(unsigned, h[3])};
+#if defined(H8_EXP) && H8_EXP == 1
+                    __builtin_amdgcn_raw_buffer_store_b128(pk, rso, H8_OOB + r, 0, 0);
+#else
                     __builtin_amdgcn_raw_buffer_store_b128(pk, rso, colok ? (r * p.out_cs + nl) * 2 : H8_OOB, 0, 0);
+#endif
                     if (gn) {       // sums of the stored (rounded) values: two fp16 products per v_dot2, fp32 accumulation
                         const h16x2 one = {(_Float16)1.f, (_Float16)1.f};
                         const float a = __builtin_amdgcn_fdot2(h[1], one, __builtin_amdgcn_fdot2(h[0], one, 0.f, false), false);
