@@ -113,14 +113,14 @@ __device__ __forceinline__ void h8_tile_state(const ConvP& p, int tile, int wave
 // on their way, and its epilogue (stores, GroupNorm sums) runs under those loads.  With one tile per block launch the epilogue
 // stores and the next prologue's cold loads of all 256 CUs fell into the same moments: 54 k of a 36-K-tile layer's 149 k cycles
 // per tile (profiles/r11_h8_kernel.md).
-template <int QT, bool K3>
+template <int QT, bool K3, bool RES, bool GN>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_h8_kernel(const ConvP p) {
     using G = H8Geo<QT>;
     constexpr int BN = G::BN, SLOT = G::SLOT;
     static_assert(QT == 8, "geometry");
     // ONE shared object: a second one beside a DMA target makes hipcc wait vmcnt(0) before the fragment reads
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * SLOT + 1024 + 2 * H8_SS];
-    double* const gacc = reinterpret_cast<double*>(smem + 2 * SLOT);       // [image b0 / b0 + 1][group][sum, sum of squares]
+    // smem + 2 * SLOT: the block's GroupNorm sums, f64 [image b0 / b0 + 1][group][sum, sum of squares]
     constexpr int SSBASE = 2 * SLOT + 1024;       // two images of [scale (256 floats) | shift (256 floats)]: this tile's and the next one's
 
     const int t = threadIdx.x;
@@ -205,10 +205,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     // the affine vectors of a tile's 256 channels: one DMA each (wave 0; 64 lanes x 16 bytes), issued a whole tile ahead, so that
     // the epilogue loads nothing from global memory (a plain load there waits for the DMAs of the next tile queued before it)
-    const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.scale), 0, p.scale ? p.h8_ss_bytes : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.shift), 0, p.scale ? p.h8_ss_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.scale), 0, p.h8_ss_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.shift), 0, p.h8_ss_bytes, 0x00020000);
     auto issue_ss = [&](int buf, int tg, int tn0) __attribute__((always_inline)) {
-        if (wave == 0 && p.scale) {
+        if (wave == 0) {
             const int off = (tg * p.ss_gs + tn0) * 4 + lane * 16;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rss, (lds_ptr_t)(smem + SSBASE + buf * H8_SS), 16, off, 0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsh, (lds_ptr_t)(smem + SSBASE + buf * H8_SS + 1024), 16, off, 0, 0, 0);
@@ -296,7 +296,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // ---- epilogue: y = acc * scale + shift (+ residual) (ReLU), 8 channels = 16 bytes per lane ----
         // Buffer stores through a descriptor of this tile's rows: a row past M is past its range and dropped; raw barriers and
         // explicit LDS waits (a __syncthreads() here would drain the next tile's DMAs); the affine vectors come from the LDS image
-        // the DMA of a tile ago filled, by ds_read in asm (hipcc orders a plain read of DMA-written LDS behind vmcnt(0)).
+        // the DMA of a tile ago filled, and the block's GroupNorm sums live in LDS too - all by ds_ instructions in asm: before a
+        // plain access to DMA-written LDS hipcc waits for the vector-memory queue (here: for the stores just issued).
+        // RES / GN are template parameters: as run-time flags they cost the epilogue ~800 register moves around its branches.
         {
             const int rows = min(p.M - m0, H8_BM);
             const long org = (long)g * p.out_gs + (long)m0 * p.out_cs + n0;
@@ -304,21 +306,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 reinterpret_cast<_Float16*>(p.out) + org, 0, ((rows - 1) * p.out_cs + min(p.Cout - n0, BN)) * 2, 0x00020000);
             const long rorg = (long)g * p.res_gs + (long)m0 * p.res_cs + n0;
             const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<_Float16*>(reinterpret_cast<const _Float16*>(p.res)) + (p.res ? rorg : 0), 0,
-                p.res ? ((rows - 1) * p.res_cs + min(p.Cout - n0, BN)) * 2 : 0, 0x00020000);
-            const bool affine = p.scale != nullptr, has_res = p.res != nullptr;
+                const_cast<_Float16*>(reinterpret_cast<const _Float16*>(p.res)) + (RES ? rorg : 0), 0,
+                RES ? ((rows - 1) * p.res_cs + min(p.Cout - n0, BN)) * 2 : 0, 0x00020000);
             const float lo = p.relu ? 0.f : -__builtin_inff();
-#if defined(H8_EXP) && H8_EXP == 2
-            const bool gn = false;
-#else
-            const bool gn = p.gn_sum != nullptr;
-#endif
-            const int b0 = gn ? (int)h8_div((unsigned)m0, p.dv_m[0], p.dv_s[0]) : 0;
+            const int b0 = GN ? (int)h8_div((unsigned)m0, p.dv_m[0], p.dv_s[0]) : 0;
             const int m_next = (b0 + 1) * p.ohw;
             // one image and whole rows (the common case): every lane adds into the same pair of sums
             const bool plain = m0 + H8_BM <= p.M && m0 + H8_BM <= m_next;
-            if (gn) {
-                if (t < 128) gacc[t] = 0.0;
+            const unsigned gacc_b = 2 * SLOT;
+            if constexpr (GN) {
+                if (t < 128) {
+                    const unsigned long long z = 0;
+                    asm volatile("ds_write_b64 %0, %1" :: "v"(gacc_b + t * 8), "v"(z) : "memory");
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
@@ -330,88 +330,102 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int gg = 0; gg < QT / 2; ++gg) {
                 const int nl = QT * 16 * wq + 32 * gg + 8 * fq_e;    // first of this lane's 8 channels inside the tile
                 const bool colok = n0 + nl < p.Cout;                 // (Cout is a multiple of 8)
+                const int obase = colok ? (prow0 * p.out_cs + nl) * 2 : H8_OOB;      // (+ 32 rows: still past every range)
+                u32x4 rbuf[4];                                       // residual: the four loads of this channel block in flight together
+                if constexpr (RES) {
+                    const int rbase = colok ? (prow0 * p.res_cs + nl) * 2 : H8_OOB;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) rbuf[i] = __builtin_amdgcn_raw_buffer_load_b128(rsr, rbase + i * 32 * p.res_cs, 0, 0);
+                }
                 f32x4 sc0, sc1, sh0, sh1;
-                if (affine) {
+                {
                     const unsigned ad = SSBASE + ssb * H8_SS + nl * 4;
                     asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:1024\n\tds_read_b128 %3, %4 offset:1040\n\ts_waitcnt lgkmcnt(0)"
                                  : "=&v"(sc0), "=&v"(sc1), "=&v"(sh0), "=&v"(sh1) : "v"(ad) : "memory");
                 }
-                float s0[2] = {0.f, 0.f}, q0[2] = {0.f, 0.f}, s1[2] = {0.f, 0.f}, q1[2] = {0.f, 0.f};   // [channel half] of image b0 / b0 + 1
+                float sA = 0.f, qA = 0.f, sB = 0.f, qB = 0.f;        // channel halves A / B of image b0 ...
+                float sA1 = 0.f, qA1 = 0.f, sB1 = 0.f, qB1 = 0.f;    // ... and of image b0 + 1 (a tile across an image boundary)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int r = prow0 + 16 * i;
                     float v[8];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] = acc[2 * gg][i][e]; v[4 + e] = acc[2 * gg + 1][i][e]; }
-                    if (affine) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { v[e] = fmaf(v[e], sc0[e], sh0[e]); v[4 + e] = fmaf(v[4 + e], sc1[e], sh1[e]); }
-                    }
-                    if (has_res) {
-                        const h16x8 rh = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rsr, colok ? (r * p.res_cs + nl) * 2 : H8_OOB, 0, 0));
+                    for (int e = 0; e < 4; ++e) { v[e] = fmaf(acc[2 * gg][i][e], sc0[e], sh0[e]); v[4 + e] = fmaf(acc[2 * gg + 1][i][e], sc1[e], sh1[e]); }
+                    if constexpr (RES) {
+                        const h16x8 rh = __builtin_bit_cast(h16x8, rbuf[i]);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += (float)rh[e];
                     }
                     h16x2 h[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float x0 = __builtin_amdgcn_fmed3f(v[2 * e], lo, __builtin_inff()), x1 = __builtin_amdgcn_fmed3f(v[2 * e + 1], lo, __builtin_inff());
+                        float x0, x1;       // (asm: fmaxf / fmed3 add a canonicalising v_max per value)
+                        asm("v_max_f32 %0, %1, %2" : "=v"(x0) : "v"(v[2 * e]), "v"(lo));
+                        asm("v_max_f32 %0, %1, %2" : "=v"(x1) : "v"(v[2 * e + 1]), "v"(lo));
                         h[e] = h16x2{(_Float16)x0, (_Float16)x1};
                     }
-                    u32x4 pk = {__builtin_bit_cast(unsigned, h[0]), __builtin_bit_cast(unsigned, h[1]), __builtin_bit_cast(unsigned, h[2]), __builtin_bit_cast(unsigned, h[3])};
-#if defined(H8_EXP) && H8_EXP == 1
-                    __builtin_amdgcn_raw_buffer_store_b128(pk, rso, H8_OOB + r, 0, 0);
-#else
-                    __builtin_amdgcn_raw_buffer_store_b128(pk, rso, colok ? (r * p.out_cs + nl) * 2 : H8_OOB, 0, 0);
-#endif
-                    if (gn) {       // sums of the stored (rounded) values: two fp16 products per v_dot2, fp32 accumulation
+                    const u32x4 pk = {__builtin_bit_cast(unsigned, h[0]), __builtin_bit_cast(unsigned, h[1]), __builtin_bit_cast(unsigned, h[2]), __builtin_bit_cast(unsigned, h[3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(pk, rso, obase + i * 32 * p.out_cs, 0, 0);
+                    if constexpr (GN) {       // sums of the stored (rounded) values: two fp16 products per v_dot2, fp32 accumulation
                         const h16x2 one = {(_Float16)1.f, (_Float16)1.f};
-                        const float a = __builtin_amdgcn_fdot2(h[1], one, __builtin_amdgcn_fdot2(h[0], one, 0.f, false), false);
-                        const float b = __builtin_amdgcn_fdot2(h[1], h[1], __builtin_amdgcn_fdot2(h[0], h[0], 0.f, false), false);
-                        const float a2 = __builtin_amdgcn_fdot2(h[3], one, __builtin_amdgcn_fdot2(h[2], one, 0.f, false), false);
-                        const float b2 = __builtin_amdgcn_fdot2(h[3], h[3], __builtin_amdgcn_fdot2(h[2], h[2], 0.f, false), false);
                         if (plain) {
-                            s0[0] += a; q0[0] += b; s0[1] += a2; q0[1] += b2;
+                            sA = __builtin_amdgcn_fdot2(h[1], one, __builtin_amdgcn_fdot2(h[0], one, sA, false), false);
+                            qA = __builtin_amdgcn_fdot2(h[1], h[1], __builtin_amdgcn_fdot2(h[0], h[0], qA, false), false);
+                            sB = __builtin_amdgcn_fdot2(h[3], one, __builtin_amdgcn_fdot2(h[2], one, sB, false), false);
+                            qB = __builtin_amdgcn_fdot2(h[3], h[3], __builtin_amdgcn_fdot2(h[2], h[2], qB, false), false);
                         } else {
-                            const int m = m0 + r;
-                            if (m < p.M) {
-                                if (m < m_next) { s0[0] += a; q0[0] += b; s0[1] += a2; q0[1] += b2; } else { s1[0] += a; q1[0] += b; s1[1] += a2; q1[1] += b2; }
-                            }
+                            const int m = m0 + prow0 + 16 * i;
+                            const float a = __builtin_amdgcn_fdot2(h[1], one, __builtin_amdgcn_fdot2(h[0], one, 0.f, false), false);
+                            const float b = __builtin_amdgcn_fdot2(h[1], h[1], __builtin_amdgcn_fdot2(h[0], h[0], 0.f, false), false);
+                            const float a2 = __builtin_amdgcn_fdot2(h[3], one, __builtin_amdgcn_fdot2(h[2], one, 0.f, false), false);
+                            const float b2 = __builtin_amdgcn_fdot2(h[3], h[3], __builtin_amdgcn_fdot2(h[2], h[2], 0.f, false), false);
+                            const bool in0 = m < p.M && m < m_next, in1 = m < p.M && m >= m_next;
+                            sA += in0 ? a : 0.f; qA += in0 ? b : 0.f; sB += in0 ? a2 : 0.f; qB += in0 ? b2 : 0.f;
+                            sA1 += in1 ? a : 0.f; qA1 += in1 ? b : 0.f; sB1 += in1 ? a2 : 0.f; qB1 += in1 ? b2 : 0.f;
                         }
                     }
                 }
-                if (gn && colok) {
+                if constexpr (GN) {
                     // the 16 lanes fr = 0..15 of a DPP row hold the same channels: four row_shr adds leave the row's sum in lane fr = 15;
                     // fp32 inside a wave (at most 256 values per sum), fp64 from there on
                     const int n = n0 + nl;
-                    const int grp0 = n / p.gn_cpg, grp1 = (n + 4) / p.gn_cpg;
-                    float d[8] = {s0[0], q0[0], s1[0], q1[0], s0[1], q0[1], s1[1], q1[1]};
-                    if (grp0 == grp1) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) d[e] += d[4 + e];
+                    const int grp0 = (int)h8_div((unsigned)n, p.dv_m[4], p.dv_s[4]), grp1 = (int)h8_div((unsigned)(n + 4), p.dv_m[4], p.dv_s[4]);   // / channels per group
+                    auto row_sum = [](float x) __attribute__((always_inline)) {
+                        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xf, 0xf, true));
+                        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x112, 0xf, 0xf, true));
+                        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x114, 0xf, 0xf, true));
+                        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x118, 0xf, 0xf, true));
+                        return x;
+                    };
+                    auto lds_add = [&](unsigned slot, float x) __attribute__((always_inline)) {
+                        const double dx = (double)x;
+                        asm volatile("ds_add_f64 %0, %1" :: "v"(gacc_b + slot * 8), "v"(dx) : "memory");
+                    };
+                    const bool one_group = grp0 == grp1;
+                    if (one_group) { sA += sB; qA += qB; sA1 += sB1; qA1 += qB1; }
+                    sA = row_sum(sA); qA = row_sum(qA);
+                    if (!one_group) { sB = row_sum(sB); qB = row_sum(qB); }
+                    if (!plain) {
+                        sA1 = row_sum(sA1); qA1 = row_sum(qA1);
+                        if (!one_group) { sB1 = row_sum(sB1); qB1 = row_sum(qB1); }
                     }
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        d[e] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d[e]), 0x111, 0xf, 0xf, true));
-                        d[e] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d[e]), 0x112, 0xf, 0xf, true));
-                        d[e] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d[e]), 0x114, 0xf, 0xf, true));
-                        d[e] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d[e]), 0x118, 0xf, 0xf, true));
-                    }
-                    if (fr_e == 15) {
-                        atomicAdd(&gacc[grp0 * 2], (double)d[0]); atomicAdd(&gacc[grp0 * 2 + 1], (double)d[1]);
-                        if (d[2] != 0.f || d[3] != 0.f) { atomicAdd(&gacc[64 + grp0 * 2], (double)d[2]); atomicAdd(&gacc[64 + grp0 * 2 + 1], (double)d[3]); }
-                        if (grp0 != grp1) {
-                            atomicAdd(&gacc[grp1 * 2], (double)d[4]); atomicAdd(&gacc[grp1 * 2 + 1], (double)d[5]);
-                            if (d[6] != 0.f || d[7] != 0.f) { atomicAdd(&gacc[64 + grp1 * 2], (double)d[6]); atomicAdd(&gacc[64 + grp1 * 2 + 1], (double)d[7]); }
+#if !(defined(H8_EXP) && H8_EXP == 3)
+                    if (fr_e == 15 && colok) {
+                        lds_add(grp0 * 2, sA); lds_add(grp0 * 2 + 1, qA);
+                        if (!one_group) { lds_add(grp1 * 2, sB); lds_add(grp1 * 2 + 1, qB); }
+                        if (!plain) {
+                            lds_add(64 + grp0 * 2, sA1); lds_add(64 + grp0 * 2 + 1, qA1);
+                            if (!one_group) { lds_add(64 + grp1 * 2, sB1); lds_add(64 + grp1 * 2 + 1, qB1); }
                         }
                     }
+#endif
                 }
             }
-            if (gn) {
+            if constexpr (GN) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 if (t < 128) {
-                    const double v = gacc[t];
+                    double v;
+                    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(gacc_b + t * 8) : "memory");
                     const int b = b0 + (t >> 6);
                     if (v != 0.0 && b < p.B) atomicAdd(&p.gn_sum[(((long)g * p.B + b) * p.gn_groups) * 2 + (t & 63)], v);
                 }
@@ -456,7 +470,7 @@ static void h8_magic(unsigned d, unsigned& m, unsigned& s) {
 // views below 2 GiB, 16-byte epilogue accesses, no second input, and enough tiles to fill the chip.
 // returns 0 = launched, 1 = not covered (the caller runs conv_igemm.hip), -1 = error
 int launch_conv_h8(ConvP p, int G, hipStream_t st) {
-    if (!tune().h8 || p.es != 2 || p.in2 || p.prelu || p.skip_rows) return 1;
+    if (!tune().h8 || p.es != 2 || p.in2 || p.prelu || p.skip_rows || !p.scale) return 1;     // (layers without an affine keep conv_igemm.hip: none of them is wide)
     // (ConvP of the fp16 path: Cin / in_cs / K / Kpad / in_gs / w_gs are in 4-byte units)
     if (p.Cin % 32 || p.K != p.Kpad || p.Kpad / 32 < 3) return 1;
     const bool k3 = p.kh == 3 && p.kw == 3 && p.kmode == 1;
@@ -483,6 +497,7 @@ int launch_conv_h8(ConvP p, int G, hipStream_t st) {
     h8_magic((unsigned)p.OW, p.dv_m[1], p.dv_s[1]);
     h8_magic((unsigned)p.pk_tpg, p.dv_m[2], p.dv_s[2]);
     h8_magic((unsigned)p.ntiles, p.dv_m[3], p.dv_s[3]);
+    h8_magic((unsigned)(p.gn_sum && p.gn_cpg > 0 ? p.gn_cpg : 1), p.dv_m[4], p.dv_s[4]);
     p.h8_ss_bytes = ((G - 1) * p.ss_gs + p.Cout) * 4;
     // GroupNorm sums in the epilogue: whole 4-channel halves inside one norm group, at most 32 groups, images of at least one
     // tile of rows (a tile then meets at most two images); otherwise a separate pass over the output
@@ -502,8 +517,18 @@ int launch_conv_h8(ConvP p, int G, hipStream_t st) {
         const double conv_flops = 2.0 * G * (double)p.M * p.K * p.Cout * 2.0;
         ProfScope prof(p.tag ? p.tag : "conv_gemm_h8", conv_bytes, conv_flops, st);
         const int blocks = (int)std::min<long>(tiles, cus);        // one block per CU (128 KB of LDS), each walks its share of the tiles
-        if (k3) hipLaunchKernelGGL((conv_h8_kernel<8, true>), dim3(blocks), dim3(512), 0, st, p);
-        else hipLaunchKernelGGL((conv_h8_kernel<8, false>), dim3(blocks), dim3(512), 0, st, p);
+        const dim3 grid(blocks), block(512);
+        const int variant = (k3 ? 4 : 0) | (p.res ? 2 : 0) | (p.gn_sum ? 1 : 0);
+        switch (variant) {
+            case 0: hipLaunchKernelGGL((conv_h8_kernel<8, false, false, false>), grid, block, 0, st, p); break;
+            case 1: hipLaunchKernelGGL((conv_h8_kernel<8, false, false, true>), grid, block, 0, st, p); break;
+            case 2: hipLaunchKernelGGL((conv_h8_kernel<8, false, true, false>), grid, block, 0, st, p); break;
+            case 3: hipLaunchKernelGGL((conv_h8_kernel<8, false, true, true>), grid, block, 0, st, p); break;
+            case 4: hipLaunchKernelGGL((conv_h8_kernel<8, true, false, false>), grid, block, 0, st, p); break;
+            case 5: hipLaunchKernelGGL((conv_h8_kernel<8, true, false, true>), grid, block, 0, st, p); break;
+            case 6: hipLaunchKernelGGL((conv_h8_kernel<8, true, true, false>), grid, block, 0, st, p); break;
+            default: hipLaunchKernelGGL((conv_h8_kernel<8, true, true, true>), grid, block, 0, st, p); break;
+        }
     }
     QB_CHECK(hipGetLastError());
     if (gn_sep) {

@@ -46,8 +46,8 @@ CASES = [
     (3, 40, 52, 128, 256, 3, 1, 2, 2, 1, True, False, False, 32, 1),     # dilated; GroupNorm sums, tiles across image boundaries
     (2, 33, 47, 128, 512, 1, 1, 0, 1, 0, True, True, True, 0, 1),        # 1x1 + residual + ReLU (bottleneck conv3)
     (2, 48, 64, 256, 256, 1, 2, 0, 1, 0, True, False, True, 0, 1),       # strided 1x1 (first block of a stage)
-    (1, 36, 44, 64, 320, 3, 1, 1, 1, 1, False, False, False, 0, 1),      # ragged channel tile, no affine
-    (2, 32, 40, 128, 128, 3, 1, 1, 1, 1, False, False, False, 32, 2),    # 128 channels (key 31 = 2): 4 channels per norm group
+    (1, 36, 44, 64, 320, 3, 1, 1, 1, 1, True, False, False, 0, 1),       # ragged channel tile
+    (2, 32, 40, 128, 128, 3, 1, 1, 1, 1, True, False, False, 32, 2),     # 128 channels (key 31 = 2): 4 channels per norm group
     (1, 64, 64, 512, 512, 3, 1, 4, 4, 1, True, False, True, 0, 1),       # res5-like: K = 4608
     (1, 20, 24, 2048, 256, 1, 1, 0, 1, 0, True, False, True, 32, 1),     # long 1x1 (ASPP convs.0 / fusion_res5-like)
 ]
