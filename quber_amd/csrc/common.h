@@ -161,6 +161,8 @@ struct Tuning {
     int fuse_shortcut = 1;       // key 18 (plan): conv3 + projection shortcut of a bottleneck as one dual-input GEMM
     int lanes = 1;               // key 24 (launch): side lanes for batches <= 2 (0 = everything on the caller's stream)
     int h8 = 1;                  // key 31 (launch): fp16 data path: 256 x 256 tiles with the LDS-DMA pipeline for the wide layers (conv_h8.hip); 0 = conv_igemm.hip everywhere
+    int f8 = 1;                  // key 33 (launch): exact fp32: the wide 1x1 layers and the Winograd position GEMMs on 256 x 128 tiles with the LDS-DMA pipeline (conv_f8.hip); 0 = conv_igemm.hip / conv_persist.hip everywhere
+    int f8_min_rounds = 3;       // key 34 (launch): fewest rounds of tiles (tiles / CUs) of a launch that takes it
     int h8_min_tiles = 224;      // key 32 (launch): fewest tiles (all groups) of a launch that takes it (one block per CU: a launch of fewer tiles leaves CUs idle)
 };
 extern Tuning g_tune;
@@ -181,6 +183,7 @@ bool conv_persistent_ok(const ConvP& p);
 int conv_persistent_segments(int T, int P, int nk, int min_slices, int bid, int* out4, int cap);
 int conv_persistent_fixup(int T, int P, int nk, int min_slices, int xcd, int j, int* tile, int* slots, int cap);
 int launch_conv_dual(ConvP p, int G, hipStream_t st);   // 0 done, 1 not covered (run the two convolutions), -1 error
+int launch_conv_f8(ConvP p, int G, hipStream_t st);     // exact fp32 1x1 / grouped GEMM, 256 x 128 tiles (conv_f8.hip): 0 done, 1 not covered, -1 error
 int launch_conv_h8(ConvP p, int G, hipStream_t st);     // fp16 data path, 256 x 256 tiles (conv_h8.hip): 0 done, 1 not covered, -1 error
 #ifdef PK_STAMPS
 int pk_read_stamps(unsigned long long* dst, int n);

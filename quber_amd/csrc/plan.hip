@@ -56,6 +56,8 @@ static int* tuning_field(Tuning& t, int key) {
         case 30: return &t.lean_loader;
         case 31: return &t.h8;
         case 32: return &t.h8_min_tiles;
+        case 33: return &t.f8;
+        case 34: return &t.f8_min_rounds;
         default: return nullptr;
     }
 }
