@@ -161,7 +161,9 @@ struct Tuning {
     int fuse_shortcut = 1;       // key 18 (plan): conv3 + projection shortcut of a bottleneck as one dual-input GEMM
     int lanes = 1;               // key 24 (launch): side lanes for batches <= 2 (0 = everything on the caller's stream)
     int h8 = 1;                  // key 31 (launch): fp16 data path: 256 x 256 tiles with the LDS-DMA pipeline for the wide layers (conv_h8.hip); 0 = conv_igemm.hip everywhere
-    int f8 = 1;                  // key 33 (launch): exact fp32: the wide 1x1 layers and the Winograd position GEMMs on 256 x 128 tiles with the LDS-DMA pipeline (conv_f8.hip); 0 = conv_igemm.hip / conv_persist.hip everywhere
+    int f8 = 0;                  // key 33 (launch): exact fp32: wide 1x1 launches and Winograd position GEMMs on 256 x 128 tiles with the LDS-DMA pipeline (conv_f8.hip), bit-identical to
+                                 //   conv_igemm.hip.  OFF by default: the persistent kernels already sit at the clock-limited bound - in the network it measured 33.08 against 32.94 ms per step
+                                 //   (profiles/r11_f8.md); 1 = where its tile count fits, 2 = every covered launch (tests)
     int f8_min_rounds = 3;       // key 34 (launch): fewest rounds of tiles (tiles / CUs) of a launch that takes it
     int h8_min_tiles = 224;      // key 32 (launch): fewest tiles (all groups) of a launch that takes it (one block per CU: a launch of fewer tiles leaves CUs idle)
 };

@@ -374,7 +374,10 @@ int launch_conv_f8(ConvP p, int G, hipStream_t st) {
     }
     // rounds of tiles: at least f8_min_rounds, and the ragged last round at least 3/4 full unless there are many rounds
     const long rounds = (tiles + cus - 1) / cus;
-    if (tune().f8 < 2) {         // (key 33 = 2: every covered launch, whatever its tile count - the tests)
+    if (tune().f8 < 2) {         // (key 33 = 2: every covered launch, whatever its shape and tile count - the tests)
+        // short K (the HBM-bound residual 1x1 layers live on conv_igemm.hip's 64 x 64 tiles, 7 blocks per CU) and narrow outputs
+        // (half a tile of zero rows) are not for this kernel: measured slower in the network (profiles/r11_f8.md)
+        if (p.Kpad / 32 < 8 || p.Cout < F8_BN) return 1;
         if (tiles < (long)tune().f8_min_rounds * cus) return 1;
         if (rounds < 8 && tiles % cus != 0 && tiles % cus < (3 * cus) / 4) return 1;
     }
