@@ -347,6 +347,8 @@ def main():
         e = engine.Engine(qc, dev)
         for kv in filter(None, a.tuning.split(",")):      # before the plan is built: some options act at plan time
             k, v = kv.split("=")
+            if int(k) in (2, 11, 12, 26):     # keys of the stand-alone test ops: process-wide, no engine reads them
+                raise SystemExit(f"--tuning {k}={v}: key {k} belongs to the quber_op_* test harness (quber_set_tuning), not to an engine")
             e.set_option(int(k), int(v))
         e.load_state_dict(sd)
         return e
@@ -483,7 +485,11 @@ def main():
                  "elapsed_ms_per_step": elapsed / a.steps * 1e3,
                  "gather_ms_per_step": gather_host_s[0] / a.steps * 1e3 if dist is not None else 0.0,
                  "gather_alone_ms": gather_alone_ms,
-                 "instances_out": int(cnt_host.sum()), "frames": int(B), "cpus": cpu_share, "hipgraph": graph is not None}
+                 "instances_out": int(cnt_host.sum()), "frames": int(B), "cpus": cpu_share, "hipgraph": graph is not None,
+                 # what a first contact with an 8-GPU node needs to explain itself: the collective library, the visible devices
+                 "rccl_version": _rccl_version(torch), "hip_visible_devices": os.environ.get("HIP_VISIBLE_DEVICES"),
+                 "rocr_visible_devices": os.environ.get("ROCR_VISIBLE_DEVICES"), "local_rank": os.environ.get("LOCAL_RANK"),
+                 "hip_runtime": getattr(torch.version, "hip", None)}
     ranks = [rank_info]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
@@ -723,6 +729,15 @@ def host_io_run(a, eng, host, offsets, logits, post, max_inst, dev):
                     "double-buffered copy streams; single GPU"}
 
 
+def _rccl_version(torch):
+    """RCCL's version as torch reports it (backend "nccl" IS RCCL on ROCm), or the reason it cannot."""
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception as e:      # noqa: BLE001 - a diagnostic field must never fail the benchmark
+        return f"unavailable ({type(e).__name__})"
+
+
 def report(a, eng, world, elapsed, ranks, center_bias, sd, host, step_ms, t, gpu_step):
     import torch
     B, H, W, N = a.batch, a.height, a.width, a.instances
@@ -798,6 +813,9 @@ def report(a, eng, world, elapsed, ranks, center_bias, sd, host, step_ms, t, gpu
                     "gather costs the step loop); alone = one synchronous gather with nothing beside it (what it would cost "
                     "un-overlapped); per-rank values and step medians in rccl_ranks"},
         "roofline": {"bound": "mfma", "achieved": ex_tf, "peak": peak, "unit": "TFLOP/s", "frac": ex_tf / peak,
+                     # SURVEY 8(d)'s definition beside the conservative one above: the ALGORITHMIC FLOPs of the direct convolutions
+                     # (2 x MAC) over the same time and peak - above `frac`, and possibly above 1, exactly by what Winograd does not multiply
+                     "frac_algorithmic": (algorithmic / (fam_ms * 1e-3) / 1e12 / peak) if fam_ms else None,
                      "traffic": traffic, "traffic_note": traffic_note,
                      "kernel": "conv_igemm (all instantiations).  achieved = FLOPs the matrix pipe EXECUTES per step (2*M*K*N of "
                                "every GEMM launch; the Winograd layers' transformed GEMMs count what they multiply, not the direct "

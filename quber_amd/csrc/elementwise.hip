@@ -154,7 +154,8 @@ int launch_maxpool3x3s2(const View& in, const View& out, int B, int G, hipStream
     ProfScope prof("maxpool", (double)in.es * G * B * in.C * ((double)in.H * in.W + (double)out.H * out.W), 0.0, st);
     if (in.es != out.es) return fail("maxpool: mixed element types");
     if (in.es == 2) {
-        const bool wide = in.C % 8 == 0 && in.cs % 8 == 0 && out.cs % 8 == 0 && (in.gs & 7) == 0 && (out.gs & 7) == 0;
+        const bool wide = in.C % 8 == 0 && in.cs % 8 == 0 && out.cs % 8 == 0 && (in.gs & 7) == 0 && (out.gs & 7) == 0 &&
+                          (((uintptr_t)in.p | (uintptr_t)out.p) & 15) == 0;      // 16-byte accesses: a channel-slice view may start 8 bytes in
         const int V = wide ? 8 : 4, CV = in.C / V;
         const dim3 grid((out.W * CV + 255) / 256, out.H, G * B);
         if (wide)
@@ -422,7 +423,7 @@ int launch_bilinear(const View& in, const View& out, int B, hipStream_t st) {
     if (in.es != out.es) return fail("bilinear: mixed element types");
     const float sy = (float)in.H / (float)out.H, sx = (float)in.W / (float)out.W;
     if (in.es == 2) {
-        const bool wide = in.C % 8 == 0 && in.cs % 8 == 0 && out.cs % 8 == 0;
+        const bool wide = in.C % 8 == 0 && in.cs % 8 == 0 && out.cs % 8 == 0 && (((uintptr_t)in.p | (uintptr_t)out.p) & 15) == 0;
         const int V = wide ? 8 : 4, CV = in.C / V;
         const dim3 grid((out.W * CV + 255) / 256, out.H, B);
         if (wide)

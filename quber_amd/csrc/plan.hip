@@ -693,7 +693,10 @@ struct Builder {
         // fp32 tensors (exact fp32 and bf16x3 modes): a3 runs inside the first convolution's kernel - the normalised 8-channel input
         // (315 MB per 16-frame step) is neither written nor read back (option key 29)
         // fp16 tensors: the same kernel on the fp16-rounded operands (no 16-channel fp16 input tensor, no zero channels multiplied)
-        const bool stem_one = tune().stem_fused != 0;
+        // (the fused kernel is exact fp32 arithmetic with one fold per K-slice - what the implicit GEMM does in the exact and bf16x3 modes and,
+        //  on the fp16-rounded operands, in the fp16 data path; bf16 / fp16 OPERANDS on fp32 tensors - compute_dtype 1, or 2 without the
+        //  fp16 tensors - keep the preprocess kernel + implicit GEMM, so that option 29 never changes a mode's arithmetic)
+        const bool stem_one = tune().stem_fused != 0 && !(aes == 4 && (cf.compute_dtype == 1 || cf.compute_dtype == 2));
         View s1 = make(32, h2, w2, NS), s2 = make(32, h2, w2, NS), s3 = make(64, h2, w2, NS);
         if (stem_one) {
             emit_stem_fused(two("stem.conv1", false), s1);

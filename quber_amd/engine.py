@@ -101,6 +101,7 @@ def resize_u8(img, dh, dw, linear=True):
 
 
 _INPAINT_WS = {}
+_INPAINT_WS_MAX = 32       # ~22 MB each at 640x480
 
 
 def inpaint_depth(depth3, kernel_size=3):
@@ -118,6 +119,9 @@ def inpaint_depth(depth3, kernel_size=3):
     ws = _INPAINT_WS.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=depth3.device)
+        _INPAINT_WS.pop(key, None)
+        while len(_INPAINT_WS) >= _INPAINT_WS_MAX:          # worker threads and side streams come and go (predict_stream): oldest first
+            _INPAINT_WS.pop(next(iter(_INPAINT_WS)))
         _INPAINT_WS[key] = ws
     out = torch.empty_like(depth3)
     _lib.check(lib.quber_inpaint_depth_device(_ptr(depth3), B, H, W, int(kernel_size), _ptr(ws), ws.numel(), _ptr(out), _stream()))

@@ -60,6 +60,7 @@ class RefinerModel:
         self.state_dict = state_dict
         self.device = torch.device(device)
         self._engines = {}
+        self._retired = {}        # (H, W) -> the engine a larger one replaced last; see engine_for
         self._staging = {}
         self.training = False
 
@@ -73,7 +74,12 @@ class RefinerModel:
             # grow, never shrink: alternating workloads must not trigger repeated multi-GB rebuilds
             if eng is not None:
                 batch, n_masks = max(batch, eng.qcfg.max_batch), max(n_masks, eng.qcfg.max_instances)
-                eng.close()
+                # not closed here: a batch enqueued on it may still be waiting for collect_batch (predict_stream keeps one batch in
+                # flight); the replaced engine is closed when the NEXT replacement of this size happens or with the model
+                old = self._retired.pop(key, None)
+                if old is not None:
+                    old.close()
+                self._retired[key] = eng
             qc = qengine.make_config(h, w, max_batch=max(batch, 1), max_instances=max(64, n_masks), cfg=self.cfg)
             eng = qengine.Engine(qc, self.device)
             eng.load_state_dict(self.state_dict)
