@@ -16,6 +16,10 @@
 //     loop never drains the queue, and its barriers are raw s_barrier (a __syncthreads() would wait for vmcnt(0));
 //   * four phases per K-tile, each {fragment reads + one half-tile of DMA | barrier | 16 MFMAs | barrier}; the two waves of a
 //     SIMD run half a phase apart (waves 4-7 pass one extra barrier up front), so one multiplies while the other reads;
+//   * persistent: a block walks its share of the tiles and the DMA pipeline runs across the tile boundaries (the next tile's
+//     first K-tiles are in flight under the epilogue); the epilogue's LDS traffic (affine vectors filled by DMA a tile ahead,
+//     GroupNorm sums) is written as asm ds_ instructions: before a plain access to LDS that a DMA may have written hipcc
+//     waits for the whole vector-memory queue, stores included;
 //   * LDS rows are 128 bytes with the 16-byte chunks XOR-swizzled (on the DMA source side: the LDS image of a DMA is
 //     lane-linear) so that every 16-lane group of a ds_read_b128 covers all 64 banks once;
 //   * v_mfma_f32_16x16x32_f16 with the WEIGHTS as the row operand: a lane's four accumulator values are four consecutive
@@ -225,6 +229,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __builtin_amdgcn_s_barrier();
     int gk = 0;                           // K-tiles consumed so far: K-tile gk lives in image gk & 1
 
+// (the s_setprio pair keeps hipcc from moving the MFMAs across the barriers: without it the layers run 11-14 % slower; the fragment
+//  reads are waited for by the compiler's own counted lgkmcnt ladders in front of the MFMAs that need them: +1-2 % over one lgkmcnt(0))
+#define H8_PRIO(x) __builtin_amdgcn_s_setprio(x)
 #define H8_READ_Q(JH, KS)                                                                                              \
     _Pragma("unroll") for (int c4 = 0; c4 < 4; ++c4) {                                                                  \
         const int c = 4 * (JH) + c4;                                                                                    \
@@ -232,12 +239,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 #define H8_MMA(JH, KS)                                                                                                 \
     __builtin_amdgcn_s_barrier();                                                                                       \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                  \
-    __builtin_amdgcn_s_setprio(1);                                                                                      \
+    H8_PRIO(1);                                                                                                         \
     _Pragma("unroll") for (int c4 = 0; c4 < 4; ++c4)                                                                    \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                   \
             acc[4 * (JH) + c4][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[c4], pf[KS][i], acc[4 * (JH) + c4][i], 0, 0, 0); \
-    __builtin_amdgcn_s_setprio(0);                                                                                      \
+    H8_PRIO(0);                                                                                                         \
     __builtin_amdgcn_s_barrier();
 
 #ifdef H8_STAMPS
@@ -265,20 +271,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (kt == 4) H8_STAMP(4);
             if (kt == nk - 4) H8_STAMP(5);
 #endif
-            // phase 0: every pixel fragment of the K-tile + channel tiles 0-3, k-step 0; DMA: channel half 0 of K-tile kt + 1
+            // phase 0: the pixel fragments of k-step 0 + channel tiles 0-3, k-step 0; DMA: channel half 0 of K-tile kt + 1
             H8_READ_Q(0, 0)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) pf[ks][i] = *reinterpret_cast<const h16x8*>(smem + sbase + paddr[ks] + i * 16 * H8_KB);
+            for (int i = 0; i < 4; ++i) pf[0][i] = *reinterpret_cast<const h16x8*>(smem + sbase + paddr[0] + i * 16 * H8_KB);
             issue_q(0, s ^ 1, kt + 1);
             H8_MMA(0, 0)
-            // phase 1: channel tiles 4-7, k-step 0; DMA: channel half 1 of K-tile kt + 1
+            // phase 1: the pixel fragments of k-step 1, channel tiles 4-7, k-step 0; DMA: channel half 1 of K-tile kt + 1.  The pixel reads
+            // are issued first and retired BEFORE the phase's first barrier (LDS returns in order): from phase 2 on the pixel rows of this
+            // image may be refilled
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pf[1][i] = *reinterpret_cast<const h16x8*>(smem + sbase + paddr[1] + i * 16 * H8_KB);
+            __builtin_amdgcn_sched_barrier(0);
             H8_READ_Q(1, 0)
             issue_q(1, s ^ 1, kt + 1);
+            asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
             H8_MMA(1, 0)
-            // phase 2: channel tiles 4-7, k-step 1; DMA: pixel half 0 of K-tile kt + 2 (this image's pixel rows were read in phase 0)
+            // phase 2: channel tiles 4-7, k-step 1; DMA: pixel half 0 of K-tile kt + 2
             H8_READ_Q(1, 1)
             issue_p(0, s);
             H8_MMA(1, 1)
@@ -408,7 +418,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         sA1 = row_sum(sA1); qA1 = row_sum(qA1);
                         if (!one_group) { sB1 = row_sum(sB1); qB1 = row_sum(qB1); }
                     }
-#if !(defined(H8_EXP) && H8_EXP == 3)
                     if (fr_e == 15 && colok) {
                         lds_add(grp0 * 2, sA); lds_add(grp0 * 2 + 1, qA);
                         if (!one_group) { lds_add(grp1 * 2, sB); lds_add(grp1 * 2 + 1, qB); }
@@ -417,7 +426,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                             if (!one_group) { lds_add(64 + grp1 * 2, sB1); lds_add(64 + grp1 * 2 + 1, qB1); }
                         }
                     }
-#endif
                 }
             }
             if constexpr (GN) {
