@@ -60,6 +60,8 @@ struct ConvP {
                          // second register set every acc_chunk slices); 0 = one sequential chain over K
     int lean_in_bytes;   // LEAN loader (conv_igemm.hip): bytes of one group's input view (buffer descriptor range)
     unsigned dv_m[5], dv_s[5];   // conv_h8.hip: magic numbers of the divisions by ohw, OW, tiles per group, channel tiles, channels per norm group (h8_magic)
+    int dil_g[4];        // per-group dilation = padding of a grouped 3x3 launch (dil_g[0] == 0: `dil` / `pad` for every group); conv_h8.hip reads it, any other
+                         //   kernel gets the groups one launch at a time (launch_conv)
     int h8_ss_bytes;     // conv_h8.hip: bytes of the scale / shift vectors over all groups (descriptor range)
     int bf16;            // quber_config.compute_dtype: 0 = fp32 MFMA, 1 = bf16 / 2 = fp16 operands, 3 = fp32 operands split into 3 bf16 terms
 };

@@ -75,8 +75,10 @@ __device__ __forceinline__ unsigned h8_div(unsigned n, unsigned m, unsigned s) {
 // the LOGICAL chunk (l & 7) ^ swizzle(row).  Offsets are bytes from the first group's base (one descriptor for all groups).
 template <int BN, bool K3>
 __device__ __forceinline__ void h8_tile_state(const ConvP& p, int tile, int wave, int lane, int (&aoff)[4], unsigned (&amask)[4], int (&boff)[4],
-                                              int& m0, int& n0, int& g) {
+                                              int& m0, int& n0, int& g, int& dil) {
     g = (int)h8_div((unsigned)tile, p.dv_m[2], p.dv_s[2]);          // tile / tiles per group
+    dil = p.dil_g[0] ? p.dil_g[g & 3] : p.dil;                      // (a grouped launch of the ASPP branches: dilation = padding per group)
+    const int pad = p.dil_g[0] ? dil : p.pad;
     const int rem = tile - g * p.pk_tpg;
     const int mt = (int)h8_div((unsigned)rem, p.dv_m[3], p.dv_s[3]);   // rem / ntiles
     const int nt = rem - mt * p.ntiles;
@@ -93,13 +95,13 @@ __device__ __forceinline__ void h8_tile_state(const ConvP& p, int tile, int wave
         const int r2 = m - b * p.ohw;
         const int oy = (int)h8_div((unsigned)r2, p.dv_m[1], p.dv_s[1]);         // r2 / OW
         const int ox = r2 - oy * p.OW;
-        const int y0 = oy * p.stride - p.pad, x0 = ox * p.stride - p.pad;
+        const int y0 = oy * p.stride - pad, x0 = ox * p.stride - pad;
         aoff[i] = gin + (((b * p.H + y0) * p.W + x0) * p.in_cs) * 4 + chunk * 16;
         unsigned mk = 1;
         if constexpr (K3) {          // bit 3 ky + kx: tap (ky, kx) of this pixel lies inside the image
             const unsigned W = (unsigned)p.W, H = (unsigned)p.H;
-            const unsigned xb = ((unsigned)x0 < W ? 1u : 0u) | ((unsigned)(x0 + p.dil) < W ? 2u : 0u) | ((unsigned)(x0 + 2 * p.dil) < W ? 4u : 0u);
-            mk = ((unsigned)y0 < H ? xb : 0u) | ((unsigned)(y0 + p.dil) < H ? xb << 3 : 0u) | ((unsigned)(y0 + 2 * p.dil) < H ? xb << 6 : 0u);
+            const unsigned xb = ((unsigned)x0 < W ? 1u : 0u) | ((unsigned)(x0 + dil) < W ? 2u : 0u) | ((unsigned)(x0 + 2 * dil) < W ? 4u : 0u);
+            mk = ((unsigned)y0 < H ? xb : 0u) | ((unsigned)(y0 + dil) < H ? xb << 3 : 0u) | ((unsigned)(y0 + 2 * dil) < H ? xb << 6 : 0u);
         }
         amask[i] = m < p.M ? mk : 0u;
     }
@@ -146,8 +148,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     int aoff[4], boff[4], aoffN[4], boffN[4];
     unsigned amask[4], amaskN[4];
-    int m0, n0, g, m0N = 0, n0N = 0, gN = 0;
-    h8_tile_state<BN, K3>(p, tile, wave, lane, aoff, amask, boff, m0, n0, g);
+    int m0, n0, g, dilC, m0N = 0, n0N = 0, gN = 0, dilN = 1;
+    h8_tile_state<BN, K3>(p, tile, wave, lane, aoff, amask, boff, m0, n0, g, dilC);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { aoffN[i] = 0; amaskN[i] = 0; boffN[i] = H8_OOB; }
     const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.lean_in_bytes, 0x00020000);
@@ -159,7 +161,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto issue_p = [&](int half, int slot) __attribute__((always_inline)) {
         const bool live = !pnext || has_next;
         const int tap = live ? (K3 ? sky * 3 + skx : 0) : 31;     // past the last tile: every lane out of range (no traffic)
-        const int soff = K3 ? (((sky * p.dil) * p.W + skx * p.dil) * p.in_cs + skc) * 4 : skc * 4;
+        const int dl = pnext ? dilN : dilC;
+        const int soff = K3 ? (((sky * dl) * p.W + skx * dl) * p.in_cs + skc) * 4 : skc * 4;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int i = 2 * half + j;
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // the block's next tile: its source state is needed from the last two K-tiles of this one on
         has_next = tile + tile_step < tile_end;
         if (has_next) {
-            h8_tile_state<BN, K3>(p, tile + tile_step, wave, lane, aoffN, amaskN, boffN, m0N, n0N, gN);
+            h8_tile_state<BN, K3>(p, tile + tile_step, wave, lane, aoffN, amaskN, boffN, m0N, n0N, gN, dilN);
             issue_ss(ssb ^ 1, gN, n0N);
         }
 #pragma unroll
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         tile += tile_step;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { aoff[i] = aoffN[i]; amask[i] = amaskN[i]; boff[i] = boffN[i]; }
-        m0 = m0N; n0 = n0N; g = gN;
+        m0 = m0N; n0 = n0N; g = gN; dilC = dilN;
         pnext = false;
         ssb ^= 1;
     }

@@ -1051,6 +1051,24 @@ int launch_conv(const ConvP& p0, int G, hipStream_t st) {
         const int rc = launch_conv_h8(p, G, st);
         if (rc != 1) return rc;
     }
+    if (p0.dil_g[0]) {
+        // a grouped launch with per-group dilation that conv_h8.hip did not take: the groups one after the other, each with its own
+        for (int g = 0; g < G; ++g) {
+            ConvP q = p0;
+            const long es = p0.es == 2 ? 2 : 4;
+            q.dil = q.pad = p0.dil_g[g];
+            q.dil_g[0] = 0;
+            q.in = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p0.in) + (long)g * p0.in_gs * es);
+            q.w = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p0.w) + (long)g * p0.w_gs * es);
+            q.out = reinterpret_cast<float*>(reinterpret_cast<char*>(p0.out) + (long)g * p0.out_gs * es);
+            if (p0.res) q.res = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p0.res) + (long)g * p0.res_gs * es);
+            if (p0.scale) { q.scale = p0.scale + (long)g * p0.ss_gs; q.shift = p0.shift + (long)g * p0.ss_gs; }
+            if (p0.gn_sum) q.gn_sum = p0.gn_sum + (long)g * p0.B * p0.gn_groups * 2;
+            const int rc = launch_conv(q, 1, st);
+            if (rc) return rc;
+        }
+        return 0;
+    }
     if (p.es == 4 && tune().force_tile == 0 && tune().force_split == 0) {      // exact fp32: the wide 1x1 launches on 256 x 128 tiles, LDS-DMA pipeline (conv_f8.hip)
         const int rc = launch_conv_f8(p, G, st);
         if (rc != 1) return rc;

@@ -288,7 +288,8 @@ struct Builder {
     // [G*Cout] per-channel epilogue vectors (prelu may be empty).
     void emit_conv(const std::string& name, const std::vector<const float*>& w, const View& in, int cin_real,
                    const View& out, int k, int stride, int pad, int dil, bool affine, const std::vector<float>& scale,
-                   const std::vector<float>& shift, const std::vector<float>& prelu, const View* res, bool relu) {
+                   const std::vector<float>& shift, const std::vector<float>& prelu, const View* res, bool relu,
+                   const std::vector<int>& dil_g = {}) {
         const int G = (int)w.size();
         const int Cin = in.C, Cout = out.C;
         const int KS = aes == 2 ? 64 : 32;        // K-slice of the kernel in elements (32 four-byte units: 64 halfs in the fp16 data path)
@@ -331,8 +332,12 @@ struct Builder {
         }
         p.es = aes;
         if (in.es != aes || out.es != aes || (res && res->es != aes)) { if (err.empty()) err = "internal: element type mismatch at " + name; return; }
-        p.scale = affine ? upload(scale) : nullptr;
-        p.shift = affine ? upload(shift) : nullptr;
+        // (fp16 data path, wide layers without an affine - the ASPP branches: an identity affine, so that conv_h8.hip, whose epilogue
+        //  always reads one, takes them; fma(v, 1, 0) == v)
+        const bool ident = !affine && aes == 2 && Cout >= 256;
+        p.scale = affine ? upload(scale) : ident ? upload(std::vector<float>((size_t)G * Cout, 1.f)) : nullptr;
+        p.shift = affine ? upload(shift) : ident ? upload(std::vector<float>((size_t)G * Cout, 0.f)) : nullptr;
+        for (size_t g = 0; g < dil_g.size() && g < 4; ++g) p.dil_g[g] = dil_g[g];      // per-group dilation (= padding) of a grouped launch
         p.prelu = prelu.empty() ? nullptr : upload(prelu);
         p.res = res ? res->p : nullptr;
         p.out = out.p;
@@ -448,7 +453,7 @@ struct Builder {
 
     // refiner convolutions: `names` = one detectron2 Conv2d key prefix per group (e.g. "backbone.rgb_backbone.stem.conv1")
     void conv(const std::vector<std::string>& names, const View& in, int cin_real, const View& out, int k, int stride,
-              int pad, int dil, Affine af, const View* res, bool relu) {
+              int pad, int dil, Affine af, const View* res, bool relu, const std::vector<int>& dil_g = {}) {
         const int G = (int)names.size(), Cout = out.C;
         std::vector<float> scale((size_t)G * Cout, 1.f), shift((size_t)G * Cout, 0.f);
         std::vector<const float*> w;
@@ -478,7 +483,7 @@ struct Builder {
                 shift[(size_t)g * Cout + o] = sh;
             }
         }
-        emit_conv(names[0], w, in, cin_real, out, k, stride, pad, dil, af != AF_NONE, scale, shift, {}, res, relu);
+        emit_conv(names[0], w, in, cin_real, out, k, stride, pad, dil, af != AF_NONE, scale, shift, {}, res, relu, dil_g);
     }
 
     // Projection block of a stage: the two ops emitted last - `shortcut` (1x1, stride s, FrozenBN) and `conv3` (1x1, FrozenBN,
@@ -804,7 +809,21 @@ struct Builder {
         const int adil[3] = {6, 12, 18};
         // (the three dilated branches on lanes of their own were measured too: no gain at batch 1 - 3.92 against 3.85 ms in the
         // bf16x3 mode - so they stay on the caller's stream)
-        for (int i = 0; i < 3; ++i) conv_gn(A + "convs." + std::to_string(i + 1), F[3], tA, slice(catA, 256 * (i + 1), 256), 3, adil[i]);
+        // fp16 data path on maps large enough that no branch skips padded filter rows: the three dilated branches as ONE grouped launch
+        // (they read the same tensor; per-group dilation, ConvP::dil_g) - 3 x 128 tiles at 1024x1024 batch 8 instead of three launches
+        // that each leave half of conv_h8.hip's one-block-per-CU grid empty
+        const int aspp_oh = F[3].H;
+        const bool aspp_grouped = aes == 2 && tune().h8 && 10 * 2 * adil[2] < 2 * 3 * aspp_oh;
+        if (aspp_grouped) {
+            View tA3 = make(256, h16, w16, 3);
+            View xin = F[3];
+            xin.gs = 0;
+            const std::vector<std::string> an = {A + "convs.1", A + "convs.2", A + "convs.3"};
+            conv(an, xin, F[3].C, tA3, 3, 1, adil[2], adil[2], AF_NONE, nullptr, false, {adil[0], adil[1], adil[2]});
+            gn_relu({an[0] + ".norm", an[1] + ".norm", an[2] + ".norm"}, tA3, slice(catA, 256, 256, 256));
+        } else {
+            for (int i = 0; i < 3; ++i) conv_gn(A + "convs." + std::to_string(i + 1), F[3], tA, slice(catA, 256 * (i + 1), 256), 3, adil[i]);
+        }
         {
             View pooled = make(2048, 1, 1), pc = make(256, 1, 1);
             View f5 = F[3];

@@ -97,11 +97,13 @@ def test_h8_conv_matches_float32_convolution_and_the_128_tile_kernel(case):
         assert torch.allclose(sums0, torch.stack([yd0.sum((1, 3)), (yd0 * yd0).sum((1, 3))], -1), rtol=1e-11, atol=1e-9)
 
 
-def test_h8_takes_the_wide_layers_of_the_network():
-    """The fp16 network with the kernel on and off: same plan, logits within the fp16 path's own noise of each other."""
+@pytest.mark.parametrize("h,w,b,grouped", [(256, 320, 4, False), (1024, 1024, 1, True)], ids=["256x320x4", "1024x1024-grouped-aspp"])
+def test_h8_takes_the_wide_layers_of_the_network(h, w, b, grouped):
+    """The fp16 network with the kernel on and off: same plan, logits within the fp16 path's own noise of each other.  At 1024x1024
+    the three dilated ASPP branches (model.py:610-651, ASPP_DILATIONS 6 / 12 / 18) are ONE grouped launch with per-group dilation;
+    with the kernel off the same plan entry runs them as three launches of the 128-tile kernel."""
     from quber_amd import arch, engine, synth
     from oracle import encode_np
-    h, w, b = 256, 320, 4
     qc = engine.make_config(h, w, max_batch=b)
     qc.compute_dtype = 2
     e = engine.Engine(qc, "cuda:0")
@@ -116,11 +118,13 @@ def test_h8_takes_the_wide_layers_of_the_network():
         e.profile_begin()
         outs[mode] = e.forward(bgr, dep, off).clone()
         stages[mode] = e.profile_end()
+    names = [p_[0] for p_ in e.plan()]
     e.close()
     assert torch.isfinite(outs[1]).all()
     # the kernel is on the path: the stage profile shows its launches (fusion convolutions, res4 / res5 bottlenecks), none with key 31 = 0
     assert "conv_gemm_h8" not in stages[0] and stages[1]["conv_gemm_h8"]["launches"] >= 10
-    assert stages[1]["conv_gemm"]["launches"] + stages[1]["conv_gemm_h8"]["launches"] == stages[0]["conv_gemm"]["launches"]
+    assert sum("project_conv.convs." in n and n.endswith(("convs.1", "convs.2", "convs.3")) for n in names) == (1 if grouped else 3)
+    assert stages[1]["conv_gemm"]["launches"] + stages[1]["conv_gemm_h8"]["launches"] == stages[0]["conv_gemm"]["launches"] - (2 if grouped else 0)
     d = (outs[0] - outs[1]).abs()
     scale = max(1.0, float(outs[0].abs().max()))
     assert float(d.max()) < 2e-2 * scale, float(d.max())
