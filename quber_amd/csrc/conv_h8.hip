@@ -73,9 +73,9 @@ __device__ __forceinline__ unsigned h8_div(unsigned n, unsigned m, unsigned s) {
 // per-tile DMA source state of a thread: 4 pixel rows and 4 channel rows
 // piece u (8 rows x 128 B) of a half-tile goes to wave u / 2; lane l fills row l >> 3, physical chunk l & 7 of it and fetches
 // the LOGICAL chunk (l & 7) ^ swizzle(row).  Offsets are bytes from the first group's base (one descriptor for all groups).
-template <int BN, bool K3>
+template <int BN, bool K3, bool DUAL>
 __device__ __forceinline__ void h8_tile_state(const ConvP& p, int tile, int wave, int lane, int (&aoff)[4], unsigned (&amask)[4], int (&boff)[4],
-                                              int& m0, int& n0, int& g, int& dil) {
+                                              int (&aoff2)[4], int& m0, int& n0, int& g, int& dil) {
     g = (int)h8_div((unsigned)tile, p.dv_m[2], p.dv_s[2]);          // tile / tiles per group
     dil = p.dil_g[0] ? p.dil_g[g & 3] : p.dil;                      // (a grouped launch of the ASPP branches: dilation = padding per group)
     const int pad = p.dil_g[0] ? dil : p.pad;
@@ -97,6 +97,8 @@ __device__ __forceinline__ void h8_tile_state(const ConvP& p, int tile, int wave
         const int ox = r2 - oy * p.OW;
         const int y0 = oy * p.stride - pad, x0 = ox * p.stride - pad;
         aoff[i] = gin + (((b * p.H + y0) * p.W + x0) * p.in_cs) * 4 + chunk * 16;
+        // second input of a dual launch (bottleneck conv3 + projection shortcut as one GEMM): pixel (oy, ox) * stride2 of a [B][H2][W2] tensor
+        aoff2[i] = DUAL ? g * (int)p.in2_gs * 4 + (((b * p.H2 + oy * p.stride2) * p.W2 + ox * p.stride2) * p.in2_cs) * 4 + chunk * 16 : 0;
         unsigned mk = 1;
         if constexpr (K3) {          // bit 3 ky + kx: tap (ky, kx) of this pixel lies inside the image
             const unsigned W = (unsigned)p.W, H = (unsigned)p.H;
@@ -119,7 +121,7 @@ __device__ __forceinline__ void h8_tile_state(const ConvP& p, int tile, int wave
 // on their way, and its epilogue (stores, GroupNorm sums) runs under those loads.  With one tile per block launch the epilogue
 // stores and the next prologue's cold loads of all 256 CUs fell into the same moments: 54 k of a 36-K-tile layer's 149 k cycles
 // per tile (profiles/r11_h8_kernel.md).
-template <int QT, bool K3, bool RES, bool GN>
+template <int QT, bool K3, bool RES, bool GN, bool DUAL = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_h8_kernel(const ConvP p) {
     using G = H8Geo<QT>;
     constexpr int BN = G::BN, SLOT = G::SLOT;
@@ -146,14 +148,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         tile = start + (bid >> 3);
     }
 
-    int aoff[4], boff[4], aoffN[4], boffN[4];
+    static_assert(!DUAL || (!K3 && !RES && !GN), "the dual-input form is the 1x1 conv3 + shortcut GEMM");
+    int aoff[4], boff[4], aoffN[4], boffN[4], aoff2[4], aoff2N[4];
     unsigned amask[4], amaskN[4];
     int m0, n0, g, dilC, m0N = 0, n0N = 0, gN = 0, dilN = 1;
-    h8_tile_state<BN, K3>(p, tile, wave, lane, aoff, amask, boff, m0, n0, g, dilC);
+    h8_tile_state<BN, K3, DUAL>(p, tile, wave, lane, aoff, amask, boff, aoff2, m0, n0, g, dilC);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { aoffN[i] = 0; amaskN[i] = 0; boffN[i] = H8_OOB; }
+    for (int i = 0; i < 4; ++i) { aoffN[i] = 0; amaskN[i] = 0; boffN[i] = H8_OOB; aoff2N[i] = 0; }
     const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.lean_in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.pk_in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsa2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DUAL ? p.in2 : p.in), 0, DUAL ? p.pk_in2_bytes : 0, 0x00020000);
+    const int nk1 = DUAL ? p.K1 / 32 : nk;        // dual launch: K-tiles [0, nk1) come from `in`, [nk1, nk) from `in2`
 
     // block-uniform position of the next pixel K-tile to issue: K-tile sk of (pnext ? the next : this) tile, tap (ky, kx), channel block
     int sk = 0, skc = 0, skx = 0, sky = 0;
@@ -163,14 +168,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int tap = live ? (K3 ? sky * 3 + skx : 0) : 31;     // past the last tile: every lane out of range (no traffic)
         const int dl = pnext ? dilN : dilC;
         const int soff = K3 ? (((sky * dl) * p.W + skx * dl) * p.in_cs + skc) * 4 : skc * 4;
+        const bool second = DUAL && sk >= nk1;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int i = 2 * half + j;
             const unsigned mk = pnext ? amaskN[i] : amask[i];
-            const int ao = pnext ? aoffN[i] : aoff[i];
             const bool ok = (mk >> tap) & 1u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr_t)(smem + slot * SLOT + half * H8_HALF + (2 * wave + j) * 1024), 16,
-                                                     ok ? ao + soff : H8_OOB, 0, 0, 0);
+            if (second) {
+                const int ao = pnext ? aoff2N[i] : aoff2[i];
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa2, (lds_ptr_t)(smem + slot * SLOT + half * H8_HALF + (2 * wave + j) * 1024), 16,
+                                                         ok ? ao + (sk - nk1) * H8_KB : H8_OOB, 0, 0, 0);
+            } else {
+                const int ao = pnext ? aoffN[i] : aoff[i];
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr_t)(smem + slot * SLOT + half * H8_HALF + (2 * wave + j) * 1024), 16,
+                                                         ok ? ao + soff : H8_OOB, 0, 0, 0);
+            }
         }
     };
     auto advance_p = [&]() __attribute__((always_inline)) {
@@ -257,7 +269,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // the block's next tile: its source state is needed from the last two K-tiles of this one on
         has_next = tile + tile_step < tile_end;
         if (has_next) {
-            h8_tile_state<BN, K3>(p, tile + tile_step, wave, lane, aoffN, amaskN, boffN, m0N, n0N, gN, dilN);
+            h8_tile_state<BN, K3, DUAL>(p, tile + tile_step, wave, lane, aoffN, amaskN, boffN, aoff2N, m0N, n0N, gN, dilN);
             issue_ss(ssb ^ 1, gN, n0N);
         }
 #pragma unroll
@@ -450,7 +462,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // the next tile becomes this one; its K-tiles 0 and 1 are already issued (sk == 2)
         tile += tile_step;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { aoff[i] = aoffN[i]; amask[i] = amaskN[i]; boff[i] = boffN[i]; }
+        for (int i = 0; i < 4; ++i) { aoff[i] = aoffN[i]; amask[i] = amaskN[i]; boff[i] = boffN[i]; aoff2[i] = aoff2N[i]; }
         m0 = m0N; n0 = n0N; g = gN; dilC = dilN;
         pnext = false;
         ssb ^= 1;
@@ -481,11 +493,18 @@ static void h8_magic(unsigned d, unsigned& m, unsigned& s) {
 // views below 2 GiB, 16-byte epilogue accesses, no second input, and enough tiles to fill the chip.
 // returns 0 = launched, 1 = not covered (the caller runs conv_igemm.hip), -1 = error
 int launch_conv_h8(ConvP p, int G, hipStream_t st) {
-    if (!tune().h8 || p.es != 2 || p.in2 || p.prelu || p.skip_rows || !p.scale) return 1;     // (layers without an affine keep conv_igemm.hip: none of them is wide)
+    if (!tune().h8 || p.es != 2 || p.prelu || p.skip_rows || !p.scale) return 1;     // (layers without an affine keep conv_igemm.hip: none of them is wide)
     // (ConvP of the fp16 path: Cin / in_cs / K / Kpad / in_gs / w_gs are in 4-byte units)
     if (p.Cin % 32 || p.K != p.Kpad || p.Kpad / 32 < 3) return 1;
     const bool k3 = p.kh == 3 && p.kw == 3 && p.kmode == 1;
     if (!k3 && !(p.kh == 1 && p.kw == 1 && p.pad == 0)) return 1;
+    const bool dual = p.in2 != nullptr;       // launch_conv_dual: K = K1 channels of `in`, then the channels of `in2` sampled at stride2
+    if (dual) {
+        if (k3 || p.res || p.gn_sum || p.stride != 1 || p.K1 % 32 || p.K1 <= 0 || p.K1 >= p.Kpad || p.in2_cs % 4 || (p.in2_gs & 3) || ((uintptr_t)p.in2 & 15)) return 1;
+        const long in2_all = ((long)p.B * p.H2 * p.W2 * p.in2_cs) * 4 + (long)(G - 1) * p.in2_gs * 4;
+        if (in2_all >= 0x7fffff00L) return 1;
+        p.pk_in2_bytes = (int)in2_all;
+    }
     if (p.Cout < 256 && tune().h8 < 2) return 1;
     const long in_bytes = ((long)p.B * p.H * p.W * p.in_cs) * 4, w_bytes = (long)p.Cout * p.Kpad * 4;
     if (in_bytes >= 0x7fffff00L || w_bytes >= 0x7fffff00L) return 1;
@@ -529,8 +548,9 @@ int launch_conv_h8(ConvP p, int G, hipStream_t st) {
         ProfScope prof(p.tag ? p.tag : "conv_gemm_h8", conv_bytes, conv_flops, st);
         const int blocks = (int)std::min<long>(tiles, cus);        // one block per CU (128 KB of LDS), each walks its share of the tiles
         const dim3 grid(blocks), block(512);
-        const int variant = (k3 ? 4 : 0) | (p.res ? 2 : 0) | (p.gn_sum ? 1 : 0);
+        const int variant = dual ? 8 : (k3 ? 4 : 0) | (p.res ? 2 : 0) | (p.gn_sum ? 1 : 0);
         switch (variant) {
+            case 8: hipLaunchKernelGGL((conv_h8_kernel<8, false, false, false, true>), grid, block, 0, st, p); break;
             case 0: hipLaunchKernelGGL((conv_h8_kernel<8, false, false, false>), grid, block, 0, st, p); break;
             case 1: hipLaunchKernelGGL((conv_h8_kernel<8, false, false, true>), grid, block, 0, st, p); break;
             case 2: hipLaunchKernelGGL((conv_h8_kernel<8, false, true, false>), grid, block, 0, st, p); break;

@@ -913,6 +913,11 @@ int launch_conv_dual(ConvP p, int G, hipStream_t st) {
         if (p.bf16 != 2 || p.Cin % 8 || p.in_cs % 8 || p.in2_cs % 8 || p.Kpad % 64 || p.K1 % 64 || (p.in_gs & 7) || (p.in2_gs & 7) || (p.w_gs & 1))
             return 1;
         p.Cin /= 2; p.in_cs /= 2; p.in2_cs /= 2; p.K /= 2; p.Kpad /= 2; p.K1 /= 2; p.in_gs /= 2; p.in2_gs /= 2; p.w_gs /= 2;
+        if (p.kh == 1 && p.kw == 1 && p.pad == 0 && p.stride == 1 && !p.kmode && p.K == p.Kpad) {      // 256 x 256 tiles, LDS-DMA pipeline (conv_h8.hip)
+            p.ohw = p.OH * p.OW;
+            const int rc = launch_conv_h8(p, G, st);
+            if (rc != 1) return rc;
+        }
     } else {
         p.es = 4;
     }
