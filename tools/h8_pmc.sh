@@ -13,4 +13,4 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_A
   python3 $R/tools/kernel_pmc.py $O/${TAG}_pmc$i/p_counter_collection.csv "$FLT" >> $O/${TAG}_pmc.txt 2>&1
   rm -rf $O/${TAG}_pmc$i
 done
-cat $O/${TAG}_pmc.txt
+cat $O/${TAG}_pmc.txt > /dev/null
