@@ -282,7 +282,7 @@ double quber_forward_flops_padding(quber_ctx* ctx);
  *         V | M intermediates in HBM (csrc/wino_fused.hip): the eligible layers, or never (0);
  * key 27 (160; plan, ARITHMETIC) widest input, in channels, that takes the single-kernel form.  Its two accumulation chains are
  *         Cin / 2 long - 80 channels at the default, with which the float64-anchor ratios stay 0.64-1.11; admitting 256 / 320
- *         channels (chains of 128-160) measures 1.20 / 1.21 and no speed-up inside the network (DESIGN.md section 4,
+ *         channels (chains of 128-160) measures 1.20 / 1.21 and no speed-up inside the network (DECISIONS.md section 4,
  *         profiles/r05_fused_anchor.md, r05_wino_fused_layers.md).
  * key 29 (1; plan) the input normalisation + concatenation (a3, model.py:137-153) inside the first stem convolution's kernel
  *         (csrc/stem.hip: same fmaf chains as the implicit GEMM, no normalised input tensor in HBM; fp16 data path: the same kernel
@@ -290,6 +290,15 @@ double quber_forward_flops_padding(quber_ctx* ctx);
  * key 30 (1; launch) implicit GEMM loader: block-uniform filter taps in scalar registers, a tap-validity bit mask and a 32-bit byte
  *         offset per row, buffer loads whose out-of-range offset returns the zero padding (conv_igemm.hip LEAN; layers with
  *         Cin % 32 == 0 - fp16 data path: % 64 - and tensors below 2 GiB), or per-thread tap arithmetic everywhere (0).  Same bits.
+ * key 31 (1; launch) fp16 data path: the layers with >= 256 output channels and K a multiple of 64 on 256 x 256 tiles with the LDS-DMA
+ *         operand pipeline (csrc/conv_h8.hip: resnet.py:395-449 res4 / res5 bottlenecks, :472-485 fusion convolutions, the ASPP
+ *         branches of model.py:610-651), 0 = the 128-tile kernel everywhere, 2 = also narrower outputs (tests).  Same arithmetic
+ *         (fp16 products, fp32 accumulation), another summation order inside a K-tile.
+ * key 32 (224; launch) fewest tiles (all groups) of a launch that key 31 takes: its blocks own a CU each.
+ * key 33 (0; launch) exact fp32: wide 1x1 launches and Winograd position GEMMs on csrc/conv_f8.hip (256 x 128 tiles, the same
+ *         pipeline; bit-identical to conv_igemm.hip).  Off: no faster in the network (profiles/r11_f8.md).  1 = where its tile
+ *         count fits, 2 = every covered launch (tests).
+ * key 34 (3; launch) fewest rounds of tiles (tiles / CUs) of a launch that key 33 = 1 takes.
  * Process-only keys (quber_set_tuning): key 2 = give the stand-alone conv ops a split-K workspace (value != 0) or drop it (0);
  * key 11 = stand-alone conv op: dilated 3x3 layers in tap-major K order with the zero-padding filter rows skipped;
  * key 12 = stand-alone conv ops: quber_config.compute_dtype of the launch (1 = bf16 / 2 = fp16 operands, 3 = bf16x3);

@@ -148,7 +148,7 @@ struct Tuning {
     int wino_fused = 1;          // key 25 (plan): the eligible F(4x4) layers of the exact fp32 / bf16x3 modes as ONE kernel (wino_fused.hip); 0 = the three-kernel pipeline
     int wino_fused_max_cin = 160;  // key 27 (plan): widest input (channels) the single-kernel form takes.  Its two accumulation chains are Cin / 2 long: 80
                                  //   channels at the default - the float64-anchor ratios stay 0.64-1.11 (0.67-0.98 on the final plan); admitting 256 / 320
-                                 //   channels (chains of 128-160) measures 1.20 / 1.21 (profiles/r05_fused_anchor.md)
+                                 //   channels (chains of 128-160) measures 1.20 / 1.21 (DECISIONS.md section 4, profiles/r05_fused_anchor.md)
     int acc_chunk = 2;           // key 21 (launch, arithmetic): K-slices per chunk of the two-level fp32 accumulation (2 = 64 k; 0 = one chain over K)
     int tile_128x64 = 1;         // key 19 (launch): 128x64 tiles for the 33-64 channel layers (0: 64x64)
     int force_tile = 0;          // key 4 (launch, test harness): force the tile shape: 1 = 64x64, 2 = 128x128, 3 = 128x64, 4 = 256x32 (0 = automatic)

@@ -14,7 +14,7 @@
 // (hardware range check instead of predicates).  Epilogue variants: affine + ReLU, + residual, + GroupNorm sums, and a
 // 1x1 convolution over TWO inputs (a bottleneck's conv3 and its projection shortcut as one GEMM).
 // Layers with padded filter rows skipped (MODE 3 / 4 of conv_igemm.hip) keep the one-tile-per-block kernel: their K range
-// depends on the tile; so do the 16-bit operand modes and launches of a few dozen tiles.
+// depends on the tile; so do the 16-bit operand modes and launches of a few dozen tiles (DECISIONS.md section 4).
 #include "common.h"
 
 namespace quber {

@@ -5,7 +5,7 @@
 //   maskrefiner/modeling/mask_refiner/post_processing.py:44-76   group_pixels
 //   maskrefiner/modeling/mask_refiner/post_processing.py:110-162 merge_semantic_and_instance
 //   maskrefiner/modeling/mask_refiner/model.py:291-356           sigmoid().round(), instance extraction
-// Bit-exactness notes (all probed against torch CPU):
+// Bit-exactness notes (all probed against torch CPU, see DECISIONS.md section 2):
 //   * sigmoid(x).round() == 1  <=>  x > 1.5 * 2^-24 in correctly rounded fp32 arithmetic,
 //   * torch.norm over the (dy,dx) pair evaluates sqrt(fma(dx, dx, dy*dy)); argmin keeps the first minimum,
 //   * top-k keeps values STRICTLY greater than max(k-th largest, 0): at most k-1 centres, raster order,

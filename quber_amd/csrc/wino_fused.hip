@@ -4,7 +4,7 @@
 // layer's input), reads it back in the GEMM, writes M (2.25x the output) and reads that back: 27 GB of the 81 GB the
 // convolution family moved per 16-frame step (profiles/r03_final_conv_hbm_traffic.json), and two HBM-bound passes of 5.2 ms.
 // Used for the layers of up to 160 input channels (tuning key 27): there it beats the pipeline by 1.2-2.1x and, below 128
-// channels, the direct kernel by 1.2-1.7x (profiles/r05_wino_fused_layers.md); DESIGN.md section 4 has the measurements that
+// channels, the direct kernel by 1.2-1.7x (profiles/r05_wino_fused_layers.md); DECISIONS.md section 4 has the measurements that
 // shaped it.  Two kernels:
 //   wino_fused64_kernel   16 tiles x 64 output channels per block, v_mfma_f32_16x16x4_f32, rounds of 32 input channels
 //                         (64 | Cout and an even number of rounds)

@@ -14,7 +14,7 @@
 // m = 2: all transform entries are in {0, +-1, +-1/2}; the result is as accurate as the direct kernel.
 // m = 4 (interpolation points 0, +-3/4, +-3/2, inf - Lavin & Gray's 0, +-1, +-2 scaled by 3/4, which measured 2.7x less
 // fp32 error): about half a decimal digit less accurate than the direct kernel
-// (tests/test_gpu_parity.py::test_conv3x3_winograd_vs_float64 bounds it); see DESIGN.md for where each is used.
+// (tests/test_gpu_parity.py::test_conv3x3_winograd_vs_float64 bounds it); see DESIGN.md section 4 for where each is used.
 // m = 6 (points 0, +-1, +-2, +-1/2, inf): 64 GEMMs per layer, about a decimal digit less accurate than the direct
 // kernel; taken only where the 6x6 tiles fit the map with little padding.
 // With dilation d the layer is d*d independent dense convolutions on the phase sub-images in[d*Y + py][d*X + px]
