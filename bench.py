@@ -33,7 +33,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide, "Peak BF16/FP16 MFMA" (dense)
 HBM_PEAK_GBPS = 8000.0          # same guide, "HBM3E peak BW" (spec; 6.29 TB/s measured float4 copy)
 
 # stage tags (quber_profile_stage) of the convolution family and of the HBM-bound stages reported in `hbm_stages`
-CONV_GEMM = ("conv_gemm", "conv_gemm_h8", "conv_gemm_f8", "wino_gemm", "wino_gemm_f8", "wino_fused")   # *_f8: exact fp32 on 256 x 128 tiles with the LDS-DMA pipeline (csrc/conv_f8.hip); conv_gemm_h8: the fp16 path's 256 x 256 LDS-DMA kernel (csrc/conv_h8.hip); wino_fused: a Winograd layer as ONE kernel (transforms inside), priced on what it multiplies
+CONV_GEMM = ("conv_gemm", "conv_gemm_h8", "conv_gemm_f8", "conv_gemm_x8", "wino_gemm", "wino_gemm_f8", "wino_gemm_x8", "wino_fused")   # *_f8: exact fp32 on 256 x 128 tiles with the LDS-DMA pipeline (csrc/conv_f8.hip); conv_gemm_h8: the fp16 path's 256 x 256 LDS-DMA kernel (csrc/conv_h8.hip); wino_fused: a Winograd layer as ONE kernel (transforms inside), priced on what it multiplies
 CONV_GEMM_F32PIPE = ("conv_gemm_f32pipe",)   # launches of the bf16x3 mode that keep the exact fp32 MFMA kernel (short K, narrow tiles)
 CONV_FAMILY = CONV_GEMM + CONV_GEMM_F32PIPE + ("splitk_reduce", "wino_input", "wino_output", "stem_fused")   # stem_fused: a3 + stem.conv1, vector FMAs (csrc/stem.hip)
 HBM_STAGES = ("encode_reduce", "encode_paint", "errmaps_pack", "errmaps_erode", "errmaps_quadruple", "preprocess", "stem_fused", "wino_input",

@@ -299,6 +299,11 @@ double quber_forward_flops_padding(quber_ctx* ctx);
  *         pipeline; bit-identical to conv_igemm.hip).  Off: no faster in the network (profiles/r11_f8.md).  1 = where its tile
  *         count fits, 2 = every covered launch (tests).
  * key 34 (3; launch) fewest rounds of tiles (tiles / CUs) of a launch that key 33 = 1 takes.
+ * key 35 (1; launch) bf16x3 mode: the wide 1x1 launches and the Winograd position GEMMs on csrc/conv_x8.hip (256 x 128 tiles, LDS-DMA
+ *         pipeline, the weights pre-split into three bf16 planes when the plan is built, the activations split in registers by the
+ *         wave that is not multiplying); the same six partial products in the same order as conv_igemm.hip's bf16x3 kernels.
+ *         0 = those kernels everywhere, 2 = every covered launch (tests).
+ * key 36 (2; launch) fewest rounds of tiles (tiles / CUs), key 37 (8; launch) fewest K-slices of 32 of a launch that key 35 = 1 takes.
  * Process-only keys (quber_set_tuning): key 2 = give the stand-alone conv ops a split-K workspace (value != 0) or drop it (0);
  * key 11 = stand-alone conv op: dilated 3x3 layers in tap-major K order with the zero-padding filter rows skipped;
  * key 12 = stand-alone conv ops: quber_config.compute_dtype of the launch (1 = bf16 / 2 = fp16 operands, 3 = bf16x3);

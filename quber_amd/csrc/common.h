@@ -60,6 +60,8 @@ struct ConvP {
                          // second register set every acc_chunk slices); 0 = one sequential chain over K
     int lean_in_bytes;   // LEAN loader (conv_igemm.hip): bytes of one group's input view (buffer descriptor range)
     unsigned dv_m[5], dv_s[5];   // conv_h8.hip: magic numbers of the divisions by ohw, OW, tiles per group, channel tiles, channels per norm group (h8_magic)
+    const void* w3;      // bf16x3 mode: the weights pre-split into three bf16 planes [3][w3_plane] (launch_split_bf16x3), same [G][Cout][Kpad] order inside a plane; or null
+    long w3_plane;       // elements of one plane
     int dil_g[4];        // per-group dilation = padding of a grouped 3x3 launch (dil_g[0] == 0: `dil` / `pad` for every group); conv_h8.hip reads it, any other
                          //   kernel gets the groups one launch at a time (launch_conv)
     int h8_ss_bytes;     // conv_h8.hip: bytes of the scale / shift vectors over all groups (descriptor range)
@@ -96,6 +98,8 @@ struct WinoNorm {
 struct WinoP {
     View in, out;            // NHWC views; groups via View::gs
     const float* u;          // transformed weights [G][16][Cout][Cin]
+    const void* u3;          // bf16x3 mode: `u` pre-split into three bf16 planes (conv_x8.hip), or null
+    long u3_plane;           // elements of one plane
     const float* uf;         // F(4x4) only: the same weights in the operand order of the single-kernel form (wino_fused.hip), or null
     int algo;                // 1 = the three-kernel pipeline, 2 = the single kernel: fixed when the plan is built, for max_batch, and
                              // honoured at every launch (a layer's algorithm never depends on the batch); 0 = decide at launch
@@ -163,6 +167,10 @@ struct Tuning {
     int fuse_shortcut = 1;       // key 18 (plan): conv3 + projection shortcut of a bottleneck as one dual-input GEMM
     int lanes = 1;               // key 24 (launch): side lanes for batches <= 2 (0 = everything on the caller's stream)
     int h8 = 1;                  // key 31 (launch): fp16 data path: 256 x 256 tiles with the LDS-DMA pipeline for the wide layers (conv_h8.hip); 0 = conv_igemm.hip everywhere
+    int x8 = 1;                  // key 35 (launch): bf16x3 mode: the wide 1x1 launches and the Winograd position GEMMs on 256 x 128 tiles with the LDS-DMA pipeline, weights pre-split at plan time
+                                 //   (conv_x8.hip); 0 = conv_igemm.hip / conv_persist.hip everywhere, 2 = every covered launch (tests)
+    int x8_min_nk = 8;           // key 37 (launch): fewest K-slices (of 32) of a launch that key 35 = 1 takes
+    int x8_min_rounds = 2;       // key 36 (launch): fewest rounds of tiles (tiles / CUs) of a launch that key 35 = 1 takes
     int f8 = 0;                  // key 33 (launch): exact fp32: wide 1x1 launches and Winograd position GEMMs on 256 x 128 tiles with the LDS-DMA pipeline (conv_f8.hip), bit-identical to
                                  //   conv_igemm.hip.  OFF by default: the persistent kernels already sit at the clock-limited bound - in the network it measured 33.08 against 32.94 ms per step
                                  //   (profiles/r11_f8.md); 1 = where its tile count fits, 2 = every covered launch (tests)
@@ -188,6 +196,8 @@ int conv_persistent_segments(int T, int P, int nk, int min_slices, int bid, int*
 int conv_persistent_fixup(int T, int P, int nk, int min_slices, int xcd, int j, int* tile, int* slots, int cap);
 int launch_conv_dual(ConvP p, int G, hipStream_t st);   // 0 done, 1 not covered (run the two convolutions), -1 error
 int launch_conv_f8(ConvP p, int G, hipStream_t st);     // exact fp32 1x1 / grouped GEMM, 256 x 128 tiles (conv_f8.hip): 0 done, 1 not covered, -1 error
+int launch_conv_x8(ConvP p, int G, hipStream_t st);     // bf16x3 1x1 / grouped GEMM, 256 x 128 tiles (conv_x8.hip): 0 done, 1 not covered, -1 error
+int launch_split_bf16x3(const float* w, long n, void* planes, hipStream_t st);     // w [n] -> bf16 terms [3][n]
 int launch_conv_h8(ConvP p, int G, hipStream_t st);     // fp16 data path, 256 x 256 tiles (conv_h8.hip): 0 done, 1 not covered, -1 error
 #ifdef PK_STAMPS
 int pk_read_stamps(unsigned long long* dst, int n);

@@ -1069,6 +1069,10 @@ int launch_conv(const ConvP& p0, int G, hipStream_t st) {
         }
         return 0;
     }
+    if (p.es == 4 && p.bf16 == 3 && tune().force_tile == 0 && tune().force_split == 0) {      // bf16x3: the wide 1x1 launches, pre-split weights, LDS-DMA pipeline (conv_x8.hip)
+        const int rc = launch_conv_x8(p, G, st);
+        if (rc != 1) return rc;
+    }
     if (p.es == 4 && tune().force_tile == 0 && tune().force_split == 0) {      // exact fp32: the wide 1x1 launches on 256 x 128 tiles, LDS-DMA pipeline (conv_f8.hip)
         const int rc = launch_conv_f8(p, G, st);
         if (rc != 1) return rc;

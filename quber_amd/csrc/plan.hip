@@ -58,6 +58,9 @@ static int* tuning_field(Tuning& t, int key) {
         case 32: return &t.h8_min_tiles;
         case 33: return &t.f8;
         case 34: return &t.f8_min_rounds;
+        case 35: return &t.x8;
+        case 36: return &t.x8_min_rounds;
+        case 37: return &t.x8_min_nk;
         default: return nullptr;
     }
 }
@@ -268,6 +271,13 @@ struct Builder {
             err = "upload of " + std::to_string(v.size()) + " floats failed";
         return d;
     }
+    // bf16x3 mode: an uploaded fp32 weight array as three planes of bf16 terms (conv_x8.hip); on the null stream, finalize synchronises
+    const void* split3(const float* dev_w, size_t n) {
+        if (dry || !dev_w || c->cfg.compute_dtype != 3) return nullptr;
+        void* planes = dalloc_bytes(n * 3 * sizeof(unsigned short));
+        if (planes && launch_split_bf16x3(dev_w, (long)n, planes, nullptr) && err.empty()) err = "bf16x3 weight split failed";
+        return planes;
+    }
     View make(int C, int h, int w, int G = 1) {
         View v;
         v.B = Bmax; v.H = h; v.W = w; v.C = C; v.cs = C;
@@ -329,6 +339,7 @@ struct Builder {
             p.w = upload16(ph);
         } else {
             p.w = upload(packed);
+            if (k == 1) { p.w3 = split3(p.w, packed.size()); p.w3_plane = (long)packed.size(); }
         }
         p.es = aes;
         if (in.es != aes || out.es != aes || (res && res->es != aes)) { if (err.empty()) err = "internal: element type mismatch at " + name; return; }
@@ -393,6 +404,7 @@ struct Builder {
                 std::vector<float> u((size_t)G * P * Cout * Cin);
                 for (int g = 0; g < G; ++g) winograd_weights_host(w[g], Cout, Cin, m, &u[(size_t)g * P * Cout * Cin]);
                 wq.in = in; wq.out = out; wq.u = upload(u);
+                wq.u3 = split3(wq.u, u.size()); wq.u3_plane = (long)u.size();
                 if (m == 4 && (c->cfg.compute_dtype == 0 || c->cfg.compute_dtype == 3) && Cout % 32 == 0 && tune().wino_fused && Cin <= tune().wino_fused_max_cin) {     // operand order of the single-kernel form
                     std::vector<float> uf(u.size());
                     for (int g = 0; g < G; ++g) winograd_fused_pack_host(&u[(size_t)g * P * Cout * Cin], Cout, Cin, &uf[(size_t)g * P * Cout * Cin]);
@@ -1695,6 +1707,20 @@ int quber_op_conv2d(const float* x, int32_t B, int32_t h, int32_t w, int32_t cin
     // the stand-alone op splits K only when the test harness asked for a workspace (tuning key 2)
     p.ws = g_op_ws;
     p.ws_floats = g_op_ws ? g_op_ws_floats : 0;
+    if (g_op_bf16 == 3 && k == 1 && tune().x8) {       // the pre-split weight planes conv_x8.hip reads (test harness: a grow-only scratch of the process)
+        static void* planes = nullptr;
+        static size_t cap = 0;
+        const size_t need = (size_t)cout * Kpad * 3 * sizeof(unsigned short);
+        if (need > cap) {
+            if (planes) (void)hipFree(planes);
+            planes = nullptr; cap = 0;
+            if (hipMalloc(&planes, need) != hipSuccess) return fail("conv2d: cannot allocate the bf16x3 weight planes");
+            cap = need;
+        }
+        const int rc = launch_split_bf16x3(packed, (long)cout * Kpad, planes, st);
+        if (rc) return rc;
+        p.w3 = planes; p.w3_plane = (long)cout * Kpad;
+    }
     return launch_conv(p, 1, st);
 }
 

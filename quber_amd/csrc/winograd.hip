@@ -360,6 +360,7 @@ static int run_winograd(const WinoP& q, int Ball, int G, hipStream_t st) {
         QB_CHECK(hipGetLastError());
         ConvP p{};
         p.in = v; p.w = q.u; p.out = m;
+        p.w3 = q.u3; p.w3_plane = q.u3_plane;          // bf16x3 mode: the same filters as three bf16 planes (conv_x8.hip)
         p.B = 1; p.H = (int)tiles; p.W = 1; p.Cin = Cin; p.in_cs = Cin;
         p.OH = (int)tiles; p.OW = 1; p.Cout = Cout; p.out_cs = Cout;
         p.K = Cin; p.Kpad = Cin;
@@ -372,6 +373,7 @@ static int run_winograd(const WinoP& q, int Ball, int G, hipStream_t st) {
         if (shared_v) {
             for (int g = 0; g < G; ++g) {          // P position-GEMMs per group, all on the one V
                 p.w = q.u + (size_t)g * P * Cout * Cin;
+                if (q.u3) p.w3 = reinterpret_cast<const unsigned short*>(q.u3) + (size_t)g * P * Cout * Cin;
                 p.out = m + (size_t)g * P * tiles * Cout;
                 const int rc = launch_conv(p, P, st);
                 if (rc) return rc;
