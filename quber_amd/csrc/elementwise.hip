@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ in,
             s[0] += (double)v.x; s[1] += (double)v.y; s[2] += (double)v.z; s[3] += (double)v.w;
             ss[0] += (double)v.x * v.x; ss[1] += (double)v.y * v.y; ss[2] += (double)v.z * v.z; ss[3] += (double)v.w * v.w;
         }
-        if (cpg >= 4) {
+        if (cpg % 4 == 0) {          // the lane's four channels lie in one norm group (cpg = 10, 320 channels in 32 groups, does not: found by tests/test_gpu_h8.py's random geometries)
             const int grp = (c4 * 4) / cpg;
             atomicAdd(&acc[grp * 2], (s[0] + s[1]) + (s[2] + s[3]));
             atomicAdd(&acc[grp * 2 + 1], (ss[0] + ss[1]) + (ss[2] + ss[3]));

@@ -7,6 +7,7 @@ Layers this kernel runs in the network: maskrefiner/modeling/backbone/resnet.py:
 :472-485 (fusion convolutions, bias + GroupNorm).  Tolerance: the result is rounded to fp16 once (2^-11 relative) after an
 fp32 accumulation over K <= 4608 fp16 products; 3e-3 of the layer's output scale covers both."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -131,3 +132,50 @@ def test_h8_takes_the_wide_layers_of_the_network(h, w, b, grouped):
     d = (outs[0] - outs[1]).abs()
     scale = max(1.0, float(outs[0].abs().max()))
     assert float(d.max()) < 2e-2 * scale, float(d.max())
+
+
+def test_h8_random_geometries_are_deterministic_and_match():
+    """Randomised launches (ragged pixel and channel tiles, dilation, stride, every epilogue variant, few and many tiles per block so
+    that the DMA pipeline crosses tile boundaries): every launch three times - the LDS-DMA pipeline has no data-dependent control, so
+    ANY run-to-run difference of the output tensor would be a race between a DMA and a fragment read - and against the 128-tile kernel."""
+    lib = _lib.load()
+    rng = np.random.default_rng(20251)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t_: C.c_void_p(t_.data_ptr()) if t_ is not None else None
+    try:
+        lib.quber_set_tuning(32, 1)
+        for it in range(int(os.environ.get("QUBER_H8_FUZZ", "48"))):      # (profiles/r11_h8_fuzz.txt: 600 launches)
+            k = int(rng.choice([1, 3]))
+            cin = int(rng.choice([64, 128, 192, 256, 384])) if k == 3 else int(rng.choice([192, 256, 512, 1024]))
+            cout = int(rng.choice([256, 256, 320, 512]))
+            B, H, W = int(rng.integers(1, 4)), int(rng.integers(17, 90)), int(rng.integers(17, 90))
+            if rng.random() < 0.3:
+                H, W = int(rng.integers(90, 200)), int(rng.integers(90, 200))      # several tiles per block
+            dil = int(rng.integers(1, 4)) if k == 3 else 1
+            stride = int(rng.choice([1, 2])) if k == 1 else 1
+            pad = dil if k == 3 else 0
+            residual = bool(rng.random() < 0.3)
+            groups = 32 if (not residual and rng.random() < 0.5 and ((H - 1) // stride + 1) * ((W - 1) // stride + 1) >= 256) else 0
+            relu = bool(rng.random() < 0.5)
+            g = torch.Generator().manual_seed(1000 + it)
+            x = torch.randn((B, H, W, cin), generator=g).half().cuda()
+            wp = pack((torch.randn((cout, cin, k, k), generator=g) / (cin * k * k) ** 0.5).half(), 1 if k == 3 else 0).cuda()
+            scale, shift = (0.5 + torch.rand(cout, generator=g)).cuda(), (torch.randn(cout, generator=g) * 0.3).cuda()
+            oh, ow = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1, (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+            res = torch.randn((B, oh, ow, cout), generator=g).half().cuda() if residual else None
+            args = (x, wp, cout, k, stride, pad, dil, 1 if k == 3 else 0, scale, shift, res, relu, groups)
+            lib.quber_set_tuning(31, 1)
+            ys = [run(lib, *args) for _ in range(3)]
+            lib.quber_set_tuning(31, 0)
+            y0, _ = run(lib, *args)
+            what = f"case {it}: k{k} {cin}>{cout} B{B} {H}x{W} d{dil} s{stride} res{int(residual)} gn{groups} relu{int(relu)}"
+            assert torch.equal(ys[0][0], ys[1][0]) and torch.equal(ys[0][0], ys[2][0]), what
+            d = float((ys[0][0].float() - y0.float()).abs().max())
+            assert d < 3e-3 * max(1.0, float(y0.float().abs().max())), (what, d)
+            if groups:
+                yd = ys[0][0].double().reshape(B, oh * ow, groups, cout // groups)
+                exp = torch.stack([yd.sum((1, 3)), (yd * yd).sum((1, 3))], -1)
+                assert torch.allclose(ys[0][1], exp, rtol=2e-6, atol=1e-4), what
+    finally:
+        lib.quber_set_tuning(31, 1)
+        lib.quber_set_tuning(32, 224)
