@@ -15,6 +15,7 @@ for r in csv.DictReader(open(counters_csv)):
     x = d.setdefault(r["Dispatch_Id"], {"name": r["Kernel_Name"], "ns": int(r["End_Timestamp"]) - int(r["Start_Timestamp"]),
                                         "t0": int(r["Start_Timestamp"])})
     x[r["Counter_Name"]] = float(r["Counter_Value"])
+GEMM = ("conv_igemm", "conv_h8", "conv_x8", "conv_f8")     # the implicit-GEMM kernels (csrc/conv_igemm.hip, conv_persist.hip, conv_h8 / x8 / f8.hip)
 # one group of GEMM launches per convolution op (a Winograd op whose groups share one input transform launches several)
 disp = sorted(d.values(), key=lambda v: v["t0"])
 groups, i = [], 0
@@ -24,12 +25,12 @@ while i < len(disp):
         j = i + 1
         while j < len(disp) and "wino_output" not in disp[j]["name"]:
             j += 1
-        groups.append([v for v in disp[i:j + 1] if "conv_igemm" in v["name"]])
+        groups.append([v for v in disp[i:j + 1] if any(t in v["name"] for t in GEMM)])
         i = j + 1
     elif "wino_fused" in n_ or "stem_conv1" in n_:
         groups.append([disp[i]])
         i += 1
-    elif "conv_igemm" in n_:
+    elif any(t in n_ for t in GEMM):
         groups.append([disp[i]])
         i += 1
     else:
