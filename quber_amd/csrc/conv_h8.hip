@@ -74,7 +74,7 @@ __device__ __forceinline__ unsigned h8_div(unsigned n, unsigned m, unsigned s) {
 // piece u (8 rows x 128 B) of a half-tile goes to wave u / 2; lane l fills row l >> 3, physical chunk l & 7 of it and fetches
 // the LOGICAL chunk (l & 7) ^ swizzle(row).  Offsets are bytes from the first group's base (one descriptor for all groups).
 template <int BN, bool K3, bool DUAL>
-__device__ __forceinline__ void h8_tile_state(const ConvP& p, int tile, int wave, int lane, int (&aoff)[4], unsigned (&amask)[4], int (&boff)[4],
+__device__ __forceinline__ void h8_tile_state(const ConvP& p, int tile, int wave, int lane, int (&aoff)[4], unsigned (&amask)[4], int (&boff)[BN / 64],
                                               int (&aoff2)[4], int& m0, int& n0, int& g, int& dil) {
     g = (int)h8_div((unsigned)tile, p.dv_m[2], p.dv_s[2]);          // tile / tiles per group
     dil = p.dil_g[0] ? p.dil_g[g & 3] : p.dil;                      // (a grouped launch of the ASPP branches: dilation = padding per group)
@@ -107,12 +107,152 @@ __device__ __forceinline__ void h8_tile_state(const ConvP& p, int tile, int wave
         }
         amask[i] = m < p.M ? mk : 0u;
     }
+    constexpr int QPW = BN / 128;          // DMA pieces (8 rows) of a channel half-tile per wave: 2 (256 channels) or 1 (128)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int R = (BN / 2) * (i >> 1) + 8 * (2 * wave + (i & 1)) + prow;    // channel row of the tile
+    for (int i = 0; i < 2 * QPW; ++i) {
+        const int R = (BN / 2) * (i / QPW) + 8 * (QPW * wave + (i % QPW)) + prow;    // channel row of the tile
         const int n = n0 + R;
         const int chunk = pc ^ (((R >> 1) & 1) | (((R >> 3) & 3) << 1));
         boff[i] = n < p.Cout ? gw + (n * p.Kpad) * 4 + chunk * 16 : H8_OOB;     // rows past Cout: zeros
+    }
+}
+
+// ---- epilogue: y = acc * scale + shift (+ residual) (ReLU), 8 channels = 16 bytes per lane ----
+// Buffer stores through a descriptor of this tile's rows: a row past M is past its range and dropped; raw barriers and
+// explicit LDS waits (a __syncthreads() here would drain the next tile's DMAs); the affine vectors come from the LDS image
+// the DMA of a tile ago filled, and the block's GroupNorm sums live in LDS too - all by ds_ instructions in asm: before a
+// plain access to DMA-written LDS hipcc waits for the vector-memory queue (here: for the stores just issued).
+// RES / GN are template parameters: as run-time flags they cost the epilogue ~800 register moves around its branches.
+template <int QT, bool RES, bool GN>
+__device__ __forceinline__ void h8_epilogue(const ConvP& p, const f32x4 (&acc)[QT][4], unsigned gacc_b, unsigned ssaddr, int m0, int n0, int g,
+                                            int t, int wp, int wq, int fr, int fq) {
+    constexpr int BN = 2 * QT * 16;
+    const int rows = min(p.M - m0, H8_BM);
+    const long org = (long)g * p.out_gs + (long)m0 * p.out_cs + n0;
+    const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<_Float16*>(p.out) + org, 0, ((rows - 1) * p.out_cs + min(p.Cout - n0, BN)) * 2, 0x00020000);
+    const long rorg = (long)g * p.res_gs + (long)m0 * p.res_cs + n0;
+    const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<_Float16*>(reinterpret_cast<const _Float16*>(p.res)) + (RES ? rorg : 0), 0,
+        RES ? ((rows - 1) * p.res_cs + min(p.Cout - n0, BN)) * 2 : 0, 0x00020000);
+    const float lo = p.relu ? 0.f : -__builtin_inff();
+    const int b0 = GN ? (int)h8_div((unsigned)m0, p.dv_m[0], p.dv_s[0]) : 0;
+    const int m_next = (b0 + 1) * p.ohw;
+    // one image and whole rows (the common case): every lane adds into the same pair of sums
+    const bool plain = m0 + H8_BM <= p.M && m0 + H8_BM <= m_next;
+        if constexpr (GN) {
+        if (t < 128) {
+            const unsigned long long z = 0;
+            asm volatile("ds_write_b64 %0, %1" :: "v"(gacc_b + t * 8), "v"(z) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    // (opaque copies: the offsets derived from them are recomputed per tile instead of living in registers across the K loop)
+    int fr_e = fr, fq_e = fq;
+    asm volatile("" : "+v"(fr_e), "+v"(fq_e));
+    const int prow0 = 64 * wp + fr_e;
+#pragma unroll
+    for (int gg = 0; gg < QT / 2; ++gg) {
+        const int nl = QT * 16 * wq + 32 * gg + 8 * fq_e;    // first of this lane's 8 channels inside the tile
+        const bool colok = n0 + nl < p.Cout;                 // (Cout is a multiple of 8)
+        const int obase = colok ? (prow0 * p.out_cs + nl) * 2 : H8_OOB;      // (+ 32 rows: still past every range)
+        u32x4 rbuf[4];                                       // residual: the four loads of this channel block in flight together
+        if constexpr (RES) {
+            const int rbase = colok ? (prow0 * p.res_cs + nl) * 2 : H8_OOB;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rbuf[i] = __builtin_amdgcn_raw_buffer_load_b128(rsr, rbase + i * 32 * p.res_cs, 0, 0);
+        }
+        f32x4 sc0, sc1, sh0, sh1;
+        {
+            const unsigned ad = ssaddr + nl * 4;
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:1024\n\tds_read_b128 %3, %4 offset:1040\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(sc0), "=&v"(sc1), "=&v"(sh0), "=&v"(sh1) : "v"(ad) : "memory");
+        }
+        float sA = 0.f, qA = 0.f, sB = 0.f, qB = 0.f;        // channel halves A / B of image b0 ...
+        float sA1 = 0.f, qA1 = 0.f, sB1 = 0.f, qB1 = 0.f;    // ... and of image b0 + 1 (a tile across an image boundary)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = fmaf(acc[2 * gg][i][e], sc0[e], sh0[e]); v[4 + e] = fmaf(acc[2 * gg + 1][i][e], sc1[e], sh1[e]); }
+            if constexpr (RES) {
+                const h16x8 rh = __builtin_bit_cast(h16x8, rbuf[i]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)rh[e];
+            }
+            h16x2 h[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x0, x1;       // (asm: fmaxf / fmed3 add a canonicalising v_max per value)
+                asm("v_max_f32 %0, %1, %2" : "=v"(x0) : "v"(v[2 * e]), "v"(lo));
+                asm("v_max_f32 %0, %1, %2" : "=v"(x1) : "v"(v[2 * e + 1]), "v"(lo));
+                h[e] = h16x2{(_Float16)x0, (_Float16)x1};
+            }
+            const u32x4 pk = {__builtin_bit_cast(unsigned, h[0]), __builtin_bit_cast(unsigned, h[1]), __builtin_bit_cast(unsigned, h[2]), __builtin_bit_cast(unsigned, h[3])};
+            __builtin_amdgcn_raw_buffer_store_b128(pk, rso, obase + i * 32 * p.out_cs, 0, 0);
+            if constexpr (GN) {       // sums of the stored (rounded) values: two fp16 products per v_dot2, fp32 accumulation
+                const h16x2 one = {(_Float16)1.f, (_Float16)1.f};
+                if (plain) {
+                    sA = __builtin_amdgcn_fdot2(h[1], one, __builtin_amdgcn_fdot2(h[0], one, sA, false), false);
+                    qA = __builtin_amdgcn_fdot2(h[1], h[1], __builtin_amdgcn_fdot2(h[0], h[0], qA, false), false);
+                    sB = __builtin_amdgcn_fdot2(h[3], one, __builtin_amdgcn_fdot2(h[2], one, sB, false), false);
+                    qB = __builtin_amdgcn_fdot2(h[3], h[3], __builtin_amdgcn_fdot2(h[2], h[2], qB, false), false);
+                } else {
+                    const int m = m0 + prow0 + 16 * i;
+                    const float a = __builtin_amdgcn_fdot2(h[1], one, __builtin_amdgcn_fdot2(h[0], one, 0.f, false), false);
+                    const float b = __builtin_amdgcn_fdot2(h[1], h[1], __builtin_amdgcn_fdot2(h[0], h[0], 0.f, false), false);
+                    const float a2 = __builtin_amdgcn_fdot2(h[3], one, __builtin_amdgcn_fdot2(h[2], one, 0.f, false), false);
+                    const float b2 = __builtin_amdgcn_fdot2(h[3], h[3], __builtin_amdgcn_fdot2(h[2], h[2], 0.f, false), false);
+                    const bool in0 = m < p.M && m < m_next, in1 = m < p.M && m >= m_next;
+                    sA += in0 ? a : 0.f; qA += in0 ? b : 0.f; sB += in0 ? a2 : 0.f; qB += in0 ? b2 : 0.f;
+                    sA1 += in1 ? a : 0.f; qA1 += in1 ? b : 0.f; sB1 += in1 ? a2 : 0.f; qB1 += in1 ? b2 : 0.f;
+                }
+            }
+        }
+        if constexpr (GN) {
+            // the 16 lanes fr = 0..15 of a DPP row hold the same channels: four row_shr adds leave the row's sum in lane fr = 15;
+            // fp32 inside a wave (at most 256 values per sum), fp64 from there on
+            const int n = n0 + nl;
+            const int grp0 = (int)h8_div((unsigned)n, p.dv_m[4], p.dv_s[4]), grp1 = (int)h8_div((unsigned)(n + 4), p.dv_m[4], p.dv_s[4]);   // / channels per group
+            auto row_sum = [](float x) __attribute__((always_inline)) {
+                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xf, 0xf, true));
+                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x112, 0xf, 0xf, true));
+                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x114, 0xf, 0xf, true));
+                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x118, 0xf, 0xf, true));
+                return x;
+            };
+            auto lds_add = [&](unsigned slot, float x) __attribute__((always_inline)) {
+                const double dx = (double)x;
+                asm volatile("ds_add_f64 %0, %1" :: "v"(gacc_b + slot * 8), "v"(dx) : "memory");
+            };
+            const bool one_group = grp0 == grp1;
+            if (one_group) { sA += sB; qA += qB; sA1 += sB1; qA1 += qB1; }
+            sA = row_sum(sA); qA = row_sum(qA);
+            if (!one_group) { sB = row_sum(sB); qB = row_sum(qB); }
+            if (!plain) {
+                sA1 = row_sum(sA1); qA1 = row_sum(qA1);
+                if (!one_group) { sB1 = row_sum(sB1); qB1 = row_sum(qB1); }
+            }
+            if (fr_e == 15 && colok) {
+                lds_add(grp0 * 2, sA); lds_add(grp0 * 2 + 1, qA);
+                if (!one_group) { lds_add(grp1 * 2, sB); lds_add(grp1 * 2 + 1, qB); }
+                if (!plain) {
+                    lds_add(64 + grp0 * 2, sA1); lds_add(64 + grp0 * 2 + 1, qA1);
+                    if (!one_group) { lds_add(64 + grp1 * 2, sB1); lds_add(64 + grp1 * 2 + 1, qB1); }
+                }
+            }
+        }
+    }
+    if constexpr (GN) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t < 128) {
+            double v;
+            asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(gacc_b + t * 8) : "memory");
+            const int b = b0 + (t >> 6);
+            if (v != 0.0 && b < p.B) atomicAdd(&p.gn_sum[(((long)g * p.B + b) * p.gn_groups) * 2 + (t & 63)], v);
+        }
     }
 }
 
@@ -318,142 +458,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         H8_STAMP(2);
         if (wq == 0) __builtin_amdgcn_s_barrier();      // the two halves level again: the epilogue's barriers are ordinary ones
 
-        // ---- epilogue: y = acc * scale + shift (+ residual) (ReLU), 8 channels = 16 bytes per lane ----
-        // Buffer stores through a descriptor of this tile's rows: a row past M is past its range and dropped; raw barriers and
-        // explicit LDS waits (a __syncthreads() here would drain the next tile's DMAs); the affine vectors come from the LDS image
-        // the DMA of a tile ago filled, and the block's GroupNorm sums live in LDS too - all by ds_ instructions in asm: before a
-        // plain access to DMA-written LDS hipcc waits for the vector-memory queue (here: for the stores just issued).
-        // RES / GN are template parameters: as run-time flags they cost the epilogue ~800 register moves around its branches.
-        {
-            const int rows = min(p.M - m0, H8_BM);
-            const long org = (long)g * p.out_gs + (long)m0 * p.out_cs + n0;
-            const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(
-                reinterpret_cast<_Float16*>(p.out) + org, 0, ((rows - 1) * p.out_cs + min(p.Cout - n0, BN)) * 2, 0x00020000);
-            const long rorg = (long)g * p.res_gs + (long)m0 * p.res_cs + n0;
-            const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<_Float16*>(reinterpret_cast<const _Float16*>(p.res)) + (RES ? rorg : 0), 0,
-                RES ? ((rows - 1) * p.res_cs + min(p.Cout - n0, BN)) * 2 : 0, 0x00020000);
-            const float lo = p.relu ? 0.f : -__builtin_inff();
-            const int b0 = GN ? (int)h8_div((unsigned)m0, p.dv_m[0], p.dv_s[0]) : 0;
-            const int m_next = (b0 + 1) * p.ohw;
-            // one image and whole rows (the common case): every lane adds into the same pair of sums
-            const bool plain = m0 + H8_BM <= p.M && m0 + H8_BM <= m_next;
-            const unsigned gacc_b = 2 * SLOT;
-            if constexpr (GN) {
-                if (t < 128) {
-                    const unsigned long long z = 0;
-                    asm volatile("ds_write_b64 %0, %1" :: "v"(gacc_b + t * 8), "v"(z) : "memory");
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            }
-            // (opaque copies: the offsets derived from them are recomputed per tile instead of living in registers across the K loop)
-            int fr_e = fr, fq_e = fq;
-            asm volatile("" : "+v"(fr_e), "+v"(fq_e));
-            const int prow0 = 64 * wp + fr_e;
-#pragma unroll
-            for (int gg = 0; gg < QT / 2; ++gg) {
-                const int nl = QT * 16 * wq + 32 * gg + 8 * fq_e;    // first of this lane's 8 channels inside the tile
-                const bool colok = n0 + nl < p.Cout;                 // (Cout is a multiple of 8)
-                const int obase = colok ? (prow0 * p.out_cs + nl) * 2 : H8_OOB;      // (+ 32 rows: still past every range)
-                u32x4 rbuf[4];                                       // residual: the four loads of this channel block in flight together
-                if constexpr (RES) {
-                    const int rbase = colok ? (prow0 * p.res_cs + nl) * 2 : H8_OOB;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) rbuf[i] = __builtin_amdgcn_raw_buffer_load_b128(rsr, rbase + i * 32 * p.res_cs, 0, 0);
-                }
-                f32x4 sc0, sc1, sh0, sh1;
-                {
-                    const unsigned ad = SSBASE + ssb * H8_SS + nl * 4;
-                    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:1024\n\tds_read_b128 %3, %4 offset:1040\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&v"(sc0), "=&v"(sc1), "=&v"(sh0), "=&v"(sh1) : "v"(ad) : "memory");
-                }
-                float sA = 0.f, qA = 0.f, sB = 0.f, qB = 0.f;        // channel halves A / B of image b0 ...
-                float sA1 = 0.f, qA1 = 0.f, sB1 = 0.f, qB1 = 0.f;    // ... and of image b0 + 1 (a tile across an image boundary)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float v[8];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] = fmaf(acc[2 * gg][i][e], sc0[e], sh0[e]); v[4 + e] = fmaf(acc[2 * gg + 1][i][e], sc1[e], sh1[e]); }
-                    if constexpr (RES) {
-                        const h16x8 rh = __builtin_bit_cast(h16x8, rbuf[i]);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += (float)rh[e];
-                    }
-                    h16x2 h[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float x0, x1;       // (asm: fmaxf / fmed3 add a canonicalising v_max per value)
-                        asm("v_max_f32 %0, %1, %2" : "=v"(x0) : "v"(v[2 * e]), "v"(lo));
-                        asm("v_max_f32 %0, %1, %2" : "=v"(x1) : "v"(v[2 * e + 1]), "v"(lo));
-                        h[e] = h16x2{(_Float16)x0, (_Float16)x1};
-                    }
-                    const u32x4 pk = {__builtin_bit_cast(unsigned, h[0]), __builtin_bit_cast(unsigned, h[1]), __builtin_bit_cast(unsigned, h[2]), __builtin_bit_cast(unsigned, h[3])};
-                    __builtin_amdgcn_raw_buffer_store_b128(pk, rso, obase + i * 32 * p.out_cs, 0, 0);
-                    if constexpr (GN) {       // sums of the stored (rounded) values: two fp16 products per v_dot2, fp32 accumulation
-                        const h16x2 one = {(_Float16)1.f, (_Float16)1.f};
-                        if (plain) {
-                            sA = __builtin_amdgcn_fdot2(h[1], one, __builtin_amdgcn_fdot2(h[0], one, sA, false), false);
-                            qA = __builtin_amdgcn_fdot2(h[1], h[1], __builtin_amdgcn_fdot2(h[0], h[0], qA, false), false);
-                            sB = __builtin_amdgcn_fdot2(h[3], one, __builtin_amdgcn_fdot2(h[2], one, sB, false), false);
-                            qB = __builtin_amdgcn_fdot2(h[3], h[3], __builtin_amdgcn_fdot2(h[2], h[2], qB, false), false);
-                        } else {
-                            const int m = m0 + prow0 + 16 * i;
-                            const float a = __builtin_amdgcn_fdot2(h[1], one, __builtin_amdgcn_fdot2(h[0], one, 0.f, false), false);
-                            const float b = __builtin_amdgcn_fdot2(h[1], h[1], __builtin_amdgcn_fdot2(h[0], h[0], 0.f, false), false);
-                            const float a2 = __builtin_amdgcn_fdot2(h[3], one, __builtin_amdgcn_fdot2(h[2], one, 0.f, false), false);
-                            const float b2 = __builtin_amdgcn_fdot2(h[3], h[3], __builtin_amdgcn_fdot2(h[2], h[2], 0.f, false), false);
-                            const bool in0 = m < p.M && m < m_next, in1 = m < p.M && m >= m_next;
-                            sA += in0 ? a : 0.f; qA += in0 ? b : 0.f; sB += in0 ? a2 : 0.f; qB += in0 ? b2 : 0.f;
-                            sA1 += in1 ? a : 0.f; qA1 += in1 ? b : 0.f; sB1 += in1 ? a2 : 0.f; qB1 += in1 ? b2 : 0.f;
-                        }
-                    }
-                }
-                if constexpr (GN) {
-                    // the 16 lanes fr = 0..15 of a DPP row hold the same channels: four row_shr adds leave the row's sum in lane fr = 15;
-                    // fp32 inside a wave (at most 256 values per sum), fp64 from there on
-                    const int n = n0 + nl;
-                    const int grp0 = (int)h8_div((unsigned)n, p.dv_m[4], p.dv_s[4]), grp1 = (int)h8_div((unsigned)(n + 4), p.dv_m[4], p.dv_s[4]);   // / channels per group
-                    auto row_sum = [](float x) __attribute__((always_inline)) {
-                        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xf, 0xf, true));
-                        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x112, 0xf, 0xf, true));
-                        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x114, 0xf, 0xf, true));
-                        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x118, 0xf, 0xf, true));
-                        return x;
-                    };
-                    auto lds_add = [&](unsigned slot, float x) __attribute__((always_inline)) {
-                        const double dx = (double)x;
-                        asm volatile("ds_add_f64 %0, %1" :: "v"(gacc_b + slot * 8), "v"(dx) : "memory");
-                    };
-                    const bool one_group = grp0 == grp1;
-                    if (one_group) { sA += sB; qA += qB; sA1 += sB1; qA1 += qB1; }
-                    sA = row_sum(sA); qA = row_sum(qA);
-                    if (!one_group) { sB = row_sum(sB); qB = row_sum(qB); }
-                    if (!plain) {
-                        sA1 = row_sum(sA1); qA1 = row_sum(qA1);
-                        if (!one_group) { sB1 = row_sum(sB1); qB1 = row_sum(qB1); }
-                    }
-                    if (fr_e == 15 && colok) {
-                        lds_add(grp0 * 2, sA); lds_add(grp0 * 2 + 1, qA);
-                        if (!one_group) { lds_add(grp1 * 2, sB); lds_add(grp1 * 2 + 1, qB); }
-                        if (!plain) {
-                            lds_add(64 + grp0 * 2, sA1); lds_add(64 + grp0 * 2 + 1, qA1);
-                            if (!one_group) { lds_add(64 + grp1 * 2, sB1); lds_add(64 + grp1 * 2 + 1, qB1); }
-                        }
-                    }
-                }
-            }
-            if constexpr (GN) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if (t < 128) {
-                    double v;
-                    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(gacc_b + t * 8) : "memory");
-                    const int b = b0 + (t >> 6);
-                    if (v != 0.0 && b < p.B) atomicAdd(&p.gn_sum[(((long)g * p.B + b) * p.gn_groups) * 2 + (t & 63)], v);
-                }
-            }
-        }
+        h8_epilogue<QT, RES, GN>(p, acc, 2 * SLOT, SSBASE + ssb * H8_SS, m0, n0, g, t, wp, wq, fr, fq);
         H8_STAMP(3);
 #ifdef H8_STAMPS
         ++stamp_tile;
@@ -470,6 +475,170 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef H8_READ_Q
 #undef H8_MMA
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the out-of-range tail DMAs still write (zeros) into the images
+}
+
+
+// The same pipeline for layers of 128 output channels (tile 256 pixels x 128 channels: decoder fuse convolutions, model.py:610-651;
+// prediction heads and head-fusion stack, model.py:386-403, 431-451; res3 conv2, resnet.py:395-449).  A wave owns 64 x 64, a K-tile is
+// 48 KB, so THREE K-tile images fit and both operands are issued two K-tiles ahead; two phases per K-tile (one per k-step of 32:
+// 4 + 4 fragment reads, 16 MFMAs), six DMA pieces per wave and K-tile (4 in phase 0, 2 in phase 1), one counted vmcnt(6) per K-tile.
+// Half the MFMAs per DMA piece and per barrier of the 256-channel kernel: it runs at ~0.8 of that kernel's rate.
+template <bool K3, bool RES, bool GN>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_h8n_kernel(const ConvP p) {
+    constexpr int QT = 4;
+    using G = H8Geo<QT>;
+    constexpr int BN = G::BN, SLOT = G::SLOT;
+    static_assert(BN == 128 && SLOT == 49152, "geometry");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * SLOT + 1024 + 2 * H8_SS];
+    constexpr int SSBASE = 3 * SLOT + 1024;
+
+    const int t = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+    const int wp = wave & 3, wq = wave >> 2;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nk = p.Kpad / 32;
+
+    int tile, tile_step, tile_end;
+    {
+        const int bid = blockIdx.x, nblk = gridDim.x, T = p.pk_T;
+        const int xcd = bid & 7, q = T >> 3, r = T & 7;
+        const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        tile_end = start + q + (xcd < r ? 1 : 0);
+        tile_step = (nblk >> 3) + (xcd < (nblk & 7) ? 1 : 0);
+        tile = start + (bid >> 3);
+    }
+
+    int aoff[4], aoffN[4], boff[2], boffN[2], aoff2[4];
+    unsigned amask[4], amaskN[4];
+    int m0, n0, g, dilC, m0N = 0, n0N = 0, gN = 0, dilN = 1;
+    h8_tile_state<BN, K3, false>(p, tile, wave, lane, aoff, amask, boff, aoff2, m0, n0, g, dilC);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { aoffN[i] = 0; amaskN[i] = 0; }
+    boffN[0] = boffN[1] = H8_OOB;
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.lean_in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.pk_in_bytes, 0x00020000);
+
+    int sk = 0, skc = 0, skx = 0, sky = 0;          // K-tile of (pnext ? the next : this) tile that is issued next
+    bool pnext = false, has_next = false;
+    auto issue_p = [&](int half, int sbase) __attribute__((always_inline)) {
+        const bool live = !pnext || has_next;
+        const int tap = live ? (K3 ? sky * 3 + skx : 0) : 31;
+        const int dl = pnext ? dilN : dilC;
+        const int soff = K3 ? (((sky * dl) * p.W + skx * dl) * p.in_cs + skc) * 4 : skc * 4;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = 2 * half + j;
+            const unsigned mk = pnext ? amaskN[i] : amask[i];
+            const int ao = pnext ? aoffN[i] : aoff[i];
+            const bool ok = (mk >> tap) & 1u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr_t)(smem + sbase + half * H8_HALF + (2 * wave + j) * 1024), 16, ok ? ao + soff : H8_OOB, 0, 0, 0);
+        }
+    };
+    auto issue_q = [&](int sbase) __attribute__((always_inline)) {     // both channel halves (one piece each) of the K-tile `sk` points at
+        const bool live = !pnext || has_next;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int bo = pnext ? boffN[half] : boff[half];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lds_ptr_t)(smem + sbase + G::QBASE + half * G::QHALF + wave * 1024), 16, live ? bo : H8_OOB, sk * H8_KB, 0, 0);
+        }
+    };
+    auto advance_p = [&]() __attribute__((always_inline)) {
+        if constexpr (K3) {
+            if (++skx == 3) {
+                skx = 0;
+                if (++sky == 3) { sky = 0; skc += 32; }
+            }
+        } else {
+            skc += 32;
+        }
+        if (++sk == nk) { sk = 0; skc = 0; skx = 0; sky = 0; pnext = true; }
+    };
+    const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.scale), 0, p.h8_ss_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.shift), 0, p.h8_ss_bytes, 0x00020000);
+    auto issue_ss = [&](int buf, int tg, int tn0) __attribute__((always_inline)) {
+        if (wave == 0) {
+            const int off = (tg * p.ss_gs + tn0) * 4 + lane * 16;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rss, (lds_ptr_t)(smem + SSBASE + buf * H8_SS), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsh, (lds_ptr_t)(smem + SSBASE + buf * H8_SS + 1024), 16, off, 0, 0, 0);
+        }
+    };
+    int ssb = 0;
+
+    const int sp = fr >> 1, sq = ((fr & 3) >> 1) | ((fr >> 2) << 1);
+    int paddr[2], qaddr[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        paddr[ks] = (64 * wp + fr) * H8_KB + (((4 * ks + fq) ^ sp) << 4);
+        qaddr[ks] = G::QBASE + (QT * 16 * wq + 8 * (fr >> 2) + (fr & 3)) * H8_KB + (((4 * ks + fq) ^ sq) << 4);
+    }
+
+    f32x4 acc[QT][4];
+    h16x8 pf[4], qf[4];
+
+    // ---- prologue: K-tiles 0 and 1 ----
+    issue_ss(0, g, n0);
+    issue_q(0); issue_p(0, 0); issue_p(1, 0); advance_p();
+    issue_q(SLOT); issue_p(0, SLOT); issue_p(1, SLOT); advance_p();
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int rbase = 0, wbase = 2 * SLOT;          // image of the K-tile being multiplied / of the K-tile being issued (two ahead)
+
+#define H8N_READ(KS)                                                                                                    \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                                        \
+        qf[c] = *reinterpret_cast<const h16x8*>(smem + rbase + qaddr[KS] + ((c >> 1) * 32 + (c & 1) * 4) * H8_KB);        \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) pf[i] = *reinterpret_cast<const h16x8*>(smem + rbase + paddr[KS] + i * 16 * H8_KB);
+#define H8N_MMA()                                                                                                       \
+    __builtin_amdgcn_s_barrier();                                                                                        \
+    __builtin_amdgcn_s_setprio(1);                                                                                       \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) acc[c][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[c], pf[i], acc[c][i], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                                       \
+    __builtin_amdgcn_s_barrier();
+
+    for (;;) {
+        has_next = tile + tile_step < tile_end;
+        if (has_next) {
+            h8_tile_state<BN, K3, false>(p, tile + tile_step, wave, lane, aoffN, amaskN, boffN, aoff2, m0N, n0N, gN, dilN);
+            issue_ss(ssb ^ 1, gN, n0N);
+        }
+#pragma unroll
+        for (int c = 0; c < QT; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[c][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (wq == 1) __builtin_amdgcn_s_barrier();      // stagger: waves 4-7 run half a phase behind their SIMD partners
+
+        for (int kt = 0; kt < nk; ++kt) {
+            // phase 0: k-step 0; DMA: both channel halves and pixel half 0 of the K-tile two ahead (its image was last read in phase 1 of
+            // the previous K-tile, whose reads were retired before that phase's first barrier)
+            H8N_READ(0)
+            issue_q(wbase);
+            issue_p(0, wbase);
+            H8N_MMA()
+            // phase 1: k-step 1; DMA: pixel half 1; the K-tile ONE ahead has landed after this wait + barrier pair
+            H8N_READ(1)
+            issue_p(1, wbase);
+            advance_p();
+            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            H8N_MMA()
+            rbase = rbase == 2 * SLOT ? 0 : rbase + SLOT;
+            wbase = wbase == 2 * SLOT ? 0 : wbase + SLOT;
+        }
+        if (wq == 0) __builtin_amdgcn_s_barrier();
+
+        h8_epilogue<QT, RES, GN>(p, acc, 3 * SLOT, SSBASE + ssb * H8_SS, m0, n0, g, t, wp, wq, fr, fq);
+        if (!has_next) break;
+        tile += tile_step;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { aoff[i] = aoffN[i]; amask[i] = amaskN[i]; }
+        boff[0] = boffN[0]; boff[1] = boffN[1];
+        m0 = m0N; n0 = n0N; g = gN; dilC = dilN;
+        pnext = false;
+        ssb ^= 1;
+    }
+#undef H8N_READ
+#undef H8N_MMA
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 }  // namespace
@@ -498,6 +667,9 @@ int launch_conv_h8(ConvP p, int G, hipStream_t st) {
     if (p.Cin % 32 || p.K != p.Kpad || p.Kpad / 32 < 3) return 1;
     const bool k3 = p.kh == 3 && p.kw == 3 && p.kmode == 1;
     if (!k3 && !(p.kh == 1 && p.kw == 1 && p.pad == 0)) return 1;
+    const bool narrow = p.Cout == 128;            // 256 x 128 tiles (conv_h8n_kernel)
+    if (p.Cout < 256 && !narrow && tune().h8 < 2) return 1;
+    if (narrow && p.in2) return 1;
     const bool dual = p.in2 != nullptr;       // launch_conv_dual: K = K1 channels of `in`, then the channels of `in2` sampled at stride2
     if (dual) {
         if (k3 || p.res || p.gn_sum || p.stride != 1 || p.K1 % 32 || p.K1 <= 0 || p.K1 >= p.Kpad || p.in2_cs % 4 || (p.in2_gs & 3) || ((uintptr_t)p.in2 & 15)) return 1;
@@ -505,7 +677,6 @@ int launch_conv_h8(ConvP p, int G, hipStream_t st) {
         if (in2_all >= 0x7fffff00L) return 1;
         p.pk_in2_bytes = (int)in2_all;
     }
-    if (p.Cout < 256 && tune().h8 < 2) return 1;
     const long in_bytes = ((long)p.B * p.H * p.W * p.in_cs) * 4, w_bytes = (long)p.Cout * p.Kpad * 4;
     if (in_bytes >= 0x7fffff00L || w_bytes >= 0x7fffff00L) return 1;
     const bool vec8 = p.Cout % 8 == 0 && p.out_cs % 8 == 0 && p.out_gs % 8 == 0 && (((uintptr_t)p.out & 15) == 0) &&
@@ -513,7 +684,7 @@ int launch_conv_h8(ConvP p, int G, hipStream_t st) {
                       (!p.scale || (p.ss_gs % 4 == 0 && (((uintptr_t)p.scale & 15) == 0) && (((uintptr_t)p.shift & 15) == 0)));
     if (!vec8) return 1;
     p.mtiles = (p.M + H8_BM - 1) / H8_BM;
-    p.ntiles = (p.Cout + 255) / 256;
+    p.ntiles = narrow ? 1 : (p.Cout + 255) / 256;
     const long tiles = (long)p.mtiles * p.ntiles * G;
     if (tiles < tune().h8_min_tiles || tiles > 0x3fffffff) return 1;
     // one descriptor per operand over all groups: 31-bit byte offsets
@@ -548,8 +719,16 @@ int launch_conv_h8(ConvP p, int G, hipStream_t st) {
         ProfScope prof(p.tag ? p.tag : "conv_gemm_h8", conv_bytes, conv_flops, st);
         const int blocks = (int)std::min<long>(tiles, cus);        // one block per CU (128 KB of LDS), each walks its share of the tiles
         const dim3 grid(blocks), block(512);
-        const int variant = dual ? 8 : (k3 ? 4 : 0) | (p.res ? 2 : 0) | (p.gn_sum ? 1 : 0);
+        const int variant = (narrow ? 16 : 0) + (dual ? 8 : (k3 ? 4 : 0) | (p.res ? 2 : 0) | (p.gn_sum ? 1 : 0));
         switch (variant) {
+            case 16: hipLaunchKernelGGL((conv_h8n_kernel<false, false, false>), grid, block, 0, st, p); break;
+            case 17: hipLaunchKernelGGL((conv_h8n_kernel<false, false, true>), grid, block, 0, st, p); break;
+            case 18: hipLaunchKernelGGL((conv_h8n_kernel<false, true, false>), grid, block, 0, st, p); break;
+            case 19: hipLaunchKernelGGL((conv_h8n_kernel<false, true, true>), grid, block, 0, st, p); break;
+            case 20: hipLaunchKernelGGL((conv_h8n_kernel<true, false, false>), grid, block, 0, st, p); break;
+            case 21: hipLaunchKernelGGL((conv_h8n_kernel<true, false, true>), grid, block, 0, st, p); break;
+            case 22: hipLaunchKernelGGL((conv_h8n_kernel<true, true, false>), grid, block, 0, st, p); break;
+            case 23: hipLaunchKernelGGL((conv_h8n_kernel<true, true, true>), grid, block, 0, st, p); break;
             case 8: hipLaunchKernelGGL((conv_h8_kernel<8, false, false, false, true>), grid, block, 0, st, p); break;
             case 0: hipLaunchKernelGGL((conv_h8_kernel<8, false, false, false>), grid, block, 0, st, p); break;
             case 1: hipLaunchKernelGGL((conv_h8_kernel<8, false, false, true>), grid, block, 0, st, p); break;

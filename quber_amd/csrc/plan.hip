@@ -343,9 +343,9 @@ struct Builder {
         }
         p.es = aes;
         if (in.es != aes || out.es != aes || (res && res->es != aes)) { if (err.empty()) err = "internal: element type mismatch at " + name; return; }
-        // (fp16 data path, wide layers without an affine - the ASPP branches: an identity affine, so that conv_h8.hip, whose epilogue
+        // (fp16 data path, layers of >= 128 channels without an affine - ASPP branches, decoder convolutions, heads: an identity affine, so that conv_h8.hip, whose epilogue
         //  always reads one, takes them; fma(v, 1, 0) == v)
-        const bool ident = !affine && aes == 2 && Cout >= 256;
+        const bool ident = !affine && aes == 2 && Cout >= 128;
         p.scale = affine ? upload(scale) : ident ? upload(std::vector<float>((size_t)G * Cout, 1.f)) : nullptr;
         p.shift = affine ? upload(shift) : ident ? upload(std::vector<float>((size_t)G * Cout, 0.f)) : nullptr;
         for (size_t g = 0; g < dil_g.size() && g < 4; ++g) p.dil_g[g] = dil_g[g];      // per-group dilation (= padding) of a grouped launch

@@ -48,7 +48,10 @@ CASES = [
     (2, 33, 47, 128, 512, 1, 1, 0, 1, 0, True, True, True, 0, 1),        # 1x1 + residual + ReLU (bottleneck conv3)
     (2, 48, 64, 256, 256, 1, 2, 0, 1, 0, True, False, True, 0, 1),       # strided 1x1 (first block of a stage)
     (1, 36, 44, 64, 320, 3, 1, 1, 1, 1, True, False, False, 0, 1),       # ragged channel tile
-    (2, 32, 40, 128, 128, 3, 1, 1, 1, 1, True, False, False, 32, 2),     # 128 channels (key 31 = 2): 4 channels per norm group
+    (2, 32, 40, 128, 128, 3, 1, 1, 1, 1, True, False, False, 32, 1),     # 128 channels (the 256 x 128-tile kernel): 4 channels per norm group
+    (3, 37, 45, 64, 128, 3, 1, 2, 2, 1, True, True, True, 0, 1),         # 128 channels, dilated, residual, tiles across image boundaries
+    (1, 50, 70, 320, 128, 1, 1, 0, 1, 0, True, False, True, 32, 1),      # 128 channels, 1x1, five K-tiles
+    (2, 32, 40, 128, 192, 3, 1, 1, 1, 1, True, False, False, 0, 2),      # 192 channels on 256-channel tiles (key 31 = 2)
     (1, 64, 64, 512, 512, 3, 1, 4, 4, 1, True, False, True, 0, 1),       # res5-like: K = 4608
     (1, 20, 24, 2048, 256, 1, 1, 0, 1, 0, True, False, True, 32, 1),     # long 1x1 (ASPP convs.0 / fusion_res5-like)
 ]
@@ -147,7 +150,7 @@ def test_h8_random_geometries_are_deterministic_and_match():
         for it in range(int(os.environ.get("QUBER_H8_FUZZ", "48"))):      # (profiles/r11_h8_fuzz.txt: 600 launches)
             k = int(rng.choice([1, 3]))
             cin = int(rng.choice([64, 128, 192, 256, 384])) if k == 3 else int(rng.choice([192, 256, 512, 1024]))
-            cout = int(rng.choice([256, 256, 320, 512]))
+            cout = int(rng.choice([128, 128, 256, 256, 320, 512]))
             B, H, W = int(rng.integers(1, 4)), int(rng.integers(17, 90)), int(rng.integers(17, 90))
             if rng.random() < 0.3:
                 H, W = int(rng.integers(90, 200)), int(rng.integers(90, 200))      # several tiles per block

@@ -43,6 +43,9 @@ def main():
         ("res5.conv1 1x1 2048>512", s16, 2048, 512, 1, 1, False, False),
         ("res5.conv3 1x1 512>2048 +res", s16, 512, 2048, 1, 1, True, False),
         ("res4.conv3 1x1 256>1024 +res", s16, 256, 1024, 1, 1, True, False),
+        ("head.0 / fusion_layers 3x3 128>128", s4, 128, 128, 3, 1, False, True),
+        ("res3.conv2 3x3 128>128", s8, 128, 128, 3, 1, False, False),
+        ("decoder.res3.fuse_conv.0 3x3 320>128", s8, 320, 128, 3, 1, False, True),
     ]
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     print(f"| layer (batch {B}, {S}x{S} frame) | GFLOP | conv_igemm ms | TFLOP/s | conv_h8 ms | TFLOP/s | ratio |")

@@ -82,7 +82,7 @@ def report(a):
         if "stem_conv1" in name(r):
             tile = "vector FMA, 8 x 32 pixels x 32 ch per block"
         elif any(t in name(r) for t in ("conv_h8", "conv_x8", "conv_f8")):
-            tile = ("256x256" if "conv_h8" in name(r) else "256x128") + " persistent LDS-DMA, " + name(r).split("<")[1].split(">")[0].replace(" ", "")
+            tile = ("256x256" if "conv_h8_kernel" in name(r) else "256x128") + " persistent LDS-DMA, " + name(r).split("<")[1].split(">")[0].replace(" ", "")
         elif "wino_fused" in name(r):
             tile = "16 tiles x 64 ch" if "fused64" in name(r) else "32 tiles x 32 ch"
         else:
