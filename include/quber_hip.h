@@ -285,8 +285,9 @@ double quber_forward_flops_padding(quber_ctx* ctx);
  *         channels (chains of 128-160) measures 1.20 / 1.21 and no speed-up inside the network (DECISIONS.md section 4,
  *         profiles/r05_fused_anchor.md, r05_wino_fused_layers.md).
  * key 29 (1; plan) the input normalisation + concatenation (a3, model.py:137-153) inside the first stem convolution's kernel
- *         (csrc/stem.hip: same fmaf chains as the implicit GEMM, no normalised input tensor in HBM; fp16 data path: the same kernel
- *         on the fp16-rounded operands, equal to the MFMA form up to fp32 summation order), or as a kernel of its own (0).
+ *         (csrc/stem.hip: same fmaf chains as the implicit GEMM, no normalised input tensor in HBM; fp16 data path: the layer on the
+ *         matrix pipe from 16-byte fp16 pixels staged in LDS, equal to the preprocess kernel + implicit GEMM up to fp32 summation
+ *         order; 2 = the fp16 data path keeps the vector-FMA form of the kernel), or as a kernel of its own (0).
  * key 30 (1; launch) implicit GEMM loader: block-uniform filter taps in scalar registers, a tap-validity bit mask and a 32-bit byte
  *         offset per row, buffer loads whose out-of-range offset returns the zero padding (conv_igemm.hip LEAN; layers with
  *         Cin % 32 == 0 - fp16 data path: % 64 - and tensors below 2 GiB), or per-thread tap arithmetic everywhere (0).  Same bits.

@@ -162,7 +162,7 @@ struct Tuning {
     int persist_min_nk = 32;     // key 14 (launch): shortest K (in 32-wide slices) whose remainder tiles are shared between blocks
     int persist_min_tiles = 256; // key 15 (launch): fewest tiles (all groups) of a launch that goes persistent
     int persist_debug = 0;       // key 16 (diagnostics): 1 = every store of the persistent epilogue is dropped by the range check
-    int stem_fused = 1;          // key 29 (plan): input normalisation + concat (a3) inside the first stem convolution's kernel (csrc/stem.hip); 0 = preprocess kernel + implicit GEMM
+    int stem_fused = 1;          // key 29 (plan): input normalisation + concat (a3) inside the first stem convolution's kernel (csrc/stem.hip); 0 = preprocess kernel + implicit GEMM; 2 = as 1, but the fp16 data path keeps the vector-FMA form (1: its matrix-pipe form)
     int lean_loader = 1;         // key 30 (launch): implicit GEMM with block-uniform filter taps and buffer loads where the layer allows it (conv_igemm.hip LEAN); 0 = per-thread tap arithmetic
     int fuse_shortcut = 1;       // key 18 (plan): conv3 + projection shortcut of a bottleneck as one dual-input GEMM
     int lanes = 1;               // key 24 (launch): side lanes for batches <= 2 (0 = everything on the caller's stream)
@@ -207,7 +207,8 @@ int launch_preprocess(const uint8_t* rgb, const uint8_t* depth, const float* off
                       int H, int W, const float* mean6, const float* std6, int streams, hipStream_t st);
 int launch_maxpool3x3s2(const View& in, const View& out, int B, int G, hipStream_t st);
 int launch_stem_conv1(const uint8_t* bgr, const uint8_t* depth, const float* offs, int B, int H, int W, int streams, const float* mean6,
-                      const float* std6, const float* w, const float* scale, const float* shift, float* out, long out_gs, int es, hipStream_t st);
+                      const float* std6, const float* w, const float* scale, const float* shift, float* out, long out_gs, int es, hipStream_t st,
+                      const void* wf16 = nullptr);
 int launch_zero(void* p, size_t bytes, hipStream_t st);
 int launch_gn_stats(const View& in, int B, int G, int groups, double* stats, hipStream_t st, bool zero = true);
 int launch_gn_apply(const View& in, const View& out, int B, int G, int groups, const double* stats,

@@ -670,12 +670,28 @@ struct Builder {
         const double fl = 2.0 * OH * OW * 6.0 * 9.0 * 32.0 * G;
         c->flops += fl;
         const float *dw = upload(packed), *ds = upload(scale), *dh = upload(shift);
+        // fp16 data path: the filters as fragments of v_mfma_f32_16x16x32_f16 (stem.hip): [stream][tile jj][k-step][lane][8 halfs], lane (fr, fq) =
+        // output channel 8 (fr >> 2) + 4 jj + (fr & 3), tap 4 ks + fq, channels 0-5 (6, 7 and taps 9-11: zeros)
+        const float* dwf = nullptr;
+        if (out.es == 2 && tune().stem_fused != 2) {
+            std::vector<_Float16> wf((size_t)G * 2 * 3 * 64 * 8, (_Float16)0.f);
+            for (int g = 0; g < G; ++g)
+                for (int jj = 0; jj < 2; ++jj)
+                    for (int ks = 0; ks < 3; ++ks)
+                        for (int l = 0; l < 64; ++l) {
+                            const int fr = l & 15, tap = 4 * ks + (l >> 4), n = 8 * (fr >> 2) + 4 * jj + (fr & 3);
+                            if (tap < 9)
+                                for (int ci = 0; ci < 6; ++ci)
+                                    wf[((((size_t)g * 2 + jj) * 3 + ks) * 64 + l) * 8 + ci] = (_Float16)packed[(((size_t)g * 9 + tap) * 6 + ci) * 32 + n];
+                        }
+            dwf = upload16(wf);
+        }
         quber_ctx* ctx = c;
         const View o = out;
         c->stem_fused = true;
         c->ops.push_back({[=](int B, hipStream_t st) {
             return launch_stem_conv1(ctx->cur_bgr, ctx->cur_depth, ctx->cur_off, B, ctx->cfg.height, ctx->cfg.width, G, ctx->cfg.pixel_mean,
-                                     ctx->cfg.pixel_std, dw, ds, dh, o.p, o.gs, o.es, st);
+                                     ctx->cfg.pixel_std, dw, ds, dh, o.p, o.gs, o.es, st, dwf);
         }, OP_CONV, names[0], fl, 1});
         last_conv = {nullptr, nullptr, 0, 0};
         pending_norm.reset();

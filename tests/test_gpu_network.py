@@ -464,15 +464,16 @@ def test_launch_structures_agree():
 
 @pytest.mark.parametrize("h,w,b", [(256, 320, 2), (70, 102, 3)])
 def test_stem_fused_fp16_data_path(h, w, b):
-    """fp16 data path: a3 + stem.conv1 as one kernel on the fp16-rounded operands (csrc/stem.hip H16, key 29 = 1, default) against the
-    preprocess kernel + fp16 implicit GEMM (key 29 = 0).  Both multiply the same fp16 operands exactly and sum in fp32 - in
-    different orders (the MFMA's internal tree) - so the stem output agrees to the last place of fp16 and the logits to the path's
-    tolerance; the fused plan holds no 16-channel input tensor."""
+    """fp16 data path: a3 + stem.conv1 as one kernel on the fp16-rounded operands - csrc/stem.hip, its matrix-pipe form (key 29 = 1,
+    default: v_mfma_f32_16x16x32_f16 on 16-byte LDS pixels) and its vector-FMA form (key 29 = 2) - against the preprocess kernel + fp16
+    implicit GEMM (key 29 = 0).  All three multiply the same fp16 operands exactly and sum in fp32 - in different orders (the MFMA's
+    internal tree) - so the stem output agrees to the last place of fp16 and the logits to the path's tolerance; the fused plans hold
+    no 16-channel input tensor."""
     sd = arch.init_state_dict(seed=7, loud_heads=True, center_bias=-1.5)
     batch, offs = inputs(61, b, h, w, 4)
     bgr, dep, off = torch.from_numpy(batch["rgb"]).cuda(), torch.from_numpy(batch["depth"]).cuda(), torch.from_numpy(offs).cuda()
     outs = []
-    for fused, dt in ((1, 2), (0, 2), (1, 0)):                          # the last: exact fp32, the yardstick for the logits
+    for fused, dt in ((1, 2), (2, 2), (0, 2), (1, 0)):                  # the last: exact fp32, the yardstick for the logits
         qc = engine.make_config(h, w, max_batch=b)
         qc.compute_dtype = dt
         eng = engine.Engine(qc, "cuda:0")
@@ -480,14 +481,17 @@ def test_stem_fused_fp16_data_path(h, w, b):
         eng.load_state_dict(sd)
         outs.append((eng.forward(bgr, dep, off).clone(), eng.debug_tensor("stem1", b).float().clone()))
         eng.close()
-    s1, s0 = outs[0][1], outs[1][1]
-    assert s1.shape == s0.shape and float(s0.abs().max()) > 0.1
-    d = (s1 - s0).abs()
-    assert float((d / (s0.abs() + 1e-2)).max()) < 2e-3                 # one fp16 place (2^-10 relative)
-    assert float((d > 0).float().mean()) < 0.02                          # and rarely that
-    # a last-place flip in the stem travels through 80 fp16 layers: the two forms are equally far from the fp32 network
-    e1, e0 = float((outs[0][0] - outs[2][0]).abs().max()), float((outs[1][0] - outs[2][0]).abs().max())
-    assert e0 > 0 and e1 < 1.5 * e0 + 1e-3, (e1, e0)
+    s0 = outs[2][1]
+    e0 = float((outs[2][0] - outs[3][0]).abs().max())
+    for form in (0, 1):
+        s1 = outs[form][1]
+        assert s1.shape == s0.shape and float(s0.abs().max()) > 0.1
+        d = (s1 - s0).abs()
+        assert float((d / (s0.abs() + 1e-2)).max()) < 2e-3             # one fp16 place (2^-10 relative)
+        assert float((d > 0).float().mean()) < 0.02                      # and rarely that
+        # a last-place flip in the stem travels through 80 fp16 layers: the forms are equally far from the fp32 network
+        e1 = float((outs[form][0] - outs[3][0]).abs().max())
+        assert e0 > 0 and e1 < 1.5 * e0 + 1e-3, (form, e1, e0)
 
 
 @pytest.mark.parametrize("h,w,b,name", [(150, 203, 3, None), (96, 128, 2, "single-stream"), (256, 320, 2, "m-b-f-c-o-e2")],
