@@ -305,6 +305,9 @@ double quber_forward_flops_padding(quber_ctx* ctx);
  *         wave that is not multiplying); the same six partial products in the same order as conv_igemm.hip's bf16x3 kernels.
  *         0 = those kernels everywhere, 2 = every covered launch (tests).
  * key 36 (2; launch) fewest rounds of tiles (tiles / CUs), key 37 (8; launch) fewest K-slices of 32 of a launch that key 35 = 1 takes.
+ * key 38 (1; launch) fp16 data path: the 64-channel layers (stem.conv3, res2 conv1 / conv2, resnet.py:37-63, 395-449) on 256 x 64 tiles of
+ *         key 31's pipeline, two filter taps per 128-byte K-tile row where the input has 32 channels; 0 = conv_igemm.hip there, 2 = also the
+ *         32-channel outputs (half-empty tiles).
  * Process-only keys (quber_set_tuning): key 2 = give the stand-alone conv ops a split-K workspace (value != 0) or drop it (0);
  * key 11 = stand-alone conv op: dilated 3x3 layers in tap-major K order with the zero-padding filter rows skipped;
  * key 12 = stand-alone conv ops: quber_config.compute_dtype of the launch (1 = bf16 / 2 = fp16 operands, 3 = bf16x3);
@@ -337,8 +340,9 @@ int quber_op_conv2d(const float* dev_x, int32_t batch, int32_t h, int32_t w, int
 int quber_op_conv1x1_f16(const void* dev_x, int32_t batch, int32_t h, int32_t w, int32_t cin, const void* dev_w_oi,
                          int32_t cout, const float* dev_scale, const float* dev_shift, const void* dev_residual,
                          int32_t relu, void* dev_y, void* stream);
-/* a convolution of the fp16 data path on fp16 tensors: x [batch][h][w][cin] (cin a multiple of 64), w_packed [cout][k*k*cin] in the
- * kernels' K order - kmode 0: k = (tap, channel); kmode 1: k = (channel / 64, tap, channel % 64) - residual and y fp16, scale /
+/* a convolution of the fp16 data path on fp16 tensors: x [batch][h][w][cin] (cin a multiple of 8; kmode 1: of 64), w_packed [cout][Kpad]
+ * (Kpad = k*k*cin rounded up to a multiple of 64, rows zero-filled) in the kernels' K order - kmode 0: k = (tap, channel); kmode 1:
+ * k = (channel / 64, tap, channel % 64) - residual and y fp16, scale /
  * shift fp32; gn_sums (or null): f64 [batch][gn_groups][2], the sums and sums of squares of the stored outputs per norm group
  * are ADDED to it (the GroupNorm statistics the network's convolutions gather in their epilogue).  Test hook: the layers of
  * maskrefiner/modeling/backbone/resnet.py:395-449, 472-485 reach these kernels through quber_forward. */

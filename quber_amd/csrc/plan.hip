@@ -53,6 +53,7 @@ static int* tuning_field(Tuning& t, int key) {
         case 25: return &t.wino_fused;
         case 27: return &t.wino_fused_max_cin;
         case 29: return &t.stem_fused;
+        case 38: return &t.h8_narrow;
         case 30: return &t.lean_loader;
         case 31: return &t.h8;
         case 32: return &t.h8_min_tiles;
@@ -345,7 +346,7 @@ struct Builder {
         if (in.es != aes || out.es != aes || (res && res->es != aes)) { if (err.empty()) err = "internal: element type mismatch at " + name; return; }
         // (fp16 data path, layers of >= 128 channels without an affine - ASPP branches, decoder convolutions, heads: an identity affine, so that conv_h8.hip, whose epilogue
         //  always reads one, takes them; fma(v, 1, 0) == v)
-        const bool ident = !affine && aes == 2 && Cout >= 128;
+        const bool ident = !affine && aes == 2 && Cout >= 32;
         p.scale = affine ? upload(scale) : ident ? upload(std::vector<float>((size_t)G * Cout, 1.f)) : nullptr;
         p.shift = affine ? upload(shift) : ident ? upload(std::vector<float>((size_t)G * Cout, 0.f)) : nullptr;
         for (size_t g = 0; g < dil_g.size() && g < 4; ++g) p.dil_g[g] = dil_g[g];      // per-group dilation (= padding) of a grouped launch
@@ -1757,14 +1758,14 @@ int quber_op_conv1x1_f16(const void* x, int32_t B, int32_t h, int32_t w, int32_t
 int quber_op_conv2d_f16(const void* x, int32_t B, int32_t h, int32_t w, int32_t cin, const void* w_packed, int32_t cout, int32_t ksize,
                         int32_t stride, int32_t pad, int32_t dil, int32_t kmode, const float* scale, const float* shift,
                         const void* residual, int32_t relu, double* gn_sums, int32_t gn_groups, void* y, void* stream) {
-    if (cin % 64) return fail("conv2d_f16: cin must be a multiple of 64");
+    if (cin % 8 || (kmode && cin % 64)) return fail("conv2d_f16: cin must be a multiple of 8 (slice-major K order: of 64)");
     if (ksize < 1 || stride < 1 || dil < 1 || pad < 0) return fail("conv2d_f16: bad geometry");
     ConvP p{};
     p.in = (const float*)x; p.w = (const float*)w_packed; p.scale = scale; p.shift = shift; p.res = (const float*)residual; p.out = (float*)y;
     p.B = B; p.H = h; p.W = w; p.Cin = cin; p.in_cs = cin;
     p.OH = (h + 2 * pad - dil * (ksize - 1) - 1) / stride + 1; p.OW = (w + 2 * pad - dil * (ksize - 1) - 1) / stride + 1;
     if (p.OH < 1 || p.OW < 1) return fail("conv2d_f16: empty output");
-    p.Cout = cout; p.out_cs = cout; p.res_cs = cout; p.K = ksize * ksize * cin; p.Kpad = p.K;
+    p.Cout = cout; p.out_cs = cout; p.res_cs = cout; p.K = ksize * ksize * cin; p.Kpad = (p.K + 63) / 64 * 64;      // (filter rows zero-filled up to Kpad)
     p.kh = ksize; p.kw = ksize; p.stride = stride; p.pad = pad; p.dil = dil; p.relu = relu;
     p.kmode = kmode;
     p.bf16 = 2; p.es = 2;

@@ -23,8 +23,9 @@ def pack(w, kmode):
     """OIHW -> [cout][K] in the kernels' K order (csrc/plan.hip emit_conv)."""
     co, ci, kh, kw = w.shape
     t = w.permute(0, 2, 3, 1).reshape(co, kh * kw, ci)               # [co][tap][ci]
-    if kmode == 0:
-        return t.reshape(co, kh * kw * ci).contiguous()
+    if kmode == 0:                                                    # tap-major, rows zero-filled to a multiple of 64 (one K-tile)
+        k = kh * kw * ci
+        return F.pad(t.reshape(co, k), (0, (k + 63) // 64 * 64 - k)).contiguous()
     return t.reshape(co, kh * kw, ci // 64, 64).permute(0, 2, 1, 3).reshape(co, kh * kw * ci).contiguous()
 
 
@@ -54,12 +55,25 @@ CASES = [
     (2, 32, 40, 128, 192, 3, 1, 1, 1, 1, True, False, False, 0, 2),      # 192 channels on 256-channel tiles (key 31 = 2)
     (1, 64, 64, 512, 512, 3, 1, 4, 4, 1, True, False, True, 0, 1),       # res5-like: K = 4608
     (1, 20, 24, 2048, 256, 1, 1, 0, 1, 0, True, False, True, 32, 1),     # long 1x1 (ASPP convs.0 / fusion_res5-like)
+    (2, 40, 52, 64, 64, 3, 1, 1, 1, 1, True, False, True, 0, 1),         # 64 channels (256 x 64 tiles): res2 conv2
+    (3, 37, 45, 256, 64, 1, 1, 0, 1, 0, True, True, True, 16, 1),        # 64 channels, 1x1, residual, norm sums in the epilogue (4 channels per group)
+    (2, 33, 47, 128, 64, 3, 1, 2, 2, 1, True, False, False, 32, 1),      # 64 channels, dilated, 2 channels per norm group (separate sums pass)
+    (2, 40, 52, 32, 64, 3, 1, 1, 1, 0, True, False, True, 0, 1),         # 32 input channels: two filter taps per K-tile (stem.conv3)
+    (3, 37, 45, 32, 64, 3, 1, 1, 1, 0, True, False, False, 0, 1),        # ... ragged tiles across image boundaries
+    (2, 40, 52, 32, 32, 3, 1, 1, 1, 0, True, False, True, 0, 1, 2),      # 32 > 32 channels on half-empty tiles (key 38 = 2: stem.conv2)
+    # the patch kernel (3x3, stride 1, pad 1, <= 128 output channels): 8 x 32-pixel tiles, the 10 x 34 patch of a 64-channel block fetched once
+    (3, 37, 45, 128, 128, 3, 1, 1, 1, 1, True, True, True, 0, 1),        # ragged tiles in both directions, residual, two channel blocks
+    (2, 20, 24, 320, 128, 3, 1, 1, 1, 1, True, False, False, 32, 1),     # images narrower than a tile, five channel blocks, norm sums in the epilogue
+    (1, 64, 96, 64, 128, 3, 1, 1, 1, 1, True, False, True, 0, 1),        # one channel block per tile: every patch is the NEXT tile's
+    (2, 33, 70, 128, 64, 3, 1, 1, 1, 1, True, True, False, 16, 1),       # 64 output channels, residual + norm sums
+    (2, 40, 52, 128, 32, 3, 1, 1, 1, 1, True, False, True, 0, 1, 2),     # 32 output channels on half-empty 64-channel tiles (key 38 = 2: the heads' 128 > 32)
 ]
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(str(v) for v in c[:10]))
 def test_h8_conv_matches_float32_convolution_and_the_128_tile_kernel(case):
-    B, H, W, cin, cout, k, stride, pad, dil, kmode, affine, residual, relu, groups, key31 = case
+    B, H, W, cin, cout, k, stride, pad, dil, kmode, affine, residual, relu, groups, key31 = case[:15]
+    key38 = case[15] if len(case) > 15 else 1
     lib = _lib.load()
     g = torch.Generator().manual_seed(1234 + cin + cout + k)
     x = torch.randn((B, H, W, cin), generator=g).half()
@@ -81,11 +95,13 @@ def test_h8_conv_matches_float32_convolution_and_the_128_tile_kernel(case):
     try:
         lib.quber_set_tuning(32, 1)            # these launches are a handful of tiles
         lib.quber_set_tuning(31, key31)
+        lib.quber_set_tuning(38, key38)
         y, sums = run(lib, *args)
         lib.quber_set_tuning(31, 0)
         y0, sums0 = run(lib, *args)
     finally:
         lib.quber_set_tuning(31, 1)
+        lib.quber_set_tuning(38, 1)
         lib.quber_set_tuning(32, 224)
     assert torch.isfinite(y).all()
     tol = 3e-3 * max(1.0, float(ref.abs().max()))
@@ -116,14 +132,18 @@ def test_h8_takes_the_wide_layers_of_the_network(h, w, b, grouped):
     offs = np.stack([encode_np.encode_initial_masks(m) for m in batch["masks"]])
     bgr, dep, off = torch.from_numpy(batch["rgb"]).cuda(), torch.from_numpy(batch["depth"]).cuda(), torch.from_numpy(offs).cuda()
     outs, stages = {}, {}
-    for mode in (0, 1):
-        e.set_option(31, mode)
+    for mode in (0, 1, 2):                  # 2: the 128- / 256-channel tiles only (key 38 = 0)
+        e.set_option(31, min(mode, 1))
+        e.set_option(38, 0 if mode == 2 else 1)
         e.set_option(32, 16)
         e.profile_begin()
         outs[mode] = e.forward(bgr, dep, off).clone()
         stages[mode] = e.profile_end()
     names = [p_[0] for p_ in e.plan()]
     e.close()
+    # the 64-channel layers (stem.conv3 with two taps per K-tile, res2 conv1 / conv2, decoder.res3.project_conv) on 256 x 64 tiles
+    assert stages[1]["conv_gemm_h8"]["launches"] >= stages[2]["conv_gemm_h8"]["launches"] + 5
+    assert float((outs[1] - outs[2]).abs().max()) < 2e-2 * max(1.0, float(outs[2].abs().max()))
     assert torch.isfinite(outs[1]).all()
     # the kernel is on the path: the stage profile shows its launches (fusion convolutions, res4 / res5 bottlenecks), none with key 31 = 0
     assert "conv_gemm_h8" not in stages[0] and stages[1]["conv_gemm_h8"]["launches"] >= 10

@@ -17,7 +17,8 @@ def pack(w, kmode):
     co, ci, kh, kw = w.shape
     t = w.permute(0, 2, 3, 1).reshape(co, kh * kw, ci)
     if kmode == 0:
-        return t.reshape(co, -1).contiguous()
+        k = kh * kw * ci
+        return torch.nn.functional.pad(t.reshape(co, k), (0, (k + 63) // 64 * 64 - k)).contiguous()
     return t.reshape(co, kh * kw, ci // 64, 64).permute(0, 2, 1, 3).reshape(co, -1).contiguous()
 
 
@@ -46,6 +47,9 @@ def main():
         ("head.0 / fusion_layers 3x3 128>128", s4, 128, 128, 3, 1, False, True),
         ("res3.conv2 3x3 128>128", s8, 128, 128, 3, 1, False, False),
         ("decoder.res3.fuse_conv.0 3x3 320>128", s8, 320, 128, 3, 1, False, True),
+        ("stem.conv3 3x3 32>64", S // 2, 32, 64, 3, 1, False, False),
+        ("res2.conv2 3x3 64>64", s4, 64, 64, 3, 1, False, False),
+        ("res2.conv1 1x1 256>64", s4, 256, 64, 1, 1, False, False),
     ]
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     print(f"| layer (batch {B}, {S}x{S} frame) | GFLOP | conv_igemm ms | TFLOP/s | conv_h8 ms | TFLOP/s | ratio |")
@@ -55,7 +59,7 @@ def main():
             continue
         g = torch.Generator().manual_seed(1)
         x = torch.randn((B, H, H, cin), generator=g).half().cuda()
-        kmode = 1 if k == 3 else 0
+        kmode = 1 if k == 3 and cin % 64 == 0 else 0
         w = pack((torch.randn((cout, cin, k, k), generator=g) / (cin * k * k) ** 0.5).half(), kmode).cuda()
         scale, shift = torch.ones(cout).cuda(), torch.zeros(cout).cuda()
         res = torch.randn((B, H, H, cout), generator=g).half().cuda() if residual else None

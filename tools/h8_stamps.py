@@ -33,6 +33,9 @@ for ti in range(int(ok.sum(1).max())):
     pre, loop, epi = v[:, 1] - v[:, 0], v[:, 2] - v[:, 1], v[:, 3] - v[:, 2]
     mid = v[:, 5] - v[:, 4]
     line = f"tile {ti}: setup+stagger p50 {np.median(pre):7.0f}  K loop p50 {np.median(loop):8.0f}  epilogue p50 {np.median(epi):7.0f} max {epi.max():7.0f}  steady K-tiles [4, nk-4) p50 {np.median(mid):8.0f} cycles"
+    if v[:, 6].any():     # the 256 x 128 / 256 x 64 kernels stamp the starts of K-tiles 1, 2, 3 instead
+        line = (f"tile {ti}: setup+stagger p50 {np.median(pre):7.0f}  K loop p50 {np.median(loop):8.0f}  epilogue p50 {np.median(epi):7.0f} max {epi.max():7.0f}  "
+                f"K-tile 0 p50 {np.median(v[:, 4] - v[:, 1]):6.0f}  K-tile 1 {np.median(v[:, 5] - v[:, 4]):6.0f}  K-tile 2 {np.median(v[:, 6] - v[:, 5]):6.0f}")
     if ti + 1 < 16 and ok[:, ti + 1].any():
         nxt = s[:, ti + 1][ok[:, ti + 1]]
         both = ok[:, ti] & ok[:, ti + 1]
