@@ -305,9 +305,10 @@ double quber_forward_flops_padding(quber_ctx* ctx);
  *         wave that is not multiplying); the same six partial products in the same order as conv_igemm.hip's bf16x3 kernels.
  *         0 = those kernels everywhere, 2 = every covered launch (tests).
  * key 36 (2; launch) fewest rounds of tiles (tiles / CUs), key 37 (8; launch) fewest K-slices of 32 of a launch that key 35 = 1 takes.
- * key 38 (1; launch) fp16 data path: the 64-channel layers (stem.conv3, res2 conv1 / conv2, resnet.py:37-63, 395-449) on 256 x 64 tiles of
- *         key 31's pipeline, two filter taps per 128-byte K-tile row where the input has 32 channels; 0 = conv_igemm.hip there, 2 = also the
- *         32-channel outputs (half-empty tiles).
+ * key 38 (1; launch) fp16 data path: the undilated 3x3 / stride 1 layers with the pixel operand as an LDS patch - a tile is 8 x 32 output
+ *         pixels, the 10 x 34-pixel patch of a 64-channel block is fetched once and the nine taps read it at shifted addresses, instead of
+ *         nine DMA gathers (conv_h8.hip: conv_h8p_kernel up to 128 output channels, conv_h8w_kernel 256 and more, conv_h8s_kernel the stem's
+ *         32-channel inputs with LDS-resident filters); 0 = key 31's DMA-gather kernels / conv_igemm.hip there, 2 = only up to 128 channels.
  * Process-only keys (quber_set_tuning): key 2 = give the stand-alone conv ops a split-K workspace (value != 0) or drop it (0);
  * key 11 = stand-alone conv op: dilated 3x3 layers in tap-major K order with the zero-padding filter rows skipped;
  * key 12 = stand-alone conv ops: quber_config.compute_dtype of the launch (1 = bf16 / 2 = fp16 operands, 3 = bf16x3);

@@ -175,7 +175,8 @@ struct Tuning {
                                  //   conv_igemm.hip.  OFF by default: the persistent kernels already sit at the clock-limited bound - in the network it measured 33.08 against 32.94 ms per step
                                  //   (profiles/r11_f8.md); 1 = where its tile count fits, 2 = every covered launch (tests)
     int f8_min_rounds = 3;       // key 34 (launch): fewest rounds of tiles (tiles / CUs) of a launch that takes it
-    int h8_narrow = 1;           // key 38 (launch): fp16 data path: the undilated 3x3 layers of up to 128 output channels with the pixel operand as an LDS patch (conv_h8.hip conv_h8p_kernel); 0 = the 256 x 128-tile kernel / conv_igemm.hip there
+    int h8_narrow = 1;           // key 38 (launch): fp16 data path: the undilated 3x3 layers with the pixel operand as an LDS patch (conv_h8.hip conv_h8p / h8w / h8s kernels); 0 = the DMA-gather kernels /
+                                 //   conv_igemm.hip there, 2 = only the layers of up to 128 output channels
     int h8_min_tiles = 224;      // key 32 (launch): fewest tiles (all groups) of a launch that takes it (one block per CU: a launch of fewer tiles leaves CUs idle)
 };
 extern Tuning g_tune;

@@ -680,7 +680,7 @@ constexpr int P8_PATCH = 48 * 1024;            // 8 waves x 6 pieces of 8 pixels
 
 template <int QT, bool RES, bool GN>
 __device__ __forceinline__ void p8_epilogue(const ConvP& p, const f32x4 (&acc)[QT][4], unsigned gacc_b, unsigned ssaddr, int b, int y0, int x0, int g,
-                                            int t, int wp, int wq, int fr, int fq) {
+                                            int t, int wp, int wq, int fr, int fq, int n0 = 0) {
     const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<_Float16*>(p.out) + (long)g * p.out_gs, 0, p.pk_min, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<_Float16*>(reinterpret_cast<const _Float16*>(p.res)) + (RES ? (long)g * p.res_gs : 0), 0, RES ? p.pk_in2_bytes : 0, 0x00020000);
@@ -707,12 +707,12 @@ __device__ __forceinline__ void p8_epilogue(const ConvP& p, const f32x4 (&acc)[Q
     }
 #pragma unroll
     for (int gg = 0; gg < QT / 2; ++gg) {
-        const int nl = QT * 16 * wq + 32 * gg + 8 * fq_e;
-        const bool colok = nl < p.Cout;
+        const int nl = QT * 16 * wq + 32 * gg + 8 * fq_e;       // first of this lane's 8 channels inside the channel tile
+        const bool colok = n0 + nl < p.Cout;
         u32x4 rbuf[4];
         if constexpr (RES) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) rbuf[i] = __builtin_amdgcn_raw_buffer_load_b128(rsr, pok[i] && colok ? (pixoff[i] * p.res_cs + nl) * 2 : H8_OOB, 0, 0);
+            for (int i = 0; i < 4; ++i) rbuf[i] = __builtin_amdgcn_raw_buffer_load_b128(rsr, pok[i] && colok ? (pixoff[i] * p.res_cs + n0 + nl) * 2 : H8_OOB, 0, 0);
         }
         f32x4 sc0, sc1, sh0, sh1;
         {
@@ -740,7 +740,7 @@ __device__ __forceinline__ void p8_epilogue(const ConvP& p, const f32x4 (&acc)[Q
                 h[e] = h16x2{(_Float16)x0_, (_Float16)x1_};
             }
             const u32x4 pk = {__builtin_bit_cast(unsigned, h[0]), __builtin_bit_cast(unsigned, h[1]), __builtin_bit_cast(unsigned, h[2]), __builtin_bit_cast(unsigned, h[3])};
-            __builtin_amdgcn_raw_buffer_store_b128(pk, rso, pok[i] && colok ? (pixoff[i] * p.out_cs + nl) * 2 : H8_OOB, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(pk, rso, pok[i] && colok ? (pixoff[i] * p.out_cs + n0 + nl) * 2 : H8_OOB, 0, 0);
             if constexpr (GN) {
                 const h16x2 one = {(_Float16)1.f, (_Float16)1.f};
                 const float a = __builtin_amdgcn_fdot2(h[1], one, __builtin_amdgcn_fdot2(h[0], one, 0.f, false), false);
@@ -752,7 +752,7 @@ __device__ __forceinline__ void p8_epilogue(const ConvP& p, const f32x4 (&acc)[Q
             }
         }
         if constexpr (GN) {
-            const int grp0 = (int)h8_div((unsigned)nl, p.dv_m[4], p.dv_s[4]), grp1 = (int)h8_div((unsigned)(nl + 4), p.dv_m[4], p.dv_s[4]);
+            const int grp0 = (int)h8_div((unsigned)(n0 + nl), p.dv_m[4], p.dv_s[4]), grp1 = (int)h8_div((unsigned)(n0 + nl + 4), p.dv_m[4], p.dv_s[4]);
             auto row_sum = [](float x) __attribute__((always_inline)) {
                 x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xf, 0xf, true));
                 x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x112, 0xf, 0xf, true));
@@ -988,6 +988,205 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 
+// The patch form for the WIDE undilated 3x3 layers (fusion_res2 / res3 conv0, conv1, resnet.py:472-485; res4 conv2): tile = 8 x 32 pixels x 256
+// channels, the four phases and the wave layout of conv_h8_kernel (64 pixels x 128 channels per wave), filters one K-tile ahead in two 32 KB
+// images, the pixel operand from two 43 KB patch buffers.  Per K-tile 32 KB of filters + 1/9 of a patch cross L2 -> LDS instead of 64 KB.
+// Channel tiles of one pixel tile are neighbours in the tile order (the patch of the second comes from L2).
+constexpr int W8_PATCH = 43 * 1024;            // 43 pieces of 8 pixels (340 pixels), no slack: a wave issues piece 8 j + wave only below 43
+
+template <bool RES, bool GN>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_h8w_kernel(const ConvP p) {
+    constexpr int QT = 8;
+    constexpr int WIMG = 256 * H8_KB, QHALF = 128 * H8_KB;
+    constexpr int WBASE = 2 * W8_PATCH, GACC = WBASE + 2 * WIMG, SSBASE = GACC + 1024;
+    static_assert(SSBASE + 2 * H8_SS <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SSBASE + 2 * H8_SS];
+
+    const int t = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+    const int wp = wave & 3, wq = wave >> 2;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int ncb = p.Kpad / (9 * 32);
+
+    int tile, tile_step, tile_end;
+    {
+        const int bid = blockIdx.x, nblk = gridDim.x, T = p.pk_T;
+        const int xcd = bid & 7, q = T >> 3, r = T & 7;
+        const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        tile_end = start + q + (xcd < r ? 1 : 0);
+        tile_step = (nblk >> 3) + (xcd < (nblk & 7) ? 1 : 0);
+        tile = start + (bid >> 3);
+    }
+    // (two lambdas, evaluated late: the next tile's patch offsets replace this tile's when its last channel block starts, its filter rows
+    //  when the last K-tile starts - 256 registers hold 128 accumulators and 48 fragment registers, a second set of offsets would spill)
+    auto patch_state = [&](int tl, int (&poff)[6], int& tb, int& ty0, int& tx0, int& tg, int& tn0) __attribute__((always_inline)) {
+        const int t1 = (int)h8_div((unsigned)tl, p.dv_m[3], p.dv_s[3]);        // / channel tiles
+        tn0 = (tl - t1 * p.ksplit) * 256;
+        tg = (int)h8_div((unsigned)t1, p.dv_m[2], p.dv_s[2]);                  // / pixel tiles per group
+        const int rem = t1 - tg * p.pk_tpg;
+        tb = (int)h8_div((unsigned)rem, p.dv_m[0], p.dv_s[0]);
+        const int r2 = rem - tb * p.mtiles;
+        const int tyi = (int)h8_div((unsigned)r2, p.dv_m[1], p.dv_s[1]);
+        ty0 = tyi * P8_TY;
+        tx0 = (r2 - tyi * p.ntiles) * P8_TX;
+        const int gin = tg * (int)p.in_gs * 4;
+        const int pc7 = lane & 7, prow = lane >> 3;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int P = 8 * (8 * j + wave) + prow;
+            const int pr = P / P8_PW, pc = P - pr * P8_PW;
+            const int y = ty0 - 1 + pr, x = tx0 - 1 + pc;
+            const bool ok = P < P8_PIX && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+            poff[j] = ok ? gin + (((tb * p.H + y) * p.W + x) * p.in_cs) * 4 + ((pc7 ^ ((pc >> 1) & 7)) << 4) : H8_OOB;
+        }
+    };
+    auto filter_state = [&](int tg, int tn0, int (&boff)[4]) __attribute__((always_inline)) {
+        const int gw = tg * (int)p.w_gs * 4;
+        const int pc7 = lane & 7, prow = lane >> 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int R = 128 * (i >> 1) + 8 * (2 * wave + (i & 1)) + prow;
+            const int chunk = pc7 ^ (((R >> 1) & 1) | (((R >> 3) & 3) << 1));
+            boff[i] = tn0 + R < p.Cout ? gw + ((tn0 + R) * p.Kpad) * 4 + chunk * 16 : H8_OOB;
+        }
+    };
+    int poff[6], boff[4];
+    int b, y0, x0, g, n0, bN = 0, y0N = 0, x0N = 0, gN = 0, n0N = 0;
+    patch_state(tile, poff, b, y0, x0, g, n0);
+    filter_state(g, n0, boff);
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.lean_in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.pk_in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.scale), 0, p.h8_ss_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.shift), 0, p.h8_ss_bytes, 0x00020000);
+    auto dma = [&](const __amdgpu_buffer_rsrc_t rs, int lds_off, int voff, int soff) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + lds_off), 16, voff, soff, 0, 0);
+    };
+    auto issue_ss = [&](int buf, int tg, int tn0) __attribute__((always_inline)) {
+        if (wave == 0) {
+            const int off = (tg * p.ss_gs + tn0) * 4 + lane * 16;
+            dma(rss, SSBASE + buf * H8_SS, off, 0);
+            dma(rsh, SSBASE + buf * H8_SS + 1024, off, 0);
+        }
+    };
+    int ssb = 0;
+
+    const int sq = ((fr & 3) >> 1) | ((fr >> 2) << 1);
+    // (k-step 1 = chunk | 4: the swizzled offset of k-step 0 with bit 6 flipped; pixel tile i = tile 0 + a constant)
+    int qaddr[2];
+    qaddr[0] = WBASE + (128 * wq + 8 * (fr >> 2) + (fr & 3)) * H8_KB + ((fq ^ sq) << 4);
+    qaddr[1] = qaddr[0] ^ 64;
+    const int pP0 = (2 * wp * P8_PW + fr) * H8_KB;
+
+    f32x4 acc[QT][4];
+    h16x8 pf[2][4], qf[4];
+
+    // ---- prologue: the first patch, filter K-tile 0 ----
+    issue_ss(0, g, n0);
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+        if (j < 5 || wave < 3) dma(rsa, (8 * j + wave) * 1024, poff[j], 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma(rsb, WBASE + (i >> 1) * QHALF + (2 * wave + (i & 1)) * 1024, boff[i], 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int cbuf = 0, wimg = 0;                       // patch buffer of the block / filter image of the K-tile being multiplied
+
+#define H8W_READ_Q(JH, KS)                                                                                             \
+    _Pragma("unroll") for (int c4 = 0; c4 < 4; ++c4) {                                                                  \
+        const int c = 4 * (JH) + c4;                                                                                    \
+        qf[c4] = *reinterpret_cast<const h16x8*>(smem + wb + qaddr[KS] + ((c >> 1) * 32 + (c & 1) * 4) * H8_KB);         \
+    }
+#define H8W_MMA(JH, KS)                                                                                                \
+    __builtin_amdgcn_s_barrier();                                                                                       \
+    __builtin_amdgcn_s_setprio(1);                                                                                      \
+    _Pragma("unroll") for (int c4 = 0; c4 < 4; ++c4)                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                   \
+            acc[4 * (JH) + c4][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[c4], pf[KS][i], acc[4 * (JH) + c4][i], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                                      \
+    __builtin_amdgcn_s_barrier();
+
+    for (;;) {
+        const bool has_next = tile + tile_step < tile_end;
+#pragma unroll
+        for (int c = 0; c < QT; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[c][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (wq == 1) __builtin_amdgcn_s_barrier();      // stagger: waves 4-7 run half a phase behind their SIMD partners
+
+        for (int cb = 0; cb < ncb; ++cb) {
+            const bool last = cb + 1 == ncb;
+            const int pb = cbuf * W8_PATCH;
+            if (last) {                                 // from here on the patch pieces are the next tile's (zeros past the last tile)
+                if (has_next) {
+                    patch_state(tile + tile_step, poff, bN, y0N, x0N, gN, n0N);
+                    issue_ss(ssb ^ 1, gN, n0N);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) poff[j] = H8_OOB;
+                }
+            }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap - 3 * (tap / 3);
+                const int wb = wimg * WIMG, wn = (wimg ^ 1) * WIMG;
+                const int toff = pb + (ky * P8_PW + kx) * H8_KB;
+                // the next K-tile's filters: tap + 1 of this block, tap 0 of the next one, or K-tile 0 of the next tile
+                const bool nxt_tile = tap == 8 && last;
+                const int kq = nxt_tile ? 0 : 9 * cb + tap + 1;
+                if (nxt_tile) {                         // (this tile's last K-tile is in LDS: the filter rows become the next tile's)
+                    if (has_next) {
+                        filter_state(gN, n0N, boff);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) boff[i] = H8_OOB;
+                    }
+                }
+                int fr_o = fr;                           // (opaque: the swizzle terms are recomputed per tap instead of living in 24 registers)
+                asm volatile("" : "+v"(fr_o));
+                const int sw0 = pP0 + ((fq ^ (((fr_o + kx) >> 1) & 7)) << 4), sw1 = sw0 ^ 64;
+                // phase 0: channel tiles 0-3, k-step 0; DMA: filter half 0 of the next K-tile
+                H8W_READ_Q(0, 0)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pf[0][i] = *reinterpret_cast<const h16x8*>(smem + toff + ((i >> 1) * P8_PW + 16 * (i & 1)) * H8_KB + sw0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) dma(rsb, WBASE + wn + (2 * wave + j) * 1024, boff[j], kq * H8_KB);
+                H8W_MMA(0, 0)
+                // phase 1: channel tiles 4-7, k-step 0; DMA: filter half 1
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pf[1][i] = *reinterpret_cast<const h16x8*>(smem + toff + ((i >> 1) * P8_PW + 16 * (i & 1)) * H8_KB + sw1);
+                __builtin_amdgcn_sched_barrier(0);
+                H8W_READ_Q(1, 0)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) dma(rsb, WBASE + wn + QHALF + (2 * wave + j) * 1024, boff[2 + j], kq * H8_KB);
+                asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                H8W_MMA(1, 0)
+                // phase 2: channel tiles 4-7, k-step 1; DMA: piece `tap` of the next block's patch (taps 0-5)
+                H8W_READ_Q(1, 1)
+                const bool piece = tap < 5 || (tap == 5 && wave < 3);
+                if (piece) dma(rsa, (cbuf ^ 1) * W8_PATCH + (8 * tap + wave) * 1024, poff[tap < 6 ? tap : 0], last ? 0 : (cb + 1) * H8_KB);
+                H8W_MMA(1, 1)
+                // phase 3: channel tiles 0-3, k-step 1; the next K-tile's filters have landed after this wait + barrier pair
+                H8W_READ_Q(0, 1)
+                if (piece) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                H8W_MMA(0, 1)
+                wimg ^= 1;
+            }
+            cbuf ^= 1;
+        }
+        if (wq == 0) __builtin_amdgcn_s_barrier();
+
+        p8_epilogue<QT, RES, GN>(p, acc, GACC, SSBASE + ssb * H8_SS, b, y0, x0, g, t, wp, wq, fr, fq, n0);
+        if (!has_next) break;
+        tile += tile_step;
+        b = bN; y0 = y0N; x0 = x0N; g = gN; n0 = n0N;
+        ssb ^= 1;
+    }
+#undef H8W_READ_Q
+#undef H8W_MMA
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // ------------------------------------------------------------------------------------------------------------------------------
 // The stem's 3x3 layers of 32 input channels (stem.conv2 32 -> 32, stem.conv3 32 -> 64, resnet.py:37-63): K = 9 taps x 32 channels, one
 // MFMA k-step per tap.  Everything is LDS-resident: the filters of both streams are fetched once per block (5 K-tiles x 64 rows x 128
@@ -1189,11 +1388,15 @@ int launch_conv_h8p(ConvP p, int G, hipStream_t st) {
                       p.ss_gs % 4 == 0 && (((uintptr_t)p.scale & 15) == 0) && (((uintptr_t)p.shift & 15) == 0) && p.in_cs % 4 == 0;
     if (!vec8) return 1;
     const int ntx = (p.W + P8_TX - 1) / P8_TX, nty = (p.H + P8_TY - 1) / P8_TY;
-    const long tiles = (long)G * p.B * nty * ntx;
+    const bool wide = p.Cout > 128;       // conv_h8w_kernel: channel tiles of 256
+    const int ntn = wide ? (p.Cout + 255) / 256 : 1;
+    const long tiles = (long)G * p.B * nty * ntx * ntn;
     if (tiles < tune().h8_min_tiles || tiles > 0x3fffffff) return 1;
     p.ntiles = ntx;
-    p.mtiles = nty * ntx;                 // tiles per image
-    p.pk_tpg = p.B * p.mtiles;
+    p.mtiles = nty * ntx;                 // pixel tiles per image
+    p.pk_tpg = p.B * p.mtiles;            // ... per group
+    p.ksplit = ntn;                       // channel tiles (fastest in the tile order)
+    h8_magic((unsigned)ntn, p.dv_m[3], p.dv_s[3]);
     p.pk_T = (int)tiles;
     p.lean_in_bytes = (int)in_all;
     p.pk_in_bytes = (int)w_all;
@@ -1220,8 +1423,12 @@ int launch_conv_h8p(ConvP p, int G, hipStream_t st) {
         const double conv_flops = 2.0 * G * (double)p.M * p.K * p.Cout * 2.0;
         ProfScope prof(p.tag ? p.tag : "conv_gemm_h8", conv_bytes, conv_flops, st);
         const dim3 grid((int)std::min<long>(tiles, cus)), block(512);
-        const int variant = (p.Cout > 64 ? 4 : 0) | (p.res ? 2 : 0) | (p.gn_sum ? 1 : 0);
+        const int variant = (wide ? 8 : p.Cout > 64 ? 4 : 0) | (p.res ? 2 : 0) | (p.gn_sum ? 1 : 0);
         switch (variant) {
+            case 8: hipLaunchKernelGGL((conv_h8w_kernel<false, false>), grid, block, 0, st, p); break;
+            case 9: hipLaunchKernelGGL((conv_h8w_kernel<false, true>), grid, block, 0, st, p); break;
+            case 10: hipLaunchKernelGGL((conv_h8w_kernel<true, false>), grid, block, 0, st, p); break;
+            case 11: hipLaunchKernelGGL((conv_h8w_kernel<true, true>), grid, block, 0, st, p); break;
             case 0: hipLaunchKernelGGL((conv_h8p_kernel<2, false, false>), grid, block, 0, st, p); break;
             case 1: hipLaunchKernelGGL((conv_h8p_kernel<2, false, true>), grid, block, 0, st, p); break;
             case 2: hipLaunchKernelGGL((conv_h8p_kernel<2, true, false>), grid, block, 0, st, p); break;
@@ -1299,9 +1506,10 @@ int launch_conv_h8(ConvP p, int G, hipStream_t st) {
         const int rc = launch_conv_h8s(p, G, st);
         if (rc != 1) return rc;
     }
-    // the patch kernel (conv_h8p_kernel): 3x3, stride 1, pad 1, undilated, slice-major K, 128 / 64 / 32 output channels (32: on half-empty 64-channel tiles)
+    // the patch kernels (conv_h8p_kernel, conv_h8w_kernel): 3x3, stride 1, pad 1, undilated, slice-major K; 128 / 64 / 32 output channels (32: on half-empty
+    // 64-channel tiles), 256 and more on channel tiles of 256 (key 38 = 2: those stay on conv_h8_kernel)
     if (tune().h8_narrow && p.kh == 3 && p.kw == 3 && p.kmode == 1 && p.stride == 1 && p.pad == 1 && p.dil == 1 && !p.dil_g[0] && !p.in2 && p.Cin % 32 == 0 &&
-        p.K == p.Kpad && p.K == 9 * p.Cin && (p.Cout == 128 || p.Cout == 64 || p.Cout == 32) && p.OH == p.H && p.OW == p.W) {
+        p.K == p.Kpad && p.K == 9 * p.Cin && (p.Cout == 128 || p.Cout == 64 || p.Cout == 32 || (p.Cout >= 256 && tune().h8_narrow != 2)) && p.OH == p.H && p.OW == p.W) {
         const int rc = launch_conv_h8p(p, G, st);
         if (rc != 1) return rc;
     }

@@ -1,4 +1,5 @@
-"""GPU: the 256 x 256-tile LDS-DMA convolution kernel of the fp16 data path (csrc/conv_h8.hip) through the C ABI
+"""GPU: the LDS-DMA convolution kernels of the fp16 data path (csrc/conv_h8.hip: the 256 x 256 / 256 x 128-tile DMA-gather kernels, and
+the patch kernels of the undilated 3x3 layers - conv_h8p / h8w / h8s, option key 38) through the C ABI
 (quber_op_conv2d_f16), against a float32 CPU convolution of the same fp16 operands (torch, the oracle's arithmetic for
 one layer: oracle/network_torch.py runs the reference's F.conv2d) and against the 128 x 128 kernel it replaces
 (conv_igemm.hip, option key 31 = 0).
@@ -60,13 +61,18 @@ CASES = [
     (2, 33, 47, 128, 64, 3, 1, 2, 2, 1, True, False, False, 32, 1),      # 64 channels, dilated, 2 channels per norm group (separate sums pass)
     (2, 40, 52, 32, 64, 3, 1, 1, 1, 0, True, False, True, 0, 1),         # 32 input channels: two filter taps per K-tile (stem.conv3)
     (3, 37, 45, 32, 64, 3, 1, 1, 1, 0, True, False, False, 0, 1),        # ... ragged tiles across image boundaries
-    (2, 40, 52, 32, 32, 3, 1, 1, 1, 0, True, False, True, 0, 1, 2),      # 32 > 32 channels on half-empty tiles (key 38 = 2: stem.conv2)
+    (2, 40, 52, 32, 32, 3, 1, 1, 1, 0, True, False, True, 0, 1),         # 32 > 32 channels (stem.conv2)
     # the patch kernel (3x3, stride 1, pad 1, <= 128 output channels): 8 x 32-pixel tiles, the 10 x 34 patch of a 64-channel block fetched once
     (3, 37, 45, 128, 128, 3, 1, 1, 1, 1, True, True, True, 0, 1),        # ragged tiles in both directions, residual, two channel blocks
     (2, 20, 24, 320, 128, 3, 1, 1, 1, 1, True, False, False, 32, 1),     # images narrower than a tile, five channel blocks, norm sums in the epilogue
     (1, 64, 96, 64, 128, 3, 1, 1, 1, 1, True, False, True, 0, 1),        # one channel block per tile: every patch is the NEXT tile's
     (2, 33, 70, 128, 64, 3, 1, 1, 1, 1, True, True, False, 16, 1),       # 64 output channels, residual + norm sums
-    (2, 40, 52, 128, 32, 3, 1, 1, 1, 1, True, False, True, 0, 1, 2),     # 32 output channels on half-empty 64-channel tiles (key 38 = 2: the heads' 128 > 32)
+    (2, 40, 52, 128, 32, 3, 1, 1, 1, 1, True, False, True, 0, 1),        # 32 output channels on half-empty 64-channel tiles (the heads' 128 > 32)
+    # ... and its 256-channel form (conv_h8w_kernel): four phases, channel tiles of 256; key 38 = 2: the same layers on the DMA-gather kernel
+    (2, 40, 52, 64, 256, 3, 1, 1, 1, 1, True, False, True, 0, 1, 2),
+    (1, 36, 44, 64, 320, 3, 1, 1, 1, 1, True, False, False, 0, 1),       # ragged channel tile
+    (3, 37, 45, 128, 512, 3, 1, 1, 1, 1, True, True, True, 0, 1),        # two channel tiles, residual
+    (2, 33, 70, 256, 256, 3, 1, 1, 1, 1, True, False, False, 32, 1),     # norm sums in the epilogue
 ]
 
 
@@ -132,7 +138,7 @@ def test_h8_takes_the_wide_layers_of_the_network(h, w, b, grouped):
     offs = np.stack([encode_np.encode_initial_masks(m) for m in batch["masks"]])
     bgr, dep, off = torch.from_numpy(batch["rgb"]).cuda(), torch.from_numpy(batch["depth"]).cuda(), torch.from_numpy(offs).cuda()
     outs, stages = {}, {}
-    for mode in (0, 1, 2):                  # 2: the 128- / 256-channel tiles only (key 38 = 0)
+    for mode in (0, 1, 2):                  # 2: the DMA-gather kernels only (key 38 = 0)
         e.set_option(31, min(mode, 1))
         e.set_option(38, 0 if mode == 2 else 1)
         e.set_option(32, 16)
@@ -141,8 +147,8 @@ def test_h8_takes_the_wide_layers_of_the_network(h, w, b, grouped):
         stages[mode] = e.profile_end()
     names = [p_[0] for p_ in e.plan()]
     e.close()
-    # the 64-channel layers (stem.conv3 with two taps per K-tile, res2 conv1 / conv2, decoder.res3.project_conv) on 256 x 64 tiles
-    assert stages[1]["conv_gemm_h8"]["launches"] >= stages[2]["conv_gemm_h8"]["launches"] + 5
+    # the stem's 32-channel layers and res2 conv2 (64 channels) run on the patch kernels only
+    assert stages[1]["conv_gemm_h8"]["launches"] >= stages[2]["conv_gemm_h8"]["launches"] + 4
     assert float((outs[1] - outs[2]).abs().max()) < 2e-2 * max(1.0, float(outs[2].abs().max()))
     assert torch.isfinite(outs[1]).all()
     # the kernel is on the path: the stage profile shows its launches (fusion convolutions, res4 / res5 bottlenecks), none with key 31 = 0
@@ -188,6 +194,7 @@ def test_h8_random_geometries_are_deterministic_and_match():
             res = torch.randn((B, oh, ow, cout), generator=g).half().cuda() if residual else None
             args = (x, wp, cout, k, stride, pad, dil, 1 if k == 3 else 0, scale, shift, res, relu, groups)
             lib.quber_set_tuning(31, 1)
+            lib.quber_set_tuning(38, 1 + it % 2)          # (odd cases: the wide undilated 3x3 layers on the DMA-gather kernel)
             ys = [run(lib, *args) for _ in range(3)]
             lib.quber_set_tuning(31, 0)
             y0, _ = run(lib, *args)
@@ -201,4 +208,5 @@ def test_h8_random_geometries_are_deterministic_and_match():
                 assert torch.allclose(ys[0][1], exp, rtol=2e-6, atol=1e-4), what
     finally:
         lib.quber_set_tuning(31, 1)
+        lib.quber_set_tuning(38, 1)
         lib.quber_set_tuning(32, 224)
