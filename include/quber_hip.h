@@ -309,6 +309,9 @@ double quber_forward_flops_padding(quber_ctx* ctx);
  *         pixels, the 10 x 34-pixel patch of a 64-channel block is fetched once and the nine taps read it at shifted addresses, instead of
  *         nine DMA gathers (conv_h8.hip: conv_h8p_kernel up to 128 output channels, conv_h8w_kernel 256 and more, conv_h8s_kernel the stem's
  *         32-channel inputs with LDS-resident filters); 0 = key 31's DMA-gather kernels / conv_igemm.hip there, 2 = only up to 128 channels.
+ * key 39 (1; plan) fp16 data path: a patch-kernel layer of up to 128 output channels that is the only reader of a GroupNorm + ReLU output
+ *         (decoder fuse convolutions, the heads' second convolution: model.py:386-403, 610-651) applies that norm to its LDS patches - the
+ *         arithmetic of the norm pass, bit for bit, without the pass over the tensor in HBM; 0 = every norm is a pass of its own.
  * Process-only keys (quber_set_tuning): key 2 = give the stand-alone conv ops a split-K workspace (value != 0) or drop it (0);
  * key 11 = stand-alone conv op: dilated 3x3 layers in tap-major K order with the zero-padding filter rows skipped;
  * key 12 = stand-alone conv ops: quber_config.compute_dtype of the launch (1 = bf16 / 2 = fp16 operands, 3 = bf16x3);

@@ -65,6 +65,10 @@ struct ConvP {
     int dil_g[4];        // per-group dilation = padding of a grouped 3x3 launch (dil_g[0] == 0: `dil` / `pad` for every group); conv_h8.hip reads it, any other
                          //   kernel gets the groups one launch at a time (launch_conv)
     int h8_ss_bytes;     // conv_h8.hip: bytes of the scale / shift vectors over all groups (descriptor range)
+    // conv_h8.hip patch kernels: the GroupNorm (+ ReLU) of the INPUT tensor applied on the LDS patch (its producer's norm pass absorbed by this consumer):
+    // the sums [G][B][n_groups][2] and affine parameters of the tensor being read (null: none), the workspace for the per-(image, channel) coefficients
+    const double* n_stats; const float* n_gamma; const float* n_beta; float* n_coef;
+    int n_groups, n_param_gs, n_relu; float n_eps;
     int bf16;            // quber_config.compute_dtype: 0 = fp32 MFMA, 1 = bf16 / 2 = fp16 operands, 3 = fp32 operands split into 3 bf16 terms
 };
 
@@ -177,6 +181,8 @@ struct Tuning {
     int f8_min_rounds = 3;       // key 34 (launch): fewest rounds of tiles (tiles / CUs) of a launch that takes it
     int h8_narrow = 1;           // key 38 (launch): fp16 data path: the undilated 3x3 layers with the pixel operand as an LDS patch (conv_h8.hip conv_h8p / h8w / h8s kernels); 0 = the DMA-gather kernels /
                                  //   conv_igemm.hip there, 2 = only the layers of up to 128 output channels
+    int h8_norm = 1;             // key 39 (plan): fp16 data path: a patch-kernel layer applies the GroupNorm + ReLU in front of it to its LDS patches (same arithmetic as the norm pass, no pass over
+                                 //   the tensor in HBM); 0 = every norm is a pass of its own
     int h8_min_tiles = 224;      // key 32 (launch): fewest tiles (all groups) of a launch that takes it (one block per CU: a launch of fewer tiles leaves CUs idle)
 };
 extern Tuning g_tune;
@@ -198,6 +204,7 @@ int conv_persistent_segments(int T, int P, int nk, int min_slices, int bid, int*
 int conv_persistent_fixup(int T, int P, int nk, int min_slices, int xcd, int j, int* tile, int* slots, int cap);
 int launch_conv_dual(ConvP p, int G, hipStream_t st);   // 0 done, 1 not covered (run the two convolutions), -1 error
 int launch_conv_f8(ConvP p, int G, hipStream_t st);     // exact fp32 1x1 / grouped GEMM, 256 x 128 tiles (conv_f8.hip): 0 done, 1 not covered, -1 error
+bool conv_h8_patch_takes(const ConvP& p, int G, bool norm);     // conv_h8.hip: this launch (ConvP as launch_conv receives it) runs on a patch kernel [that can normalise its input]
 int launch_conv_x8(ConvP p, int G, hipStream_t st);     // bf16x3 1x1 / grouped GEMM, 256 x 128 tiles (conv_x8.hip): 0 done, 1 not covered, -1 error
 int launch_split_bf16x3(const float* w, long n, void* planes, hipStream_t st);     // w [n] -> bf16 terms [3][n]
 int launch_conv_h8(ConvP p, int G, hipStream_t st);     // fp16 data path, 256 x 256 tiles (conv_h8.hip): 0 done, 1 not covered, -1 error

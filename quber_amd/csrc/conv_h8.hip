@@ -673,7 +673,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // patch (43.5 KB, zero padding = out-of-range DMA lanes) is fetched ONCE and the nine taps' fragments are read from it at shifted
 // addresses; only the filters (BN x 128 bytes per K-tile) still stream.  Same wave layout, phases, ping-pong and epilogue
 // arithmetic as conv_h8n_kernel; per K-tile a wave issues NQ filter pieces and one patch piece (taps 0-5 of a block: piece `tap`
-// of the NEXT block's patch - or of the next tile's first - into the other patch buffer; taps 6-8: a dummy).  128-byte patch
+// of the NEXT block's patch - or of the next tile's first - into the other patch buffer).  128-byte patch
 // pixels, chunks XOR-swizzled by (patch column >> 1) & 7: shifting by a tap keeps every 16-lane read conflict-free.
 constexpr int P8_TY = 8, P8_TX = 32, P8_PW = P8_TX + 2, P8_PIX = (P8_TY + 2) * P8_PW;   // 340 patch pixels
 constexpr int P8_PATCH = 48 * 1024;            // 8 waves x 6 pieces of 8 pixels (>= 43 pieces)
@@ -785,14 +785,14 @@ __device__ __forceinline__ void p8_epilogue(const ConvP& p, const f32x4 (&acc)[Q
     }
 }
 
-template <int QT, bool RES, bool GN>
+template <int QT, bool RES, bool GN, bool NORM = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_h8p_kernel(const ConvP p) {
     using G = H8Geo<QT>;
     constexpr int BN = G::BN, NQ = BN / 64;
     constexpr int WIMG = BN * H8_KB;               // one K-tile of filters: BN rows x 128 bytes
-    constexpr int WBASE = 2 * P8_PATCH;            // [patch 0][patch 1][3 filter images][8 dummy pieces][GroupNorm sums][2 scale | shift images]
-    constexpr int DUMMY = WBASE + 3 * WIMG;
-    constexpr int GACC = DUMMY + 8192;
+    constexpr int WBASE = 2 * P8_PATCH;            // [patch 0][patch 1][3 filter images][input-norm coefficients][GroupNorm sums][2 scale | shift images]
+    constexpr int COEF = WBASE + 3 * WIMG;         // one image's [channel / 8][8 scales | 8 biases] floats, at most 512 channels
+    constexpr int GACC = COEF + 4096;
     constexpr int SSBASE = GACC + 1024;
     static_assert(SSBASE + 2 * H8_SS <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[SSBASE + 2 * H8_SS];
@@ -865,6 +865,52 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + lds_off), 16, voff, soff, 0, 0);
     };
 
+    // ---- NORM: the producer's GroupNorm (+ ReLU) applied to the patch in LDS, once per patch instead of a pass over the tensor in HBM ----
+    // y = half(max(fmaf(x, scale, bias), lo)) per (image, channel): the arithmetic of gn_apply_kernel (elementwise.hip), same bits.  A lane normalises,
+    // in each of its wave's pieces, pixel l >> 3 and the LOGICAL chunk l & 7 (its 16 coefficients of a channel block live in registers); pixels
+    // outside the image stay zero (the zero padding is applied AFTER the norm).  The coefficient image of the tile's frame sits in LDS; the next
+    // tile's replaces it when the last channel block starts (nothing reads the old one any more).
+    const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(NORM ? p.n_coef : p.scale), 0, NORM ? p.pk_debug : 0, 0x00020000);
+    auto issue_coef = [&](int tg, int tb) __attribute__((always_inline)) {
+        if constexpr (NORM) {
+            // (Cin counts 4-byte units of fp16 channels: 2 Cin channels x [scale, bias] floats = 16 Cin bytes per image)
+            const int o = wave * 1024 + lane * 16;
+            if (wave < 4) dma(rsc, COEF + wave * 1024, o < p.Cin * 16 ? (tg * p.B + tb) * p.Cin * 16 + o : H8_OOB, 0);
+        }
+    };
+    f32x4 cf[4];                                   // [scale 0-3][scale 4-7][bias 0-3][bias 4-7] of this lane's 8 channels
+    const float nlo = NORM && p.n_relu ? 0.f : -__builtin_inff();
+    auto load_cf = [&](int blk) __attribute__((always_inline)) {
+        if constexpr (NORM) {
+            const unsigned ad = COEF + (blk * 8 + (lane & 7)) * 64;
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(cf[0]), "=&v"(cf[1]), "=&v"(cf[2]), "=&v"(cf[3]) : "v"(ad) : "memory");
+        }
+    };
+    auto norm_piece = [&](int buf, int j, int off) __attribute__((always_inline)) {     // piece 8 j + wave of patch buffer `buf`, fetched with offset `off`
+        if constexpr (NORM) {
+            const int P = 8 * (8 * j + wave) + (lane >> 3);
+            const int pc = P - (P / P8_PW) * P8_PW;
+            const unsigned ad = buf * P8_PATCH + (8 * j + wave) * 1024 + (lane >> 3) * H8_KB + (((lane & 7) ^ ((pc >> 1) & 7)) << 4);
+            u32x4 x;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(x) : "v"(ad) : "memory");
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned y;
+                const float s0 = cf[e >> 1][2 * (e & 1)], s1 = cf[e >> 1][2 * (e & 1) + 1], b0 = cf[2 + (e >> 1)][2 * (e & 1)], b1 = cf[2 + (e >> 1)][2 * (e & 1) + 1];
+                float v0, v1;
+                asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(v0) : "v"(x[e]), "v"(s0), "v"(b0));
+                asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(v1) : "v"(x[e]), "v"(s1), "v"(b1));
+                asm("v_max_f32 %0, %1, %2" : "=v"(v0) : "v"(v0), "v"(nlo));
+                asm("v_max_f32 %0, %1, %2" : "=v"(v1) : "v"(v1), "v"(nlo));
+                const h16x2 h = {(_Float16)v0, (_Float16)v1};
+                y = __builtin_bit_cast(unsigned, h);
+                x[e] = y;
+            }
+            if (off != H8_OOB) asm volatile("ds_write_b128 %0, %1" :: "v"(ad), "v"(x) : "memory");
+        }
+    };
+
     // fragment addresses: filters as in conv_h8n_kernel; pixel tile i of this wave = row 2 wp + (i >> 1), columns 16 (i & 1) .. + 15 of the tile,
     // tap (ky, kx) = patch pixel (row + ky) * 34 + column + kx; the swizzle term depends on kx only
     const int sq = ((fr & 3) >> 1) | ((fr >> 2) << 1);
@@ -891,8 +937,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int h = 0; h < NQ; ++h)
             dma(rsb, WBASE + kq * WIMG + h * G::QHALF + wave * 1024, boff[h], kq * H8_KB);
+    issue_coef(g, b);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if constexpr (NORM) {
+        load_cf(0);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) norm_piece(0, j, poff[j]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
     int cbuf = 0;                                 // patch buffer of the block being multiplied
 
 #define H8P_MMA()                                                                                                       \
@@ -928,6 +982,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int cb = 0; cb < ncb; ++cb) {
             const bool last = cb + 1 == ncb;            // the block after this one is the next tile's first
             const int pb = cbuf * P8_PATCH;
+            if (NORM && last && has_next && (bN != b || gN != g)) issue_coef(gN, bN);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int ky = tap / 3, kx = tap - 3 * (tap / 3);
@@ -955,13 +1010,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) pf[i] = *reinterpret_cast<const h16x8*>(smem + toff + pP[i] + sw[kx][1]);
-                if (tap < 6) {
-                    const int j = tap;
-                    dma(rsa, (cbuf ^ 1) * P8_PATCH + (8 * j + wave) * 1024, last ? poffN[j] : poff[j], last ? 0 : (cb + 1) * H8_KB);
-                } else {
-                    dma(rsa, DUMMY + wave * 1024, H8_OOB, 0);
+                if (tap < 6) dma(rsa, (cbuf ^ 1) * P8_PATCH + (8 * tap + wave) * 1024, last ? poffN[tap < 6 ? tap : 0] : poff[tap < 6 ? tap : 0], last ? 0 : (cb + 1) * H8_KB);
+                if constexpr (NORM) {          // piece tap - 2 of the next block's patch landed a K-tile ago (the counted wait of tap - 1)
+                    if (tap == 2) load_cf(last ? 0 : cb + 1);
+                    if (tap >= 2 && tap < 8) norm_piece(cbuf ^ 1, tap - 2, last ? poffN[tap >= 2 && tap < 8 ? tap - 2 : 0] : poff[tap >= 2 && tap < 8 ? tap - 2 : 0]);
                 }
-                if constexpr (NQ == 2) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+                // everything but this step's own pieces (NQ filter pieces, one patch piece at taps 0-5) has landed after this wait
+                if (tap < 6) { if constexpr (NQ == 2) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); }
+                else { if constexpr (NQ == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory"); }
                 H8P_MMA()
             }
             cbuf ^= 1;
@@ -994,11 +1050,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // Channel tiles of one pixel tile are neighbours in the tile order (the patch of the second comes from L2).
 constexpr int W8_PATCH = 43 * 1024;            // 43 pieces of 8 pixels (340 pixels), no slack: a wave issues piece 8 j + wave only below 43
 
-template <bool RES, bool GN>
+template <bool RES, bool GN, bool NORM = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_h8w_kernel(const ConvP p) {
     constexpr int QT = 8;
     constexpr int WIMG = 256 * H8_KB, QHALF = 128 * H8_KB;
-    constexpr int WBASE = 2 * W8_PATCH, GACC = WBASE + 2 * WIMG, SSBASE = GACC + 1024;
+    constexpr int WBASE = 2 * W8_PATCH, COEF = WBASE + 2 * WIMG, GACC = COEF + 4096, SSBASE = GACC + 1024;      // (COEF: conv_h8p_kernel's input-norm coefficients)
     static_assert(SSBASE + 2 * H8_SS <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[SSBASE + 2 * H8_SS];
 
@@ -1069,6 +1125,45 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
     int ssb = 0;
+    // NORM (see conv_h8p_kernel): here the 16 coefficients of a lane's chunk are read from the LDS image per piece, in two halves - there is no
+    // register to keep them in - and a piece is normalised at the start of a tap, when no fragment is live
+    const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(NORM ? p.n_coef : p.scale), 0, NORM ? p.pk_debug : 0, 0x00020000);
+    auto issue_coef = [&](int tg, int tb) __attribute__((always_inline)) {
+        if constexpr (NORM) {
+            const int o = wave * 1024 + lane * 16;
+            if (wave < 4) dma(rsc, COEF + wave * 1024, o < p.Cin * 16 ? (tg * p.B + tb) * p.Cin * 16 + o : H8_OOB, 0);
+        }
+    };
+    const float nlo = NORM && p.n_relu ? 0.f : -__builtin_inff();
+    auto norm_piece = [&](int buf, int j, int blk, int ty0, int tx0) __attribute__((always_inline)) {     // (ty0, tx0: origin of the tile the patch belongs to)
+        if constexpr (NORM) {
+            const int P = 8 * (8 * j + wave) + (lane >> 3);
+            const int pr = P / P8_PW, pc = P - pr * P8_PW;
+            const bool inside = P < P8_PIX && (unsigned)(ty0 - 1 + pr) < (unsigned)p.H && (unsigned)(tx0 - 1 + pc) < (unsigned)p.W;
+            const unsigned ad = buf * W8_PATCH + (8 * j + wave) * 1024 + (lane >> 3) * H8_KB + (((lane & 7) ^ ((pc >> 1) & 7)) << 4);
+            const unsigned ac = COEF + (blk * 8 + (lane & 7)) * 64;
+            u32x4 x;
+            asm volatile("ds_read_b128 %0, %1" : "=&v"(x) : "v"(ad) : "memory");
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                f32x4 sc, bi;
+                if (hf == 0) asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:32\n\ts_waitcnt lgkmcnt(0)" : "=&v"(sc), "=&v"(bi) : "v"(ac) : "memory");
+                else asm volatile("ds_read_b128 %0, %2 offset:16\n\tds_read_b128 %1, %2 offset:48\n\ts_waitcnt lgkmcnt(0)" : "=&v"(sc), "=&v"(bi) : "v"(ac) : "memory");
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    const int e = 2 * hf + e2;
+                    float v0, v1;
+                    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(v0) : "v"(x[e]), "v"(sc[2 * e2]), "v"(bi[2 * e2]));
+                    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(v1) : "v"(x[e]), "v"(sc[2 * e2 + 1]), "v"(bi[2 * e2 + 1]));
+                    asm("v_max_f32 %0, %1, %2" : "=v"(v0) : "v"(v0), "v"(nlo));
+                    asm("v_max_f32 %0, %1, %2" : "=v"(v1) : "v"(v1), "v"(nlo));
+                    const h16x2 h = {(_Float16)v0, (_Float16)v1};
+                    x[e] = __builtin_bit_cast(unsigned, h);
+                }
+            }
+            if (inside) asm volatile("ds_write_b128 %0, %1" :: "v"(ad), "v"(x) : "memory");
+        }
+    };
 
     const int sq = ((fr & 3) >> 1) | ((fr >> 2) << 1);
     // (k-step 1 = chunk | 4: the swizzled offset of k-step 0 with bit 6 flipped; pixel tile i = tile 0 + a constant)
@@ -1087,8 +1182,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (j < 5 || wave < 3) dma(rsa, (8 * j + wave) * 1024, poff[j], 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) dma(rsb, WBASE + (i >> 1) * QHALF + (2 * wave + (i & 1)) * 1024, boff[i], 0);
+    issue_coef(g, b);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if constexpr (NORM) {
+#pragma unroll 1
+        for (int j = 0; j < 6; ++j)
+            if (j < 5 || wave < 3) norm_piece(0, j, 0, y0, x0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
     int cbuf = 0, wimg = 0;                       // patch buffer of the block / filter image of the K-tile being multiplied
 
 #define H8W_READ_Q(JH, KS)                                                                                             \
@@ -1120,6 +1223,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if (has_next) {
                     patch_state(tile + tile_step, poff, bN, y0N, x0N, gN, n0N);
                     issue_ss(ssb ^ 1, gN, n0N);
+                    if (NORM && (bN != b || gN != g)) issue_coef(gN, bN);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 6; ++j) poff[j] = H8_OOB;
@@ -1130,6 +1234,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int ky = tap / 3, kx = tap - 3 * (tap / 3);
                 const int wb = wimg * WIMG, wn = (wimg ^ 1) * WIMG;
                 const int toff = pb + (ky * P8_PW + kx) * H8_KB;
+                if constexpr (NORM) {          // piece tap - 2 of the next block's patch landed a K-tile ago
+                    if (tap >= 2 && tap < 8 && (tap < 7 || wave < 3)) norm_piece(cbuf ^ 1, tap >= 2 && tap < 8 ? tap - 2 : 0, last ? 0 : cb + 1, last ? y0N : y0, last ? x0N : x0);
+                }
                 // the next K-tile's filters: tap + 1 of this block, tap 0 of the next one, or K-tile 0 of the next tile
                 const bool nxt_tile = tap == 8 && last;
                 const int kq = nxt_tile ? 0 : 9 * cb + tap + 1;
@@ -1360,6 +1467,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+
+// per-(image, channel) scale and bias of a GroupNorm whose sums are in `stats` (the arithmetic of gn_apply_kernel, elementwise.hip), in the order
+// the patch kernels read them: [G][B][C / 8][8 scales | 8 biases]
+__global__ void h8_norm_coef_kernel(const double* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta, int G, int B, int C,
+                                    int groups, int param_gs, double n, float eps, float* __restrict__ coef) {
+    const long total = (long)G * B * C;
+    const int cpg = C / groups;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long gb = i / C;
+        const int g = (int)(gb / B);
+        const double* sb = stats + (gb * groups + c / cpg) * 2;
+        const double mean = sb[0] / n;
+        double var = sb[1] / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = rstd * gamma[g * param_gs + c];
+        float* dst = coef + (gb * (C / 8) + c / 8) * 16 + (c & 7);
+        dst[0] = sc;
+        dst[8] = beta[g * param_gs + c] - (float)mean * sc;
+    }
+}
+
 }  // namespace
 
 #ifdef H8_STAMPS
@@ -1378,6 +1508,14 @@ static void h8_magic(unsigned d, unsigned& m, unsigned& s) {
 }
 
 
+// the patch kernels (conv_h8p_kernel, conv_h8w_kernel): 3x3, stride 1, pad 1, undilated, slice-major K; 128 / 64 / 32 output channels (32: on half-empty
+// 64-channel tiles), 256 and more on channel tiles of 256 (key 38 = 2: those stay on conv_h8_kernel).  p: as launch_conv hands it over (4-byte K units)
+static bool h8_patch_shape(const ConvP& p) {
+    return tune().h8 && tune().h8_narrow && p.es == 2 && !p.prelu && !p.skip_rows && p.scale && p.kh == 3 && p.kw == 3 && p.kmode == 1 && p.stride == 1 && p.pad == 1 &&
+           p.dil == 1 && !p.dil_g[0] && !p.in2 && p.Cin % 32 == 0 && p.K == p.Kpad && p.K == 9 * p.Cin &&
+           (p.Cout == 128 || p.Cout == 64 || p.Cout == 32 || (p.Cout >= 256 && tune().h8_narrow != 2)) && p.OH == p.H && p.OW == p.W;
+}
+
 // the patch kernel's launch: tiles of 8 x 32 output pixels; returns 0 = launched, 1 = not covered, -1 = error
 int launch_conv_h8p(ConvP p, int G, hipStream_t st) {
     const long in_all = ((long)p.B * p.H * p.W * p.in_cs) * 4 + (long)(G - 1) * p.in_gs * 4, w_all = (long)p.Cout * p.Kpad * 4 + (long)(G - 1) * p.w_gs * 4;
@@ -1391,7 +1529,9 @@ int launch_conv_h8p(ConvP p, int G, hipStream_t st) {
     const bool wide = p.Cout > 128;       // conv_h8w_kernel: channel tiles of 256
     const int ntn = wide ? (p.Cout + 255) / 256 : 1;
     const long tiles = (long)G * p.B * nty * ntx * ntn;
-    if (tiles < tune().h8_min_tiles || tiles > 0x3fffffff) return 1;
+    const bool norm = p.n_stats != nullptr;     // (a launch that normalises its input has no other kernel to go to: it runs however few its tiles)
+    if ((tiles < tune().h8_min_tiles && !norm) || tiles > 0x3fffffff) return 1;
+    if (norm && (p.res || p.Cin > 256 || p.Kpad < 2 * 9 * 32 || !p.n_coef || p.n_groups < 1 || (2 * p.Cin) % p.n_groups)) return 1;
     p.ntiles = ntx;
     p.mtiles = nty * ntx;                 // pixel tiles per image
     p.pk_tpg = p.B * p.mtiles;            // ... per group
@@ -1410,6 +1550,15 @@ int launch_conv_h8p(ConvP p, int G, hipStream_t st) {
     const bool gn_sep = p.gn_sum && !(p.gn_cpg % 4 == 0 && p.gn_groups <= 32);
     double* const gn_sum = p.gn_sum;
     if (gn_sep) p.gn_sum = nullptr;
+    if (norm) {
+        const int C = 2 * p.Cin;
+        const long n = (long)G * p.B * C;
+        if (n * 8 >= 0x7fffff00L) return 1;
+        p.pk_debug = (int)(n * 8);            // bytes of the coefficient table (descriptor range)
+        hipLaunchKernelGGL(h8_norm_coef_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p.n_stats, p.n_gamma, p.n_beta, G, p.B, C, p.n_groups, p.n_param_gs,
+                           (double)p.H * p.W * (C / p.n_groups), p.n_eps, p.n_coef);
+        QB_CHECK(hipGetLastError());
+    }
     {
         static int cus = 0;
         if (!cus) {
@@ -1423,8 +1572,14 @@ int launch_conv_h8p(ConvP p, int G, hipStream_t st) {
         const double conv_flops = 2.0 * G * (double)p.M * p.K * p.Cout * 2.0;
         ProfScope prof(p.tag ? p.tag : "conv_gemm_h8", conv_bytes, conv_flops, st);
         const dim3 grid((int)std::min<long>(tiles, cus)), block(512);
-        const int variant = (wide ? 8 : p.Cout > 64 ? 4 : 0) | (p.res ? 2 : 0) | (p.gn_sum ? 1 : 0);
+        const int variant = (norm ? 16 : 0) | (wide ? 8 : p.Cout > 64 ? 4 : 0) | (p.res ? 2 : 0) | (p.gn_sum ? 1 : 0);
         switch (variant) {
+            case 24: hipLaunchKernelGGL((conv_h8w_kernel<false, false, true>), grid, block, 0, st, p); break;
+            case 25: hipLaunchKernelGGL((conv_h8w_kernel<false, true, true>), grid, block, 0, st, p); break;
+            case 16: hipLaunchKernelGGL((conv_h8p_kernel<2, false, false, true>), grid, block, 0, st, p); break;
+            case 17: hipLaunchKernelGGL((conv_h8p_kernel<2, false, true, true>), grid, block, 0, st, p); break;
+            case 20: hipLaunchKernelGGL((conv_h8p_kernel<4, false, false, true>), grid, block, 0, st, p); break;
+            case 21: hipLaunchKernelGGL((conv_h8p_kernel<4, false, true, true>), grid, block, 0, st, p); break;
             case 8: hipLaunchKernelGGL((conv_h8w_kernel<false, false>), grid, block, 0, st, p); break;
             case 9: hipLaunchKernelGGL((conv_h8w_kernel<false, true>), grid, block, 0, st, p); break;
             case 10: hipLaunchKernelGGL((conv_h8w_kernel<true, false>), grid, block, 0, st, p); break;
@@ -1506,13 +1661,11 @@ int launch_conv_h8(ConvP p, int G, hipStream_t st) {
         const int rc = launch_conv_h8s(p, G, st);
         if (rc != 1) return rc;
     }
-    // the patch kernels (conv_h8p_kernel, conv_h8w_kernel): 3x3, stride 1, pad 1, undilated, slice-major K; 128 / 64 / 32 output channels (32: on half-empty
-    // 64-channel tiles), 256 and more on channel tiles of 256 (key 38 = 2: those stay on conv_h8_kernel)
-    if (tune().h8_narrow && p.kh == 3 && p.kw == 3 && p.kmode == 1 && p.stride == 1 && p.pad == 1 && p.dil == 1 && !p.dil_g[0] && !p.in2 && p.Cin % 32 == 0 &&
-        p.K == p.Kpad && p.K == 9 * p.Cin && (p.Cout == 128 || p.Cout == 64 || p.Cout == 32 || (p.Cout >= 256 && tune().h8_narrow != 2)) && p.OH == p.H && p.OW == p.W) {
+    if (h8_patch_shape(p)) {
         const int rc = launch_conv_h8p(p, G, st);
         if (rc != 1) return rc;
     }
+    if (p.n_stats) return fail("conv (fp16 data path): a launch that normalises its input needs the patch kernel");
     if (p.Cin % 32 || p.K != p.Kpad || p.Kpad / 32 < 3) return 1;
     const bool k3 = p.kh == 3 && p.kw == 3 && p.kmode == 1;
     if (!k3 && !(p.kh == 1 && p.kw == 1 && p.pad == 0)) return 1;
@@ -1597,6 +1750,20 @@ int launch_conv_h8(ConvP p, int G, hipStream_t st) {
         return launch_gn_stats(o, p.B, G, p.gn_groups, gn_sum, st, false);
     }
     return 0;
+}
+
+// Would this launch (ConvP in ELEMENT units, as launch_conv receives it) run on a patch kernel - and, with `norm`, on one that can apply the producer's
+// GroupNorm to its input?  The plan asks before it lets a convolution absorb the norm pass in front of it (per launch: the keys may change between them).
+bool conv_h8_patch_takes(const ConvP& p0, int G, bool norm) {
+    ConvP p = p0;
+    if (p.es != 2 || p.bf16 != 2 || p.Cin % 8 || p.in_cs % 8 || p.Kpad % 64 || p.K % 2) return false;
+    p.Cin /= 2; p.in_cs /= 2; p.K /= 2; p.Kpad /= 2;
+    if (!h8_patch_shape(p)) return false;
+    if (!norm) return true;
+    const long tiles = (long)G * p.B * ((p.W + P8_TX - 1) / P8_TX) * ((p.H + P8_TY - 1) / P8_TY);
+    const bool vec8 = p.Cout % 8 == 0 && p.out_cs % 8 == 0 && p.out_gs % 8 == 0 && (((uintptr_t)p.out & 15) == 0) && p.ss_gs % 4 == 0 && (((uintptr_t)p.scale & 15) == 0) &&
+                      (((uintptr_t)p.shift & 15) == 0) && p.in_cs % 4 == 0;
+    return !p.res && p.Cin <= 256 && p.Kpad >= 2 * 9 * 32 && vec8 && tiles <= 0x3fffffff && (long)p.B * p.H * p.W * std::max(p.in_cs * 2, p.out_cs) * 2 < 0x7fffff00L / std::max(G, 1);
 }
 
 }  // namespace quber

@@ -1051,6 +1051,7 @@ int launch_conv(const ConvP& p0, int G, hipStream_t st) {
         const int rc = launch_conv_h8(p, G, st);
         if (rc != 1) return rc;
     }
+    if (p.n_stats) return fail("conv: a launch that normalises its input needs the fp16 patch kernel (conv_h8.hip)");
     if (p0.dil_g[0]) {
         // a grouped launch with per-group dilation that conv_h8.hip did not take: the groups one after the other, each with its own
         for (int g = 0; g < G; ++g) {

@@ -54,6 +54,7 @@ static int* tuning_field(Tuning& t, int key) {
         case 27: return &t.wino_fused_max_cin;
         case 29: return &t.stem_fused;
         case 38: return &t.h8_narrow;
+        case 39: return &t.h8_norm;
         case 30: return &t.lean_loader;
         case 31: return &t.h8;
         case 32: return &t.h8_min_tiles;
@@ -71,7 +72,7 @@ bool tuning_set(Tuning& t, int key, int value) {
     return f != nullptr;
 }
 // keys that shape the plan: they act when quber_finalize_weights builds it and are refused afterwards
-bool tuning_plan_time(int key) { return key == 6 || key == 7 || key == 8 || key == 9 || key == 10 || key == 18 || key == 25 || key == 27 || key == 29; }
+bool tuning_plan_time(int key) { return key == 6 || key == 7 || key == 8 || key == 9 || key == 10 || key == 18 || key == 25 || key == 27 || key == 29 || key == 39; }
 
 static thread_local std::string g_err;
 void set_error(const std::string& m) { g_err = m; }
@@ -415,10 +416,20 @@ struct Builder {
                 wq.dtype = c->cfg.compute_dtype;
             }
         }
-        std::shared_ptr<DeferredNorm> norm;
+        std::shared_ptr<DeferredNorm> norm, norm16;
         if (wino && pending_norm && pending_norm->out.p == in.p && pending_norm->C == Cin && pending_norm->G == G) {
             norm = pending_norm;
             norm->absorbed = true;
+        }
+        // fp16 data path: an undilated 3x3 layer applies the GroupNorm + ReLU in front of it to its LDS patches
+        // (conv_h8.hip, key 39); whether a launch really does is decided per launch (conv_h8_patch_takes: the launch-time keys may say otherwise)
+        float* coef16 = nullptr;
+        if (!wino && aes == 2 && tune().h8_norm && tune().h8 && tune().h8_narrow && pending_norm && pending_norm->out.p == in.p && pending_norm->C == Cin &&
+            pending_norm->G == G && k == 3 && stride == 1 && pad == 1 && dil == 1 && dil_g.empty() && Cin % 64 == 0 && Cin >= 128 && Cin <= 512 && cin_real == Cin &&
+            (Cout == 128 || Cout == 64 || Cout == 32 || (Cout >= 256 && Cout % 8 == 0 && tune().h8_narrow != 2)) && !res && prelu.empty() && in.cs == pending_norm->in.cs && in.gs == pending_norm->in.gs) {
+            norm16 = pending_norm;
+            norm16->absorbed = true;
+            coef16 = (float*)dalloc_bytes(sizeof(float) * (size_t)G * Bmax * Cin * 2);
         }
         pending_norm.reset();
         if (wino) {     // workspace: V | M of the three-kernel pipeline, or only the fused GroupNorm's coefficients of the single-kernel form
@@ -438,7 +449,7 @@ struct Builder {
         auto fuse = std::make_shared<GnFuse>();
         last_conv = {fuse, out.p, G, Cout};
         const int L = cur_lane;
-        c->ops.push_back({[p, G, ctx, fuse, wq, wino, norm, L](int B, hipStream_t st) mutable {
+        c->ops.push_back({[p, G, ctx, fuse, wq, wino, norm, norm16, coef16, L](int B, hipStream_t st) mutable {
             const bool side = L && ctx->lane_now == L;             // launched on its side lane: that lane's workspaces
             float* const sk_ws = side ? ctx->lane_splitk_ws[L] : ctx->splitk_ws;
             const size_t sk_floats = side ? ctx->lane_splitk_floats : ctx->splitk_floats;
@@ -459,6 +470,16 @@ struct Builder {
             p.gn_sum = fuse->sums;
             p.gn_groups = fuse->groups;
             p.gn_cpg = fuse->groups ? p.Cout / fuse->groups : 0;
+            if (norm16) {
+                ConvP q = p;
+                q.in = norm16->in.p;              // the producer's raw output: normalised on the patch
+                q.n_stats = norm16->stats; q.n_gamma = norm16->gamma; q.n_beta = norm16->beta; q.n_coef = coef16;
+                q.n_groups = 32; q.n_param_gs = norm16->C; q.n_relu = 1; q.n_eps = 1e-5f;
+                if (conv_h8_patch_takes(q, G, true)) return launch_conv(q, G, st);
+                // this launch's keys keep it off the patch kernel: the norm as the pass it was, then the convolution on its output
+                const int rc = launch_gn_apply(norm16->in, norm16->out, B, G, 32, norm16->stats, norm16->gamma, norm16->beta, norm16->C, 1e-5f, 1, st);
+                if (rc) return rc;
+            }
             return launch_conv(p, G, st);
         }, OP_CONV, name, 2.0 * OH * OW * (double)cin_real * k * k * Cout * G, 1});
         c->ops.back().lane = cur_lane;

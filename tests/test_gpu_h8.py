@@ -163,6 +163,42 @@ def test_h8_takes_the_wide_layers_of_the_network(h, w, b, grouped):
     assert float(d.max()) < 2e-2 * scale, float(d.max())
 
 
+@pytest.mark.parametrize("h,w,b", [(256, 320, 3), (200, 264, 2)], ids=["256x320x3", "ragged-200x264x2"])
+def test_patch_kernels_absorb_the_norm_in_front_of_them(h, w, b):
+    """Option key 39: a patch-kernel layer that is the only reader of a GroupNorm + ReLU output (decoder fuse_conv.1, the heads' head.1:
+    model.py:386-403, 610-651) normalises its LDS patches from the producer's raw output instead of reading the result of a norm pass.  Same
+    arithmetic (half(max(fmaf(x, scale, bias), 0)) per (image, channel), the zero padding applied after it): the logits are the SAME BITS,
+    with fewer norm passes; and with key 38 = 0 at launch time the same plan falls back to the pass + the other kernels."""
+    from quber_amd import arch, engine, synth
+    from oracle import encode_np
+    sd = arch.init_state_dict(seed=13, loud_heads=True)
+    batch = synth.make_batch(9, b, h, w, 6)
+    offs = np.stack([encode_np.encode_initial_masks(m) for m in batch["masks"]])
+    bgr, dep, off = torch.from_numpy(batch["rgb"]).cuda(), torch.from_numpy(batch["depth"]).cuda(), torch.from_numpy(offs).cuda()
+    outs, stages = {}, {}
+    for key39 in (0, 1):
+        qc = engine.make_config(h, w, max_batch=b)
+        qc.compute_dtype = 2
+        e = engine.Engine(qc, "cuda:0")
+        e.set_option(39, key39)
+        e.load_state_dict(sd)
+        e.set_option(32, 1)
+        e.profile_begin()
+        outs[key39] = e.forward(bgr, dep, off).clone()
+        stages[key39] = e.profile_end()
+        if key39:
+            e.set_option(38, 0)                 # launch-time: no patch kernels -> the absorbed norms run as passes again
+            e.profile_begin()
+            outs[2] = e.forward(bgr, dep, off).clone()
+            stages[2] = e.profile_end()
+        e.close()
+    assert torch.isfinite(outs[1]).all()
+    assert stages[1]["gn_apply"]["launches"] <= stages[0]["gn_apply"]["launches"] - 4, (stages[0]["gn_apply"], stages[1]["gn_apply"])
+    assert stages[2]["gn_apply"]["launches"] == stages[0]["gn_apply"]["launches"]
+    assert torch.equal(outs[0], outs[1])
+    assert float((outs[2] - outs[0]).abs().max()) < 2e-2 * max(1.0, float(outs[0].abs().max()))
+
+
 def test_h8_random_geometries_are_deterministic_and_match():
     """Randomised launches (ragged pixel and channel tiles, dilation, stride, every epilogue variant, few and many tiles per block so
     that the DMA pipeline crosses tile boundaries): every launch three times - the LDS-DMA pipeline has no data-dependent control, so
