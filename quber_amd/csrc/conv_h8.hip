@@ -678,8 +678,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 constexpr int P8_TY = 8, P8_TX = 32, P8_PW = P8_TX + 2, P8_PIX = (P8_TY + 2) * P8_PW;   // 340 patch pixels
 constexpr int P8_PATCH = 48 * 1024;            // 8 waves x 6 pieces of 8 pixels (>= 43 pieces)
 
-template <int QT, bool RES, bool GN>
-__device__ __forceinline__ void p8_epilogue(const ConvP& p, const f32x4 (&acc)[QT][4], unsigned gacc_b, unsigned ssaddr, int b, int y0, int x0, int g,
+// PT = 16-pixel tiles per wave: 4 (two tile rows per wave: rows 2 wp, 2 wp + 1) or 2 (one tile row per wave: row wp, all of the tile's channels)
+template <int QT, bool RES, bool GN, int PT = 4>
+__device__ __forceinline__ void p8_epilogue(const ConvP& p, const f32x4 (&acc)[QT][PT], unsigned gacc_b, unsigned ssaddr, int b, int y0, int x0, int g,
                                             int t, int wp, int wq, int fr, int fq, int n0 = 0) {
     const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<_Float16*>(p.out) + (long)g * p.out_gs, 0, p.pk_min, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(
@@ -697,11 +698,11 @@ __device__ __forceinline__ void p8_epilogue(const ConvP& p, const f32x4 (&acc)[Q
     int fr_e = fr, fq_e = fq;
     asm volatile("" : "+v"(fr_e), "+v"(fq_e));
     // pixel of this lane in pixel tile i: row 2 wp + (i >> 1), column 16 (i & 1) + fr of the tile
-    int pixoff[4];
-    bool pok[4];
+    int pixoff[PT];
+    bool pok[PT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int y = y0 + 2 * wp + (i >> 1), x = x0 + 16 * (i & 1) + fr_e;
+    for (int i = 0; i < PT; ++i) {
+        const int y = y0 + (PT == 4 ? 2 * wp + (i >> 1) : wp), x = x0 + 16 * (PT == 4 ? (i & 1) : i) + fr_e;
         pok[i] = y < p.H && x < p.W;
         pixoff[i] = (b * p.H + y) * p.W + x;
     }
@@ -709,10 +710,10 @@ __device__ __forceinline__ void p8_epilogue(const ConvP& p, const f32x4 (&acc)[Q
     for (int gg = 0; gg < QT / 2; ++gg) {
         const int nl = QT * 16 * wq + 32 * gg + 8 * fq_e;       // first of this lane's 8 channels inside the channel tile
         const bool colok = n0 + nl < p.Cout;
-        u32x4 rbuf[4];
+        u32x4 rbuf[PT];
         if constexpr (RES) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) rbuf[i] = __builtin_amdgcn_raw_buffer_load_b128(rsr, pok[i] && colok ? (pixoff[i] * p.res_cs + n0 + nl) * 2 : H8_OOB, 0, 0);
+            for (int i = 0; i < PT; ++i) rbuf[i] = __builtin_amdgcn_raw_buffer_load_b128(rsr, pok[i] && colok ? (pixoff[i] * p.res_cs + n0 + nl) * 2 : H8_OOB, 0, 0);
         }
         f32x4 sc0, sc1, sh0, sh1;
         {
@@ -722,7 +723,7 @@ __device__ __forceinline__ void p8_epilogue(const ConvP& p, const f32x4 (&acc)[Q
         }
         float sA = 0.f, qA = 0.f, sB = 0.f, qB = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < PT; ++i) {
             float v[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = fmaf(acc[2 * gg][i][e], sc0[e], sh0[e]); v[4 + e] = fmaf(acc[2 * gg + 1][i][e], sc1[e], sh1[e]); }
@@ -785,10 +786,14 @@ __device__ __forceinline__ void p8_epilogue(const ConvP& p, const f32x4 (&acc)[Q
     }
 }
 
-template <int QT, bool RES, bool GN, bool NORM = false>
+// ROWS (32 output channels): a wave owns ONE tile row (32 pixels) x all 32 channels instead of two rows x half the channels - no wave multiplies the
+// empty half of a 64-channel tile
+template <int QT, bool RES, bool GN, bool NORM = false, bool ROWS = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_h8p_kernel(const ConvP p) {
     using G = H8Geo<QT>;
     constexpr int BN = G::BN, NQ = BN / 64;
+    constexpr int PT = ROWS ? 2 : 4;               // 16-pixel tiles per wave
+    static_assert(!ROWS || QT == 2, "one tile row per wave: the 32-channel layers");
     constexpr int WIMG = BN * H8_KB;               // one K-tile of filters: BN rows x 128 bytes
     constexpr int WBASE = 2 * P8_PATCH;            // [patch 0][patch 1][3 filter images][input-norm coefficients][GroupNorm sums][2 scale | shift images]
     constexpr int COEF = WBASE + 3 * WIMG;         // one image's [channel / 8][8 scales | 8 biases] floats, at most 512 channels
@@ -799,7 +804,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
-    const int wp = wave & 3, wq = wave >> 2;
+    const int wp = ROWS ? wave : wave & 3, wq = ROWS ? 0 : wave >> 2;      // pixel rows / channel half of this wave
+    const int late = wave >> 2;                    // waves w and w + 4 share a SIMD: the second of a pair runs half a phase behind
     const int fr = lane & 15, fq = lane >> 4;
     const int ncb = p.Kpad / (9 * 32);            // 64-channel blocks of the input (K = (block, tap, channel), 4-byte units)
 
@@ -922,10 +928,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int kx = 0; kx < 3; ++kx) sw[kx][ks] = ((4 * ks + fq) ^ (((fr + kx) >> 1) & 7)) << 4;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) pP[i] = ((2 * wp + (i >> 1)) * P8_PW + 16 * (i & 1) + fr) * H8_KB;
+    for (int i = 0; i < 4; ++i) pP[i] = ROWS ? (wp * P8_PW + 16 * (i & 1) + fr) * H8_KB : ((2 * wp + (i >> 1)) * P8_PW + 16 * (i & 1) + fr) * H8_KB;
 
-    f32x4 acc[QT][4];
-    h16x8 pf[4], qf[QT];
+    f32x4 acc[QT][PT];
+    h16x8 pf[PT], qf[QT];
 
     // ---- prologue: the first tile's first patch, filter K-tiles 0 and 1 ----
     issue_ss(0, g);
@@ -953,7 +959,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __builtin_amdgcn_s_barrier();                                                                                        \
     __builtin_amdgcn_s_setprio(1);                                                                                       \
     _Pragma("unroll") for (int c = 0; c < QT; ++c)                                                                       \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) acc[c][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[c], pf[i], acc[c][i], 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < PT; ++i) acc[c][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[c], pf[i], acc[c][i], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                                                       \
     __builtin_amdgcn_s_barrier();
 
@@ -975,8 +981,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int c = 0; c < QT; ++c)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[c][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (wq == 1) __builtin_amdgcn_s_barrier();      // stagger: waves 4-7 run half a phase behind their SIMD partners
+            for (int i = 0; i < PT; ++i) acc[c][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (late == 1) __builtin_amdgcn_s_barrier();      // stagger: waves 4-7 run half a phase behind their SIMD partners
         H8_STAMP(1);
 
         for (int cb = 0; cb < ncb; ++cb) {
@@ -993,7 +999,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int c = 0; c < QT; ++c) qf[c] = *reinterpret_cast<const h16x8*>(smem + rimg + qaddr[0] + ((c >> 1) * 32 + (c & 1) * 4) * H8_KB);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) pf[i] = *reinterpret_cast<const h16x8*>(smem + toff + pP[i] + sw[kx][0]);
+                for (int i = 0; i < PT; ++i) pf[i] = *reinterpret_cast<const h16x8*>(smem + toff + pP[i] + sw[kx][0]);
                 {
                     const int tq = (tap + 2) % 9;                           // tap of the K-tile issued now
                     const bool nxt_blk = tap >= 7;                          // it belongs to the block after this one
@@ -1009,7 +1015,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int c = 0; c < QT; ++c) qf[c] = *reinterpret_cast<const h16x8*>(smem + rimg + qaddr[1] + ((c >> 1) * 32 + (c & 1) * 4) * H8_KB);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) pf[i] = *reinterpret_cast<const h16x8*>(smem + toff + pP[i] + sw[kx][1]);
+                for (int i = 0; i < PT; ++i) pf[i] = *reinterpret_cast<const h16x8*>(smem + toff + pP[i] + sw[kx][1]);
                 if (tap < 6) dma(rsa, (cbuf ^ 1) * P8_PATCH + (8 * tap + wave) * 1024, last ? poffN[tap < 6 ? tap : 0] : poff[tap < 6 ? tap : 0], last ? 0 : (cb + 1) * H8_KB);
                 if constexpr (NORM) {          // piece tap - 2 of the next block's patch landed a K-tile ago (the counted wait of tap - 1)
                     if (tap == 2) load_cf(last ? 0 : cb + 1);
@@ -1023,9 +1029,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             cbuf ^= 1;
         }
         H8_STAMP(2);
-        if (wq == 0) __builtin_amdgcn_s_barrier();
+        if (late == 0) __builtin_amdgcn_s_barrier();
 
-        p8_epilogue<QT, RES, GN>(p, acc, GACC, SSBASE + ssb * H8_SS, b, y0, x0, g, t, wp, wq, fr, fq);
+        p8_epilogue<QT, RES, GN, PT>(p, acc, GACC, SSBASE + ssb * H8_SS, b, y0, x0, g, t, wp, wq, fr, fq);
         H8_STAMP(3);
 #ifdef H8_STAMPS
         ++stamp_tile;
@@ -1573,6 +1579,10 @@ int launch_conv_h8p(ConvP p, int G, hipStream_t st) {
         ProfScope prof(p.tag ? p.tag : "conv_gemm_h8", conv_bytes, conv_flops, st);
         const dim3 grid((int)std::min<long>(tiles, cus)), block(512);
         const int variant = (norm ? 16 : 0) | (wide ? 8 : p.Cout > 64 ? 4 : 0) | (p.res ? 2 : 0) | (p.gn_sum ? 1 : 0);
+        if (p.Cout == 32 && !p.res && !p.gn_sum) {      // (the heads' 128 -> 32: one tile row per wave)
+            if (norm) hipLaunchKernelGGL((conv_h8p_kernel<2, false, false, true, true>), grid, block, 0, st, p);
+            else hipLaunchKernelGGL((conv_h8p_kernel<2, false, false, false, true>), grid, block, 0, st, p);
+        } else
         switch (variant) {
             case 24: hipLaunchKernelGGL((conv_h8w_kernel<false, false, true>), grid, block, 0, st, p); break;
             case 25: hipLaunchKernelGGL((conv_h8w_kernel<false, true, true>), grid, block, 0, st, p); break;

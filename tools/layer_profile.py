@@ -80,9 +80,13 @@ def report(a):
         r = next(k for k in ks if any(t in name(k) for t in ("conv_igemm", "conv_h8", "conv_x8", "conv_f8", "wino_fused", "stem_conv1")))
         fl = c[2] * B
         if "stem_conv1" in name(r):
-            tile = "vector FMA, 8 x 32 pixels x 32 ch per block"
+            tile = ("matrix pipe" if "h16" in name(r) else "vector FMA") + ", 8 x 32 pixels x 32 ch per block"
         elif any(t in name(r) for t in ("conv_h8", "conv_x8", "conv_f8")):
-            tile = ("256x256" if "conv_h8_kernel" in name(r) else "256x128") + " persistent LDS-DMA, " + name(r).split("<")[1].split(">")[0].replace(" ", "")
+            nm, targs = name(r), name(r).split("<")[1].split(">")[0].replace(" ", "")
+            kind = ("DMA gather 256x256" if "conv_h8_kernel" in nm else "LDS patch 8x32 px x 256 ch" if "conv_h8w_kernel" in nm else
+                    "LDS patch 8x32 px x %d ch" % (128 if targs.startswith("4") else 64) if "conv_h8p_kernel" in nm else
+                    "LDS-resident filters, patch 8x32 px x %s ch" % targs if "conv_h8s_kernel" in nm else "DMA gather 256x128")
+            tile = kind + " persistent, " + targs
         elif "wino_fused" in name(r):
             tile = "16 tiles x 64 ch" if "fused64" in name(r) else "32 tiles x 32 ch"
         else:
