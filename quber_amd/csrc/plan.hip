@@ -655,8 +655,8 @@ struct Builder {
 
     // conv (no bias) -> GN -> ReLU, the [d2] Conv2d(norm=GN, activation=relu) pattern
     void conv_gn(const std::string& n, const View& in, const View& tmp, const View& out, int k, int dil,
-                 bool single_consumer = false) {
-        conv({n}, in, in.C, tmp, k, 1, k == 3 ? dil : 0, dil, AF_NONE, nullptr, false);
+                 bool single_consumer = false, int cin_real = -1) {
+        conv({n}, in, cin_real > 0 ? cin_real : in.C, tmp, k, 1, k == 3 ? dil : 0, dil, AF_NONE, nullptr, false);
         gn_relu({n + ".norm"}, tmp, out, single_consumer);
     }
 
@@ -927,9 +927,12 @@ struct Builder {
             if (cf.fusion_pred)
                 for (int k : levels[i - 1]) wd += hch[k];
             ypw[i] = wd;
-            YP[i] = make(aes == 2 ? (wd + 7) / 8 * 8 : (wd + 3) / 4 * 4, h4, w4);      // whole 16-byte units per pixel
+            // whole 16-byte units per pixel; fp16 data path: whole 64-channel K-tiles (164 -> 192: the zero channels meet zero filters), so that the
+            // 1x1 reduction in front of the head-fusion stack runs on conv_h8.hip
+            YP[i] = make(aes == 2 ? (wd + 63) / 64 * 64 : (wd + 3) / 4 * 4, h4, w4);
         }
-        View cat2 = make(32 + 128, h4, w4), t32 = make(32, h4, w4), t128 = make(128, h4, w4);
+        // (fp16 data path: 160 -> 192 channels per pixel, the last 32 never written = zero, zero filters for them: whole 64-channel blocks for the patch kernel)
+        View cat2 = make(aes == 2 ? 192 : 32 + 128, h4, w4), t32 = make(32, h4, w4), t128 = make(128, h4, w4);
         join(1);                         // fusion_res2
         conv_gn(Hd + "decoder.res2.project_conv", F[0], t32, slice(cat2, 0, 32), 1, 1);
         {
@@ -937,7 +940,7 @@ struct Builder {
             op([=](int B, hipStream_t st) { return launch_bilinear(y3, dst, B, st); });
         }
         View u2 = make(128, h4, w4);
-        conv_gn(Hd + "decoder.res2.fuse_conv.0", cat2, t128, u2, 3, 1, true);      // u2 is read only by fuse_conv.1
+        conv_gn(Hd + "decoder.res2.fuse_conv.0", cat2, t128, u2, 3, 1, true, 32 + 128);      // u2 is read only by fuse_conv.1
         View y = nlev > 1 ? slice(YP[1], 0, 128) : make(128, h4, w4);
         View t128c = make(128, h4, w4);                   // (not t128: fuse_conv.1 reads it - the absorbed norm's input)
         conv_gn(Hd + "decoder.res2.fuse_conv.1", u2, t128c, y, 3, 1);
