@@ -1676,7 +1676,9 @@ int launch_conv_h8(ConvP p, int G, hipStream_t st) {
         if (rc != 1) return rc;
     }
     if (p.n_stats) return fail("conv (fp16 data path): a launch that normalises its input needs the patch kernel");
-    if (p.Cin % 32 || p.K != p.Kpad || p.Kpad / 32 < 3) return 1;
+    // (two K-tiles - res3 conv3, 128 -> 512 with residual - work and lose: 12.04 -> 12.90 ms per step, a tile there is all epilogue and its stores stall the next
+    //  tile's first counted wait; conv_igemm.hip's many small blocks hide that)
+    if (p.Cin % 32 || p.K != p.Kpad || p.Kpad / 32 < 3) return 1;      // (a higher floor loses too: 5 K-tiles 12.31, 9 K-tiles 12.72 ms)
     const bool k3 = p.kh == 3 && p.kw == 3 && p.kmode == 1;
     if (!k3 && !(p.kh == 1 && p.kw == 1 && p.pad == 0)) return 1;
     const bool narrow = p.Cout == 128;            // 256 x 128 tiles (conv_h8n_kernel)
