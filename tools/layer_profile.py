@@ -84,7 +84,7 @@ def report(a):
         elif any(t in name(r) for t in ("conv_h8", "conv_x8", "conv_f8")):
             nm, targs = name(r), name(r).split("<")[1].split(">")[0].replace(" ", "")
             kind = ("DMA gather 256x256" if "conv_h8_kernel" in nm else "LDS patch 8x32 px x 256 ch" if "conv_h8w_kernel" in nm else
-                    "LDS patch 8x32 px x %d ch" % (128 if targs.startswith("4") else 64) if "conv_h8p_kernel" in nm else
+                    "LDS patch 8x32 px x %d ch" % (128 if targs.startswith("4") else 32 if targs.count(",") == 4 and targs.endswith("true") else 64) if "conv_h8p_kernel" in nm else
                     "LDS-resident filters, patch 8x32 px x %s ch" % targs if "conv_h8s_kernel" in nm else "DMA gather 256x128")
             tile = kind + " persistent, " + targs
         elif "wino_fused" in name(r):
