@@ -920,6 +920,11 @@ int launch_conv_dual(ConvP p, int G, hipStream_t st) {
         }
     } else {
         p.es = 4;
+        if (p.bf16 == 3 && p.w3 && p.kh == 1 && p.kw == 1 && p.pad == 0 && p.stride == 1 && !p.kmode && p.K == p.Kpad) {      // bf16x3: 256 x 128 tiles, LDS-DMA pipeline (conv_x8.hip)
+            p.ohw = p.OH * p.OW;
+            const int rc = launch_conv_x8(p, G, st);
+            if (rc != 1) return rc;
+        }
     }
     if (p.kh != 1 || p.kw != 1 || p.pad != 0 || p.stride != 1 || p.kmode || p.K1 % BK || p.K1 <= 0 || p.K1 >= p.Kpad || p.K != p.Kpad ||
         p.Kpad % BK || p.in_cs % 4 || p.in2_cs % 4 || ((uintptr_t)p.in & 15) || ((uintptr_t)p.in2 & 15) || (p.in_gs & 3) || (p.in2_gs & 3))

@@ -45,7 +45,10 @@ __device__ __forceinline__ unsigned x8_div(unsigned n, unsigned m, unsigned s) {
 
 // DMA source state of a thread for one tile: 4 pixel rows (pieces 4 w .. 4 w + 3 of the 32: 8 rows x 128 B each) and one channel
 // row per plane (piece w of a plane's 8: 16 rows x 64 B)
-__device__ __forceinline__ void x8_tile_state(const ConvP& p, int tile, int wave, int lane, int (&aoff)[4], int& boff, int& m0, int& n0, int& g) {
+// DUAL (bottleneck conv3 + projection shortcut as one GEMM, conv_persist.hip launch_conv_dual): K-slices [0, K1 / 32) come from `in`, the rest from `in2`
+// sampled at stride2; aoff2 = the rows' offsets in `in2`
+template <bool DUAL = false>
+__device__ __forceinline__ void x8_tile_state(const ConvP& p, int tile, int wave, int lane, int (&aoff)[4], int& boff, int& m0, int& n0, int& g, int (&aoff2)[4]) {
     g = (int)x8_div((unsigned)tile, p.dv_m[2], p.dv_s[2]);
     const int rem = tile - g * p.pk_tpg;
     const int mt = (int)x8_div((unsigned)rem, p.dv_m[3], p.dv_s[3]);
@@ -67,6 +70,15 @@ __device__ __forceinline__ void x8_tile_state(const ConvP& p, int tile, int wave
             pix = (b * p.H + oy * p.stride) * p.W + ox * p.stride;
         }
         aoff[j] = m < p.M ? gin + pix * p.in_cs * 4 + chunk * 16 : X8_OOB;
+        if constexpr (DUAL) {
+            const int b = (int)x8_div((unsigned)m, p.dv_m[0], p.dv_s[0]);
+            const int r2 = m - b * p.ohw;
+            const int oy = (int)x8_div((unsigned)r2, p.dv_m[1], p.dv_s[1]);
+            const int ox = r2 - oy * p.OW;
+            aoff2[j] = m < p.M ? g * (int)p.in2_gs * 4 + ((b * p.H2 + oy * p.stride2) * p.W2 + ox * p.stride2) * p.in2_cs * 4 + chunk * 16 : X8_OOB;
+        } else {
+            aoff2[j] = 0;
+        }
     }
     {
         const int R = 16 * wave + (lane >> 2);
@@ -89,15 +101,18 @@ __device__ __forceinline__ void x8_split(const f32x4 lo, const f32x4 hi, bf16x8&
     }
 }
 
-template <bool AFFINE, bool RES, bool GN>
+template <bool AFFINE, bool RES, bool GN, bool DUAL = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_x8_kernel(const ConvP p) {
+    static_assert(!DUAL || (!RES && !GN), "the dual-input form is the 1x1 conv3 + shortcut GEMM");
     // ONE shared object (conv_h8.hip): [2 K-slice images][GroupNorm sums f64 [2][32][2]][2 scale | shift images]
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * X8_SLOT + 1024 + 2 * X8_SS];
     constexpr int SSBASE = 2 * X8_SLOT + 1024;
 
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
-    const int wp = wave & 3, wq = wave >> 2;      // pixel quarter, channel half; waves w and w + 4 share a SIMD
+    // A wave owns 32 pixels x ALL 128 channels of the tile (not 64 x 64): every pixel fragment is split into its bf16 terms by ONE wave instead of two - the
+    // split's ~90 vector instructions per k-step were the longer half of a phase (the reading wave could not keep up with the multiplying one: matrix pipe 0.55 busy)
+    const int wp = wave, late = wave >> 2;        // pixel rows 32 wp .. + 31; waves w and w + 4 share a SIMD
     const int r = lane & 31, h = lane >> 5;
     const int nk = p.Kpad / 32;
 
@@ -111,22 +126,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         tile = start + (bid >> 3);
     }
 
-    int aoff[4], aoffN[4], boff, boffN = X8_OOB;
+    int aoff[4], aoffN[4], aoff2[4], aoff2N[4], boff, boffN = X8_OOB;
     int m0, n0, g, m0N = 0, n0N = 0, gN = 0;
-    x8_tile_state(p, tile, wave, lane, aoff, boff, m0, n0, g);
+    x8_tile_state<DUAL>(p, tile, wave, lane, aoff, boff, m0, n0, g, aoff2);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) aoffN[j] = X8_OOB;
+    for (int j = 0; j < 4; ++j) { aoffN[j] = X8_OOB; aoff2N[j] = X8_OOB; }
+    const __amdgpu_buffer_rsrc_t rsa2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DUAL ? p.in2 : p.in), 0, DUAL ? p.ws_rows : 0, 0x00020000);
+    const int nk1 = DUAL ? p.K1 / 32 : nk;
     const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.lean_in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w3), 0, p.pk_in_bytes, 0x00020000);
     const int plane_bytes = p.pk_in2_bytes;       // distance between the weight planes in HBM
 
     auto issue_p = [&](int half, int slot, int kq) __attribute__((always_inline)) {
         const bool nxt = kq >= nk;
-        const int soff = nxt ? 0 : kq * X8_PB;
+        const bool second = DUAL && !nxt && kq >= nk1;          // this K-slice comes from the second input
+        const int soff = nxt ? 0 : (second ? kq - nk1 : kq) * X8_PB;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const int j = 2 * half + jj;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr_t)(smem + slot * X8_SLOT + (4 * wave + j) * 1024), 16, nxt ? aoffN[j] : aoff[j], soff, 0, 0);
+            if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa2, (lds_ptr_t)(smem + slot * X8_SLOT + (4 * wave + j) * 1024), 16, aoff2[j], soff, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr_t)(smem + slot * X8_SLOT + (4 * wave + j) * 1024), 16, nxt ? aoffN[j] : aoff[j], soff, 0, 0);
         }
     };
     auto issue_q = [&](int slot, int kq) __attribute__((always_inline)) {
@@ -157,12 +176,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) paddr[s][j] = (64 * wp + r) * X8_PB + (((4 * s + 2 * h + j) ^ ((r >> 1) & 7)) << 4);
-        qaddr[s] = X8_QBASE + (64 * wq + r) * X8_QB + (((2 * s + h) ^ ((r >> 2) & 3)) << 4);
+        for (int j = 0; j < 2; ++j) paddr[s][j] = (32 * wp + r) * X8_PB + (((4 * s + 2 * h + j) ^ (((32 * wp + r) >> 1) & 7)) << 4);
+        qaddr[s] = X8_QBASE + r * X8_QB + (((2 * s + h) ^ ((r >> 2) & 3)) << 4);
     }
 
-    f32x16 acc[2][2], top[2][2];                   // [channel tile][pixel tile]
-    bf16x8 wf[2][3], xf[2][3];                     // [tile][term]
+    f32x16 acc[4], top[4];                         // [channel tile of 32]
+    bf16x8 wf[4][3], xf[3];                        // [channel tile][term], [term]
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     // ---- prologue: K-slice 0 ----
@@ -175,29 +194,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // reads of k-step S, then the split of the pixel fragments (vector instructions that run beside the partner wave's MFMAs)
 #define X8_READ(S)                                                                                                        \
     {                                                                                                                      \
-        f32x4 raw[2][2];                                                                                                   \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                      \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                  \
-                raw[i][j] = *reinterpret_cast<const f32x4*>(smem + sbase + paddr[S][j] + i * 32 * X8_PB);                  \
-        _Pragma("unroll") for (int c = 0; c < 2; ++c)                                                                      \
+        f32x4 raw[2];                                                                                                      \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) raw[j] = *reinterpret_cast<const f32x4*>(smem + sbase + paddr[S][j]); \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                                      \
             _Pragma("unroll") for (int q = 0; q < 3; ++q)                                                                  \
                 wf[c][q] = *reinterpret_cast<const bf16x8*>(smem + sbase + qaddr[S] + q * X8_QPLANE + c * 32 * X8_QB);     \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) x8_split(raw[i][0], raw[i][1], xf[i][0], xf[i][1], xf[i][2]);        \
+        x8_split(raw[0], raw[1], xf[0], xf[1], xf[2]);                                                                     \
     }
     // six partial products per output tile, smallest first: (a3 b1) (a1 b3) (a2 b2) (a2 b1) (a1 b2) (a1 b1), a = pixels, b = weights
 #define X8_MMA()                                                                                                          \
     __builtin_amdgcn_s_barrier();                                                                                          \
     __builtin_amdgcn_s_setprio(1);                                                                                         \
-    _Pragma("unroll") for (int c = 0; c < 2; ++c)                                                                          \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                    \
-            f32x16 d = acc[c][i];                                                                                          \
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c][0], xf[i][2], d, 0, 0, 0);                                   \
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c][2], xf[i][0], d, 0, 0, 0);                                   \
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c][1], xf[i][1], d, 0, 0, 0);                                   \
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c][0], xf[i][1], d, 0, 0, 0);                                   \
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c][1], xf[i][0], d, 0, 0, 0);                                   \
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c][0], xf[i][0], d, 0, 0, 0);                                   \
-            acc[c][i] = d;                                                                                                 \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                                        \
+            f32x16 d = acc[c];                                                                                             \
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c][0], xf[2], d, 0, 0, 0);                                      \
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c][2], xf[0], d, 0, 0, 0);                                      \
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c][1], xf[1], d, 0, 0, 0);                                      \
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c][0], xf[1], d, 0, 0, 0);                                      \
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c][1], xf[0], d, 0, 0, 0);                                      \
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c][0], xf[0], d, 0, 0, 0);                                      \
+            acc[c] = d;                                                                                                    \
         }                                                                                                                  \
     __builtin_amdgcn_s_setprio(0);                                                                                         \
     __builtin_amdgcn_s_barrier();
@@ -205,19 +221,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (;;) {
         const bool has_next = tile + tile_step < tile_end;
         if (has_next) {
-            x8_tile_state(p, tile + tile_step, wave, lane, aoffN, boffN, m0N, n0N, gN);
+            x8_tile_state<DUAL>(p, tile + tile_step, wave, lane, aoffN, boffN, m0N, n0N, gN, aoff2N);
             issue_ss(ssb ^ 1, gN, n0N);
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) aoffN[j] = X8_OOB;
+            for (int j = 0; j < 4; ++j) { aoffN[j] = X8_OOB; aoff2N[j] = X8_OOB; }
             boffN = X8_OOB;
         }
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) { top[c][i] = zero16; acc[c][i] = zero16; }
+        for (int c = 0; c < 4; ++c) { top[c] = zero16; acc[c] = zero16; }
         int fold_in = p.acc_chunk;
-        if (wq == 1) __builtin_amdgcn_s_barrier();      // stagger: waves 4-7 run half a phase behind their SIMD partners
+        if (late == 1) __builtin_amdgcn_s_barrier();      // stagger: waves 4-7 run half a phase behind their SIMD partners
 
         for (int kt = 0; kt < nk; ++kt, ++gk) {
             const int s = gk & 1;
@@ -238,12 +252,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (kt + 1 == nk || --fold_in == 0) {
                 fold_in = p.acc_chunk;
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) { top[c][i] += acc[c][i]; acc[c][i] = zero16; }
+                for (int c = 0; c < 4; ++c) { top[c] += acc[c]; acc[c] = zero16; }
             }
         }
-        if (wq == 0) __builtin_amdgcn_s_barrier();      // the two halves level again
+        if (late == 0) __builtin_amdgcn_s_barrier();    // the two halves level again
 
         // ---- epilogue (conv_f8.hip's: fp32 output, 4 consecutive channels = 16 bytes per lane and store) ----
         {
@@ -268,19 +280,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             int r_e = r, h_e = h;
             asm volatile("" : "+v"(r_e), "+v"(h_e));
-            const int prow0 = 64 * wp + r_e;
+            const int prow0 = 32 * wp + r_e;
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
+            for (int c = 0; c < 4; ++c) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int nl = 64 * wq + 32 * c + 8 * j + 4 * h_e;
+                    const int nl = 32 * c + 8 * j + 4 * h_e;
                     const bool colok = n0 + nl < p.Cout;
                     const int obase = colok ? (prow0 * p.out_cs + nl) * 4 : X8_OOB;
-                    u32x4 rbuf[2];
+                    u32x4 rbuf[1];
                     if constexpr (RES) {
                         const int rbase = colok ? (prow0 * p.res_cs + nl) * 4 : X8_OOB;
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) rbuf[i] = __builtin_amdgcn_raw_buffer_load_b128(rsr, rbase + i * 32 * p.res_cs * 4, 0, 0);
+                        rbuf[0] = __builtin_amdgcn_raw_buffer_load_b128(rsr, rbase, 0, 0);
                     }
                     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
                     if constexpr (AFFINE) {
@@ -289,11 +300,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                     double gs = 0.0, gq = 0.0, gs1 = 0.0, gq1 = 0.0;
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
+                    for (int i = 0; i < 1; ++i) {
                         float v[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            v[e] = top[c][i][4 * j + e];
+                            v[e] = top[c][4 * j + e];
                             if constexpr (AFFINE) v[e] = fmaf(v[e], sc[e], sh[e]);
                         }
                         if constexpr (RES) {
@@ -357,7 +368,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (!has_next) break;
         tile += tile_step;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) aoff[j] = aoffN[j];
+        for (int j = 0; j < 4; ++j) { aoff[j] = aoffN[j]; aoff2[j] = aoff2N[j]; }
         boff = boffN;
         m0 = m0N; n0 = n0N; g = gN;
         ssb ^= 1;
@@ -401,8 +412,15 @@ int launch_split_bf16x3(const float* w, long n, void* planes, hipStream_t st) {
 // bf16x3 mode, 1x1 / pad 0, K a multiple of 32, pre-split weight planes present, one input, 16-byte epilogue accesses, a tile count that
 // fills the chip's one-block-per-CU grid a few times.  returns 0 = launched, 1 = not covered, -1 = error
 int launch_conv_x8(ConvP p, int G, hipStream_t st) {
-    if (!tune().x8 || p.es != 4 || p.bf16 != 3 || !p.w3 || p.in2 || p.prelu || p.acc_chunk < 0) return 1;
-    if (p.kh != 1 || p.kw != 1 || p.pad != 0 || p.Cin % 32 || p.K != p.Kpad || p.Cin != p.K || p.Kpad / 32 < 2) return 1;
+    if (!tune().x8 || p.es != 4 || p.bf16 != 3 || !p.w3 || p.prelu || p.acc_chunk < 0) return 1;
+    const bool dual = p.in2 != nullptr;          // launch_conv_dual: K = K1 channels of `in`, then the channels of `in2` sampled at stride2
+    if (p.kh != 1 || p.kw != 1 || p.pad != 0 || p.Cin % 32 || p.K != p.Kpad || p.Cin != (dual ? p.K1 : p.K) || p.Kpad / 32 < 2) return 1;
+    if (dual) {
+        if (p.res || p.gn_sum || p.stride != 1 || !p.scale || p.K1 % 32 || p.K1 <= 0 || p.K1 >= p.Kpad || p.in2_cs % 4 || (p.in2_gs & 3) || ((uintptr_t)p.in2 & 15)) return 1;
+        const long in2_all = ((long)p.B * p.H2 * p.W2 * p.in2_cs) * 4 + (long)(G - 1) * p.in2_gs * 4;
+        if (in2_all >= 0x7fffff00L) return 1;
+        p.ws_rows = (int)in2_all;               // (descriptor range of the second input: a field the LDS-DMA kernels do not use otherwise)
+    }
     if ((p.scale == nullptr) != (p.shift == nullptr)) return 1;
     const long in_bytes = ((long)p.B * p.H * p.W * p.in_cs) * 4;
     const long in_all = in_bytes + (long)(G - 1) * p.in_gs * 4;
@@ -450,8 +468,9 @@ int launch_conv_x8(ConvP p, int G, hipStream_t st) {
         const char* tag = !p.tag ? "conv_gemm_x8" : std::string(p.tag) == "wino_gemm" ? "wino_gemm_x8" : p.tag;
         ProfScope prof(tag, conv_bytes, conv_flops, st);
         const dim3 grid((unsigned)std::min<long>(tiles, cus)), block(512);
-        const int variant = (p.scale ? 4 : 0) | (p.res ? 2 : 0) | (p.gn_sum ? 1 : 0);
+        const int variant = dual ? 8 : (p.scale ? 4 : 0) | (p.res ? 2 : 0) | (p.gn_sum ? 1 : 0);
         switch (variant) {
+            case 8: hipLaunchKernelGGL((conv_x8_kernel<true, false, false, true>), grid, block, 0, st, p); break;
             case 0: hipLaunchKernelGGL((conv_x8_kernel<false, false, false>), grid, block, 0, st, p); break;
             case 1: hipLaunchKernelGGL((conv_x8_kernel<false, false, true>), grid, block, 0, st, p); break;
             case 2: hipLaunchKernelGGL((conv_x8_kernel<false, true, false>), grid, block, 0, st, p); break;

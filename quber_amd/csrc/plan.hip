@@ -563,6 +563,7 @@ struct Builder {
             p.w = upload16(ph);
         } else {
             p.w = upload(packed);
+            p.w3 = split3(p.w, packed.size()); p.w3_plane = (long)packed.size();     // bf16x3 mode: the three bf16 planes (conv_x8.hip)
         }
         p.es = aes;
         p.H = y.H; p.W = y.W; p.Cin = mid; p.in_cs = y.cs; p.in_gs = y.gs;
@@ -1816,6 +1817,20 @@ int quber_op_conv1x1_dual(const float* y, const float* x, int32_t B, int32_t oh,
     p.bf16 = g_op_bf16;
     p.M = B * oh * ow; p.ohw = oh * ow; p.ss_gs = 0;
     p.ws = g_op_ws; p.ws_floats = g_op_ws ? g_op_ws_floats : 0;
+    if (g_op_bf16 == 3 && tune().x8) {       // the pre-split weight planes conv_x8.hip reads (as quber_op_conv2d: a grow-only scratch of the process)
+        static void* planes = nullptr;
+        static size_t cap = 0;
+        const size_t need = (size_t)cout * p.Kpad * 3 * sizeof(unsigned short);
+        if (need > cap) {
+            if (planes) (void)hipFree(planes);
+            planes = nullptr; cap = 0;
+            if (hipMalloc(&planes, need) != hipSuccess) return fail("conv1x1_dual: cannot allocate the bf16x3 weight planes");
+            cap = need;
+        }
+        const int rs = launch_split_bf16x3(w, (long)cout * p.Kpad, planes, (hipStream_t)stream);
+        if (rs) return rs;
+        p.w3 = planes; p.w3_plane = (long)cout * p.Kpad;
+    }
     const int rc = launch_conv_dual(p, 1, (hipStream_t)stream);
     if (rc == 1) return fail("conv1x1_dual: launch not covered by the dual kernel (workspace: tuning key 2)");
     return rc;

@@ -69,6 +69,54 @@ def test_x8_equals_the_128_tile_bf16x3_kernel(case):
         assert torch.equal(outs[2], outs[0])
 
 
+@pytest.mark.parametrize("case", [
+    # B, oh, ow, mid, cin, cout, stride: bottleneck conv3 + projection shortcut as ONE GEMM over two inputs (conv_persist.hip launch_conv_dual)
+    # ... , the 128-tile kernel sums K in the same chunks (with few tiles or K >= 32 slices it shares the K of its ragged round between blocks: other partial sums)
+    (4, 60, 80, 128, 256, 512, 2, True),        # res3.0: strided second input, K = 384
+    (3, 15, 21, 256, 512, 1024, 2, False),      # ragged M, odd input size
+    (2, 30, 40, 512, 1024, 2048, 1, False),     # res5.0 geometry, two frames: K = 1536
+    (8, 30, 40, 512, 1024, 2048, 1, False),     # ... (K of 48 slices: the persistent 128-tile kernel shares the K of its ragged round between blocks)
+], ids=lambda c: "x".join(str(int(v)) for v in c))
+def test_x8_dual_input_equals_the_128_tile_bf16x3_kernel(case):
+    """The dual-input form of the kernel: K-slices [0, mid / 32) from the bottleneck's conv2 output, the rest from the block's input sampled at
+    the stride - bit for bit the 128-tile persistent kernel's bf16x3 result (same six products, same order, same two-level accumulation), and
+    float64-close."""
+    B, oh, ow, mid, cin, cout, stride, same_arithmetic = case
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(17)
+    h2, w2 = (oh - 1) * stride + 1, (ow - 1) * stride + 1
+    y = torch.randn(B, oh, ow, mid, generator=g)
+    x = torch.randn(B, h2, w2, cin, generator=g)
+    w = torch.randn(cout, mid + cin, generator=g) / np.sqrt(mid + cin)
+    sh = torch.randn(cout, generator=g)
+    ref = (torch.einsum("bhwc,oc->bhwo", y.double(), w[:, :mid].double()) +
+           torch.einsum("bhwc,oc->bhwo", x[:, ::stride, ::stride].double(), w[:, mid:].double()) + sh.double()).relu()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    yd, xd, wd, shd, ones = y.cuda(), x.cuda(), w.cuda(), sh.cuda(), torch.ones(cout, device="cuda")
+    outs = {}
+    lib.quber_set_tuning(2, 1)
+    lib.quber_set_tuning(12, 3)
+    lib.quber_set_tuning(15, 0)
+    try:
+        for mode in (2, 0):
+            lib.quber_set_tuning(35, mode)
+            out = torch.full((B, oh, ow, cout), float("nan"), device="cuda")
+            _lib.check(lib.quber_op_conv1x1_dual(p(yd), p(xd), B, oh, ow, mid, h2, w2, cin, stride, p(wd), p(shd), p(ones), cout, 1,
+                                                 p(out), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            torch.cuda.synchronize()
+            outs[mode] = out
+    finally:
+        lib.quber_set_tuning(35, 1)
+        lib.quber_set_tuning(15, 256)
+        lib.quber_set_tuning(12, 0)
+        lib.quber_set_tuning(2, 0)
+    bound = 2e-6 * max(1.0, float(ref.abs().max()))
+    assert float((outs[2].double().cpu() - ref).abs().max()) < bound
+    assert float((outs[0].double().cpu() - ref).abs().max()) < bound
+    if same_arithmetic:
+        assert torch.equal(outs[2], outs[0])
+
+
 def test_x8_runs_the_wide_gemms_of_the_bf16x3_network():
     """bf16x3 network with the kernel on and off: the stage profile shows its launches (1x1 layers and Winograd position GEMMs), and
     the logits agree far inside the mode's 1e-4 bar (the persistent kernels it replaces share the K of ragged tiles between blocks:
