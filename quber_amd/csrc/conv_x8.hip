@@ -245,6 +245,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             X8_MMA()
             // phase 1: k-step 1; the next slice (issued a phase ago) has landed after this wait + barrier pair, and this image's last reads
             // are retired before the barrier
+            // (the wait has to stand in front of this phase's FIRST barrier: the partner waves run one barrier behind, and what they read after their
+            //  next barrier includes this wave's pieces - moved behind the MFMAs it raced, and bought nothing: the fill is not what this loop waits for)
             X8_READ(1)
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             X8_MMA()
