@@ -101,6 +101,14 @@ __device__ __forceinline__ void x8_split(const f32x4 lo, const f32x4 hi, bf16x8&
     }
 }
 
+#ifdef X8_STAMPS
+// diagnostic build (make X8X=-DX8_STAMPS, tools/x8_stamps.py): s_memtime of waves 0 and 4 of the first blocks at the phase boundaries of K-slice 8 of every tile
+__device__ unsigned long long g_x8_stamps[256 * 2 * 16];
+#define X8_STAMP(i) do { if (lane == 0 && (wave == 0 || wave == 4) && blockIdx.x < 256 && kt == 8) g_x8_stamps[((int)blockIdx.x * 2 + (wave >> 2)) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define X8_STAMP(i) do {} while (0)
+#endif
+
 template <bool AFFINE, bool RES, bool GN, bool DUAL = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_x8_kernel(const ConvP p) {
     static_assert(!DUAL || (!RES && !GN), "the dual-input form is the 1x1 conv3 + shortcut GEMM");
@@ -238,18 +246,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int sbase = s * X8_SLOT;
             // phase 0: k-step 0; DMA: the pixel rows and the three weight planes of the next slice into the other image (its last readers retired their reads before
             // the first barrier of the previous slice's phase 1)
+            X8_STAMP(0);
             X8_READ(0)
+            X8_STAMP(1);
             issue_p(0, s ^ 1, kt + 1);
             issue_p(1, s ^ 1, kt + 1);
             issue_q(s ^ 1, kt + 1);
+            X8_STAMP(2);
             X8_MMA()
+            X8_STAMP(3);
             // phase 1: k-step 1; the next slice (issued a phase ago) has landed after this wait + barrier pair, and this image's last reads
             // are retired before the barrier
             // (the wait has to stand in front of this phase's FIRST barrier: the partner waves run one barrier behind, and what they read after their
             //  next barrier includes this wave's pieces - moved behind the MFMAs it raced, and bought nothing: the fill is not what this loop waits for)
             X8_READ(1)
+            X8_STAMP(4);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            X8_STAMP(5);
             X8_MMA()
+            X8_STAMP(6);
             // two-level accumulation: the MFMA chain of p.acc_chunk slices into the running sums (conv_igemm.hip / conv_persist.hip `fold`)
             if (kt + 1 == nk || --fold_in == 0) {
                 fold_in = p.acc_chunk;
@@ -403,6 +418,13 @@ __global__ void split_bf16x3_kernel(const float* __restrict__ w, long n, unsigne
 }
 
 }  // namespace
+
+#ifdef X8_STAMPS
+int x8_read_stamps(unsigned long long* dst, int n) {
+    if (n > 256 * 2 * 16) n = 256 * 2 * 16;
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_x8_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int launch_split_bf16x3(const float* w, long n, void* planes, hipStream_t st) {
     if (n <= 0) return 0;

@@ -128,6 +128,9 @@ namespace quber { int wf_read_stamps(unsigned long long* dst, int n); }
 #ifdef H8_STAMPS
 namespace quber { int h8_read_stamps(unsigned long long* dst, int n); }
 #endif
+#ifdef X8_STAMPS
+namespace quber { int x8_read_stamps(unsigned long long* dst, int n); }
+#endif
 using namespace quber;
 
 constexpr int GN_SLOTS = 64;
@@ -1430,6 +1433,9 @@ int quber_wf_read_stamps(unsigned long long* dst, int n) { return quber::wf_read
 #endif
 #ifdef H8_STAMPS
 int quber_h8_read_stamps(unsigned long long* dst, int n) { return quber::h8_read_stamps(dst, n); }
+#endif
+#ifdef X8_STAMPS
+int quber_x8_read_stamps(unsigned long long* dst, int n) { return quber::x8_read_stamps(dst, n); }
 #endif
 #ifdef PK_STAMPS
 int quber_pk_read_stamps(unsigned long long* dst, int n) { return quber::pk_read_stamps(dst, n); }
