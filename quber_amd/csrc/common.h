@@ -68,7 +68,7 @@ struct ConvP {
     // conv_h8.hip patch kernels: the GroupNorm (+ ReLU) of the INPUT tensor applied on the LDS patch (its producer's norm pass absorbed by this consumer):
     // the sums [G][B][n_groups][2] and affine parameters of the tensor being read (null: none), the workspace for the per-(image, channel) coefficients
     const double* n_stats; const float* n_gamma; const float* n_beta; float* n_coef;
-    int n_groups, n_param_gs, n_relu; float n_eps;
+    int n_groups, n_param_gs, n_relu, n_coef_bytes; float n_eps;       // (n_coef_bytes: filled in by the launcher)
     int bf16;            // quber_config.compute_dtype: 0 = fp32 MFMA, 1 = bf16 / 2 = fp16 operands, 3 = fp32 operands split into 3 bf16 terms
 };
 

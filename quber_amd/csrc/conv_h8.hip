@@ -876,7 +876,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // in each of its wave's pieces, pixel l >> 3 and the LOGICAL chunk l & 7 (its 16 coefficients of a channel block live in registers); pixels
     // outside the image stay zero (the zero padding is applied AFTER the norm).  The coefficient image of the tile's frame sits in LDS; the next
     // tile's replaces it when the last channel block starts (nothing reads the old one any more).
-    const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(NORM ? p.n_coef : p.scale), 0, NORM ? p.pk_debug : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(NORM ? p.n_coef : p.scale), 0, NORM ? p.n_coef_bytes : 0, 0x00020000);
     auto issue_coef = [&](int tg, int tb) __attribute__((always_inline)) {
         if constexpr (NORM) {
             // (Cin counts 4-byte units of fp16 channels: 2 Cin channels x [scale, bias] floats = 16 Cin bytes per image)
@@ -1133,7 +1133,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int ssb = 0;
     // NORM (see conv_h8p_kernel): here the 16 coefficients of a lane's chunk are read from the LDS image per piece, in two halves - there is no
     // register to keep them in - and a piece is normalised at the start of a tap, when no fragment is live
-    const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(NORM ? p.n_coef : p.scale), 0, NORM ? p.pk_debug : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(NORM ? p.n_coef : p.scale), 0, NORM ? p.n_coef_bytes : 0, 0x00020000);
     auto issue_coef = [&](int tg, int tb) __attribute__((always_inline)) {
         if constexpr (NORM) {
             const int o = wave * 1024 + lane * 16;
@@ -1560,7 +1560,7 @@ int launch_conv_h8p(ConvP p, int G, hipStream_t st) {
         const int C = 2 * p.Cin;
         const long n = (long)G * p.B * C;
         if (n * 8 >= 0x7fffff00L) return 1;
-        p.pk_debug = (int)(n * 8);            // bytes of the coefficient table (descriptor range)
+        p.n_coef_bytes = (int)(n * 8);        // bytes of the coefficient table (descriptor range)
         hipLaunchKernelGGL(h8_norm_coef_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p.n_stats, p.n_gamma, p.n_beta, G, p.B, C, p.n_groups, p.n_param_gs,
                            (double)p.H * p.W * (C / p.n_groups), p.n_eps, p.n_coef);
         QB_CHECK(hipGetLastError());
@@ -1707,7 +1707,7 @@ int launch_conv_h8(ConvP p, int G, hipStream_t st) {
     p.lean_in_bytes = (int)in_all;
     p.pk_in_bytes = (int)w_all;
     p.pk_T = (int)tiles;
-    p.pk_debug = tune().persist_debug;
+    p.pk_debug = tune().persist_debug;       // (read by the H8_EXPERIMENT build only: tools/h8_exp.sh)
     p.pk_tpg = p.mtiles * p.ntiles;
     h8_magic((unsigned)p.ohw, p.dv_m[0], p.dv_s[0]);
     h8_magic((unsigned)p.OW, p.dv_m[1], p.dv_s[1]);

@@ -46,6 +46,7 @@ def main():
         ("res4.conv3 1x1 256>1024 +res", s16, 256, 1024, 1, 1, True, False),
         ("head.0 / fusion_layers 3x3 128>128", s4, 128, 128, 3, 1, False, True),
         ("res3.conv2 3x3 128>128", s8, 128, 128, 3, 1, False, False),
+        ("fusion_layers.1 3x3 128>128 (no norm sums)", s4, 128, 128, 3, 1, False, False),
         ("decoder.res3.fuse_conv.0 3x3 320>128", s8, 320, 128, 3, 1, False, True),
         ("stem.conv3 3x3 32>64", S // 2, 32, 64, 3, 1, False, False),
         ("res2.conv2 3x3 64>64", s4, 64, 64, 3, 1, False, False),
