@@ -33,7 +33,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide, "Peak BF16/FP16 MFMA" (dense)
 HBM_PEAK_GBPS = 8000.0          # same guide, "HBM3E peak BW" (spec; 6.29 TB/s measured float4 copy)
 
 # stage tags (quber_profile_stage) of the convolution family and of the HBM-bound stages reported in `hbm_stages`
-CONV_GEMM = ("conv_gemm", "conv_gemm_h8", "conv_gemm_f8", "conv_gemm_x8", "wino_gemm", "wino_gemm_f8", "wino_gemm_x8", "wino_fused")   # *_f8: exact fp32 on 256 x 128 tiles with the LDS-DMA pipeline (csrc/conv_f8.hip); conv_gemm_h8: the fp16 path's 256 x 256 LDS-DMA kernel (csrc/conv_h8.hip); wino_fused: a Winograd layer as ONE kernel (transforms inside), priced on what it multiplies
+CONV_GEMM = ("conv_gemm", "conv_gemm_h8", "conv_gemm_x8", "wino_gemm", "wino_gemm_x8", "wino_fused")   # conv_gemm_h8: the fp16 path's 256 x 256 LDS-DMA kernel (csrc/conv_h8.hip); wino_fused: a Winograd layer as ONE kernel (transforms inside), priced on what it multiplies
 CONV_GEMM_F32PIPE = ("conv_gemm_f32pipe",)   # launches of the bf16x3 mode that keep the exact fp32 MFMA kernel (short K, narrow tiles)
 CONV_FAMILY = CONV_GEMM + CONV_GEMM_F32PIPE + ("splitk_reduce", "wino_input", "wino_output", "stem_fused")   # stem_fused: a3 + stem.conv1, vector FMAs (csrc/stem.hip)
 HBM_STAGES = ("encode_reduce", "encode_paint", "errmaps_pack", "errmaps_erode", "errmaps_quadruple", "preprocess", "stem_fused", "wino_input",
@@ -77,6 +77,9 @@ def parse():
     ap.add_argument("--no-split-mode", action="store_true",
                     help="skip the extra timing of the fp32-equivalent bf16x3 mode that a default (f32, 1 GPU) run appends as "
                          "`fp32_equivalent_bf16x3` (never the headline `value`)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the sub-records a default (f32, 1 GPU, 640x480 batch 16) run appends under `configs`: BASELINE.json configs[2] "
+                         "(1280x720, 30 instances, batch 1, hipGraph replay) and configs[4] (fp16 data path, 1024x1024, batch 8)")
     ap.add_argument("--dry", action="store_true",
                     help="no GPU work: exercise the launch / rendezvous / broadcast / gather path only (CPU tests, gloo)")
     return ap.parse_args()
@@ -518,10 +521,110 @@ def main():
         if a.dtype == "f32" and world == 1 and not a.no_split_mode:
             line["fp32_equivalent_bf16x3"] = split_mode_run(a, make_engine, sd, gpu_step_args=(masks, bgr, depth, offsets, max_inst),
                                                             exact_logits=logits, exact_pan=post["panoptic"])
+        if (a.dtype == "f32" and world == 1 and not a.no_configs and not a.tuning and (B, H, W, N) == (16, 480, 640, 20)
+                and a.heads == "loud" and not a.graph and not a.foreground_filter):
+            eng.close()              # the headline engine's buffers are not needed any more
+            line["configs"] = {}
+            for name, kw in (("stream_1280x720_b1_graph", dict(H=720, W=1280, B=1, N=30, dtype="f32", graph=True, steps=max(2 * a.steps, 40), warmup=max(a.warmup, 10))),
+                             ("f16_1024x1024_b8", dict(H=1024, W=1024, B=8, N=20, dtype="f16", graph=False, steps=a.steps, warmup=a.warmup))):
+                try:
+                    line["configs"][name] = config_run(dev, **kw)
+                except Exception as e:           # an auxiliary record must never cost the line its headline
+                    line["configs"][name] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def conv_roofline(stages, dtype, algorithmic):
+    """`roofline` of one profiled step (stage table of quber_profile_end): the convolution family priced as report() prices it."""
+    fam_ms = sum(stages[k]["ms"] for k in CONV_FAMILY if k in stages)
+    f32p_ms = sum(stages[k]["ms"] for k in CONV_GEMM_F32PIPE if k in stages)
+    executed = sum(stages[k]["flops"] for k in CONV_GEMM if k in stages)
+    if dtype == "f32-bf16x3":
+        executed *= 6.0
+    peak = FP32_MFMA_PEAK_TFLOPS if dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
+    t = fam_ms - f32p_ms
+    ach = executed / (t * 1e-3) / 1e12 if t else 0.0
+    return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+            "frac_algorithmic": algorithmic / (fam_ms * 1e-3) / 1e12 / peak if fam_ms else None,
+            "conv_family_ms": {k: stages[k]["ms"] for k in CONV_FAMILY if k in stages}}
+
+
+def config_run(dev, H, W, B, N, dtype, graph, steps, warmup):
+    """One more BASELINE.json configuration, timed like the headline (resident inputs, encode -> network -> grouping -> mask
+    extraction per step, `warmup` untimed steps, `steps` timed ones between two synchronisations) and reported beside it - never as
+    `value`.  graph = the step captured once in a hipGraph and replayed (configs[2]: 'hipGraph-captured steady state')."""
+    import torch
+    from quber_amd import arch, engine, synth
+
+    def make(sd):
+        qc = engine.make_config(H, W, max_batch=B, max_instances=max(N, 1))
+        qc.compute_dtype = {"f32": 0, "bf16": 1, "f16": 2, "f32-bf16x3": 3}[dtype]
+        e = engine.Engine(qc, dev)
+        e.load_state_dict(sd)
+        return e
+
+    host = synth.make_batch(11, B, H, W, N)
+    masks, bgr, depth = (torch.from_numpy(host[k]).to(dev) for k in ("masks", "rgb", "depth"))
+    offsets = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
+    eng0 = make(arch.init_state_dict(seed=0, loud_heads=True))
+    lg0 = eng0.forward(bgr, depth, eng0.encode(masks))
+    bias = arch.calibrate_center_bias(lg0[:, 1:2].float().cpu(), N)
+    eng0.close()
+    del eng0, lg0
+    eng = make(arch.init_state_dict(seed=0, loud_heads=True, center_bias=bias))
+    logits = torch.empty((B, eng.planes, H, W), dtype=torch.float32, device=dev)
+    post = eng.alloc_post(B)
+    max_inst = min(eng.cap, max(N, 1) + 12)
+    om = torch.empty((B, max_inst, H, W), dtype=torch.uint8, device=dev)
+
+    def gpu_step():
+        eng.encode(masks, offsets)
+        eng.forward(bgr, depth, offsets, logits)
+        eng.postprocess(logits, post)
+        eng.extract_masks(post, max_inst, om)
+
+    g = None
+    if graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            gpu_step()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            gpu_step()
+    step = g.replay if g is not None else gpu_step
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    marks[0].record()
+    for i in range(steps):
+        step()
+        marks[i + 1].record()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    dev_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+    runs = []
+    for _ in range(3):
+        eng.profile_begin()
+        gpu_step()
+        runs.append(eng.profile_end())
+    stages = {k: dict(runs[0][k], ms=float(np.median([r[k]["ms"] for r in runs]))) for k in runs[0]}
+    count = post["count"].cpu().numpy()
+    out = {"value": B * N * steps / el, "unit": "refined masks/s", "ms_per_step": el / steps * 1e3, "steps": steps, "warmup": warmup,
+           "step_ms_min_median_max": [float(np.min(dev_ms)), float(np.median(dev_ms)), float(np.max(dev_ms))],
+           "frames_per_s": B * steps / el, "dtype": dtype, "hipgraph": g is not None,
+           "workload": f"batch={B} {W}x{H} RGB-D, {N} initial instances/frame, ResNet-50 RGB-D refiner, "
+                       f"encode+network+grouping+mask extraction, inputs resident",
+           "instances_out_per_frame_mean": float(count.mean()),
+           "roofline": conv_roofline(stages, dtype, eng.forward_flops() * B)}
+    eng.close()
+    return out
 
 
 def split_mode_run(a, make_engine, sd, gpu_step_args, exact_logits, exact_pan):

@@ -71,6 +71,10 @@ typedef struct quber_config {
                                         under this image's numpy 2.2, pinned by tests/golden/encode_*.npz);
                                         1 = numpy < 2 value-based casting (all float32; the reference's pinned numpy==1.23.1,
                                         INSTALL.md:14) - differs by 1 ulp on about a third of the mask pixels */
+    int32_t convs_dim;               /* INS_EMBED_HEAD.CONVS_DIM (128): channels of the decoder's res3 / res2 stages, of the head
+                                        convolutions and of the head-fusion stacks (model.py:610-651 decoder_channels); 128 | 256 */
+    int32_t head_channels;           /* INS_EMBED_HEAD.HEAD_CHANNELS (32): channels in front of every 1x1 predictor
+                                        (model.py:514-531, 413-422); 32 | 64 */
 } quber_config;
 
 /* logit planes produced by quber_forward: [fg, centre, off_y, off_x, eee_boundary x classes (if on), eee_mask x classes (if on)] */
@@ -296,10 +300,7 @@ double quber_forward_flops_padding(quber_ctx* ctx);
  *         branches of model.py:610-651), 0 = the 128-tile kernel everywhere, 2 = also narrower outputs (tests).  Same arithmetic
  *         (fp16 products, fp32 accumulation), another summation order inside a K-tile.
  * key 32 (224; launch) fewest tiles (all groups) of a launch that key 31 takes: its blocks own a CU each.
- * key 33 (0; launch) exact fp32: wide 1x1 launches and Winograd position GEMMs on csrc/conv_f8.hip (256 x 128 tiles, the same
- *         pipeline; bit-identical to conv_igemm.hip).  Off: no faster in the network (profiles/r11_f8.md).  1 = where its tile
- *         count fits, 2 = every covered launch (tests).
- * key 34 (3; launch) fewest rounds of tiles (tiles / CUs) of a launch that key 33 = 1 takes.
+ * keys 33, 34: retired (the exact-fp32 256 x 128 LDS-DMA kernel was no faster in the network and was removed: profiles/r11_f8.md).
  * key 35 (1; launch) bf16x3 mode: the wide 1x1 launches and the Winograd position GEMMs on csrc/conv_x8.hip (256 x 128 tiles, LDS-DMA
  *         pipeline, the weights pre-split into three bf16 planes when the plan is built, the activations split in registers by the
  *         wave that is not multiplying); the same six partial products in the same order as conv_igemm.hip's bf16x3 kernels.

@@ -20,6 +20,7 @@ class QuberConfig(C.Structure):
         ("fusion_feat", C.c_int32), ("fusion_pred", C.c_int32), ("n_levels", C.c_int32),
         ("level_heads", (C.c_int32 * 5) * 5), ("fusion_add", C.c_int32), ("streams", C.c_int32),
         ("compute_dtype", C.c_int32), ("encode_legacy_f32", C.c_int32),
+        ("convs_dim", C.c_int32), ("head_channels", C.c_int32),
     ]
 
 

@@ -14,7 +14,7 @@ HEADS = ("foreground", "center", "offset", "eee_mask", "eee_boundary")      # he
 DEFAULT_HIERARCHY = (("eee_boundary",), ("foreground", "center", "offset"))
 
 
-def head_channels(error_classes=4, eee_mask_on=False, eee_boundary_on=True):
+def head_out_channels(error_classes=4, eee_mask_on=False, eee_boundary_on=True):
     ch = {"foreground": 1, "center": 1, "offset": 2}
     if eee_mask_on:
         ch["eee_mask"] = error_classes
@@ -25,8 +25,11 @@ def head_channels(error_classes=4, eee_mask_on=False, eee_boundary_on=True):
 
 def param_specs(depth=50, backbone_fusion_layers=2, head_fusion_layers=3, error_classes=4, eee_mask_on=False,
                 eee_boundary_on=True, hierarchical=True, hierarchy=DEFAULT_HIERARCHY, fusion_target=("feat", "pred"),
-                streams=2, fusion_add=False):
-    """OrderedDict name -> (shape, kind); kind in conv|bn_w|bn_b|bn_m|bn_v|gn_w|gn_b|bias|pred_w|pred_b."""
+                streams=2, fusion_add=False, convs_dim=128, head_channels=32):
+    """OrderedDict name -> (shape, kind); kind in conv|bn_w|bn_b|bn_m|bn_v|gn_w|gn_b|bias|pred_w|pred_b.
+    convs_dim / head_channels: INS_EMBED_HEAD.CONVS_DIM / HEAD_CHANNELS (model.py:610-651: decoder_channels =
+    [CONVS_DIM, CONVS_DIM, ASPP_CHANNELS]; model.py:514-531 head widths)."""
+    cd, hc = convs_dim, head_channels
     s = OrderedDict()
 
     def conv(n, co, ci, k, bias=False):
@@ -82,36 +85,36 @@ def param_specs(depth=50, backbone_fusion_layers=2, head_fusion_layers=3, error_
     conv(a + "convs.4.1", 256, 2048, 1, bias=True)
     conv(a + "project", 256, 1280, 1)
     gn(a + "project.norm", 256)
-    for k, cin_f, pc, up in (("res3", 512, 64, 256), ("res2", 256, 32, 128)):
+    for k, cin_f, pc, up in (("res3", 512, 64, 256), ("res2", 256, 32, cd)):
         p = h + f"decoder.{k}."
         conv(p + "project_conv", pc, cin_f, 1)
         gn(p + "project_conv.norm", pc)
-        conv(p + "fuse_conv.0", 128, pc + up, 3)
-        gn(p + "fuse_conv.0.norm", 128)
-        conv(p + "fuse_conv.1", 128, 128, 3)
-        gn(p + "fuse_conv.1.norm", 128)
-    out_ch = head_channels(error_classes, eee_mask_on, eee_boundary_on)
+        conv(p + "fuse_conv.0", cd, pc + up, 3)
+        gn(p + "fuse_conv.0.norm", cd)
+        conv(p + "fuse_conv.1", cd, cd, 3)
+        gn(p + "fuse_conv.1.norm", cd)
+    out_ch = head_out_channels(error_classes, eee_mask_on, eee_boundary_on)
     for name, co in out_ch.items():
         p = h + f"{name}_pred_head.head."
-        conv(p + "0", 128, 128, 3)
-        gn(p + "0.norm", 128)
-        conv(p + "1", 32, 128, 3)
-        gn(p + "1.norm", 32)
-        s[h + f"{name}_predictor.predictor.weight"] = ((co, 32, 1, 1), "pred_w")
+        conv(p + "0", cd, cd, 3)
+        gn(p + "0.norm", cd)
+        conv(p + "1", hc, cd, 3)
+        gn(p + "1.norm", hc)
+        s[h + f"{name}_predictor.predictor.weight"] = ((co, hc, 1, 1), "pred_w")
         s[h + f"{name}_predictor.predictor.bias"] = ((co,), "pred_b")
     if hierarchical:                                     # model.py:576-608
         for i in range(1, len(hierarchy)):
-            cin = 128
+            cin = cd
             if "feat" in fusion_target:
-                cin += 32 * len(hierarchy[i - 1])
+                cin += hc * len(hierarchy[i - 1])
             if "pred" in fusion_target:
                 cin += sum(out_ch[k] for k in hierarchy[i - 1])
             f = h + f"fusion_layers_{i}.fusion_layers."
-            conv(f + "0", 128, cin, 1, bias=True)
-            bn(f + "0.norm", 128)
+            conv(f + "0", cd, cin, 1, bias=True)
+            bn(f + "0.norm", cd)
             for j in range(head_fusion_layers):
-                conv(f + f"{j + 1}", 128, 128, 3, bias=True)
-                bn(f + f"{j + 1}.norm", 128)
+                conv(f + f"{j + 1}", cd, cd, 3, bias=True)
+                bn(f + f"{j + 1}.norm", cd)
     return s
 
 

@@ -105,7 +105,8 @@ def arch_kwargs(cfg):
                 hierarchical=bool(h.HIERARCHICAL_FUSION_ON), hierarchy=tuple(tuple(l) for l in h.HIERARCHY),
                 fusion_target=tuple(h.FUSION_TARGET),
                 streams=2 if m.BACKBONE.NAME == "build_resnet_deeplab_rgbd_fusion_backbone" else 1,
-                fusion_add=m.BACKBONE.FUSION_STRATEGY == "add")
+                fusion_add=m.BACKBONE.FUSION_STRATEGY == "add",
+                convs_dim=int(h.CONVS_DIM), head_channels=int(h.HEAD_CHANNELS))
 
 
 def canonical_cfg():
@@ -165,13 +166,20 @@ def validate(cfg):
         ({"eee_boundary"} if h.EEE_BOUNDARY_ON else set())
     if h.HIERARCHICAL_FUSION_ON:
         flat = [k for lvl in h.HIERARCHY for k in lvl]
+        # an enabled head that the hierarchy omits is never evaluated by the reference's layers() (model.py:738-762) while its
+        # forward() still indexes output_dict[key] (model.py:701-708: KeyError at inference): the reference cannot run such a yaml
+        missing = sorted(heads - set(flat))
+        if missing:
+            raise UnsupportedConfig(f"quber_amd: HIERARCHY omits the enabled head(s) {missing}: the reference itself raises KeyError "
+                                    f"for them at inference (maskrefiner/modeling/mask_refiner/model.py:701-708)")
         need(1 <= len(h.HIERARCHY) <= 5 and sorted(flat) == sorted(heads),
              "a HIERARCHY that does not list every enabled head exactly once")
         need(set(h.FUSION_TARGET) <= {"feat", "pred"} and len(h.FUSION_TARGET) > 0 or len(h.HIERARCHY) == 1,
              "FUSION_TARGET outside {feat, pred}")
     need(not m.SEM_SEG_HEAD.USE_DEPTHWISE_SEPARABLE_CONV, "depthwise-separable head convs")
     need(h.ERROR_TYPE in ERROR_CLASSES, f"ERROR_TYPE {h.ERROR_TYPE}")
-    need(list(h.PROJECT_CHANNELS) == [32, 64] and h.ASPP_CHANNELS == 256 and h.HEAD_CHANNELS == 32
-         and h.CONVS_DIM == 128 and h.COMMON_STRIDE == 4 and list(h.ASPP_DILATIONS) == [6, 12, 18],
-         "non-default decoder widths")
+    need(list(h.PROJECT_CHANNELS) == [32, 64] and h.ASPP_CHANNELS == 256 and h.COMMON_STRIDE == 4
+         and list(h.ASPP_DILATIONS) == [6, 12, 18], "non-default PROJECT_CHANNELS / ASPP_CHANNELS / COMMON_STRIDE / ASPP_DILATIONS")
+    # CONVS_DIM / HEAD_CHANNELS are plan parameters (GroupNorm(32) needs multiples of 32; the predictor kernel reads 32 or 64 channels)
+    need(h.CONVS_DIM in (128, 256) and h.HEAD_CHANNELS in (32, 64), f"CONVS_DIM {h.CONVS_DIM} / HEAD_CHANNELS {h.HEAD_CHANNELS}")
     return cfg

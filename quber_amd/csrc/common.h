@@ -175,10 +175,6 @@ struct Tuning {
                                  //   (conv_x8.hip); 0 = conv_igemm.hip / conv_persist.hip everywhere, 2 = every covered launch (tests)
     int x8_min_nk = 8;           // key 37 (launch): fewest K-slices (of 32) of a launch that key 35 = 1 takes
     int x8_min_rounds = 2;       // key 36 (launch): fewest rounds of tiles (tiles / CUs) of a launch that key 35 = 1 takes
-    int f8 = 0;                  // key 33 (launch): exact fp32: wide 1x1 launches and Winograd position GEMMs on 256 x 128 tiles with the LDS-DMA pipeline (conv_f8.hip), bit-identical to
-                                 //   conv_igemm.hip.  OFF by default: the persistent kernels already sit at the clock-limited bound - in the network it measured 33.08 against 32.94 ms per step
-                                 //   (profiles/r11_f8.md); 1 = where its tile count fits, 2 = every covered launch (tests)
-    int f8_min_rounds = 3;       // key 34 (launch): fewest rounds of tiles (tiles / CUs) of a launch that takes it
     int h8_narrow = 1;           // key 38 (launch): fp16 data path: the undilated 3x3 layers with the pixel operand as an LDS patch (conv_h8.hip conv_h8p / h8w / h8s kernels); 0 = the DMA-gather kernels /
                                  //   conv_igemm.hip there, 2 = only the layers of up to 128 output channels
     int h8_norm = 1;             // key 39 (plan): fp16 data path: a patch-kernel layer applies the GroupNorm + ReLU in front of it to its LDS patches (same arithmetic as the norm pass, no pass over
@@ -203,7 +199,6 @@ bool conv_persistent_ok(const ConvP& p);
 int conv_persistent_segments(int T, int P, int nk, int min_slices, int bid, int* out4, int cap);
 int conv_persistent_fixup(int T, int P, int nk, int min_slices, int xcd, int j, int* tile, int* slots, int cap);
 int launch_conv_dual(ConvP p, int G, hipStream_t st);   // 0 done, 1 not covered (run the two convolutions), -1 error
-int launch_conv_f8(ConvP p, int G, hipStream_t st);     // exact fp32 1x1 / grouped GEMM, 256 x 128 tiles (conv_f8.hip): 0 done, 1 not covered, -1 error
 bool conv_h8_patch_takes(const ConvP& p, int G, bool norm);     // conv_h8.hip: this launch (ConvP as launch_conv receives it) runs on a patch kernel [that can normalise its input]
 int launch_conv_x8(ConvP p, int G, hipStream_t st);     // bf16x3 1x1 / grouped GEMM, 256 x 128 tiles (conv_x8.hip): 0 done, 1 not covered, -1 error
 int launch_split_bf16x3(const float* w, long n, void* planes, hipStream_t st);     // w [n] -> bf16 terms [3][n]
@@ -224,9 +219,10 @@ int launch_gn_apply(const View& in, const View& out, int B, int G, int groups, c
                     const float* gamma, const float* beta, int param_gs, float eps, int relu, hipStream_t st);
 int launch_bilinear(const View& in, const View& out, int B, hipStream_t st);
 int launch_avgpool(const View& in, const View& out, int B, hipStream_t st);
-int launch_predictor(const View& in, const float* w, const float* bias, int cout, float* q, int q_ch0,
-                     int q_nch, float* act_dst, int act_cs, int act /*0 none, 1 softmax, 2 sigmoid*/, int B,
-                     hipStream_t st);
+// the 1x1 predictors of one hierarchy level (model.py:413-422, 752-759), one launch: per head its features, weights [cout][C], bias,
+// first logit plane, optional activation destination (a channel slice of the next level's fusion input) and activation
+struct PredHeads { int n; const void* in[5]; const float* w[5]; const float* bias[5]; void* sm[5]; int cout[5], q_ch0[5], act[5] /*0 none, 1 softmax, 2 sigmoid*/; };
+int launch_predictors(const PredHeads& hs, int C, int in_cs, int es, int H, int W, float* q, int q_nch, int sm_cs, int B, hipStream_t st);
 int launch_copy_channels(const View& in, const View& out, int B, hipStream_t st);
 int launch_add_channels(const View& a, const View& b, const View& out, int B, hipStream_t st);
 int launch_upsample_logits(const float* q, float* out, int B, int nch, int h, int w, int scale, int OH, int OW,

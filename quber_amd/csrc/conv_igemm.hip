@@ -1074,10 +1074,6 @@ int launch_conv(const ConvP& p0, int G, hipStream_t st) {
         const int rc = launch_conv_x8(p, G, st);
         if (rc != 1) return rc;
     }
-    if (p.es == 4 && tune().force_tile == 0 && tune().force_split == 0) {      // exact fp32: the wide 1x1 launches on 256 x 128 tiles, LDS-DMA pipeline (conv_f8.hip)
-        const int rc = launch_conv_f8(p, G, st);
-        if (rc != 1) return rc;
-    }
     switch (tune().force_tile) {
         case 1: return run<64, 64, 2, 2>(p, G, 1, st);
         case 2: return run<128, 128, 2, 2>(p, G, 1, st);

@@ -1,6 +1,6 @@
 // bf16x3 (quber_config.compute_dtype 3: fp32 operands as three bf16 terms, six partial products per multiply, fp32 accumulation -
 // the fp32-equivalent mode that meets the exact mode's float64-anchor bars) for the wide 1x1 launches and the Winograd position
-// GEMMs, on 256 x 128 tiles with the LDS-DMA operand pipeline of conv_h8.hip / conv_f8.hip.
+// GEMMs, on 256 x 128 tiles with the LDS-DMA operand pipeline of conv_h8.hip.
 //
 // conv_igemm.hip's bf16x3 kernels split BOTH operands as a K-slice is written to LDS and keep three bf16 planes per operand there:
 // LDS-bound, MFMA busy 0.40 (DECISIONS.md section 4).  Here
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         if (late == 0) __builtin_amdgcn_s_barrier();    // the two halves level again
 
-        // ---- epilogue (conv_f8.hip's: fp32 output, 4 consecutive channels = 16 bytes per lane and store) ----
+        // ---- epilogue (fp32 output, 4 consecutive channels = 16 bytes per lane and store) ----
         {
             const int rows = min(p.M - m0, X8_BM);
             const long org = (long)g * p.out_gs + (long)m0 * p.out_cs + n0;

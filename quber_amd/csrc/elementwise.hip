@@ -492,12 +492,17 @@ int launch_avgpool(const View& in, const View& out, int B, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// 1x1 predictor on the 32-channel head features -> planar quarter-resolution logits q[B][q_nch][h*w],
-// optionally also softmax over its `cout` classes into an NHWC channel slice (the 'pred' fusion target).
-template <class T, int CIN = 32>
-__global__ void predictor_kernel(const T* __restrict__ in, int in_cs, const float* __restrict__ w,
-                                 const float* __restrict__ bias, int cout, float* __restrict__ q, int q_ch0,
-                                 int q_nch, T* __restrict__ sm, int sm_cs, int act, int B, int HW) {
+// 1x1 predictors on the head features (32 or 64 channels) -> planar quarter-resolution logits q[B][q_nch][h*w],
+// optionally also the softmax / sigmoid of a head's `cout` outputs into an NHWC channel slice (the 'pred' fusion target).
+// All heads of a hierarchy level in ONE launch: blockIdx.y = head.
+template <class T, int CIN>
+__global__ void predictor_kernel(const PredHeads hs, int in_cs, float* __restrict__ q, int q_nch, int sm_cs, int B, int HW) {
+    const int hd = blockIdx.y;
+    const T* __restrict__ in = reinterpret_cast<const T*>(hs.in[hd]);
+    const float* __restrict__ w = hs.w[hd];
+    const float* __restrict__ bias = hs.bias[hd];
+    T* __restrict__ sm = reinterpret_cast<T*>(hs.sm[hd]);
+    const int cout = hs.cout[hd], q_ch0 = hs.q_ch0[hd], act = hs.act[hd];
     __shared__ float ws[4 * CIN + 4];
     for (int i = threadIdx.x; i < cout * CIN; i += blockDim.x) ws[i] = w[i];
     if (threadIdx.x < cout) ws[4 * CIN + threadIdx.x] = bias[threadIdx.x];
@@ -533,18 +538,22 @@ __global__ void predictor_kernel(const T* __restrict__ in, int in_cs, const floa
     }
 }
 
-int launch_predictor(const View& in, const float* w, const float* bias, int cout, float* q, int q_ch0, int q_nch,
-                     float* softmax_dst, int softmax_cs, int act, int B, hipStream_t st) {
-    // softmax_dst: a channel slice of an activation buffer - same element type as `in`
-    if (in.C != 32 || cout > 4) return fail("predictor: expects 32 input channels and <= 4 outputs");
-    const long total = (long)B * in.H * in.W;
-    ProfScope prof("predictor", total * ((double)in.es * 32.0 + 4.0 * cout + (softmax_dst ? (double)in.es * cout : 0.0)), 2.0 * total * 32.0 * cout, st);
-    if (in.es == 2)
-        hipLaunchKernelGGL((predictor_kernel<half_t, 32>), dim3(cap_grid(total, 256)), dim3(256), 0, st, cptr<half_t>(in), in.cs, w, bias,
-                           cout, q, q_ch0, q_nch, (half_t*)softmax_dst, softmax_cs, act, B, in.H * in.W);
-    else
-        hipLaunchKernelGGL((predictor_kernel<float, 32>), dim3(cap_grid(total, 256)), dim3(256), 0, st, in.p, in.cs, w, bias, cout,
-                           q, q_ch0, q_nch, softmax_dst, softmax_cs, act, B, in.H * in.W);
+int launch_predictors(const PredHeads& hs, int C, int in_cs, int es, int H, int W, float* q, int q_nch, int sm_cs, int B, hipStream_t st) {
+    // hs.sm[j]: a channel slice of an activation buffer - same element type as the head features
+    if ((C != 32 && C != 64) || hs.n < 1 || hs.n > 5) return fail("predictor: expects 32 or 64 input channels and 1..5 heads");
+    double couts = 0.0, acts = 0.0;
+    for (int j = 0; j < hs.n; ++j) {
+        if (hs.cout[j] > 4) return fail("predictor: at most 4 outputs per head");
+        couts += hs.cout[j];
+        if (hs.sm[j]) acts += hs.cout[j];
+    }
+    const long total = (long)B * H * W;
+    ProfScope prof("predictor", total * ((double)es * C * hs.n + 4.0 * couts + (double)es * acts), 2.0 * total * C * couts, st);
+    const dim3 grid(cap_grid(total, 256), hs.n), block(256);
+    if (es == 2 && C == 32) hipLaunchKernelGGL((predictor_kernel<half_t, 32>), grid, block, 0, st, hs, in_cs, q, q_nch, sm_cs, B, H * W);
+    else if (es == 2) hipLaunchKernelGGL((predictor_kernel<half_t, 64>), grid, block, 0, st, hs, in_cs, q, q_nch, sm_cs, B, H * W);
+    else if (C == 32) hipLaunchKernelGGL((predictor_kernel<float, 32>), grid, block, 0, st, hs, in_cs, q, q_nch, sm_cs, B, H * W);
+    else hipLaunchKernelGGL((predictor_kernel<float, 64>), grid, block, 0, st, hs, in_cs, q, q_nch, sm_cs, B, H * W);
     QB_CHECK(hipGetLastError());
     return 0;
 }

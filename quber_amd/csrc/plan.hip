@@ -58,8 +58,6 @@ static int* tuning_field(Tuning& t, int key) {
         case 30: return &t.lean_loader;
         case 31: return &t.h8;
         case 32: return &t.h8_min_tiles;
-        case 33: return &t.f8;
-        case 34: return &t.f8_min_rounds;
         case 35: return &t.x8;
         case 36: return &t.x8_min_rounds;
         case 37: return &t.x8_min_nk;
@@ -889,16 +887,17 @@ struct Builder {
         View y5 = make(256, h16, w16);
         conv_gn(A + "project", catA, tA, y5, 1, 1);
 
-        View cat3 = make(64 + 256, F[1].H, F[1].W), t64 = make(64, F[1].H, F[1].W), t128a = make(128, F[1].H, F[1].W);
+        const int CD = cf.convs_dim, HC = cf.head_channels;      // INS_EMBED_HEAD.CONVS_DIM / HEAD_CHANNELS (128 / 32)
+        View cat3 = make(64 + 256, F[1].H, F[1].W), t64 = make(64, F[1].H, F[1].W), t128a = make(CD, F[1].H, F[1].W);
         join(2);                         // fusion_res3
         conv_gn(Hd + "decoder.res3.project_conv", F[1], t64, slice(cat3, 0, 64), 1, 1);
         {
             View dst = slice(cat3, 64, 256);
             op([=](int B, hipStream_t st) { return launch_bilinear(y5, dst, B, st); });
         }
-        View u3 = make(128, F[1].H, F[1].W), y3 = make(128, F[1].H, F[1].W);
+        View u3 = make(CD, F[1].H, F[1].W), y3 = make(CD, F[1].H, F[1].W);
         conv_gn(Hd + "decoder.res3.fuse_conv.0", cat3, t128a, u3, 3, 1, true);    // u3 is read only by fuse_conv.1
-        View t128b = make(128, F[1].H, F[1].W);           // (not t128a: fuse_conv.1 reads it - the absorbed norm's input)
+        View t128b = make(CD, F[1].H, F[1].W);           // (not t128a: fuse_conv.1 reads it - the absorbed norm's input)
         conv_gn(Hd + "decoder.res3.fuse_conv.1", u3, t128b, y3, 3, 1);
 
         // ---------------- prediction heads: generic hierarchy (model.py:738-762) ----------------
@@ -926,8 +925,8 @@ struct Builder {
         std::vector<View> YP(nlev);
         std::vector<int> ypw(nlev, 0);
         for (int i = 1; i < nlev; ++i) {
-            int wd = 128;
-            if (cf.fusion_feat) wd += 32 * (int)levels[i - 1].size();
+            int wd = CD;
+            if (cf.fusion_feat) wd += HC * (int)levels[i - 1].size();
             if (cf.fusion_pred)
                 for (int k : levels[i - 1]) wd += hch[k];
             ypw[i] = wd;
@@ -936,20 +935,20 @@ struct Builder {
             YP[i] = make(aes == 2 ? (wd + 63) / 64 * 64 : (wd + 3) / 4 * 4, h4, w4);
         }
         // (fp16 data path: 160 -> 192 channels per pixel, the last 32 never written = zero, zero filters for them: whole 64-channel blocks for the patch kernel)
-        View cat2 = make(aes == 2 ? 192 : 32 + 128, h4, w4), t32 = make(32, h4, w4), t128 = make(128, h4, w4);
+        View cat2 = make(aes == 2 ? (32 + CD + 63) / 64 * 64 : 32 + CD, h4, w4), t32 = make(32, h4, w4), t128 = make(CD, h4, w4);
         join(1);                         // fusion_res2
         conv_gn(Hd + "decoder.res2.project_conv", F[0], t32, slice(cat2, 0, 32), 1, 1);
         {
-            View dst = slice(cat2, 32, 128);
+            View dst = slice(cat2, 32, CD);
             op([=](int B, hipStream_t st) { return launch_bilinear(y3, dst, B, st); });
         }
-        View u2 = make(128, h4, w4);
-        conv_gn(Hd + "decoder.res2.fuse_conv.0", cat2, t128, u2, 3, 1, true, 32 + 128);      // u2 is read only by fuse_conv.1
-        View y = nlev > 1 ? slice(YP[1], 0, 128) : make(128, h4, w4);
-        View t128c = make(128, h4, w4);                   // (not t128: fuse_conv.1 reads it - the absorbed norm's input)
+        View u2 = make(CD, h4, w4);
+        conv_gn(Hd + "decoder.res2.fuse_conv.0", cat2, t128, u2, 3, 1, true, 32 + CD);      // u2 is read only by fuse_conv.1
+        View y = nlev > 1 ? slice(YP[1], 0, CD) : make(CD, h4, w4);
+        View t128c = make(CD, h4, w4);                   // (not t128: fuse_conv.1 reads it - the absorbed norm's input)
         conv_gn(Hd + "decoder.res2.fuse_conv.1", u2, t128c, y, 3, 1);
         for (int i = 2; i < nlev; ++i) {
-            View dst = slice(YP[i], 0, 128);
+            View dst = slice(YP[i], 0, CD);
             op([=](int B, hipStream_t st) { return launch_copy_channels(y, dst, B, st); });
         }
         if (!dry) c->taps["y"] = y;
@@ -963,11 +962,11 @@ struct Builder {
             if (i > 0) {
                 // FusionLayers_i (model.py:424-458), evaluated once (the reference re-runs it per key, model.py:760-762)
                 const std::string FL = Hd + "fusion_layers_" + std::to_string(i) + ".fusion_layers.";
-                View za = make(128, h4, w4), zb = make(128, h4, w4);
+                View za = make(CD, h4, w4), zb = make(CD, h4, w4);
                 conv({FL + "0"}, YP[i], ypw[i], za, 1, 1, 0, 1, AF_BIAS_BN, nullptr, true);
                 View cur = za, nxt = zb;
                 for (int j = 0; j < cf.head_fusion_layers; ++j) {
-                    conv({FL + std::to_string(j + 1)}, cur, 128, nxt, 3, 1, 1, 1, AF_BIAS_BN, nullptr, true);
+                    conv({FL + std::to_string(j + 1)}, cur, CD, nxt, 3, 1, 1, 1, AF_BIAS_BN, nullptr, true);
                     std::swap(cur, nxt);
                 }
                 x = cur;
@@ -980,19 +979,21 @@ struct Builder {
                 n0.push_back(h0.back() + ".norm");
                 n1.push_back(h1.back() + ".norm");
             }
-            View g128 = make(128, h4, w4, G), g128n = make(128, h4, w4, G), g32 = make(32, h4, w4, G);
+            View g128 = make(CD, h4, w4, G), g128n = make(CD, h4, w4, G), g32 = make(HC, h4, w4, G);
             const bool next = i + 1 < nlev;
-            View feat = (next && cf.fusion_feat) ? slice(YP[i + 1], 128, 32, 32) : make(32, h4, w4, G);
+            View feat = (next && cf.fusion_feat) ? slice(YP[i + 1], CD, HC, HC) : make(HC, h4, w4, G);
             View xin = x;
             xin.gs = 0;   // every head of the level reads the same features
-            conv(h0, xin, 128, g128, 3, 1, 1, 1, AF_NONE, nullptr, false);
+            conv(h0, xin, CD, g128, 3, 1, 1, 1, AF_NONE, nullptr, false);
             gn_relu(n0, g128, g128n, true);          // g128n is read only by head.1
-            conv(h1, g128n, 128, g32, 3, 1, 1, 1, AF_NONE, nullptr, false);
+            conv(h1, g128n, CD, g32, 3, 1, 1, 1, AF_NONE, nullptr, false);
             gn_relu(n1, g32, feat);
-            int act_off = 128 + (cf.fusion_feat ? 32 * G : 0);
+            int act_off = CD + (cf.fusion_feat ? HC * G : 0);
+            PredHeads ph{};
+            int ph_act_cs = 0;
             for (int j = 0; j < G; ++j) {
                 const int k = levels[i][j];
-                const float* pw = hw(Hd + HN[k] + "_predictor.predictor.weight", (int64_t)hch[k] * 32);
+                const float* pw = hw(Hd + HN[k] + "_predictor.predictor.weight", (int64_t)hch[k] * HC);
                 const float* pb = hw(Hd + HN[k] + "_predictor.predictor.bias", hch[k]);
                 View in = feat;
                 in.p = feat.at((long)j * feat.gs);
@@ -1005,12 +1006,16 @@ struct Builder {
                     act_off += hch[k];
                 }
                 if (dry || !pw || !pb) continue;
-                const float* dw = upload(std::vector<float>(pw, pw + hch[k] * 32));
+                const float* dw = upload(std::vector<float>(pw, pw + hch[k] * HC));
                 const float* db = upload(std::vector<float>(pb, pb + hch[k]));
-                const int ch0 = hplane[k], nn = hch[k], act = act_dst ? (k >= 3 ? 1 : 2) : 0;
-                op([=](int B, hipStream_t st) {
-                    return launch_predictor(in, dw, db, nn, q, ch0, planes, act_dst, act_cs, act, B, st);
-                });
+                ph.in[ph.n] = in.p; ph.w[ph.n] = dw; ph.bias[ph.n] = db; ph.sm[ph.n] = act_dst; ph.cout[ph.n] = hch[k];
+                ph.q_ch0[ph.n] = hplane[k]; ph.act[ph.n] = act_dst ? (k >= 3 ? 1 : 2) : 0;
+                if (act_dst) ph_act_cs = act_cs;
+                ++ph.n;
+            }
+            if (!dry && ph.n == G) {         // every predictor of the level in one launch
+                const int fcs = feat.cs, fes = feat.es, fh = feat.H, fw = feat.W;
+                op([=](int B, hipStream_t st) { return launch_predictors(ph, HC, fcs, fes, fh, fw, q, planes, ph_act_cs, B, st); });
             }
         }
         // x4 bilinear of every plane, offsets scaled by the stride (model.py:689-708)
@@ -1228,6 +1233,8 @@ int check_cfg(const quber_config& c) {
     if (c.res5_dilation == 1) return fail("res5_dilation 1 (output stride 32) is not supported by this build");
     if (c.error_classes < 2 || c.error_classes > 4) return fail("error_classes must be 2..4");
     if (c.streams != 1 && c.streams != 2) return fail("streams must be 1 or 2");
+    if (c.with_network == 1 && c.convs_dim != 128 && c.convs_dim != 256) return fail("convs_dim must be 128 or 256");
+    if (c.with_network == 1 && c.head_channels != 32 && c.head_channels != 64) return fail("head_channels must be 32 or 64");
     if (c.compute_dtype < 0 || c.compute_dtype > 3)
         return fail("compute_dtype must be 0 (fp32 MFMA), 1 (bf16 operands), 2 (fp16 operands) or 3 (fp32 operands as 3 bf16 terms)");
     if (c.with_network && c.hierarchical) {
@@ -1272,6 +1279,7 @@ void quber_default_config(quber_config* c) {
     c->n_levels = 2;
     c->streams = 2;
     c->fusion_add = 0;
+    c->convs_dim = 128; c->head_channels = 32;
     for (int i = 0; i < 5; ++i)
         for (int j = 0; j < 5; ++j) c->level_heads[i][j] = -1;
     c->level_heads[0][0] = 4;                                   // [[eee_boundary], [foreground, center, offset]]

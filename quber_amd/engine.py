@@ -23,13 +23,14 @@ def _stream():
 
 def set_arch(qc, depth=50, backbone_fusion_layers=2, head_fusion_layers=3, error_classes=4, eee_mask_on=False,
              eee_boundary_on=True, hierarchical=True, hierarchy=arch.DEFAULT_HIERARCHY, fusion_target=("feat", "pred"),
-             streams=2, fusion_add=False):
+             streams=2, fusion_add=False, convs_dim=128, head_channels=32):
     """Write the architecture switches (keyword arguments of arch.param_specs) into a quber_config."""
     qc.resnet_depth, qc.backbone_fusion_layers, qc.head_fusion_layers = depth, backbone_fusion_layers, head_fusion_layers
     qc.error_classes, qc.eee_mask_on, qc.eee_boundary_on = error_classes, int(eee_mask_on), int(eee_boundary_on)
     qc.hierarchical = int(hierarchical)
     qc.streams = streams
     qc.fusion_add = int(fusion_add)
+    qc.convs_dim, qc.head_channels = int(convs_dim), int(head_channels)
     qc.fusion_feat, qc.fusion_pred = int("feat" in fusion_target), int("pred" in fusion_target)
     levels = list(hierarchy) if hierarchical else []
     qc.n_levels = len(levels)

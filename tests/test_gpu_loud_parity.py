@@ -215,6 +215,11 @@ VARIANTS = {
     "single-stream": dict(streams=1),
     "add-fusion-l3": dict(fusion_add=True, backbone_fusion_layers=3),    # Base-Mask-Refiner.yaml's own defaults
     "r101": dict(depth=101),
+    # ...-m-b-f-c-o-l2-b2-cdim256-hcha64.yaml / ...-cdim256.yaml: INS_EMBED_HEAD.CONVS_DIM 256, HEAD_CHANNELS 64 (model.py:610-651)
+    "cdim256-hcha64": dict(convs_dim=256, head_channels=64, eee_mask_on=True, head_fusion_layers=2,
+                           hierarchy=(("eee_mask",), ("eee_boundary",), ("foreground",), ("center",), ("offset",))),
+    "cdim256": dict(convs_dim=256, eee_mask_on=True, head_fusion_layers=2,
+                    hierarchy=(("eee_mask",), ("eee_boundary",), ("foreground",), ("center",), ("offset",))),
 }
 
 

@@ -1,14 +1,13 @@
 #!/bin/bash
-# Evidence of the fp16 path's 256 x 256 LDS-DMA kernel (csrc/conv_h8.hip) and of its fp32 sibling (csrc/conv_f8.hip), on the GPU box:
+# Evidence of the fp16 path's 256 x 256 LDS-DMA kernel (csrc/conv_h8.hip), on the GPU box:
 #   usage: tools/h8_evidence.sh <tag>   -> gpurun_out/<tag>_h8_*.{md,txt}
 # (the undilated 3x3 layers run on the patch kernels, option key 38: the stamps are taken on a dilated layer (DMA-gather kernel) and on a head layer (patch kernel))
-# stand-alone layer tables (conv_igemm against conv_h8 / conv_f8), PMC counters of two wide layers, in-kernel tile stamps
+# stand-alone layer tables (conv_igemm against conv_h8), PMC counters of two wide layers, in-kernel tile stamps
 # (the stamps need a diagnostic build: made in a scratch copy of csrc, the product library is put back afterwards)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=${1:-rXX}; O=$R/gpurun_out
 cd $R
 python3 tools/h8_bench.py --iters 30 > $O/${TAG}_h8_layers.md 2>/dev/null
-python3 tools/f8_bench.py --iters 10 > $O/${TAG}_f8_layers.md 2>/dev/null
 rm -f $O/${TAG}_h8a_pmc.txt $O/${TAG}_h8b_pmc.txt
 tools/h8_pmc.sh ${TAG}_h8a "fusion_res2.conv0" > /dev/null 2>&1
 tools/h8_pmc.sh ${TAG}_h8b "fusion_res5.conv" > /dev/null 2>&1

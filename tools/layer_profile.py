@@ -59,8 +59,8 @@ def report(a):
         elif "stem_conv1" in n_:                  # a3 + stem.conv1 as one kernel (stem.hip)
             groups.append(("fused with a3", [allk[i]]))
             i += 1
-        elif any(t in n_ for t in ("conv_h8", "conv_x8", "conv_f8")):     # the LDS-DMA pipeline kernels (conv_h8.hip fp16, conv_x8.hip bf16x3, conv_f8.hip fp32)
-            groups.append(("direct " + ("h8" if "conv_h8" in n_ else "x8" if "conv_x8" in n_ else "f8"), [allk[i]]))
+        elif any(t in n_ for t in ("conv_h8", "conv_x8")):     # the LDS-DMA pipeline kernels (conv_h8.hip fp16, conv_x8.hip bf16x3)
+            groups.append(("direct " + ("h8" if "conv_h8" in n_ else "x8"), [allk[i]]))
             i += 1
         elif "conv_igemm" in n_:
             j = i + 1
@@ -77,11 +77,11 @@ def report(a):
            "|---|---|---|---|---|---|"]
     for i, (c, (path, ks)) in enumerate(zip(convs, groups[-n:])):
         ms = sum(dur(r) for r in ks)
-        r = next(k for k in ks if any(t in name(k) for t in ("conv_igemm", "conv_h8", "conv_x8", "conv_f8", "wino_fused", "stem_conv1")))
+        r = next(k for k in ks if any(t in name(k) for t in ("conv_igemm", "conv_h8", "conv_x8", "wino_fused", "stem_conv1")))
         fl = c[2] * B
         if "stem_conv1" in name(r):
             tile = ("matrix pipe" if "h16" in name(r) else "vector FMA") + ", 8 x 32 pixels x 32 ch per block"
-        elif any(t in name(r) for t in ("conv_h8", "conv_x8", "conv_f8")):
+        elif any(t in name(r) for t in ("conv_h8", "conv_x8")):
             nm, targs = name(r), name(r).split("<")[1].split(">")[0].replace(" ", "")
             kind = ("DMA gather 256x256" if "conv_h8_kernel" in nm else "LDS patch 8x32 px x 256 ch" if "conv_h8w_kernel" in nm else
                     "LDS patch 8x32 px x %d ch" % (128 if targs.startswith("4") else 32 if targs.count(",") == 4 and targs.endswith("true") else 64) if "conv_h8p_kernel" in nm else

@@ -15,7 +15,7 @@ for r in csv.DictReader(open(counters_csv)):
     x = d.setdefault(r["Dispatch_Id"], {"name": r["Kernel_Name"], "ns": int(r["End_Timestamp"]) - int(r["Start_Timestamp"]),
                                         "t0": int(r["Start_Timestamp"])})
     x[r["Counter_Name"]] = float(r["Counter_Value"])
-GEMM = ("conv_igemm", "conv_h8", "conv_x8", "conv_f8")     # the implicit-GEMM kernels (csrc/conv_igemm.hip, conv_persist.hip, conv_h8 / x8 / f8.hip)
+GEMM = ("conv_igemm", "conv_h8", "conv_x8")     # the implicit-GEMM kernels (csrc/conv_igemm.hip, conv_persist.hip, conv_h8 / x8)
 # one group of GEMM launches per convolution op (a Winograd op whose groups share one input transform launches several)
 disp = sorted(d.values(), key=lambda v: v["t0"])
 groups, i = [], 0

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import source_digest  # noqa: E402  (bench.py reports the file only while the kernel sources still match)
 
 
-FAMILY = ("conv_igemm", "conv_h8", "conv_x8", "conv_f8", "wino_input", "wino_output", "wino_fused", "stem_conv1", "splitk_reduce", "pk_fixup")
+FAMILY = ("conv_igemm", "conv_h8", "conv_x8", "wino_input", "wino_output", "wino_fused", "stem_conv1", "splitk_reduce", "pk_fixup")
 
 
 def family_bytes(path, counter):
