@@ -295,10 +295,14 @@ double quber_forward_flops_padding(quber_ctx* ctx);
  * key 30 (1; launch) implicit GEMM loader: block-uniform filter taps in scalar registers, a tap-validity bit mask and a 32-bit byte
  *         offset per row, buffer loads whose out-of-range offset returns the zero padding (conv_igemm.hip LEAN; layers with
  *         Cin % 32 == 0 - fp16 data path: % 64 - and tensors below 2 GiB), or per-thread tap arithmetic everywhere (0).  Same bits.
- * key 31 (1; launch) fp16 data path: the layers with >= 256 output channels and K a multiple of 64 on 256 x 256 tiles with the LDS-DMA
+ * key 31 (1; plan + launch) fp16 data path: the layers with >= 256 output channels and K a multiple of 64 on 256 x 256 tiles with the LDS-DMA
  *         operand pipeline (csrc/conv_h8.hip: resnet.py:395-449 res4 / res5 bottlenecks, :472-485 fusion convolutions, the ASPP
  *         branches of model.py:610-651), 0 = the 128-tile kernel everywhere, 2 = also narrower outputs (tests).  Same arithmetic
  *         (fp16 products, fp32 accumulation), another summation order inside a K-tile.
+ *         (plan + launch, keys 31 and 38: the value at quber_finalize_weights decides the SHAPE of the plan - with 31 on, the three dilated
+ *         ASPP branches are one grouped op; with 31, 38 and 39 on, a norm in front of a patch-kernel layer is planned as absorbed - so op
+ *         list, GroupNorm slots and quber_op_info names differ between plans built under different values.  The value at LAUNCH only
+ *         selects kernels: with a key switched off afterwards the same ops run on conv_igemm.hip and an absorbed norm as the pass it was.)
  * key 32 (224; launch) fewest tiles (all groups) of a launch that key 31 takes: its blocks own a CU each.
  * keys 33, 34: retired (the exact-fp32 256 x 128 LDS-DMA kernel was no faster in the network and was removed: profiles/r11_f8.md).
  * key 35 (1; launch) bf16x3 mode: the wide 1x1 launches and the Winograd position GEMMs on csrc/conv_x8.hip (256 x 128 tiles, LDS-DMA
@@ -306,7 +310,7 @@ double quber_forward_flops_padding(quber_ctx* ctx);
  *         wave that is not multiplying); the same six partial products in the same order as conv_igemm.hip's bf16x3 kernels.
  *         0 = those kernels everywhere, 2 = every covered launch (tests).
  * key 36 (2; launch) fewest rounds of tiles (tiles / CUs), key 37 (8; launch) fewest K-slices of 32 of a launch that key 35 = 1 takes.
- * key 38 (1; launch) fp16 data path: the undilated 3x3 / stride 1 layers with the pixel operand as an LDS patch - a tile is 8 x 32 output
+ * key 38 (1; plan + launch) fp16 data path: the undilated 3x3 / stride 1 layers with the pixel operand as an LDS patch - a tile is 8 x 32 output
  *         pixels, the 10 x 34-pixel patch of a 64-channel block is fetched once and the nine taps read it at shifted addresses, instead of
  *         nine DMA gathers (conv_h8.hip: conv_h8p_kernel up to 128 output channels, conv_h8w_kernel 256 and more, conv_h8s_kernel the stem's
  *         32-channel inputs with LDS-resident filters); 0 = key 31's DMA-gather kernels / conv_igemm.hip there, 2 = only up to 128 channels.

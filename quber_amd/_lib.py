@@ -4,7 +4,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libquber_hip.so")
+# QUBER_LIB: another build of the same library (diagnostic builds with in-kernel time stamps live in a scratch directory,
+# tools/diag_build.sh - never in quber_amd/csrc); the default is the in-tree product library
+LIB_PATH = os.environ.get("QUBER_LIB") or os.path.join(_HERE, "libquber_hip.so")
 
 
 class QuberConfig(C.Structure):

@@ -72,6 +72,7 @@ struct ConvP {
     int bf16;            // quber_config.compute_dtype: 0 = fp32 MFMA, 1 = bf16 / 2 = fp16 operands, 3 = fp32 operands split into 3 bf16 terms
 };
 
+int device_cus();         // compute units of the CURRENT device (cached per device id; plan.hip), <= 0: the query failed
 void set_error(const std::string& msg);
 int fail(const std::string& msg);
 
@@ -170,12 +171,12 @@ struct Tuning {
     int lean_loader = 1;         // key 30 (launch): implicit GEMM with block-uniform filter taps and buffer loads where the layer allows it (conv_igemm.hip LEAN); 0 = per-thread tap arithmetic
     int fuse_shortcut = 1;       // key 18 (plan): conv3 + projection shortcut of a bottleneck as one dual-input GEMM
     int lanes = 1;               // key 24 (launch): side lanes for batches <= 2 (0 = everything on the caller's stream)
-    int h8 = 1;                  // key 31 (launch): fp16 data path: 256 x 256 tiles with the LDS-DMA pipeline for the wide layers (conv_h8.hip); 0 = conv_igemm.hip everywhere
+    int h8 = 1;                  // key 31 (plan + launch: the plan's ASPP grouping and norm absorption read it too, include/quber_hip.h): fp16 data path: 256 x 256 tiles with the LDS-DMA pipeline for the wide layers (conv_h8.hip); 0 = conv_igemm.hip everywhere
     int x8 = 1;                  // key 35 (launch): bf16x3 mode: the wide 1x1 launches and the Winograd position GEMMs on 256 x 128 tiles with the LDS-DMA pipeline, weights pre-split at plan time
                                  //   (conv_x8.hip); 0 = conv_igemm.hip / conv_persist.hip everywhere, 2 = every covered launch (tests)
     int x8_min_nk = 8;           // key 37 (launch): fewest K-slices (of 32) of a launch that key 35 = 1 takes
     int x8_min_rounds = 2;       // key 36 (launch): fewest rounds of tiles (tiles / CUs) of a launch that key 35 = 1 takes
-    int h8_narrow = 1;           // key 38 (launch): fp16 data path: the undilated 3x3 layers with the pixel operand as an LDS patch (conv_h8.hip conv_h8p / h8w / h8s kernels); 0 = the DMA-gather kernels /
+    int h8_narrow = 1;           // key 38 (plan + launch, as key 31): fp16 data path: the undilated 3x3 layers with the pixel operand as an LDS patch (conv_h8.hip conv_h8p / h8w / h8s kernels); 0 = the DMA-gather kernels /
                                  //   conv_igemm.hip there, 2 = only the layers of up to 128 output channels
     int h8_norm = 1;             // key 39 (plan): fp16 data path: a patch-kernel layer applies the GroupNorm + ReLU in front of it to its LDS patches (same arithmetic as the norm pass, no pass over
                                  //   the tensor in HBM); 0 = every norm is a pass of its own

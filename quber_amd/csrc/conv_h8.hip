@@ -1523,7 +1523,8 @@ static bool h8_patch_shape(const ConvP& p) {
 }
 
 // the patch kernel's launch: tiles of 8 x 32 output pixels; returns 0 = launched, 1 = not covered, -1 = error
-int launch_conv_h8p(ConvP p, int G, hipStream_t st) {
+// (dry: every check of the real launch and nothing else - conv_h8_patch_takes() asks with it, so the plan's gate and the launcher cannot disagree)
+int launch_conv_h8p(ConvP p, int G, hipStream_t st, bool dry = false) {
     const long in_all = ((long)p.B * p.H * p.W * p.in_cs) * 4 + (long)(G - 1) * p.in_gs * 4, w_all = (long)p.Cout * p.Kpad * 4 + (long)(G - 1) * p.w_gs * 4;
     const long out_g = (long)p.B * p.H * p.W * p.out_cs * 2, res_g = p.res ? (long)p.B * p.H * p.W * p.res_cs * 2 : 0;
     if (in_all >= 0x7fffff00L || w_all >= 0x7fffff00L || out_g >= 0x7fffff00L || res_g >= 0x7fffff00L) return 1;
@@ -1560,19 +1561,16 @@ int launch_conv_h8p(ConvP p, int G, hipStream_t st) {
         const int C = 2 * p.Cin;
         const long n = (long)G * p.B * C;
         if (n * 8 >= 0x7fffff00L) return 1;
+        if (dry) return 0;
         p.n_coef_bytes = (int)(n * 8);        // bytes of the coefficient table (descriptor range)
         hipLaunchKernelGGL(h8_norm_coef_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p.n_stats, p.n_gamma, p.n_beta, G, p.B, C, p.n_groups, p.n_param_gs,
                            (double)p.H * p.W * (C / p.n_groups), p.n_eps, p.n_coef);
         QB_CHECK(hipGetLastError());
     }
+    if (dry) return 0;
     {
-        static int cus = 0;
-        if (!cus) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail("conv_h8: cannot query the device");
-            cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        }
+        const int cus = device_cus();          // per device: a process may drive several
+        if (cus <= 0) return fail("conv_h8: cannot query the device");
         const double out_bytes = 2.0 * G * (double)p.M * p.Cout;
         const double conv_bytes = 4.0 * G * ((double)p.B * p.H * p.W * p.Cin + (double)p.Cout * p.K) + out_bytes * (p.res ? 2.0 : 1.0);
         const double conv_flops = 2.0 * G * (double)p.M * p.K * p.Cout * 2.0;
@@ -1637,13 +1635,8 @@ int launch_conv_h8s(ConvP p, int G, hipStream_t st) {
     double* const gn_sum = p.gn_sum;
     p.gn_sum = nullptr;
     {
-        static int cus = 0;
-        if (!cus) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail("conv_h8: cannot query the device");
-            cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        }
+        const int cus = device_cus();          // per device: a process may drive several
+        if (cus <= 0) return fail("conv_h8: cannot query the device");
         const double conv_bytes = 4.0 * G * ((double)p.B * p.H * p.W * p.Cin + (double)p.Cout * p.K) + 2.0 * G * (double)p.M * p.Cout;
         ProfScope prof(p.tag ? p.tag : "conv_gemm_h8", conv_bytes, 2.0 * G * (double)p.M * p.K * p.Cout * 2.0, st);
         const dim3 grid((int)std::min<long>(tiles, cus)), block(512);
@@ -1721,13 +1714,8 @@ int launch_conv_h8(ConvP p, int G, hipStream_t st) {
     double* const gn_sum = p.gn_sum;
     if (gn_sep) p.gn_sum = nullptr;
     {
-        static int cus = 0;
-        if (!cus) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail("conv_h8: cannot query the device");
-            cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        }
+        const int cus = device_cus();          // per device: a process may drive several
+        if (cus <= 0) return fail("conv_h8: cannot query the device");
         const double out_bytes = 2.0 * G * (double)p.M * p.Cout;
         const double conv_bytes = 4.0 * G * ((double)p.B * p.H * p.W * p.Cin + (double)p.Cout * p.K) + out_bytes * (p.res ? 2.0 : 1.0);
         const double conv_flops = 2.0 * G * (double)p.M * p.K * p.Cout * 2.0;
@@ -1767,15 +1755,14 @@ int launch_conv_h8(ConvP p, int G, hipStream_t st) {
 // Would this launch (ConvP in ELEMENT units, as launch_conv receives it) run on a patch kernel - and, with `norm`, on one that can apply the producer's
 // GroupNorm to its input?  The plan asks before it lets a convolution absorb the norm pass in front of it (per launch: the keys may change between them).
 bool conv_h8_patch_takes(const ConvP& p0, int G, bool norm) {
+    // exactly what launch_conv (conv_igemm.hip) -> launch_conv_h8 -> launch_conv_h8p accept for this launch, options included
     ConvP p = p0;
-    if (p.es != 2 || p.bf16 != 2 || p.Cin % 8 || p.in_cs % 8 || p.Kpad % 64 || p.K % 2) return false;
-    p.Cin /= 2; p.in_cs /= 2; p.K /= 2; p.Kpad /= 2;
+    if (tune().force_tile != 0 || !tune().h8) return false;        // launch_conv skips conv_h8.hip under a forced tile shape
+    if (p.es != 2 || p.bf16 != 2 || p.Cin % 8 || p.in_cs % 8 || p.Kpad % 64 || p.K % 2 || (p.in_gs & 7) || (p.w_gs & 1) || p.in2 || p.prelu) return false;
+    p.Cin /= 2; p.in_cs /= 2; p.K /= 2; p.Kpad /= 2; p.in_gs /= 2; p.w_gs /= 2;
     if (!h8_patch_shape(p)) return false;
-    if (!norm) return true;
-    const long tiles = (long)G * p.B * ((p.W + P8_TX - 1) / P8_TX) * ((p.H + P8_TY - 1) / P8_TY);
-    const bool vec8 = p.Cout % 8 == 0 && p.out_cs % 8 == 0 && p.out_gs % 8 == 0 && (((uintptr_t)p.out & 15) == 0) && p.ss_gs % 4 == 0 && (((uintptr_t)p.scale & 15) == 0) &&
-                      (((uintptr_t)p.shift & 15) == 0) && p.in_cs % 4 == 0;
-    return !p.res && p.Cin <= 256 && p.Kpad >= 2 * 9 * 32 && vec8 && tiles <= 0x3fffffff && (long)p.B * p.H * p.W * std::max(p.in_cs * 2, p.out_cs) * 2 < 0x7fffff00L / std::max(G, 1);
+    if (norm && !p.n_stats) return false;
+    return launch_conv_h8p(p, G, nullptr, true) == 0;
 }
 
 }  // namespace quber

@@ -459,13 +459,8 @@ int launch_conv_x8(ConvP p, int G, hipStream_t st) {
     p.ntiles = (p.Cout + X8_BN - 1) / X8_BN;
     const long tiles = (long)p.mtiles * p.ntiles * G;
     if (tiles > 0x3fffffff) return 1;
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail("conv_x8: cannot query the device");
-        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int cus = device_cus();          // per device: a process may drive several
+    if (cus <= 0) return fail("conv_x8: cannot query the device");
     if (tune().x8 < 2) {         // (key 35 = 2: every covered launch - the tests)
         if (p.Kpad / 32 < tune().x8_min_nk || p.Cout < X8_BN) return 1;      // short K: the HBM-bound residual layers keep conv_igemm.hip's 64 x 64 tiles
         if (tiles < (long)tune().x8_min_rounds * cus) return 1;

@@ -16,6 +16,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <atomic>
 #include <functional>
 #include <map>
 #include <memory>
@@ -71,6 +72,23 @@ bool tuning_set(Tuning& t, int key, int value) {
 }
 // keys that shape the plan: they act when quber_finalize_weights builds it and are refused afterwards
 bool tuning_plan_time(int key) { return key == 6 || key == 7 || key == 8 || key == 9 || key == 10 || key == 18 || key == 25 || key == 27 || key == 29 || key == 39; }
+
+// compute units of the current device, cached per device id (a process may drive several devices with different counts)
+int device_cus() {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    const bool cached = dev >= 0 && dev < 64;
+    if (cached) {
+        const int v = cache[dev].load(std::memory_order_relaxed);
+        if (v > 0) return v;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+    const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (cached) cache[dev].store(cus, std::memory_order_relaxed);
+    return cus;
+}
 
 static thread_local std::string g_err;
 void set_error(const std::string& m) { g_err = m; }
@@ -346,7 +364,7 @@ struct Builder {
         }
         p.es = aes;
         if (in.es != aes || out.es != aes || (res && res->es != aes)) { if (err.empty()) err = "internal: element type mismatch at " + name; return; }
-        // (fp16 data path, layers of >= 128 channels without an affine - ASPP branches, decoder convolutions, heads: an identity affine, so that conv_h8.hip, whose epilogue
+        // (fp16 data path, layers of >= 32 output channels without an affine - ASPP branches, decoder convolutions, heads: an identity affine, so that conv_h8.hip, whose epilogue
         //  always reads one, takes them; fma(v, 1, 0) == v)
         const bool ident = !affine && aes == 2 && Cout >= 32;
         p.scale = affine ? upload(scale) : ident ? upload(std::vector<float>((size_t)G * Cout, 1.f)) : nullptr;

@@ -75,11 +75,13 @@ class RefinerModel:
             if eng is not None:
                 batch, n_masks = max(batch, eng.qcfg.max_batch), max(n_masks, eng.qcfg.max_instances)
                 # not closed here: a batch enqueued on it may still be waiting for collect_batch (predict_stream keeps one batch in
-                # flight); the replaced engine is closed when the NEXT replacement of this size happens or with the model
-                old = self._retired.pop(key, None)
-                if old is not None:
-                    old.close()
-                self._retired[key] = eng
+                # flight).  The replaced engine is closed as soon as that batch has been collected (collect_batch), or - with nothing
+                # in flight - right away; close() below takes whatever is left.
+                if getattr(eng, "_in_flight", 0) > 0:
+                    self._retired.setdefault(key, []).append(eng)
+                else:
+                    torch.cuda.current_stream().synchronize()      # its last launches may still be running
+                    eng.close()
             qc = qengine.make_config(h, w, max_batch=max(batch, 1), max_instances=max(64, n_masks), cfg=self.cfg)
             eng = qengine.Engine(qc, self.device)
             eng.load_state_dict(self.state_dict)
@@ -199,6 +201,7 @@ class RefinerModel:
         count = torch.empty((B,), dtype=torch.int32).pin_memory()
         count.copy_(post["count"], non_blocking=True)
         e1.record()
+        eng._in_flight = getattr(eng, "_in_flight", 0) + 1
         return {"eng": eng, "logits": logits, "post": post, "masks": masks, "slots": slots, "count": count, "e0": e0, "e1": e1}
 
     def collect_batch(self, hd, host_masks=False):
@@ -218,9 +221,12 @@ class RefinerModel:
         outs = [self.frame_dict(eng, hd["logits"][b], post, b, int(count[b]), masks[b, :int(count[b])].view(torch.bool) if count[b] > 0 else None)
                 for b in range(len(count))]
         ms = hd["e0"].elapsed_time(hd["e1"])
+        eng._in_flight = max(0, getattr(eng, "_in_flight", 1) - 1)
         if not host_masks:
+            self._release_retired(eng)
             return outs, ms
         if kmax == 0:
+            self._release_retired(eng)
             return outs, ms, [[] for _ in count]
         # The copy runs on a stream of its own, behind this batch's end event only: on the caller's stream it would queue behind
         # the NEXT batch, which predict_stream has already enqueued - and the host would wait 33 ms for masks that are ready.
@@ -228,7 +234,34 @@ class RefinerModel:
         side.wait_event(ready)
         with torch.cuda.stream(side):
             host = masks[:, :kmax].contiguous().cpu().numpy().view(np.bool_)
+        self._release_retired(eng)
         return outs, ms, [host[b, :int(count[b])] if count[b] > 0 else [] for b in range(len(count))]
+
+    def _release_retired(self, eng):
+        """An engine that a larger one has replaced and whose last batch in flight has just been collected: closed now.  (The tensors in
+        the dicts collect_batch returned are torch allocations the engine wrote INTO - logits, post tables, masks - not buffers of the
+        engine's context, so closing it invalidates nothing the caller holds.)"""
+        if getattr(eng, "_in_flight", 0) > 0:
+            return
+        for key, lst in list(self._retired.items()):
+            if eng in lst:
+                lst.remove(eng)
+                torch.cuda.synchronize(self.device)
+                eng.close()
+            if not lst:
+                self._retired.pop(key, None)
+
+    def close(self):
+        """Release every engine (plan buffers, workspaces, weights in kernel layout) this model holds."""
+        torch.cuda.synchronize(self.device)
+        for lst in self._retired.values():
+            for e in lst:
+                e.close()
+        for e in self._engines.values():
+            e.close()
+        self._retired.clear()
+        self._engines.clear()
+        self._staging.clear()
 
     def _copy_stream(self):
         st = getattr(self, "_d2h_stream", None)

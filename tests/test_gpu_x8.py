@@ -4,7 +4,13 @@ activations split fragment by fragment in registers) through the C ABI, against 
 bf16x3 itself - and against float64.
 
 Layers: the bottleneck / fusion 1x1 convolutions of maskrefiner/modeling/backbone/resnet.py:395-449, 472-485 and the position GEMMs
-of the wide Winograd layers, in the fp32-equivalent bf16x3 mode (quber_config.compute_dtype 3)."""
+of the wide Winograd layers, in the fp32-equivalent bf16x3 mode (quber_config.compute_dtype 3).
+
+What this file is: KERNEL AGAINST KERNEL (plus a float64 convolution of the same operands) - it shows that conv_x8.hip and the
+128-tile kernels are the same arithmetic, not that either equals the reference path.  The tie to the oracle
+(oracle/network_torch.py, the restatement of model.py / resnet.py) is at network level: the `*-bf16x3` ids of
+tests/test_gpu_loud_parity.py::test_benchmarked_plan_float64_anchor and ::test_benchmarked_plan_taps_heads_and_instances run the plan that contains
+these launches and hold every tap and head to the 1e-4 / float64-anchor bars."""
 import ctypes as C
 
 import numpy as np

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where a tile's time goes inside csrc/conv_h8.hip (diagnostic build: make -C quber_amd/csrc H8X=-DH8_STAMPS, into another
+"""Where a tile's time goes inside csrc/conv_h8.hip (diagnostic build in a scratch copy: QUBER_LIB=$(tools/diag_build.sh h8stamps H8X=-DH8_STAMPS), i.e. another
 directory than the product build).  s_memtime of wave 0 of every block at: tile start, K loop start, K loop end, epilogue end,
 start of K-tile 4, start of K-tile nk - 4.  usage (GPU box): h8_stamps.py [layer substring of tools/h8_bench.py]"""
 import ctypes as C

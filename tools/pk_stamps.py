@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase timing inside the persistent convolution kernel (diagnostic build: make -C quber_amd/csrc clean all STAMPS=1).
+"""Phase timing inside the persistent convolution kernel (diagnostic build in a scratch copy: QUBER_LIB=$(tools/diag_build.sh pk STAMPS=1)).
 For the first tiles of the first 48 blocks: K loop, staging of the next tile's first K-slice, epilogue, restart.
 GPU box only.  usage: pk_stamps.py [K] [N] [B]"""
 import ctypes as C

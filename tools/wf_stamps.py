@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase timing inside the single-kernel Winograd layer (diagnostic build: make -C quber_amd/csrc WFX=-DWF_STAMPS; wino_fused.hip
+"""Phase timing inside the single-kernel Winograd layer (diagnostic build in a scratch copy: QUBER_LIB=$(tools/diag_build.sh wfstamps WFX=-DWF_STAMPS); wino_fused.hip
 WF_STAMP): per wave of the first 512 blocks, shader-clock stamps at entry, after the prologue, after the first / second round,
 at the end of the K loop, after the accumulators are in LDS, after the output transform + stores, at exit; plus the chip-wide
 100 MHz clock at entry / exit and the hardware id.   GPU box only.

@@ -5,11 +5,10 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R
 B="python bench.py --steps 12 --warmup 4 --cpu-frames 0 --predict-calls 0 --no-split-mode"
 for sp in ${1:-9}; do
-  rm -f quber_amd/csrc/wino_fused.o
-  make -C quber_amd/csrc WFX=-DWF_SPLIT=$sp > /dev/null 2>&1
+  DL=$(tools/diag_build.sh wfsplit$sp WFX=-DWF_SPLIT=$sp) || exit 1      # scratch copy: the product library is never touched
+  export QUBER_LIB=$DL
   for t in "25=0" "25=1" "25=1,27=160" "25=1,27=320" "25=1,27=512"; do
     echo "WF_SPLIT=$sp tuning $t: $($B --tuning $t 2>/dev/null | python3 -c 'import json,sys; j=json.loads(sys.stdin.readlines()[-1]); print(round(j["value"],1), "masks/s", round(j["ms_per_step"],2), "ms", "frac", round(j["roofline"]["frac"],3))')"
   done
 done
-rm -f quber_amd/csrc/wino_fused.o
-make -C quber_amd/csrc > /dev/null 2>&1
+unset QUBER_LIB

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where a K-slice's time goes inside csrc/conv_x8.hip (diagnostic build: make -C quber_amd/csrc X8X=-DX8_STAMPS).  s_memtime of waves 0 and 4
+"""Where a K-slice's time goes inside csrc/conv_x8.hip (diagnostic build in a scratch copy: QUBER_LIB=$(tools/diag_build.sh x8stamps X8X=-DX8_STAMPS)).  s_memtime of waves 0 and 4
 (SIMD partners: wave 4 runs half a phase behind) of every block at the phase boundaries of K-slice 8 of the block's last tile:
 0 slice start | 1 reads + split of k-step 0 done | 2 DMA issued | 3 MFMAs of phase 0 + both barriers | 4 reads + split of k-step 1 | 5 DMA wait | 6 MFMAs of phase 1.
 usage (GPU box): x8_stamps.py [layer substring of tools/x8_bench.py]"""
