@@ -241,3 +241,46 @@ def test_inpaint_telea_restatement():
     np.testing.assert_array_equal(inpaint_depth(d3b), inpaint_np.inpaint_depth(d3b))
     no_holes = np.repeat(d[:, :, None], 3, 2)
     np.testing.assert_array_equal(inpaint_depth(no_holes), no_holes)
+
+
+@pytest.mark.parametrize("path", golden("wiring"), ids=os.path.basename)
+def test_reference_wiring_fixture(path):
+    """EXTRA EVIDENCE (it pins nothing): tests/golden/wiring_*.npz are outputs of the REFERENCE's own module code -
+    mask_refiner/model.py (MaskRefiner.forward, MaskRefinerInsEmbedHead incl. the hierarchy loop :738-762, FusionLayers,
+    SinglePredictionHead / SinglePredictor, the instance extraction :313-356) and backbone/resnet.py (DeepLabStem, ResNet stages,
+    RGBDFusionBackbone) - imported unmodified with stand-ins for the detectron2 / fvcore / monai symbols they use
+    (oracle/gen_wiring.py), on quber_amd.arch's seeded weights (loaded by key: the reference's module tree names every tensor as
+    arch.param_specs does).  The oracle restatement must reproduce every head output, the label map and the instances.
+    The detectron2 layers themselves (Conv2d wrapper, FrozenBN, BottleneckBlock, ASPP, DeepLabV3PlusHead.layers) are the generator's
+    stand-ins, i.e. the same recollection of detectron2 the oracle rests on: that part stays unpinned."""
+    import ast
+    from oracle.network_torch import ArchCfg, MaskRefinerNet
+    from quber_amd import arch
+    z = np.load(path)
+    kw = ast.literal_eval(str(z["arch_kwargs"]))
+    sd = arch.init_state_dict(seed=int(z["seed"]), loud_heads=True, center_bias=float(z["center_bias"]), **kw)
+    okw = dict(kw, hierarchy=[list(l) for l in kw["hierarchy"]], fusion_target=list(kw["fusion_target"]))
+    net = MaskRefinerNet(ArchCfg(**okw)).eval()
+    missing, unexpected = net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing)
+    np.testing.assert_array_equal(encode_np.encode_initial_masks(z["masks"]), z["offsets"])
+    image = torch.from_numpy(np.concatenate([z["rgb"], z["depth"]], -1)).permute(2, 0, 1)[None]
+    with torch.no_grad():
+        out = net(image, torch.from_numpy(z["offsets"][None]))
+    heads = [k[5:] for k in z.files if k.startswith("head_")]
+    assert set(heads) == set(out) and len(heads) >= 4
+    for k in heads:
+        ref = torch.from_numpy(z["head_" + k])
+        assert out[k].shape == ref.shape, k
+        assert float(ref.abs().max()) > 0.3, k                                       # loud heads: the check means something
+        # two CPU torch evaluations of the same graph: summation order of fused vs unfused ops only
+        assert float((out[k] - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), (k, float((out[k] - ref).abs().max()))
+    # model.py:266-289 (sem_seg_postprocess at the frame's own size = identity) and :290-356 on the REFERENCE's logits: bit-exact
+    np.testing.assert_array_equal(z["sem_seg"], z["head_foreground"][0])
+    o = postproc_ref.postprocess(torch.from_numpy(z["head_foreground"][0]), torch.from_numpy(z["head_center"][0]), torch.from_numpy(z["head_offset"][0]))
+    np.testing.assert_array_equal(o["panoptic"].numpy(), z["panoptic"])
+    assert len(z["inst_scores"]) >= 1
+    np.testing.assert_array_equal(o["masks"].numpy(), z["inst_masks"])
+    np.testing.assert_array_equal(o["boxes"].numpy(), z["inst_boxes"])
+    np.testing.assert_array_equal(o["classes"].numpy(), z["inst_classes"])
+    np.testing.assert_allclose(o["scores"].numpy(), z["inst_scores"], rtol=1e-6, atol=1e-7)
