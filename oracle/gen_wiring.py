@@ -383,56 +383,94 @@ VARIANTS = {
 }
 
 
-def main():
+def stable_under_perturbation(fg, center, offset, pan, trials=6, eps=1e-4):
+    """Would another correct fp32 evaluation (logits within 1e-4 in head units; offsets x4) give the same label map?  A fixture whose
+    instance sits at the 512-pixel area filter, or whose centre peak sits at the 0.3 threshold, flips wholesale on 1e-5 of noise
+    and would test nothing but that coincidence."""
+    from oracle import postproc_ref
+    g = torch.Generator().manual_seed(1)
+    for _ in range(trials):
+        nz = lambda t, s: t + (torch.rand(t.shape, generator=g) * 2 - 1) * s
+        o = postproc_ref.postprocess(nz(fg, eps), nz(center, eps), nz(offset, 4 * eps))
+        if float((o["panoptic"] != pan).float().mean()) > 2e-3:
+            return False
+    return True
+
+
+def run_scene(net, arch, kw, sc, weight_seed, n):
+    """One frame through the reference-authored forward on the seeded loud weights (centre bias calibrated on the reference's own centre
+    logits); None if no instance survives.  out["stable"]: the label map survives 1e-4 perturbations of the logits."""
     from oracle import encode_np
+    h, w = sc["rgb"].shape[:2]
+    offs = encode_np.encode_initial_masks(sc["masks"])
+    image = torch.from_numpy(np.concatenate([sc["rgb"], sc["depth"]], -1)).permute(2, 0, 1).float()
+    inp = [{"image": image, "initial_pred_offset": torch.from_numpy(offs), "height": h, "width": w}]
+
+    def load(sd):
+        ref_keys = {k for k in net.state_dict() if not k.endswith("num_batches_tracked")}
+        assert ref_keys == set(sd), sorted(ref_keys ^ set(sd))[:8]          # the reference's module tree names every tensor as arch.param_specs does
+        missing, unexpected = net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing)
+
+    grabbed = {}
+    hook = net.ins_embed_head.register_forward_hook(lambda m, i, o: grabbed.update({k: v.detach().clone() for k, v in o[0].items()}))
+    try:
+        load(arch.init_state_dict(seed=weight_seed, loud_heads=True, **kw))
+        with torch.no_grad():
+            net(inp)
+        bias = arch.calibrate_center_bias(grabbed["center"], n)
+        load(arch.init_state_dict(seed=weight_seed, loud_heads=True, center_bias=bias, **kw))
+        with torch.no_grad():
+            res = net(inp)[0]
+    finally:
+        hook.remove()
+    if "instances" not in res:               # no instance survived: the fixture would not exercise model.py:313-356
+        return None
+    stable = stable_under_perturbation(grabbed["foreground"][0], grabbed["center"][0], grabbed["offset"][0], res["panoptic_seg"][0])
+    out = {"stable": np.bool_(stable),"rgb": sc["rgb"], "depth": sc["depth"], "masks": sc["masks"], "offsets": offs, "seed": np.int64(weight_seed),
+           "center_bias": np.float64(bias), "arch_kwargs": np.array(repr(kw)),
+           "panoptic": res["panoptic_seg"][0].numpy(), "sem_seg": res["sem_seg"].numpy()}
+    for k, v in grabbed.items():
+        out["head_" + k] = v.numpy()
+    for k in ("eee_boundary", "eee_mask"):
+        if k in res:
+            out["out_" + k] = res[k].numpy()
+    ins = res["instances"]
+    out.update(inst_masks=ins.pred_masks.numpy(), inst_scores=ins.scores.numpy(), inst_boxes=ins.pred_boxes.tensor.numpy(),
+               inst_classes=ins.pred_classes.numpy())
+    return out
+
+
+def main():
     from quber_amd import arch, config as qconfig, synth
     _, model = import_reference()
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    h, w, n = 64, 96, 3
+    h, w, n = 96, 128, 3           # (at 64 x 96 the instances sit near the 512-pixel area filter: no stable scene)
     for vi, (name, over) in enumerate(VARIANTS.items()):
         cfg = reference_cfg(**over)
         kw = qconfig.arch_kwargs(cfg)
         net = model.MaskRefiner(cfg).eval()
-        sc = synth.make_scene(40 + vi, h, w, n)
-        offs = encode_np.encode_initial_masks(sc["masks"])
-        image = torch.from_numpy(np.concatenate([sc["rgb"], sc["depth"]], -1)).permute(2, 0, 1).float()
-        inp = [{"image": image, "initial_pred_offset": torch.from_numpy(offs), "height": h, "width": w}]
-
-        def load(sd):
-            ref_keys = {k for k in net.state_dict() if not k.endswith("num_batches_tracked")}
-            assert ref_keys == set(sd), (sorted(ref_keys ^ set(sd))[:8], name)         # the reference's module tree names every tensor as arch.param_specs does
-            missing, unexpected = net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
-            assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing)
-
-        grabbed = {}
-        hook = net.ins_embed_head.register_forward_hook(lambda m, i, o: grabbed.update({k: v.detach().clone() for k, v in o[0].items()}))
-        load(arch.init_state_dict(seed=30 + vi, loud_heads=True, **kw))
-        with torch.no_grad():
-            net(inp)
-        bias = arch.calibrate_center_bias(grabbed["center"], n)
-        sd = arch.init_state_dict(seed=30 + vi, loud_heads=True, center_bias=bias, **kw)
-        load(sd)
-        with torch.no_grad():
-            res = net(inp)[0]
-        hook.remove()
-        out = {"rgb": sc["rgb"], "depth": sc["depth"], "masks": sc["masks"], "offsets": offs, "seed": np.int64(30 + vi),
-               "center_bias": np.float64(bias), "arch_kwargs": np.array(repr(kw)),
-               "panoptic": res["panoptic_seg"][0].numpy(), "sem_seg": res["sem_seg"].numpy()}
-        for k, v in grabbed.items():
-            out["head_" + k] = v.numpy()
-        for k in ("eee_boundary", "eee_mask"):
-            if k in res:
-                out["out_" + k] = res[k].numpy()
-        if "instances" in res:
-            ins = res["instances"]
-            out.update(inst_masks=ins.pred_masks.numpy(), inst_scores=ins.scores.numpy(), inst_boxes=ins.pred_boxes.tensor.numpy(),
-                       inst_classes=ins.pred_classes.numpy())
-        k_inst = len(out.get("inst_scores", []))
-        assert k_inst >= 1, (name, "no instance survived: the fixture would not exercise model.py:313-356")
+        # the first scene whose label map survives 1e-4 perturbations of the logits; failing that, the first with an instance, flagged
+        # `stable = False` (random loud heads put the centre maxima on the frame's border, where the x4 bilinear up-sampling repeats
+        # rows: exact two-pixel plateaus, two centres per maximum (post_processing.py:9-41 keeps both), and which of the twins owns a
+        # pixel - hence which instance passes the 512-pixel filter - turns on the last bit of a logit)
+        out, fallback = None, None
+        for scene_seed in range(40 + 12 * vi, 52 + 12 * vi):
+            cand = run_scene(net, arch, kw, synth.make_scene(scene_seed, h, w, n), 30 + vi, n)
+            if cand is None:
+                continue
+            cand["scene_seed"] = np.int64(scene_seed)
+            if bool(cand["stable"]):
+                out = cand
+                break
+            fallback = fallback or cand
+        out = out or fallback
+        assert out is not None, name
+        scene_seed = int(out["scene_seed"])
         np.savez_compressed(os.path.join(OUT, f"wiring_{name}.npz"), **out)
-        print(f"wiring_{name}.npz: {len(sd)} tensors loaded into the reference's module tree, heads {sorted(grabbed)}, "
-              f"{k_inst} instances, labels {sorted(set(out['panoptic'].ravel().tolist()))}")
+        print(f"wiring_{name}.npz: scene {scene_seed} (stable {bool(out['stable'])}), {len(net.state_dict())} tensors in the reference's module tree, heads "
+              f"{sorted(k[5:] for k in out if k.startswith('head_'))}, {len(out['inst_scores'])} instances, labels {sorted(set(out['panoptic'].ravel().tolist()))}")
 
 
 if __name__ == "__main__":

@@ -177,7 +177,9 @@ def calibrate_center_bias(center, target=20, threshold=0.3, nms_kernel=7):
     pooled = F.max_pool2d(c, nms_kernel, 1, nms_kernel // 2)
     cuts = []
     for b in range(c.shape[0]):
-        peaks = torch.sort(c[b][c[b] == pooled[b]], descending=True).values
+        # distinct peak VALUES: the x4 bilinear up-sampling of the quarter-resolution head output makes every maximum a plateau of
+        # 2-4 equal pixels - cutting between two pixels of one plateau would put the threshold exactly ON a peak
+        peaks = torch.unique(c[b][c[b] == pooled[b]], sorted=True).flip(0)
         k = min(target, peaks.numel() - 1)
         cuts.append(float(0.5 * (peaks[k - 1] + peaks[k])) if k >= 1 else float(peaks[0]) - 1.0)
     return float(threshold - np.median(cuts))

@@ -234,10 +234,16 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ in,
     if (t < groups * 2) atomicAdd(&stats[((long)(g * B + b) * groups) * 2 + t], acc[t]);
 }
 
-static int gn_pixels_per_block(int HW, int C, int B, int G) {
-    // ~64K floats per block at large batch, but never fewer than ~1000 blocks in flight at small batch
+static int gn_pixels_per_block(int HW, int C, int B, int G, bool stats = false) {
+    // ~64K floats per block at large batch, but never fewer than ~1000 blocks in flight at small batch.
+    // stats: one block per ~8K floats at most (128 blocks at least): every block of the statistics pass ends in 2 x groups fp64 atomics on
+    // the SAME addresses, and a thousand blocks of 19 pixels each (a 32-channel head tensor of one frame) spent 16-25 us queueing on them
+    // (profiles/r13d_b1_kernels_480x640_before.txt)
     int ppb = 65536 / C;
-    const long want = ((long)HW * B * G + 1023) / 1024;
+    const long pixels = (long)HW * B * G;
+    long blocks = 1024;
+    if (stats) blocks = std::min<long>(1024, std::max<long>(128, pixels * C / 8192));
+    const long want = (pixels + blocks - 1) / blocks;
     if (ppb > want) ppb = (int)want;
     if (ppb < 8) ppb = 8;
     return ppb;
@@ -267,7 +273,7 @@ int launch_gn_stats(const View& in, int B, int G, int groups, double* stats, hip
         const int rc = launch_zero(stats, sizeof(double) * 2 * groups * B * G, st);
         if (rc) return rc;
     }
-    const int ppb = gn_pixels_per_block(HW, in.C, B, G);
+    const int ppb = gn_pixels_per_block(HW, in.C, B, G, true);
     const int chunks = (HW + ppb - 1) / ppb;
     ProfScope prof("gn_stats", (double)in.es * G * B * (double)HW * in.C, 0.0, st);
     if (in.es == 2)

@@ -1289,10 +1289,15 @@ def test_hip_against_reference_wiring_fixture(path):
         assert float((got - ref).abs().max()) / scale < 1e-4, (k, float((got - ref).abs().max()) / scale)
     post = eng.postprocess(lg.cuda())
     pan = post["panoptic"][0].cpu().numpy()
-    if not np.array_equal(pan, z["panoptic"]):          # only float near-ties may differ: re-derive the reference's map from the HIP logits
-        exp = postproc_ref.postprocess(lg[0, 0:1], lg[0, 1:2], lg[0, 2:4])["panoptic"].numpy()
-        np.testing.assert_array_equal(pan, exp)
-        assert (pan != z["panoptic"]).mean() < 1e-3
+    # the HIP label map is the reference algorithm's (oracle/postproc_ref.py, pinned bit-exact by the imported post_processing.py) on the HIP logits
+    exp = postproc_ref.postprocess(lg[0, 0:1], lg[0, 1:2], lg[0, 2:4])["panoptic"].numpy()
+    np.testing.assert_array_equal(pan, exp)
+    if not np.array_equal(pan, z["panoptic"]):
+        # ... and differs from the reference's own map only where 1e-4 of logit noise flips a decision.  Fixtures flagged unstable
+        # (gen_wiring.py: centre maxima on exact two-pixel plateaus of the x4 up-sampling, twin centres, an instance at the 512-pixel
+        # filter) change wholesale under such noise in the reference itself - for them the line above is the whole statement.
+        if bool(z["stable"]):
+            assert (pan != z["panoptic"]).mean() < 2e-3
     else:
         k = int(post["count"][0])
         assert k == len(z["inst_scores"]) >= 1
