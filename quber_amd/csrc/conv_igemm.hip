@@ -988,7 +988,9 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
     // bf16x3 pays where the matrix pipe is the limit.  The HBM-bound short-K launches on 64x64 tiles (bottleneck conv3 +
     // residual) and the 32-column head layers on 256x32 tiles lose occupancy to its three LDS planes and gain nothing
     // (profiles/r02j_conv_layers_dtype{0,3}.md): they keep the exact fp32 MFMA kernel, which is at least as accurate.
-    if (p.bf16 == 3 && (BM == 256 || (BM == 64 && nk <= 8))) exact_fallback();
+    // (so does the dilated layer that skips padded filter rows on 64x64 tiles - ASPP d = 18 on a 30-row map: 1.49 ms as bf16x3 against 1.03 ms
+    //  exact at batch 16, profiles/r12_final_conv_layers_dtype{0,3}.md)
+    if (p.bf16 == 3 && (BM == 256 || (BM == 64 && (nk <= 8 || skip)))) exact_fallback();
     if (p.bf16) {
         {
             ProfScope prof(tag, conv_bytes, conv_flops, st);

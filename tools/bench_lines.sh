@@ -14,7 +14,7 @@ print(sys.argv[1].split("/")[-1], round(j["value"], 1), j["unit"], round(j["ms_p
 PY
 }
 run bench --steps 20 --warmup 5
-Q="--cpu-frames 0 --predict-calls 0 --no-split-mode"
+Q="--cpu-frames 0 --predict-calls 0 --no-split-mode --no-configs"
 run bench_bf16x3 --steps 20 --warmup 5 --dtype f32-bf16x3 $Q
 run bench_hostio --steps 20 --warmup 5 --host-io $Q
 run bench_b1 --steps 100 --warmup 20 --batch 1 $Q

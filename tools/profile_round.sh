@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=${1:-rXX}
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_bench -o b -- python3 $R/bench.py --cpu-frames 0 --predict-calls 0 --no-split-mode --steps 20 --warmup 5 > $O/${TAG}_bench_under_rocprof.json 2> $O/${TAG}_prof_bench.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_bench -o b -- python3 $R/bench.py --cpu-frames 0 --predict-calls 0 --no-split-mode --no-configs --steps 20 --warmup 5 > $O/${TAG}_bench_under_rocprof.json 2> $O/${TAG}_prof_bench.log
 cp $O/${TAG}_prof_bench/b_kernel_stats.csv $O/${TAG}_bench_kernel_stats.csv
 for DT in 0 3; do
   rocprofv3 --kernel-trace --output-format csv -d $O/${TAG}_prof_layers_$DT -o lay -- python3 $R/tools/layer_profile.py run --plan $O/${TAG}_plan_$DT.json --compute-dtype $DT > $O/${TAG}_prof_layers_$DT.log 2>&1
