@@ -55,7 +55,9 @@ def rel_err(got, ref):
 
 @pytest.mark.parametrize("h,w,b,depth", [(64, 96, 2, 50), (128, 160, 1, 50), (64, 64, 1, 101), (70, 102, 2, 50), (53, 75, 1, 50)])
 def test_network_vs_oracle_small(h, w, b, depth):
-    sd = arch.init_state_dict(seed=1, depth=depth)
+    # loud predictors (O(1) logits that depend on the features): with the reference's N(0, 0.001) init the logits are ~3e-3 and an
+    # absolute 1e-4 bar on them checks little (the taps below are relative either way)
+    sd = arch.init_state_dict(seed=1, depth=depth, loud_heads=True)
     net = oracle_net(sd, depth)
     batch, offs = inputs(3, b, h, w, 4)
     qc = engine.make_config(h, w, max_batch=b + 1)
@@ -72,8 +74,9 @@ def test_network_vs_oracle_small(h, w, b, depth):
         got = eng.debug_tensor(name, b).cpu().permute(0, 3, 1, 2)
         assert rel_err(got, taps[name]) < TOL, name
     exp = torch.cat([ref["foreground"], ref["center"], ref["offset"], ref["eee_boundary"]], 1)
-    assert logits.shape == exp.shape
-    assert float((logits - exp).abs().max()) < TOL
+    assert logits.shape == exp.shape and float(exp[:, 0].abs().max()) > 0.5
+    d = (logits - exp).abs()
+    assert float(d[:, :2].max()) < TOL and float(d[:, 2:4].max()) < 4 * TOL and float(d[:, 4:].max()) < TOL      # head units: offsets are emitted x4 (model.py:700)
     if depth == 50 and h % 16 == 0 and w % 16 == 0:
         assert abs(eng.forward_flops() / 2e9 - 187.8 * (h * w) / (480 * 640)) < 0.02 * 187.8 * (h * w) / (480 * 640)
     eng.close()
