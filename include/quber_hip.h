@@ -317,6 +317,8 @@ double quber_forward_flops_padding(quber_ctx* ctx);
  * key 39 (1; plan) fp16 data path: a patch-kernel layer of up to 128 output channels that is the only reader of a GroupNorm + ReLU output
  *         (decoder fuse convolutions, the heads' second convolution: model.py:386-403, 610-651) applies that norm to its LDS patches - the
  *         arithmetic of the norm pass, bit for bit, without the pass over the tensor in HBM; 0 = every norm is a pass of its own.
+ * key 41 (1; plan) small batches (side lanes, key 24): the dilated ASPP branches d = 6 / 12 (model.py:610-651) on the two side lanes,
+ *         beside the d = 18 and 1x1 branches on the caller's stream; 0 = one after the other.  Same launches, same bits.
  * Process-only keys (quber_set_tuning): key 2 = give the stand-alone conv ops a split-K workspace (value != 0) or drop it (0);
  * key 11 = stand-alone conv op: dilated 3x3 layers in tap-major K order with the zero-padding filter rows skipped;
  * key 12 = stand-alone conv ops: quber_config.compute_dtype of the launch (1 = bf16 / 2 = fp16 operands, 3 = bf16x3);

@@ -511,7 +511,7 @@ __global__ void predictor_kernel(const PredHeads hs, int in_cs, float* __restric
     const int cout = hs.cout[hd], q_ch0 = hs.q_ch0[hd], act = hs.act[hd];
     __shared__ float ws[4 * CIN + 4];
     for (int i = threadIdx.x; i < cout * CIN; i += blockDim.x) ws[i] = w[i];
-    if (threadIdx.x < cout) ws[4 * CIN + threadIdx.x] = bias[threadIdx.x];
+    if ((int)threadIdx.x < cout) ws[4 * CIN + threadIdx.x] = bias[threadIdx.x];
     __syncthreads();
     const long total = (long)B * HW;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {

@@ -56,6 +56,7 @@ static int* tuning_field(Tuning& t, int key) {
         case 29: return &t.stem_fused;
         case 38: return &t.h8_narrow;
         case 39: return &t.h8_norm;
+        case 41: return &t.aspp_lanes;
         case 30: return &t.lean_loader;
         case 31: return &t.h8;
         case 32: return &t.h8_min_tiles;
@@ -71,7 +72,7 @@ bool tuning_set(Tuning& t, int key, int value) {
     return f != nullptr;
 }
 // keys that shape the plan: they act when quber_finalize_weights builds it and are refused afterwards
-bool tuning_plan_time(int key) { return key == 6 || key == 7 || key == 8 || key == 9 || key == 10 || key == 18 || key == 25 || key == 27 || key == 29 || key == 39; }
+bool tuning_plan_time(int key) { return key == 6 || key == 7 || key == 8 || key == 9 || key == 10 || key == 18 || key == 25 || key == 27 || key == 29 || key == 39 || key == 41; }
 
 // compute units of the current device, cached per device id (a process may drive several devices with different counts)
 int device_cus() {
@@ -754,9 +755,13 @@ struct Builder {
         if (!dry) {
             c->gn_stats = (double*)dalloc_bytes(sizeof(double) * GN_SLOTS * gn_slot_doubles(Bmax));
             quber_ctx* ctx = c;
+            // (on side lane 2, joined where lane 1 is first forked - long before the first kernel that accumulates into the sums: at small
+            // batches the stem starts at once instead of behind a 5 us fill)
+            fork(2);
             op([ctx](int, hipStream_t st) {
                 return launch_zero(ctx->gn_stats, sizeof(double) * ctx->gn_slots * gn_slot_doubles(ctx->cfg.max_batch), st);
             });
+            back_to_main();
         }
         if (!dry) {
             c->splitk_floats = (size_t)40 << 20;   // 160 MiB of partial tiles: S x blocks stays near 1-2 rounds of 128x128 tiles at any batch
@@ -824,6 +829,14 @@ struct Builder {
             F[s] = a;
             if (!dry) c->taps["res" + std::to_string(s + 2)] = a;
         };
+        // decoder inputs that depend on ONE fused stage output only - the 1x1 projections of res3 / res2 (+ GroupNorm) into their slice of the
+        // decoder's concatenated buffers - are emitted on that stage's side lane, right behind its fusion convolutions: at small batches
+        // they are off the caller's stream altogether (2 x ~30 us per batch-1 forward)
+        const std::string Hd = "ins_embed_head.";
+        const int CD = cf.convs_dim, HC = cf.head_channels;      // INS_EMBED_HEAD.CONVS_DIM / HEAD_CHANNELS (128 / 32)
+        View cat3 = make(64 + 256, h8, w8), t64 = make(64, h8, w8);
+        // (fp16 data path: 160 -> 192 channels per pixel, the last 32 never written = zero, zero filters for them: whole 64-channel blocks for the patch kernel)
+        View cat2 = make(aes == 2 ? (32 + CD + 63) / 64 * 64 : 32 + CD, h4, w4), t32 = make(32, h4, w4);
         int cin = 64, cout = 256, mid = 64, ch = h4, cw = w4;
         for (int s = 0; s < 4; ++s) {
             const int stage = s + 2;
@@ -861,24 +874,37 @@ struct Builder {
             // the fusion convolutions of this stage's output: a side lane for res2 / res3 (they run beside the later stages at small
             // batches and are joined where the decoder first reads them), the main stream for res5 (the ASPP waits for it anyway)
             if (s == 0 || s == 1) {
+                if (s == 0) join(2);          // the cleared GroupNorm sums: every accumulating kernel is launched behind this point
                 fork(1 + s);
                 emit_fusion(s);
+                if (s == 1) conv_gn(Hd + "decoder.res3.project_conv", F[1], t64, slice(cat3, 0, 64), 1, 1);
+                else conv_gn(Hd + "decoder.res2.project_conv", F[0], t32, slice(cat2, 0, 32), 1, 1);
                 back_to_main();
             } else if (s == 3) {
                 emit_fusion(3);
             }
         }
 
-        (void)h8; (void)w8;
 
         // ---------------- decoder ([d2] DeepLabV3PlusHead.layers) ----------------
-        const std::string Hd = "ins_embed_head.";
         const std::string A = Hd + "decoder.res5.project_conv.";
         View catA = make(1280, h16, w16), tA = make(256, h16, w16);
+        // the image-pooling branch (global average -> 1x1 -> broadcast) on side lane 2 (idle since fusion_res3): four latency-bound launches
+        // beside the other branches instead of in front of the projection
+        fork(2);
+        {
+            View pooled = make(2048, 1, 1), pc = make(256, 1, 1);
+            View f5 = F[3];
+            op([=](int B, hipStream_t st) { return launch_avgpool(f5, pooled, B, st); });
+            conv({A + "convs.4.1"}, pooled, 2048, pc, 1, 1, 0, 1, AF_BIAS, nullptr, true);
+            View dst = slice(catA, 1024, 256);
+            op([=](int B, hipStream_t st) { return launch_bilinear(pc, dst, B, st); });
+        }
+        back_to_main();
         conv_gn(A + "convs.0", F[3], tA, slice(catA, 0, 256), 1, 1);
         const int adil[3] = {6, 12, 18};
-        // (the three dilated branches on lanes of their own were measured too: no gain at batch 1 - 3.92 against 3.85 ms in the
-        // bf16x3 mode - so they stay on the caller's stream)
+        // (round 2 measured the three dilated branches on lanes of their own in the bf16x3 mode: 3.92 against 3.85 ms; round 6, exact fp32, two
+        // of them on the lanes that the fusion convolutions have long left: 3.74 -> 3.70 ms - key 41)
         // fp16 data path on maps large enough that no branch skips padded filter rows: the three dilated branches as ONE grouped launch
         // (they read the same tensor; per-group dilation, ConvP::dil_g) - 3 x 128 tiles at 1024x1024 batch 8 instead of three launches
         // that each leave half of conv_h8.hip's one-block-per-CU grid empty
@@ -891,24 +917,25 @@ struct Builder {
             const std::vector<std::string> an = {A + "convs.1", A + "convs.2", A + "convs.3"};
             conv(an, xin, F[3].C, tA3, 3, 1, adil[2], adil[2], AF_NONE, nullptr, false, {adil[0], adil[1], adil[2]});
             gn_relu({an[0] + ".norm", an[1] + ".norm", an[2] + ".norm"}, tA3, slice(catA, 256, 256, 256));
+        } else if (tune().aspp_lanes) {
+            // key 41: the dilated branches d = 6 / 12 on the two side lanes (temporaries of their own), d = 18 on the caller's stream
+            View tA1 = make(256, h16, w16), tA2 = make(256, h16, w16);
+            fork(1);
+            conv_gn(A + "convs.1", F[3], tA1, slice(catA, 256, 256), 3, adil[0]);
+            back_to_main();
+            fork(2);
+            conv_gn(A + "convs.2", F[3], tA2, slice(catA, 512, 256), 3, adil[1]);
+            back_to_main();
+            conv_gn(A + "convs.3", F[3], tA, slice(catA, 768, 256), 3, adil[2]);
+            join(1);
         } else {
             for (int i = 0; i < 3; ++i) conv_gn(A + "convs." + std::to_string(i + 1), F[3], tA, slice(catA, 256 * (i + 1), 256), 3, adil[i]);
         }
-        {
-            View pooled = make(2048, 1, 1), pc = make(256, 1, 1);
-            View f5 = F[3];
-            op([=](int B, hipStream_t st) { return launch_avgpool(f5, pooled, B, st); });
-            conv({A + "convs.4.1"}, pooled, 2048, pc, 1, 1, 0, 1, AF_BIAS, nullptr, true);
-            View dst = slice(catA, 1024, 256);
-            op([=](int B, hipStream_t st) { return launch_bilinear(pc, dst, B, st); });
-        }
+        join(2);                         // fusion_res3 + decoder.res3.project_conv + the pooling branch
         View y5 = make(256, h16, w16);
         conv_gn(A + "project", catA, tA, y5, 1, 1);
 
-        const int CD = cf.convs_dim, HC = cf.head_channels;      // INS_EMBED_HEAD.CONVS_DIM / HEAD_CHANNELS (128 / 32)
-        View cat3 = make(64 + 256, F[1].H, F[1].W), t64 = make(64, F[1].H, F[1].W), t128a = make(CD, F[1].H, F[1].W);
-        join(2);                         // fusion_res3
-        conv_gn(Hd + "decoder.res3.project_conv", F[1], t64, slice(cat3, 0, 64), 1, 1);
+        View t128a = make(CD, F[1].H, F[1].W);
         {
             View dst = slice(cat3, 64, 256);
             op([=](int B, hipStream_t st) { return launch_bilinear(y5, dst, B, st); });
@@ -952,10 +979,8 @@ struct Builder {
             // 1x1 reduction in front of the head-fusion stack runs on conv_h8.hip
             YP[i] = make(aes == 2 ? (wd + 63) / 64 * 64 : (wd + 3) / 4 * 4, h4, w4);
         }
-        // (fp16 data path: 160 -> 192 channels per pixel, the last 32 never written = zero, zero filters for them: whole 64-channel blocks for the patch kernel)
-        View cat2 = make(aes == 2 ? (32 + CD + 63) / 64 * 64 : 32 + CD, h4, w4), t32 = make(32, h4, w4), t128 = make(CD, h4, w4);
-        join(1);                         // fusion_res2
-        conv_gn(Hd + "decoder.res2.project_conv", F[0], t32, slice(cat2, 0, 32), 1, 1);
+        View t128 = make(CD, h4, w4);
+        join(1);                         // fusion_res2 + decoder.res2.project_conv
         {
             View dst = slice(cat2, 32, CD);
             op([=](int B, hipStream_t st) { return launch_bilinear(y3, dst, B, st); });
