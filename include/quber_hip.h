@@ -319,6 +319,10 @@ double quber_forward_flops_padding(quber_ctx* ctx);
  *         arithmetic of the norm pass, bit for bit, without the pass over the tensor in HBM; 0 = every norm is a pass of its own.
  * key 41 (1; plan) small batches (side lanes, key 24): the dilated ASPP branches d = 6 / 12 (model.py:610-651) on the two side lanes,
  *         beside the d = 18 and 1x1 branches on the caller's stream; 0 = one after the other.  Same launches, same bits.
+ * key 42 (1; launch) exact fp32 (and the bf16x3 mode's launches that conv_x8.hip does not take): 1x1 GEMMs - bottleneck / fusion / ASPP 1x1
+ *         convolutions of resnet.py:395-449, 472-485 and model.py:610-651, Winograd position GEMMs - on 64 x 64 tiles, one per block, instead of
+ *         the 128 x 128 split-K / persistent launch when (a) the 128 x 128 tiling has at most 1 280 tiles (small batches), or (b, exact fp32 only)
+ *         K <= 1024 whatever the size; 2 = rule (a) only, 0 = neither.  The same K order per output element: a re-association at most.
  * Process-only keys (quber_set_tuning): key 2 = give the stand-alone conv ops a split-K workspace (value != 0) or drop it (0);
  * key 11 = stand-alone conv op: dilated 3x3 layers in tap-major K order with the zero-padding filter rows skipped;
  * key 12 = stand-alone conv ops: quber_config.compute_dtype of the launch (1 = bf16 / 2 = fp16 operands, 3 = bf16x3);

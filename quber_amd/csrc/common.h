@@ -176,6 +176,8 @@ struct Tuning {
                                  //   (conv_x8.hip); 0 = conv_igemm.hip / conv_persist.hip everywhere, 2 = every covered launch (tests)
     int x8_min_nk = 8;           // key 37 (launch): fewest K-slices (of 32) of a launch that key 35 = 1 takes
     int x8_min_rounds = 2;       // key 36 (launch): fewest rounds of tiles (tiles / CUs) of a launch that key 35 = 1 takes
+    int small_n_64 = 1;          // key 42 (launch): 64 x 64 tiles, one per block, for the 1x1 GEMMs (1) with at most 1 280 tiles of 128 x 128, and - exact fp32 - of K <= 1024 whatever their
+                                 //   size; 2 = only the first rule; 0 = the 128 x 128 split-K / persistent launches as before round 6 (conv_igemm.hip launch_conv)
     int aspp_lanes = 1;          // key 41 (plan): the dilated ASPP branches d = 6 / 12 on the two side lanes (idle since the fusion convolutions), d = 18 and the 1x1 branch on the caller's
                                  //   stream: 3.74 -> 3.70 ms per batch-1 step (the branches share the chip rather than fill it: each is 430 blocks of short K); 0 = one after the other
     int h8_narrow = 1;           // key 38 (plan + launch, as key 31): fp16 data path: the undilated 3x3 layers with the pixel operand as an LDS patch (conv_h8.hip conv_h8p / h8w / h8s kernels); 0 = the DMA-gather kernels /

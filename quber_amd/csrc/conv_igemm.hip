@@ -1101,6 +1101,20 @@ int launch_conv(const ConvP& p0, int G, hipStream_t st) {
     const long tiles128 = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * G;
     const int s128 = choose_split(p, G, 128, 128, igemm_occupancy(128, 128));
     if (tiles128 < 64 || (tiles128 < 384 && s128 == 1)) return run<64, 64, 2, 2>(p, G, choose_split(p, G, 64, 64, igemm_occupancy(64, 64)), st);
+    // 1x1 layers whose 128 x 128 tiling is at most ~5 tiles per CU (res4 / res5 conv1, the ASPP 1x1 and res3 conv1 at batch 16; every wide 1x1 layer
+    // at batches 1-4): 64 x 64 tiles, one per block - five to seven resident blocks per CU hide what two 128 x 128 blocks (split-K or persistent) cannot.
+    // tools/conv_sweep.py at 1 / 2 / 4 / 8 / 16 frames, round 6: 0.211 -> 0.176 ms on res4 conv1 and 0.357 -> 0.322 on res5.0 conv1 at batch 16,
+    // 0.134 -> 0.107 on res5 conv3 at batch 2; the batch-1 step 3.71 -> 3.50 ms, 1280x720 7.40 -> 6.96 ms (profiles/r14d_tile_rule.md)
+    if (tune().small_n_64 && p.es != 2 && p.kh == 1 && p.kw == 1 && !p.in2 && nk >= 16 && tiles128 <= 1280)
+        return run<64, 64, 2, 2>(p, G, choose_split(p, G, 64, 64, igemm_occupancy(64, 64)), st);
+    // ... and, exact fp32, every 1x1 GEMM of K <= 1024 however large the launch - the Winograd position GEMMs of the 256- / 512-channel layers
+    // (fusion_res2 / res3, res4 / res5 conv2), the fusion 1x1 convolutions of res2 / res3, res5 conv3: a K loop of 8-32 slices is over before a
+    // 128 x 128 block has amortised its prologue and epilogue, and only two of those fit a CU.  Per layer at batch 16 (rocprofv3, forced tiles):
+    // fusion_res3 conv0 0.992 -> 0.936 ms, res4 conv2 0.170 -> 0.154, res5.1 conv3 0.685 -> 0.639; K = 2048 / 4096 (ASPP, fusion_res5) lose 1-3 %
+    // on 64 x 64 tiles and keep the persistent 128 x 128 launch (profiles/r14d_tile_rule.md)
+    // (128 x 64 tiles for fusion_res5.conv, K = 4096: 2.42 against 2.49 ms in the layer table, nothing in the step - not kept)
+    if (tune().small_n_64 == 1 && p.es != 2 && p.bf16 == 0 && p.kh == 1 && p.kw == 1 && !p.in2 && nk <= 32)
+        return run<64, 64, 2, 2>(p, G, choose_split(p, G, 64, 64, igemm_occupancy(64, 64)), st);
     return run<128, 128, 2, 2>(p, G, s128, st);
 }
 

@@ -884,11 +884,25 @@ def test_conv_persistent_vs_torch(case, dt):
     lib.quber_set_tuning(2, 1)
     lib.quber_set_tuning(13, 2)
     lib.quber_set_tuning(15, 0)
+    lib.quber_set_tuning(42, 0)           # the tile shapes these cases were written for (key 42 sends the short-K 1x1 cases to 64 x 64 tiles)
     try:
         assert _conv_case(*case, bf16=dt) < 2e-6
     finally:
+        lib.quber_set_tuning(42, 1)
         lib.quber_set_tuning(15, 256)
         lib.quber_set_tuning(13, 1)
+        lib.quber_set_tuning(2, 0)
+
+
+@pytest.mark.parametrize("case", PERSISTENT_CASES)
+def test_conv_default_routing_vs_torch(case):
+    """The same geometries under the DEFAULT launch rules (round 6: 1x1 GEMMs of K <= 1024, or of at most 1 280 tiles of 128 x 128, on 64 x 64
+    tiles, one per block - option key 42; persistent launches where they still apply), exact fp32, same bar."""
+    lib = _lib.load()
+    lib.quber_set_tuning(2, 1)
+    try:
+        assert _conv_case(*case, bf16=0) < 2e-6
+    finally:
         lib.quber_set_tuning(2, 0)
 
 
@@ -939,9 +953,11 @@ def test_conv3x3_winograd_persistent_gemm(case, m):
     lib.quber_set_tuning(2, 1)
     lib.quber_set_tuning(13, 2)
     lib.quber_set_tuning(15, 0)
+    lib.quber_set_tuning(42, 0)           # (the position GEMMs of K <= 1024 would otherwise take 64 x 64 tiles: test_conv3x3_winograd_vs_float64 covers that default)
     try:
         test_conv3x3_winograd_vs_float64(case, m)
     finally:
+        lib.quber_set_tuning(42, 1)
         lib.quber_set_tuning(15, 256)
         lib.quber_set_tuning(13, 1)
         lib.quber_set_tuning(2, 0)
@@ -1027,6 +1043,7 @@ def test_conv_split_tail_equals_whole(case):
     outs = []
     lib.quber_set_tuning(2, 1)
     lib.quber_set_tuning(13, 0)           # the one-tile-per-block kernel
+    lib.quber_set_tuning(42, 0)           # ... on 128 x 128 tiles (key 42 would send the K <= 1024 case to 64 x 64 tiles, which have no split tail)
     try:
         for tail in (0, 2):               # never / whenever feasible
             lib.quber_set_tuning(5, tail)
@@ -1037,6 +1054,7 @@ def test_conv_split_tail_equals_whole(case):
     finally:
         lib.quber_set_tuning(5, 1)
         lib.quber_set_tuning(13, 1)
+        lib.quber_set_tuning(42, 1)
         lib.quber_set_tuning(2, 0)
     whole, tail = outs
     assert torch.isfinite(tail).all()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Sweeps (tile shape, K partitions) for every distinct convolution shape of the refiner on the stand-alone conv op and
-prints, per shape, the automatic choice next to the best forced one.  usage: conv_sweep.py [frames=16]"""
+prints, per shape, the automatic choice next to the best forced one.  usage: conv_sweep.py [frames=16] [json out | -] [frame height=480] [frame width=640]"""
 import ctypes as C
 import os
 import sys
@@ -13,6 +13,7 @@ sys.path.insert(0, ROOT)
 from quber_amd import _lib  # noqa: E402
 
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+FH, FW = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (480, 640)      # the table below is written for 640 x 480 frames
 # name, images per frame (streams / grouped heads), H_in, W_in, Cin, Cout, k, stride, dil, residual
 SHAPES = [
     ("stem.conv1 3x3s2 8>32", 2, 480, 640, 8, 32, 3, 2, 1, 0),
@@ -70,6 +71,7 @@ def main():
     print("|---|---|---|---|---|---|---|---|---|")
     tot_auto = tot_best = 0.0
     for (name, ipf, H, W, Cin, Cout, k, s, d, res) in SHAPES:
+        H, W = H * FH // 480, W * FW // 640
         B = ipf * F
         pad = d * (k // 2)
         OH, OW = (H + 2 * pad - d * (k - 1) - 1) // s + 1, (W + 2 * pad - d * (k - 1) - 1) // s + 1
@@ -123,7 +125,7 @@ def main():
             name, flops / 1e9, auto, flops / auto / 1e9, TILES[btile][0], TILES[btile][1], bS, bt, flops / bt / 1e9,
             (auto / bt - 1) * 100, ru), flush=True)
     print("| sum over distinct shapes | | %.3f | | | %.3f | | | |" % (tot_auto, tot_best))
-    if len(sys.argv) > 2:
+    if len(sys.argv) > 2 and sys.argv[2] != "-":
         import json
         json.dump(ALL, open(sys.argv[2], "w"))
     lib.quber_set_tuning(3, 0)
