@@ -940,7 +940,10 @@ int launch_conv_dual(ConvP p, int G, hipStream_t st) {
         tag = "conv_gemm_f32pipe";                         // profiled apart: this launch runs on the fp32 matrix pipe
     }
     const long tiles128 = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * G;
-    if (tiles128 < tune().persist_min_tiles) return 1;          // small batches: the two separate launches with their split-K model
+    // small batches: the two separate launches (64 x 64 tiles, split-K model).  With the launch rule of round 6 (key 42) the separate launches win up to
+    // ~500 tiles: res3.0 at batch 1 (304 tiles) 85 us as one dual-input launch against 34 + 24 us as two (profiles/r15_final_b1_layers_480x640.md)
+    // (twice key 15's threshold: 512 tiles by default; the tests lower key 15 to 0 to send a few tiles through this kernel)
+    if (tiles128 < (tune().small_n_64 ? 2 : 1) * (long)tune().persist_min_tiles) return 1;
     const bool big = tiles128 >= 192 && p.Cout > 64;
     if (p.es == 2 && !big) return 1;                       // the fp16 data path has the 128x128 persistent kernel only
     const int bpc = big ? (p.es == 2 ? 3 : 2) : 5;         // pk_occupancy()
