@@ -609,6 +609,16 @@ def config_run(dev, H, W, B, N, dtype, graph, steps, warmup):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     dev_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+    eager_ms = None
+    if g is not None:                 # the same step launched eagerly, beside the replayed graph (at batch <= 2 the side lanes do better outside a graph)
+        for _ in range(warmup):
+            gpu_step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            gpu_step()
+        torch.cuda.synchronize()
+        eager_ms = (time.perf_counter() - t1) / steps * 1e3
     runs = []
     for _ in range(3):
         eng.profile_begin()
@@ -618,7 +628,7 @@ def config_run(dev, H, W, B, N, dtype, graph, steps, warmup):
     count = post["count"].cpu().numpy()
     out = {"value": B * N * steps / el, "unit": "refined masks/s", "ms_per_step": el / steps * 1e3, "steps": steps, "warmup": warmup,
            "step_ms_min_median_max": [float(np.min(dev_ms)), float(np.median(dev_ms)), float(np.max(dev_ms))],
-           "frames_per_s": B * steps / el, "dtype": dtype, "hipgraph": g is not None,
+           "frames_per_s": B * steps / el, "dtype": dtype, "hipgraph": g is not None, "eager_ms_per_step": eager_ms,
            "workload": f"batch={B} {W}x{H} RGB-D, {N} initial instances/frame, ResNet-50 RGB-D refiner, "
                        f"encode+network+grouping+mask extraction, inputs resident",
            "instances_out_per_frame_mean": float(count.mean()),
