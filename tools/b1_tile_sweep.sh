@@ -6,6 +6,6 @@ cd /tmp && export TMPDIR=/tmp
 for T in "$@"; do
   N=$(echo "$T" | tr '=,' '__')
   rm -rf $O/b1_forced
-  rocprofv3 --kernel-trace --output-format csv -d $O/b1_forced -o lay -- python3 $R/tools/layer_profile.py run --plan $O/b1_forced_plan.json --batch ${BATCH:-1} --iters ${ITERS:-4} --height $H --width $W --tuning "24=0${T:+,$T}" > $O/b1_forced.log 2>&1 || { echo "run failed $T"; continue; }
+  rocprofv3 --kernel-trace --output-format csv -d $O/b1_forced -o lay -- python3 $R/tools/layer_profile.py run --plan $O/b1_forced_plan.json --batch ${BATCH:-1} --iters ${ITERS:-4} --height $H --width $W --tuning "24=0${T:+,$T}" ${DTYPE:+--compute-dtype $DTYPE} > $O/b1_forced.log 2>&1 || { echo "run failed $T"; continue; }
   python3 $R/tools/layer_profile.py report --plan $O/b1_forced_plan.json --trace $O/b1_forced/lay_kernel_trace.csv > $O/${TAG}_b1_forced_${S}_$N.md || echo "report failed $T"
 done
