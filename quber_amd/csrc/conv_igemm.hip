@@ -580,8 +580,44 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(ig
         m_next = (b0 + 1) * p.ohw;
     }
     __syncthreads();
+    // The 16-byte path of the fp32 tensors: thread t owns channel column 4 * (t % CPR) of the pass and the rows t / CPR + i * RSTEP, i < NCH.
+    // Everything it reads from memory - the affine parameters, the PReLU slopes, the residual of its first GRP rows - is requested BEFORE the
+    // accumulators go through LDS, and the residual of the next GRP rows before the stores of the rows in hand (vmcnt counts loads and
+    // stores in issue order).  Written as a loop of load-use-store per chunk, the compiler waits for every load where it is issued: eight
+    // memory latencies in a row per 64 x 64 tile, 12 of the ~21 us a block of the K = 64 residual layers lives (profiles/r17_epilogue.md).
+    constexpr int CPR = SW / 4;         // float4 chunks per row
+    static_assert(NTH % CPR == 0, "a thread keeps its channel column across the rows of a pass");
+    constexpr int RSTEP = NTH / CPR, NCH = BM / RSTEP, GRP = NCH < 4 ? NCH : 4;
+    static_assert(BM % RSTEP == 0 && NCH % GRP == 0, "whole groups of chunks per thread");
+    const bool vec4 = !HOUT && p.vec_out;     // block-uniform (the fp16 kernels are compiled for 64 / 128 registers: their loops stay as they were)
+    const int eq = (t % CPR) * 4, erow0 = t / CPR;
+    auto res_load = [&](int i, int n) __attribute__((always_inline)) -> float4 {
+        const int m = min(m0 + erow0 + i * RSTEP, p.M - 1);       // rows past the end: a valid address, the value is never used
+        return *reinterpret_cast<const float4*>(res + (long)m * p.res_cs + n);
+    };
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
+        const int nb = n0 + j * SW;    // first channel of this pass
+        const int en = nb + eq;
+        const bool nok = vec4 && en < p.Cout;
+        float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f), sl4 = sh4;
+        float4 rv[GRP];
+#pragma unroll
+        for (int i = 0; i < GRP; ++i) rv[i] = sh4;
+        auto request = [&]() __attribute__((always_inline)) {
+            if (nok) {
+                if (scale) {
+                    sc4 = *reinterpret_cast<const float4*>(scale + en);
+                    sh4 = *reinterpret_cast<const float4*>(shift + en);
+                }
+                if (prelu) sl4 = *reinterpret_cast<const float4*>(prelu + en);
+                if (res) {
+#pragma unroll
+                    for (int i = 0; i < GRP; ++i) rv[i] = res_load(i, en);
+                }
+            }
+        };
+        if constexpr (!HOUT) request();
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -590,7 +626,6 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(ig
                 smem[row * SP + wn * 32 + r] = TWO ? top[i][j][e] : acc[i][j][e];
             }
         __syncthreads();
-        const int nb = n0 + j * SW;    // first channel of this pass
         if (HOUT && hstore && p.vec_out == 2) {
             // fp16 tensors: 8 channels = 16 bytes per lane (stores, residual loads); the two float4 halves may sit in different norm groups
             constexpr int CPR8 = SW / 8;
@@ -648,50 +683,96 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(ig
                 }
             }
         } else if (p.vec_out) {
-            constexpr int CPR = SW / 4;  // float4 chunks per row
-            static_assert(NTH % CPR == 0, "a thread keeps its channel column across the rows of a pass");
             double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
+            if constexpr (HOUT) {
 #pragma unroll
-            for (int c = t; c < BM * CPR; c += NTH) {
-                const int row = c / CPR, q = (c - row * CPR) * 4;
-                const int m = m0 + row, n = nb + q;
-                if (m < p.M && n < p.Cout) {
-                    float4 v = *reinterpret_cast<const float4*>(&smem[row * SP + q]);
-                    if (scale) {
-                        const float4 sc = *reinterpret_cast<const float4*>(scale + n);
-                        const float4 sh = *reinterpret_cast<const float4*>(shift + n);
-                        v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
-                        v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
-                    }
-                    if (res) {
-                        float4 rv;
-                        if constexpr (HOUT) {
-                            const h16x4 rh = *reinterpret_cast<const h16x4*>(reinterpret_cast<const H16*>(res) + (long)m * p.res_cs + n);
-                            rv = make_float4((float)rh.x, (float)rh.y, (float)rh.z, (float)rh.w);
-                        } else {
-                            rv = *reinterpret_cast<const float4*>(res + (long)m * p.res_cs + n);
+                for (int c = t; c < BM * CPR; c += NTH) {
+                    const int row = c / CPR, q = (c - row * CPR) * 4;
+                    const int m = m0 + row, n = nb + q;
+                    if (m < p.M && n < p.Cout) {
+                        float4 v = *reinterpret_cast<const float4*>(&smem[row * SP + q]);
+                        if (scale) {
+                            const float4 sc = *reinterpret_cast<const float4*>(scale + n);
+                            const float4 sh = *reinterpret_cast<const float4*>(shift + n);
+                            v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
+                            v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
                         }
-                        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                        if (res) {
+                            float4 rv;
+                            if constexpr (HOUT) {
+                                const h16x4 rh = *reinterpret_cast<const h16x4*>(reinterpret_cast<const H16*>(res) + (long)m * p.res_cs + n);
+                                rv = make_float4((float)rh.x, (float)rh.y, (float)rh.z, (float)rh.w);
+                            } else {
+                                rv = *reinterpret_cast<const float4*>(res + (long)m * p.res_cs + n);
+                            }
+                            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                        }
+                        if (relu) {
+                            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                        }
+                        if (prelu) {
+                            const float4 sl = *reinterpret_cast<const float4*>(prelu + n);
+                            v.x = v.x > 0.f ? v.x : v.x * sl.x; v.y = v.y > 0.f ? v.y : v.y * sl.y;
+                            v.z = v.z > 0.f ? v.z : v.z * sl.z; v.w = v.w > 0.f ? v.w : v.w * sl.w;
+                        }
+                        if (hstore) {           // rounded once to fp16; the GroupNorm sums are of the stored values
+                            const h16x4 hv = {(H16)v.x, (H16)v.y, (H16)v.z, (H16)v.w};
+                            *reinterpret_cast<h16x4*>(reinterpret_cast<H16*>(out) + (long)m * out_cs + n) = hv;
+                            v = make_float4((float)hv.x, (float)hv.y, (float)hv.z, (float)hv.w);
+                        } else {
+                            *reinterpret_cast<float4*>(out + (long)m * out_cs + n) = v;
+                        }
+                        if (gn) {
+                            const double a = (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+                            const double b = (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+                            if (m < m_next) { s0 += a; q0 += b; } else { s1 += a; q1 += b; }
+                        }
                     }
-                    if (relu) {
-                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                    }
-                    if (prelu) {
-                        const float4 sl = *reinterpret_cast<const float4*>(prelu + n);
-                        v.x = v.x > 0.f ? v.x : v.x * sl.x; v.y = v.y > 0.f ? v.y : v.y * sl.y;
-                        v.z = v.z > 0.f ? v.z : v.z * sl.z; v.w = v.w > 0.f ? v.w : v.w * sl.w;
-                    }
-                    if (hstore) {           // rounded once to fp16; the GroupNorm sums are of the stored values
-                        const h16x4 hv = {(H16)v.x, (H16)v.y, (H16)v.z, (H16)v.w};
-                        *reinterpret_cast<h16x4*>(reinterpret_cast<H16*>(out) + (long)m * out_cs + n) = hv;
-                        v = make_float4((float)hv.x, (float)hv.y, (float)hv.z, (float)hv.w);
-                    } else {
-                        *reinterpret_cast<float4*>(out + (long)m * out_cs + n) = v;
-                    }
-                    if (gn) {
-                        const double a = (double)v.x + (double)v.y + (double)v.z + (double)v.w;
-                        const double b = (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
-                        if (m < m_next) { s0 += a; q0 += b; } else { s1 += a; q1 += b; }
+                }
+            } else {
+                if (nok) {
+#pragma unroll
+                    for (int i0 = 0; i0 < NCH; i0 += GRP) {
+                        // everything requested so far has arrived from here on: said once, outside the per-row branches - left to the compiler, the
+                        // wait sits inside the first row's branch and every later row waits again, then for the stores before it as well
+                        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
+                        float4 rn[GRP];
+#pragma unroll
+                        for (int i = 0; i < GRP; ++i) rn[i] = rv[i];
+                        if (res && i0 + GRP < NCH) {
+#pragma unroll
+                            for (int i = 0; i < GRP; ++i) rn[i] = res_load(i0 + GRP + i, en);
+                        }
+#pragma unroll
+                        for (int i = 0; i < GRP; ++i) {
+                            const int row = erow0 + (i0 + i) * RSTEP;
+                            const int m = m0 + row, n = en;
+                            if (m < p.M) {
+                                float4 v = *reinterpret_cast<const float4*>(&smem[row * SP + eq]);
+                                if (scale) {
+                                    v.x = fmaf(v.x, sc4.x, sh4.x); v.y = fmaf(v.y, sc4.y, sh4.y);
+                                    v.z = fmaf(v.z, sc4.z, sh4.z); v.w = fmaf(v.w, sc4.w, sh4.w);
+                                }
+                                if (res) {
+                                    v.x += rv[i].x; v.y += rv[i].y; v.z += rv[i].z; v.w += rv[i].w;
+                                }
+                                if (relu) {
+                                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                                }
+                                if (prelu) {
+                                    v.x = v.x > 0.f ? v.x : v.x * sl4.x; v.y = v.y > 0.f ? v.y : v.y * sl4.y;
+                                    v.z = v.z > 0.f ? v.z : v.z * sl4.z; v.w = v.w > 0.f ? v.w : v.w * sl4.w;
+                                }
+                                *reinterpret_cast<float4*>(out + (long)m * out_cs + n) = v;
+                                if (gn) {
+                                    const double a = (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+                                    const double b = (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+                                    if (m < m_next) { s0 += a; q0 += b; } else { s1 += a; q1 += b; }
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < GRP; ++i) rv[i] = rn[i];
                     }
                 }
             }
@@ -762,16 +843,30 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvP p, int S
         const long mr = i / p.Cout;
         const int n = (int)(i - mr * p.Cout);
         const long m = mr + p.ws_row0;
-        vec v = *reinterpret_cast<const vec*>(p.ws + (long)g * MN + i);
-        for (int s = 1; s < S; ++s) v += *reinterpret_cast<const vec*>(p.ws + ((long)s * G + g) * MN + i);
+        // everything this element needs is requested before the first value is used (V == 4: n, the strides and the bases are multiples of
+        // 4 floats - host), the slabs four at a time; the slabs are added one by one in slab order, as they always were
+        vec sc, sh, sl, rr;
+        if (scale) { sc = *reinterpret_cast<const vec*>(scale + n); sh = *reinterpret_cast<const vec*>(shift + n); }
+        if (prelu) sl = *reinterpret_cast<const vec*>(prelu + n);
+        if (res) rr = *reinterpret_cast<const vec*>(res + m * p.res_cs + n);
+        const float* const w0 = p.ws + (long)g * MN + i;
+        const long sstep = (long)G * MN;
+        vec v = *reinterpret_cast<const vec*>(w0);
+        int s = 1;
+        for (; s + 3 < S; s += 4) {
+            const vec a = *reinterpret_cast<const vec*>(w0 + s * sstep), b = *reinterpret_cast<const vec*>(w0 + (s + 1) * sstep);
+            const vec c = *reinterpret_cast<const vec*>(w0 + (s + 2) * sstep), d = *reinterpret_cast<const vec*>(w0 + (s + 3) * sstep);
+            v += a; v += b; v += c; v += d;
+        }
+        for (; s < S; ++s) v += *reinterpret_cast<const vec*>(w0 + s * sstep);
         float o[V];
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             float x = V == 1 ? v[0] : v[e];
-            if (scale) x = fmaf(x, scale[n + e], shift[n + e]);
-            if (res) x += res[m * p.res_cs + n + e];
+            if (scale) x = fmaf(x, V == 1 ? sc[0] : sc[e], V == 1 ? sh[0] : sh[e]);
+            if (res) x += V == 1 ? rr[0] : rr[e];
             if (p.relu) x = fmaxf(x, 0.f);
-            if (prelu) x = x > 0.f ? x : x * prelu[n + e];
+            if (prelu) x = x > 0.f ? x : x * (V == 1 ? sl[0] : sl[e]);
             o[e] = x;
         }
         if constexpr (V == 4) {

@@ -735,32 +735,32 @@ __global__ __launch_bounds__(256) void pk_fixup_kernel(const ConvP p, int P) {
         const int m = m0 + row, n = n0 + q;
         if (m >= p.M || n >= p.Cout) continue;
         const long e = (long)row * BN + q;
+        // the affine parameters, the slopes and the residual are requested with the pieces, not one after the other where they are used
+        float4 sc, sh, sl, rv;
+        h16x4_t rh;
+        if (scale) { sc = *reinterpret_cast<const float4*>(scale + n); sh = *reinterpret_cast<const float4*>(shift + n); }
+        if (prelu) sl = *reinterpret_cast<const float4*>(prelu + n);
+        if (res) {
+            if (h16) rh = *reinterpret_cast<const h16x4_t*>(reinterpret_cast<const _Float16*>(res) + (long)m * p.res_cs + n);
+            else rv = *reinterpret_cast<const float4*>(res + (long)m * p.res_cs + n);
+        }
         float4 v = *reinterpret_cast<const float4*>(first + e);
         for (int b = bf + 1; b <= bl; ++b) {
             const float4 w = *reinterpret_cast<const float4*>(p.ws + (long)(2 * (b * 8 + xcd)) * (BM * BN) + e);
             v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
         }
         if (scale) {
-            const float4 sc = *reinterpret_cast<const float4*>(scale + n);
-            const float4 sh = *reinterpret_cast<const float4*>(shift + n);
             v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
             v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
         }
         if (res) {
-            float4 rv;
-            if (h16) {
-                const h16x4_t rh = *reinterpret_cast<const h16x4_t*>(reinterpret_cast<const _Float16*>(res) + (long)m * p.res_cs + n);
-                rv = make_float4((float)rh.x, (float)rh.y, (float)rh.z, (float)rh.w);
-            } else {
-                rv = *reinterpret_cast<const float4*>(res + (long)m * p.res_cs + n);
-            }
+            if (h16) rv = make_float4((float)rh.x, (float)rh.y, (float)rh.z, (float)rh.w);
             v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
         }
         if (p.relu) {
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
         if (prelu) {
-            const float4 sl = *reinterpret_cast<const float4*>(prelu + n);
             v.x = v.x > 0.f ? v.x : v.x * sl.x; v.y = v.y > 0.f ? v.y : v.y * sl.y;
             v.z = v.z > 0.f ? v.z : v.z * sl.z; v.w = v.w > 0.f ? v.w : v.w * sl.w;
         }

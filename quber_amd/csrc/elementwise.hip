@@ -129,22 +129,25 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ in, 
     float m[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) m[e] = -INFINITY;
+    // A tap outside the map is read from the nearest pixel inside instead of being skipped: that pixel belongs to the same window (row
+    // 2 oy - 1 < 0 -> row 0 = 2 oy; row 2 oy + 1 = H -> row H - 1 = 2 oy; columns alike), so the maximum is the same - and the nine
+    // loads are unconditional, requested together, where nine `if inside: load` made nine memory latencies in a row.
+    float v[9][V];
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
-        const int iy = oy * 2 - 1 + dy;
-        if ((unsigned)iy >= (unsigned)H) continue;
+        const int iy = min(max(oy * 2 - 1 + dy, 0), H - 1);
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
-            const int ix = ox * 2 - 1 + dx;
-            if ((unsigned)ix >= (unsigned)W) continue;
-            float v[V];
+            const int ix = min(max(ox * 2 - 1 + dx, 0), W - 1);
             const T* src = in + ((long)(b * H + iy) * W + ix) * in_cs + cv * V;
-            if constexpr (V == Vec16<T>::N) Vec16<T>::load(src, v);
-            else { const float4 q = ldv4(src); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
-#pragma unroll
-            for (int e = 0; e < V; ++e) m[e] = fmaxf(m[e], v[e]);
+            if constexpr (V == Vec16<T>::N) Vec16<T>::load(src, v[dy * 3 + dx]);
+            else { const float4 q = ldv4(src); v[dy * 3 + dx][0] = q.x; v[dy * 3 + dx][1] = q.y; v[dy * 3 + dx][2] = q.z; v[dy * 3 + dx][3] = q.w; }
         }
     }
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int e = 0; e < V; ++e) m[e] = fmaxf(m[e], v[k][e]);
     T* dst = out + ((long)(b * OH + oy) * OW + ox) * out_cs + cv * V;
     if constexpr (V == Vec16<T>::N) Vec16<T>::store(dst, m);
     else stv4(dst, make_float4(m[0], m[1], m[2], m[3]));

@@ -33,12 +33,17 @@ namespace {
 // the normalisation (same arithmetic as gn_apply_kernel) is applied to the in-range pixels as they are loaded, which
 // saves the separate read + write pass over the activations.
 // CV = C / V channel groups; a block holds 256 / CV tiles (CV <= 256) or a tile needs CV / 256 blocks (grid.y).
-// waves per SIMD the transforms are compiled for (F(4x4): the input transform needs 4 registers fewer than hipcc takes
-// unasked to fit a third wave; the output transform's 36 loads in flight fill the register file of a single wave)
-constexpr int wino_in_waves(int O, int V) { return O == 4 ? (V == 4 ? 3 : 5) : O == 2 ? 4 : 2; }
+// waves per SIMD the transforms are compiled for (F(4x4) on 16-byte vectors: the input transform keeps a column's six loads - and,
+// as far as the scheduler dares, the next column's - in flight: 182-205 registers, two waves; held to three waves (168) it spills 31
+// registers and the 16-frame step loses 0.2 ms, profiles/r17_epilogue.md; the output transform's 36 loads in flight fill the
+// register file of a single wave)
+#ifndef QB_WINO_IN_WAVES44
+#define QB_WINO_IN_WAVES44 2
+#endif
+constexpr int wino_in_waves(int O, int V) { return O == 4 ? (V == 4 ? QB_WINO_IN_WAVES44 : 5) : O == 2 ? 4 : 2; }
 constexpr int wino_out_waves(int O, int V) { return O == 4 ? (V == 4 ? 2 : 3) : O == 2 ? 4 : 1; }
 
-template <int O, int V>
+template <int O, int V, bool NORM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(wino_in_waves(O, V)))) void wino_input_kernel(const float* __restrict__ in, int B, int H, int W, int CV, int in_cs,
                                                          long in_gs, int TH, int TW, int d, float* __restrict__ v, long v_gs,
                                                          const WinoNorm np, int Ball, int boff) {
@@ -61,7 +66,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(wino_in_wav
     const int c = cv * V;
     const float* base = in + (long)ta.b * H * W * in_cs + c;
     VT nsc, nbi;
-    if (np.stats) {
+    if constexpr (NORM) {
         const double* sb = np.stats + (((long)g * Ball + boff + ta.b) * np.groups + c / np.cpg) * 2;
         const double mean = sb[0] / np.n;
         double var = sb[1] / np.n - mean * mean;
@@ -74,24 +79,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(wino_in_wav
             nbi.v[e] = be.v[e] - (float)mean * nsc.v[e];
         }
     }
+    const float relu_lo = (NORM && np.relu) ? 0.f : -__builtin_inff();       // the fused norm's ReLU as max(v, lo)
     VT t[T][T];                                      // t = B^T d, one input column at a time
 #pragma unroll
     for (int j = 0; j < T; ++j) {
         const int x = d * (O * ta.tx - 1 + j) + ta.px;
         VT col[T], tc[T];
+        // No branch around a load: a pixel of the zero padding is read from the nearest pixel of the map (a line its neighbours read
+        // anyway) and replaced by zero afterwards, and the six loads of a column are requested before the first is used.  With
+        // `inside ? load : 0` every load sat in a branch of its own and the compiler waited for it there: 36 memory latencies in a row
+        // per thread - at one frame the whole kernel (16 us per launch for 1-3 MB of traffic, profiles/r17_epilogue.md).
+        const int xc = min(max(x, 0), W - 1);
+        const bool xin = (unsigned)x < (unsigned)W;
 #pragma unroll
         for (int i = 0; i < T; ++i) {
             const int y = d * (O * ta.ty - 1 + i) + ta.py;
-            const bool inside = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-            VT px = inside ? vload<V>(base + ((long)y * W + x) * in_cs) : vzero<V>();
-            if (np.stats && inside) {
+            col[i] = vload<V>(base + ((long)min(max(y, 0), H - 1) * W + xc) * in_cs);
+        }
 #pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    px.v[e] = fmaf(px.v[e], nsc.v[e], nbi.v[e]);
-                    if (np.relu) px.v[e] = fmaxf(px.v[e], 0.f);
-                }
+        for (int i = 0; i < T; ++i) {
+            const int y = d * (O * ta.ty - 1 + i) + ta.py;
+            const bool inside = xin && (unsigned)y < (unsigned)H;
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                float q = col[i].v[e];
+                if constexpr (NORM) q = fmaxf(fmaf(q, nsc.v[e], nbi.v[e]), relu_lo);
+                col[i].v[e] = inside ? q : 0.f;
             }
-            col[i] = px;
         }
         bt<O>(col, tc);
 #pragma unroll
@@ -354,8 +368,12 @@ static int run_winograd(const WinoP& q, int Ball, int G, hipStream_t st) {
         };
         {   // activations in once, V = P / m^2 times their size out
             ProfScope prof("wino_input", 4.0 * Gv * Cin * ((double)B * H * W + (double)P * tiles), 0.0, st);
-            hipLaunchKernelGGL((wino_input_kernel<O, V>), grid_v(Cin / V), dim3(256), 0, st, in_p, B, H, W, Cin / V, in.cs, in.gs, TH,
-                               TW, d, v, (long)P * tiles * Cin, np, Ball, b0);
+            if (np.stats)
+                hipLaunchKernelGGL((wino_input_kernel<O, V, true>), grid_v(Cin / V), dim3(256), 0, st, in_p, B, H, W, Cin / V, in.cs, in.gs, TH,
+                                   TW, d, v, (long)P * tiles * Cin, np, Ball, b0);
+            else
+                hipLaunchKernelGGL((wino_input_kernel<O, V, false>), grid_v(Cin / V), dim3(256), 0, st, in_p, B, H, W, Cin / V, in.cs, in.gs, TH,
+                                   TW, d, v, (long)P * tiles * Cin, np, Ball, b0);
         }
         QB_CHECK(hipGetLastError());
         ConvP p{};
