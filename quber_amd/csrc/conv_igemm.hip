@@ -749,11 +749,16 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(ig
                             const int m = m0 + row, n = en;
                             if (m < p.M) {
                                 float4 v = *reinterpret_cast<const float4*>(&smem[row * SP + eq]);
+                                // (real block-uniform branches: with the operands in registers either way, the compiler turns `if (scale)` / `if (res)`
+                                // into compute-and-select - 12 vector instructions per chunk that the launches without affine or residual, the
+                                // Winograd position GEMMs, do not need: +1.5 % on those, profiles/r17_epilogue.md)
                                 if (scale) {
+                                    asm volatile("");
                                     v.x = fmaf(v.x, sc4.x, sh4.x); v.y = fmaf(v.y, sc4.y, sh4.y);
                                     v.z = fmaf(v.z, sc4.z, sh4.z); v.w = fmaf(v.w, sc4.w, sh4.w);
                                 }
                                 if (res) {
+                                    asm volatile("");
                                     v.x += rv[i].x; v.y += rv[i].y; v.z += rv[i].z; v.w += rv[i].w;
                                 }
                                 if (relu) {
