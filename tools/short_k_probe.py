@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""One short-K residual 1x1 layer, stand-alone, for counter passes and timing: tools/short_k_probe.py [layer] [iters] [res 0|1] [affine 0|1]
+"""One short-K residual 1x1 layer, stand-alone, for counter passes and timing: tools/short_k_probe.py [layer] [iters] [res 0|1] [affine 0|1] [tuning] [sets]
+(sets > 1: that many (x, residual, y) tensor sets used in rotation, so that no launch finds its operands in the 256 MB infinity cache)
 layers: res2 (64 -> 256 @120x160 x16), res3 (128 -> 512 @60x80 x16), res4 (256 -> 1024 @30x40 x16).  GPU box only."""
 import ctypes as C
 import os
@@ -24,6 +25,7 @@ def main():
     lib = _lib.load()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    sets = int(sys.argv[6]) if len(sys.argv) > 6 else 1
     x = torch.randn(B, H, W, Cin, device="cuda")
     w = torch.randn(Cout, Cin, 1, 1, device="cuda") / np.sqrt(Cin)
     sc = torch.rand(Cout, device="cuda") + 0.5 if affine else None
@@ -31,18 +33,22 @@ def main():
     r = torch.randn(B, H, W, Cout, device="cuda") if with_res else None
     y = torch.empty(B, H, W, Cout, device="cuda")
     packed = torch.empty(Cout * Cin, device="cuda")
-    for kv in (sys.argv[5].split(",") if len(sys.argv) > 5 else []):
+    for kv in (sys.argv[5].split(",") if len(sys.argv) > 5 and sys.argv[5] else []):
         lib.quber_set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    xs = [x] + [torch.randn_like(x) for _ in range(sets - 1)]
+    rs = [r] + [torch.randn_like(r) if with_res else None for _ in range(sets - 1)]
+    ys = [y] + [torch.empty_like(y) for _ in range(sets - 1)]
     for it in range(iters + 3):
         if it == 3:
             ev[0].record()
-        _lib.check(lib.quber_op_conv2d(p(x), B, H, W, Cin, p(w), Cout, 1, 1, 0, 1, p(sc), p(sh), p(r), 1, p(packed), p(y), st))
+        k = it % sets
+        _lib.check(lib.quber_op_conv2d(p(xs[k]), B, H, W, Cin, p(w), Cout, 1, 1, 0, 1, p(sc), p(sh), p(rs[k]), 1, p(packed), p(ys[k]), st))
     ev[1].record()
     torch.cuda.synchronize()
     us = ev[0].elapsed_time(ev[1]) / iters * 1e3
     traffic = 4.0 * B * H * W * (Cin + Cout * (2 if with_res else 1))
-    print(f"{name} res={with_res} affine={affine}: {us:.1f} us, {2e-6 * B * H * W * Cin * Cout / us:.1f} TFLOP/s, {traffic / us * 1e-6:.2f} TB/s of algorithmic traffic")
+    print(f"{name} res={with_res} affine={affine} sets={sets}: {us:.1f} us, {2e-6 * B * H * W * Cin * Cout / us:.1f} TFLOP/s, {traffic / us * 1e-6:.2f} TB/s of algorithmic traffic")
 
 
 if __name__ == "__main__":
