@@ -906,6 +906,24 @@ def test_conv_default_routing_vs_torch(case):
         lib.quber_set_tuning(2, 0)
 
 
+@pytest.mark.parametrize("tile", [1, 2, 3, 4], ids=["64x64", "128x128", "128x64", "256x32"])
+@pytest.mark.parametrize("case", [
+    # B, H, W, Cin, Cout, k, stride, dil, affine, residual, relu: the fp32 epilogue requests a thread's affine parameters and residual rows
+    # together, rows past the end of a ragged last tile from a clamped address (csrc/conv_igemm.hip, profiles/r17_epilogue.md)
+    (3, 33, 47, 64, 256, 1, 1, 1, True, True, True),       # ragged M (4 653 rows), residual + affine: every tile shape's last tile is partial
+    (3, 33, 47, 64, 256, 1, 1, 1, False, True, False),     # residual without affine
+    (1, 5, 7, 96, 132, 1, 1, 1, True, True, True),         # fewer rows than one tile (35), ragged N (132 = 4 x 33)
+    (2, 21, 19, 32, 64, 3, 1, 1, True, True, True),        # 3x3 with residual
+])
+def test_conv_epilogue_every_tile_shape(case, tile):
+    lib = _lib.load()
+    lib.quber_set_tuning(4, tile)
+    try:
+        assert _conv_case(*case) < 2e-6
+    finally:
+        lib.quber_set_tuning(4, 0)
+
+
 @pytest.mark.parametrize("dt", [0, 3], ids=["f32", "bf16x3"])
 @pytest.mark.parametrize("case", [
     # B, oh, ow, mid, cin, cout, stride: conv3 + projection shortcut of a bottleneck as one GEMM over both inputs
@@ -1267,11 +1285,12 @@ def test_groupnorm_bilinear_maxpool_vs_torch():
         y = torch.empty((B, OH, OW, Cc), device="cuda")
         _lib.check(lib.quber_op_bilinear(p(xd), B, H, W, Cc, OH, OW, p(y), st))
         np.testing.assert_allclose(y.cpu().permute(0, 3, 1, 2).numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
-    for (B, H, W, Cc) in [(2, 48, 64, 64), (1, 10, 14, 8)]:
+    # (odd sizes: the last window's bottom row / right column lies outside the map; a single row or column: every window is clipped)
+    for (B, H, W, Cc) in [(2, 48, 64, 64), (1, 10, 14, 8), (2, 11, 15, 8), (1, 1, 9, 4), (1, 7, 1, 4)]:
         x = torch.randn(B, Cc, H, W, generator=g)
         ref = torch.nn.functional.max_pool2d(x, 3, 2, 1)
         xd = x.permute(0, 2, 3, 1).contiguous().cuda()
-        y = torch.empty((B, H // 2, W // 2, Cc), device="cuda")
+        y = torch.empty((B, (H + 1) // 2, (W + 1) // 2, Cc), device="cuda")
         _lib.check(lib.quber_op_maxpool3x3s2(p(xd), B, H, W, Cc, p(y), st))
         np.testing.assert_array_equal(y.cpu().permute(0, 3, 1, 2).numpy(), ref.numpy())
 
