@@ -323,6 +323,10 @@ double quber_forward_flops_padding(quber_ctx* ctx);
  *         convolutions of resnet.py:395-449, 472-485 and model.py:610-651, Winograd position GEMMs - on 64 x 64 tiles, one per block, instead of
  *         the 128 x 128 split-K / persistent launch when (a) the 128 x 128 tiling has at most 1 280 tiles (small batches), or (b, exact fp32 only)
  *         K <= 1024 whatever the size; 2 = rule (a) only, 0 = neither.  The same K order per output element: a re-association at most.
+ * key 43 (1; launch) the dilated 3x3 layers whose launch skips the filter rows that lie in the zero padding (ASPP d = 18, model.py:610-651, on
+ *         64-row tiles) skip the padded filter COLUMNS as well: the GEMM rows of an image run through three column zones (left tap padded |
+ *         both taps inside or both padded | right tap padded) as a serpentine, a tile multiplies only the filter columns its zones meet.
+ *         The skipped taps multiply zeros: same bits unless the launch is split over K (then a re-association); 0 = rows only.
  * Process-only keys (quber_set_tuning): key 2 = give the stand-alone conv ops a split-K workspace (value != 0) or drop it (0);
  * key 11 = stand-alone conv op: dilated 3x3 layers in tap-major K order with the zero-padding filter rows skipped;
  * key 12 = stand-alone conv ops: quber_config.compute_dtype of the launch (1 = bf16 / 2 = fp16 operands, 3 = bf16x3);

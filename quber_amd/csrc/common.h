@@ -70,6 +70,11 @@ struct ConvP {
     const double* n_stats; const float* n_gamma; const float* n_beta; float* n_coef;
     int n_groups, n_param_gs, n_relu, n_coef_bytes; float n_eps;       // (n_coef_bytes: filled in by the launcher)
     int bf16;            // quber_config.compute_dtype: 0 = fp32 MFMA, 1 = bf16 / 2 = fp16 operands, 3 = fp32 operands split into 3 bf16 terms
+    // conv_igemm.hip, skip-rows launch of a dilated 3x3 layer: filter COLUMNS skipped as well.  The GEMM rows of an image are ordered
+    // (column zone, y, x) instead of (y, x) - as a serpentine, see zone_pixel there: zone A = columns [0, zx1) - the left tap is padding,
+    // B = [zx1, zx2), C = [zx2, W) - the right tap is; a tile inside one zone multiplies only the filter columns that meet the image.
+    // 0 = off, 1 = zone B needs all three columns (dil <= W - dil), 2 = only the centre one
+    int zones, zx1, zx2;
 };
 
 int device_cus();         // compute units of the CURRENT device (cached per device id; plan.hip), <= 0: the query failed
@@ -176,6 +181,7 @@ struct Tuning {
                                  //   (conv_x8.hip); 0 = conv_igemm.hip / conv_persist.hip everywhere, 2 = every covered launch (tests)
     int x8_min_nk = 8;           // key 37 (launch): fewest K-slices (of 32) of a launch that key 35 = 1 takes
     int x8_min_rounds = 2;       // key 36 (launch): fewest rounds of tiles (tiles / CUs) of a launch that key 35 = 1 takes
+    int zone_cols = 1;           // key 43 (launch): the dilated layers that skip padded filter rows (ASPP d = 18) skip padded filter columns as well (ConvP::zones)
     int small_n_64 = 1;          // key 42 (launch): 64 x 64 tiles, one per block, for the 1x1 GEMMs (1) with at most 1 280 tiles of 128 x 128, and - exact fp32 - of K <= 1024 whatever their
                                  //   size; 2 = only the first rule; 0 = the 128 x 128 split-K / persistent launches as before round 6 (conv_igemm.hip launch_conv)
     int aspp_lanes = 1;          // key 41 (plan): the dilated ASPP branches d = 6 / 12 on the two side lanes (idle since the fusion convolutions), d = 18 and the 1x1 branch on the caller's

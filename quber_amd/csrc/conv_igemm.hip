@@ -97,6 +97,30 @@ constexpr int igemm_occupancy(int BM, int BN, int DT = 0, bool LEAN = false) {
 // run beside vector instructions of the same SIMD: the loader's ~95 vector instructions cost it as much time as the MFMAs
 // (SQ_INSTS_VALU / SQ_INSTS_MFMA = 8.3, MFMA busy 0.39: profiles/r10b_h16_loader.md).
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+// ConvP::zones: pixel (oy, ox) of GEMM row `rem` of image b.  The rows of an image run through the column zones A = [0, zx1), B = [zx1, zx2),
+// C = [zx2, W) as a serpentine: zone A top to bottom, zone B bottom to top, zone C top to bottom, and every odd image backwards - a tile
+// that straddles two zones or two images then holds neighbouring map rows on both sides of the seam and needs few filter rows, where the
+// plain order (A, B, C top to bottom) gave it the bottom of one zone and the top of the next: all nine taps (52 of 300 tiles at 16
+// frames of 30 x 40, against 8 this way)
+__device__ __forceinline__ void zone_pixel_of(const ConvP& p, int b, int rem, int& oy, int& ox) {
+    if (b & 1) rem = p.ohw - 1 - rem;
+    const int nA = p.zx1 * p.OH, nAB = p.zx2 * p.OH;
+    const int zb = rem < nA ? 0 : rem < nAB ? nA : nAB;                       // first row of the zone
+    const int c0 = rem < nA ? 0 : rem < nAB ? p.zx1 : p.zx2;                   // its first column ...
+    const int zw = rem < nA ? p.zx1 : rem < nAB ? p.zx2 - p.zx1 : p.OW - p.zx2;      // ... and width (> 0: the zone holds `rem`)
+    oy = (rem - zb) / zw;
+    ox = c0 + (rem - zb) - oy * zw;
+    if (rem >= nA && rem < nAB) oy = p.OH - 1 - oy;
+}
+// ... and the tensor row (pixel index) of GEMM row m
+__device__ __forceinline__ long zone_row_of(const ConvP& p, long m) {
+    const int b = (int)(m / p.ohw), rem = (int)(m - (long)b * p.ohw);
+    int oy, ox;
+    zone_pixel_of(p, b, rem, oy, ox);
+    return (long)b * p.ohw + oy * p.OW + ox;
+}
+
 template <int BM, int BN, int WM, int WN, int MODE, int DT = 0, bool LEAN = false>
 __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(igemm_occupancy(BM, BN, DT, LEAN)))) void conv_igemm_f32(const ConvP p) {
     constexpr int NTH = WM * WN * 64;
@@ -154,25 +178,75 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(ig
         k_begin = part * p.kchunk;
         nk = min(nk - k_begin, p.kchunk);
     }
+    // ZON (host: ConvP::zones, 3x3, stride 1, pad = dil): the rows of an image in (column zone, y, x) order, so that a tile inside one zone
+    // skips the filter COLUMNS of the padding too (dilation 18 on a 30 x 40 map: per pixel 42 % of the taps meet the image; rows alone
+    // leave ~62 % to execute).  The valid K-slices are then (valid filter rows) x (one range of filter columns): kx_lo..kx_hi, and
+    // row_skip K-slices are jumped at the end of each filter row.
+    constexpr bool ZON = (MODE == 3 || MODE == 4) && LEAN && DT == 0;
+    int kx_lo = 0, kx_hi = 0, row_skip = 0, z_nA = 0, z_nAB = 0;
+    bool zon = false;
+    if constexpr (ZON) {
+        zon = p.zones != 0;
+        kx_hi = p.kw - 1;
+        z_nA = p.zx1 * p.OH;
+        z_nAB = p.zx2 * p.OH;
+    }
+    auto zone_pixel = [&](int b, int rem, int& oy, int& ox) __attribute__((always_inline)) { zone_pixel_of(p, b, rem, oy, ox); };
     if constexpr (MODE == 3 || MODE == 4) {
         // Skip the filter rows that fall in the zero padding for every output row of this tile (dilated layers: with
         // dilation 18 on a 30-row map 58 % of the multiplies are with padding).  Tap-major K order (host: kmode 0,
         // Cin % 32 == 0): the K-slices of filter row ky are contiguous, so the valid rows are one K range.
-        const int oy_lo = (m0 % p.ohw) / p.OW;
+        const int rem0 = m0 % p.ohw;
         const int last = min(m0 + BM, p.M) - 1;
+        const int rem1 = last % p.ohw;
         const bool one_image = m0 / p.ohw == last / p.ohw;
-        const int oy_hi = one_image ? (last % p.ohw) / p.OW : p.OH - 1;
-        const int oy_min = one_image ? oy_lo : 0;
+        int oy_min = one_image ? rem0 / p.OW : 0;
+        int oy_hi = one_image ? rem1 / p.OW : p.OH - 1;
+        if (ZON && zon) {
+            // the tile piece by piece - a piece = consecutive rows inside one zone of one image, where the map row moves monotonically -:
+            // bounding box of the map rows, union of the zones' filter columns (A = {1, 2}, B = {0, 1, 2} or {1}, C = {0, 1})
+            oy_min = p.OH - 1; oy_hi = 0;
+            kx_lo = 2; kx_hi = 0;
+            for (int m = m0; m <= last;) {
+                const int b = m / p.ohw, rem = m - b * p.ohw;
+                const int rf = (b & 1) ? p.ohw - 1 - rem : rem;                     // forward position inside the image
+                const int z = rf < z_nA ? 0 : rf < z_nAB ? 1 : 2;
+                const int zs = z == 0 ? 0 : z == 1 ? z_nA : z_nAB, ze = z == 0 ? z_nA : z == 1 ? z_nAB : p.ohw;      // the zone's rows [zs, ze)
+                // rows of the image left in this zone, walking forwards (even image) or backwards (odd image)
+                const int left = (b & 1) ? rf - zs + 1 : ze - rf;
+                const int len = min(left, last - m + 1);
+                int ya, yb, x;
+                zone_pixel(b, rem, ya, x);
+                zone_pixel(b, rem + len - 1, yb, x);
+                oy_min = min(oy_min, min(ya, yb)); oy_hi = max(oy_hi, max(ya, yb));
+                const int lo = z == 0 ? 1 : z == 2 ? 0 : (p.zones == 1 ? 0 : 1);
+                const int hi = z == 0 ? 2 : z == 2 ? 1 : (p.zones == 1 ? 2 : 1);
+                kx_lo = min(kx_lo, lo); kx_hi = max(kx_hi, hi);
+                m += len;
+            }
+        }
         int ky_lo = 0, ky_hi = p.kh - 1;
         while (ky_lo < ky_hi && oy_hi * p.stride - p.pad + ky_lo * p.dil < 0) ++ky_lo;
         while (ky_hi > ky_lo && oy_min * p.stride - p.pad + ky_hi * p.dil >= p.H) --ky_hi;
-        const int per_row = p.kw * (p.Cin / BK);
+        const int cpt = p.Cin / BK;               // K-slices per filter tap
+        const int per_row = p.kw * cpt;
         k_begin = ky_lo * per_row;
         nk = (ky_hi - ky_lo + 1) * per_row;
+        if (ZON && zon) {
+            k_begin += kx_lo * cpt;
+            nk = (ky_hi - ky_lo + 1) * (kx_hi - kx_lo + 1) * cpt;
+            row_skip = (p.kw - (kx_hi - kx_lo + 1)) * cpt;
+        }
         if constexpr (MODE == 4) {               // the valid range again in gridDim.y partitions (a trailing one may be empty)
             const int chunk = (nk + (int)gridDim.y - 1) / (int)gridDim.y;
             const int done = min(part * chunk, nk);
-            k_begin += done;
+            if (ZON && zon) {                    // slice `done` of the valid ones: filter row, column, channel slice -> its K-slice
+                const int rowlen = (kx_hi - kx_lo + 1) * cpt;
+                const int r = done / rowlen, w = done - r * rowlen;
+                k_begin += r * per_row + w;      // (w < rowlen: inside the row's column range, which starts at kx_lo - already in k_begin)
+            } else {
+                k_begin += done;
+            }
             nk = min(nk - done, chunk);
             if (nk == 0) k_begin = ky_lo * per_row;   // keep the (unused) prologue loads inside the weight rows
         }
@@ -240,6 +314,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(ig
     int aoff[AL], boff[BL];
     unsigned amask[AL];
     int skc = 0, skx = 0, sky = 0;        // block-uniform tap position of the next K-slice
+    int swk = 0;                          // ZON: its K-slice index relative to k_begin
     __amdgpu_buffer_rsrc_t rsa, rsb;
     if constexpr (LEAN) {
 #pragma unroll
@@ -254,8 +329,9 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(ig
                 const int ohw = p.OH * p.OW;
                 const int b = m / ohw;
                 const int rem = m - b * ohw;
-                const int oy = rem / p.OW;
-                const int ox = rem - oy * p.OW;
+                int oy = rem / p.OW;
+                int ox = rem - oy * p.OW;
+                if (ZON && zon) zone_pixel(b, rem, oy, ox);
                 const int y0 = oy * p.stride - p.pad, x0 = ox * p.stride - p.pad;
                 aoff[i] = (((b * p.H + y0) * p.W + x0) * p.in_cs + kq) * 4;
                 // a tap is inside the image when its row and its column are: kh + kw tests and kh shifts instead of kh x kw double
@@ -307,7 +383,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(ig
                 const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsa, ok ? aoff[i] + soff : (int)0x80000000, 0, 0);
                 ra[i] = __builtin_bit_cast(f32x4, v);
             }
-            const int wso = kt * BK * 4;
+            const int wso = (ZON ? swk : kt) * BK * 4;           // ZON: the K-slices of a tile are not consecutive (row_skip)
 #pragma unroll
             for (int i = 0; i < BL; ++i) rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsb, boff[i], wso, 0));
             if (p.kmode) {
@@ -317,9 +393,14 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(ig
                 }
             } else {
                 skc += BK;
+                if constexpr (ZON) ++swk;
                 if (skc >= p.Cin) {
                     skc = 0;
-                    if (++skx == p.kw) { skx = 0; ++sky; }
+                    if constexpr (ZON) {
+                        if (++skx > kx_hi) { skx = kx_lo; ++sky; swk += row_skip; }
+                    } else {
+                        if (++skx == p.kw) { skx = 0; ++sky; }
+                    }
                 }
             }
             return;
@@ -591,9 +672,16 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(ig
     static_assert(BM % RSTEP == 0 && NCH % GRP == 0, "whole groups of chunks per thread");
     const bool vec4 = !HOUT && p.vec_out;     // block-uniform (the fp16 kernels are compiled for 64 / 128 registers: their loops stay as they were)
     const int eq = (t % CPR) * 4, erow0 = t / CPR;
+    // tensor row (pixel index) of GEMM row m: m itself, or - ZON - the pixel the zone order puts there
+    auto pixel_row = [&](int m) __attribute__((always_inline)) -> long {
+        if constexpr (ZON) {
+            if (zon && !raw) return zone_row_of(p, m);      // (a partial tile goes to the workspace in GEMM row order: the reduce kernel maps it)
+        }
+        return m;
+    };
     auto res_load = [&](int i, int n) __attribute__((always_inline)) -> float4 {
         const int m = min(m0 + erow0 + i * RSTEP, p.M - 1);       // rows past the end: a valid address, the value is never used
-        return *reinterpret_cast<const float4*>(res + (long)m * p.res_cs + n);
+        return *reinterpret_cast<const float4*>(res + pixel_row(m) * p.res_cs + n);
     };
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -768,7 +856,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(ig
                                     v.x = v.x > 0.f ? v.x : v.x * sl4.x; v.y = v.y > 0.f ? v.y : v.y * sl4.y;
                                     v.z = v.z > 0.f ? v.z : v.z * sl4.z; v.w = v.w > 0.f ? v.w : v.w * sl4.w;
                                 }
-                                *reinterpret_cast<float4*>(out + (long)m * out_cs + n) = v;
+                                *reinterpret_cast<float4*>(out + pixel_row(m) * out_cs + n) = v;
                                 if (gn) {
                                     const double a = (double)v.x + (double)v.y + (double)v.z + (double)v.w;
                                     const double b = (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
@@ -800,11 +888,12 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(ig
                 if (m < p.M && n < p.Cout) {
                     float v = smem[row * SP + q];
                     if (scale) v = fmaf(v, scale[n], shift[n]);
-                    if (res) v += HOUT ? (float)reinterpret_cast<const H16*>(res)[(long)m * p.res_cs + n] : res[(long)m * p.res_cs + n];
+                    const long pm = pixel_row(m);
+                    if (res) v += HOUT ? (float)reinterpret_cast<const H16*>(res)[pm * p.res_cs + n] : res[pm * p.res_cs + n];
                     if (relu) v = fmaxf(v, 0.f);
                     if (prelu) v = v > 0.f ? v : v * prelu[n];
-                    if (hstore) reinterpret_cast<H16*>(out)[(long)m * out_cs + n] = (H16)v;
-                    else out[(long)m * out_cs + n] = v;
+                    if (hstore) reinterpret_cast<H16*>(out)[pm * out_cs + n] = (H16)v;
+                    else out[pm * out_cs + n] = v;
                 }
             }
         }
@@ -848,12 +937,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvP p, int S
         const long mr = i / p.Cout;
         const int n = (int)(i - mr * p.Cout);
         const long m = mr + p.ws_row0;
+        const long pm = p.zones ? zone_row_of(p, m) : m;          // tensor row of GEMM row m (ConvP::zones: the rows of an image in zone order)
         // everything this element needs is requested before the first value is used (V == 4: n, the strides and the bases are multiples of
         // 4 floats - host), the slabs four at a time; the slabs are added one by one in slab order, as they always were
         vec sc, sh, sl, rr;
         if (scale) { sc = *reinterpret_cast<const vec*>(scale + n); sh = *reinterpret_cast<const vec*>(shift + n); }
         if (prelu) sl = *reinterpret_cast<const vec*>(prelu + n);
-        if (res) rr = *reinterpret_cast<const vec*>(res + m * p.res_cs + n);
+        if (res) rr = *reinterpret_cast<const vec*>(res + pm * p.res_cs + n);
         const float* const w0 = p.ws + (long)g * MN + i;
         const long sstep = (long)G * MN;
         vec v = *reinterpret_cast<const vec*>(w0);
@@ -875,7 +965,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvP p, int S
             o[e] = x;
         }
         if constexpr (V == 4) {
-            *reinterpret_cast<vec*>(out + m * p.out_cs + n) = vec{o[0], o[1], o[2], o[3]};
+            *reinterpret_cast<vec*>(out + pm * p.out_cs + n) = vec{o[0], o[1], o[2], o[3]};
             if (gn) {   // host: V == 4 and 4 | channels per group whenever sums are requested
                 const double a = (double)o[0] + (double)o[1] + (double)o[2] + (double)o[3];
                 const double b = (double)o[0] * o[0] + (double)o[1] * o[1] + (double)o[2] * o[2] + (double)o[3] * o[3];
@@ -884,7 +974,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvP p, int S
                 atomicAdd(&gacc[slot + 1], b);
             }
         } else {
-            out[m * p.out_cs + n] = o[0];
+            out[pm * p.out_cs + n] = o[0];
         }
     }
     if (gn) {
@@ -1109,6 +1199,20 @@ static int run(ConvP p, int G, int S, hipStream_t st) {
         if (S > 1) reduce(S);
         QB_CHECK(hipGetLastError());
         return gn_separate();
+    }
+    p.zones = 0;
+    if (skip && tune().zone_cols && lean && BM == 64 && p.kh == 3 && p.kw == 3 && p.stride == 1 && p.pad == p.dil && p.OH == p.H && p.OW == p.W) {
+        // filter columns skipped as well (ConvP::zones): 3x3, stride 1, pad = dil, the LEAN kernel on 64-row tiles (a 128-row tile of an
+        // 18-column zone spans 7 map rows and loses in filter rows what it gains in columns), at least a quarter of the columns without
+        // one of their taps.  The split-K form too: its partial tiles go to the workspace in GEMM row order, the reduce kernel maps them.
+        const int a = p.dil, b = p.W - p.dil;
+        p.zx1 = std::max(0, std::min(std::min(a, b), p.W));
+        p.zx2 = std::max(0, std::min(std::max(a, b), p.W));
+        if (a > b || 8 * p.zx1 >= p.W) p.zones = a <= b ? 1 : 2;
+        // (one frame of 30 x 40 is 19 tiles whose partitions all run at once: the launch lasts as long as its longest block, and the two tiles of
+        // the 4-column middle zone - 16 map rows each, all nine taps - are longer than any tile of the row order: 119 -> 127 us; from 38 tiles on
+        // - two frames, or one of 45 x 80 - the shorter average wins: 210 -> 186 us, 318 -> 283 us)
+        if (S > 1 && p.mtiles < 32) p.zones = 0;
     }
     if (S > 1) {
         {

@@ -58,6 +58,7 @@ static int* tuning_field(Tuning& t, int key) {
         case 39: return &t.h8_norm;
         case 41: return &t.aspp_lanes;
         case 42: return &t.small_n_64;
+        case 43: return &t.zone_cols;
         case 30: return &t.lean_loader;
         case 31: return &t.h8;
         case 32: return &t.h8_min_tiles;

@@ -1041,6 +1041,60 @@ def test_conv_skip_padded_filter_rows(case):
 
 
 @pytest.mark.parametrize("case", [
+    # B, H, W, Cin, Cout, dil, residual: the skip-rows launch with the GEMM rows of an image in (column zone, y, x) order, so that tiles skip
+    # the padded filter COLUMNS too (ConvP::zones, option key 43).  Skipped taps multiply zeros, the order of the others is unchanged:
+    # the output must equal the rows-only launch BIT FOR BIT, and torch within the fp32 bar.
+    (100, 30, 40, 96, 128, 18, False),     # ASPP d = 18 geometry: zones [0, 18) | [18, 22) | [22, 40), more than a round of tiles (no split)
+    (101, 30, 40, 64, 256, 18, True),      # ragged M (tiles straddle images and zones), residual
+    (120, 30, 40, 64, 128, 24, False),     # d > W - d: the middle zone [16, 24) meets only the centre column
+    (90, 23, 31, 64, 128, 18, True),       # odd map: zones [0, 13) | [13, 18) | [18, 31)
+    (130, 15, 16, 64, 128, 18, False),     # d >= W: one zone, centre column only (and centre row only)
+    (110, 30, 40, 64, 128, 12, False),     # d = 12: wide middle zone with all three columns
+    (16, 30, 40, 256, 256, 18, True),      # few tiles: split-K over the valid K-slices (partial tiles in zone order, mapped by the reduce kernel)
+    (3, 30, 40, 512, 128, 18, False),      # ... three images (odd images run backwards), partitions that start inside a filter row
+    (1, 45, 80, 256, 256, 18, True),       # 1280x720 geometry, one frame
+    (2, 15, 16, 512, 128, 18, False),      # split, centre tap only
+])
+def test_conv_skip_padded_filter_columns(case):
+    B, H, W, Cin, Cout, dil, residual = case
+    lib = _lib.load()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    g = torch.Generator(device="cuda").manual_seed(dil + W)
+    x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) / np.sqrt(Cin * 9)
+    sc, sh = torch.rand(Cout, device="cuda", generator=g) + 0.5, torch.randn(Cout, device="cuda", generator=g)
+    r = torch.randn(B, H, W, Cout, device="cuda", generator=g) if residual else None
+    packed = torch.empty(Cout * 9 * Cin, device="cuda")
+    outs = []
+    lib.quber_set_tuning(11, 1)               # skip-rows launches for the stand-alone op (the plan sets it per layer)
+    lib.quber_set_tuning(2, 1 if B <= 16 else 0)      # a split-K workspace for the small launches
+    try:
+        for zones in (0, 1):
+            lib.quber_set_tuning(43, zones)
+            y = torch.full((B, H, W, Cout), float("nan"), device="cuda")
+            _lib.check(lib.quber_op_conv2d(p(x), B, H, W, Cin, p(w), Cout, 3, 1, dil, dil, p(sc), p(sh), p(r), 1, p(packed), p(y), st))
+            torch.cuda.synchronize()
+            outs.append(y)
+    finally:
+        lib.quber_set_tuning(43, 1)
+        lib.quber_set_tuning(11, 0)
+        lib.quber_set_tuning(2, 0)
+    rows_only, zoned = outs
+    assert torch.isfinite(zoned).all()
+    if B > 16:
+        assert torch.equal(zoned, rows_only)
+    else:           # split-K: the valid K-slices are cut into partitions at other places, the partial sums group differently
+        assert float((zoned - rows_only).abs().max()) / max(1.0, float(rows_only.abs().max())) < 2e-6
+    ref = torch.nn.functional.conv2d(x[:2].permute(0, 3, 1, 2).cpu().double(), w.cpu().double(), None, 1, dil, dil)
+    ref = ref * sc.cpu().double().view(1, -1, 1, 1) + sh.cpu().double().view(1, -1, 1, 1)
+    if residual:
+        ref = ref + r[:2].permute(0, 3, 1, 2).cpu().double()
+    ref = ref.relu().permute(0, 2, 3, 1)
+    assert (zoned[:2].cpu().double() - ref).abs().max().item() / max(1.0, ref.abs().max().item()) < 2e-6
+
+
+@pytest.mark.parametrize("case", [
     # B, H, W, Cin, Cout, k, dil, residual: split tail (MODE 2) against the same launch computed whole
     (6, 119, 160, 128, 256, 3, 1, True),     # 1786 tiles (ragged M, 2 n-tiles): 1536 whole + 250 in 2 pieces
     (8, 72, 128, 256, 128, 3, 1, False),     # 576 tiles: 512 whole (2 resident blocks per CU) + 64 in 8 pieces
