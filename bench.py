@@ -80,6 +80,10 @@ def parse():
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the sub-records a default (f32, 1 GPU, 640x480 batch 16) run appends under `configs`: BASELINE.json configs[2] "
                          "(1280x720, 30 instances, batch 1, hipGraph replay) and configs[4] (fp16 data path, 1024x1024, batch 8)")
+    ap.add_argument("--rccl-selftest", action="store_true",
+                    help="N = 1 through the N > 1 code path: a ONE-rank RCCL process group on this GPU (broadcast of the weights, hipGraph "
+                         "capture beside the group's watchdog, the asynchronous label-map gather, MAX all-reduce, barrier) - the contact "
+                         "with ProcessGroupNCCL / RCCL a one-GPU box allows; the auxiliary records are skipped")
     ap.add_argument("--dry", action="store_true",
                     help="no GPU work: exercise the launch / rendezvous / broadcast / gather path only (CPU tests, gloo)")
     return ap.parse_args()
@@ -286,7 +290,7 @@ def dry_main(a, world, rank):
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                           "dry": True, "config": {"workload": "dry run: rendezvous + broadcast + gather only"},
                           "rccl_ranks": ranks,
-                          "gather": None if world == 1 else {
+                          "gather": None if ranks[0].get("backend") is None else {
                               "ms_per_step_max_over_ranks": max(r["gather_ms_per_step"] for r in ranks),
                               "alone_ms_max_over_ranks": max((r["gather_alone_ms"] or 0.0) for r in ranks),
                               "bytes_per_rank_per_step": B * H * W * 2, "wire_dtype": "int16"},
@@ -308,12 +312,15 @@ def main():
                  f"(use `python bench.py --gpus {a.gpus}` alone, or torchrun with --nproc-per-node {a.gpus})")
     if a.dry:
         return dry_main(a, world, rank)
+    multi = world > 1 or a.rccl_selftest       # the collective path (a one-rank group exercises the same calls)
+    if a.rccl_selftest and "MASTER_ADDR" not in os.environ:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
 
     import torch
     from quber_amd import arch, dist as qdist, engine, synth
     dist = None
     cpu_share = None
-    if world > 1:
+    if multi:
         # one rank per GPU on ONE node: give every rank its own slice of the host's CPUs and one OpenMP thread - eight ranks each
         # forking a 128-thread OpenMP team for a torch CPU op cost 90 ms per occurrence (profiles/r03q_predict_profile.txt)
         try:
@@ -405,7 +412,7 @@ def main():
             lmff.foreground(b_, d_, om)
 
     graph = None
-    use_graph = a.graph or (world > 1 and not a.no_graph)      # N > 1: one launch per step keeps eight host processes out of each other's way
+    use_graph = a.graph or (multi and not a.no_graph)      # N > 1: one launch per step keeps eight host processes out of each other's way
     if use_graph:
         # every launch of the step goes to torch's current stream and nothing allocates or synchronises,
         # so the whole step is capturable (include/quber_hip.h contract)
@@ -418,7 +425,7 @@ def main():
             graph = torch.cuda.CUDAGraph()
             # with a process group alive its watchdog thread queries events while this thread captures: "thread_local" keeps those
             # calls from invalidating the capture (the default "global" mode treats them as errors)
-            with torch.cuda.graph(graph, capture_error_mode="thread_local" if world > 1 else "global"):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local" if multi else "global"):
                 gpu_step()
         except RuntimeError as e:                 # a node that cannot capture must still produce the line: eager steps
             if a.graph:
@@ -511,17 +518,17 @@ def main():
                            out_masks=out_masks, max_inst=max_inst), gpu_step)
         if host_io is not None:
             line["host_io"] = host_io
-        if world == 1 and a.predict_calls > 0 and a.dtype == "f32":
+        if not multi and a.predict_calls > 0 and a.dtype == "f32":
             line["predict_api"] = predict_api_run(a, sd, host, dev)
             if H == 480 and W == 640:        # the adapter resizes every frame to 640x480 (eval/refiner_model.py:246)
                 try:
                     line["predict_api"]["streamed"] = predict_stream_run(a, sd, host, dev)
                 except Exception as e:           # an auxiliary figure must never cost the line its headline
                     line["predict_api"]["streamed"] = {"error": repr(e)}
-        if a.dtype == "f32" and world == 1 and not a.no_split_mode:
+        if a.dtype == "f32" and not multi and not a.no_split_mode:
             line["fp32_equivalent_bf16x3"] = split_mode_run(a, make_engine, sd, gpu_step_args=(masks, bgr, depth, offsets, max_inst),
                                                             exact_logits=logits, exact_pan=post["panoptic"])
-        if (a.dtype == "f32" and world == 1 and not a.no_configs and not a.tuning and (B, H, W, N) == (16, 480, 640, 20)
+        if (a.dtype == "f32" and not multi and not a.no_configs and not a.tuning and (B, H, W, N) == (16, 480, 640, 20)
                 and a.heads == "loud" and not a.graph and not a.foreground_filter):
             eng.close()              # the headline engine's buffers are not needed any more
             line["configs"] = {}
@@ -961,7 +968,7 @@ def report(a, eng, world, elapsed, ranks, center_bias, sd, host, step_ms, t, gpu
                                  "per step, frac = GB/s / 8000 (HBM3E spec; 6.3 TB/s is the measured copy ceiling)"},
         "stage_ms_other": {k: stages[k]["ms"] for k in stages if k not in CONV_FAMILY and k not in hbm},
     }
-    if world == 1 and a.cpu_frames > 0:
+    if world == 1 and a.cpu_frames > 0 and not a.rccl_selftest:
         bt = {"logits": t["logits"], "panoptic": t["post"]["panoptic"], "host": host}
         gpu_step()
         torch.cuda.synchronize()
