@@ -925,7 +925,7 @@ def report(a, eng, world, elapsed, ranks, center_bias, sd, host, step_ms, t, gpu
                    "instances_out_per_frame_mean": float(count.mean()),
                    "instances_out_per_frame_min_max": [int(count.min()), int(count.max())]},
         "rccl_ranks": ranks,
-        "gather": None if world == 1 else {
+        "gather": None if ranks[0].get("backend") is None else {
             "ms_per_step_max_over_ranks": max(r["gather_ms_per_step"] for r in ranks),
             "alone_ms_max_over_ranks": max((r["gather_alone_ms"] or 0.0) for r in ranks),
             "bytes_per_rank_per_step": B * H * W * 2, "wire_dtype": "int16 (labels -1, 1000 ... 1200; f32 again on rank 0)",
