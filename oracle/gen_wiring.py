@@ -18,7 +18,7 @@ BottleneckBlock, ASPP, DeepLabV3PlusHead.layers, ImageList, sem_seg_postprocess,
 the same recollection of detectron2 the oracle itself rests on.  tests/test_oracle_golden.py::test_reference_wiring_fixture compares
 oracle/network_torch.py + oracle/postproc_ref.py with the stored outputs.
 
-usage (build container): python3 oracle/gen_wiring.py          -> tests/golden/wiring_*.npz
+usage (build container): python3 oracle/gen_wiring.py [variant ...]   -> tests/golden/wiring_*.npz
 """
 import copy
 import importlib.util
@@ -380,6 +380,12 @@ VARIANTS = {
                        "MODEL.INS_EMBED_HEAD.HIERARCHY": [["eee_mask"], ["eee_boundary"], ["foreground"], ["center"], ["offset"]]},
     # Base-Mask-Refiner.yaml's backbone defaults: add-fusion, three fusion layers; flat (non-hierarchical) heads
     "add_l3_flat": {"MODEL.BACKBONE.FUSION_STRATEGY": "add", "MODEL.BACKBONE.NUM_FUSION_LAYERS": 3, "MODEL.INS_EMBED_HEAD.HIERARCHICAL_FUSION_ON": False},
+    # a deeper backbone (resnet.py:330-356: 3 / 4 / 23 / 3 blocks) with the three-class error map e33
+    "r101_e33": {"MODEL.RESNETS.DEPTH": 101, "MODEL.INS_EMBED_HEAD.ERROR_TYPE": "e33"},
+    # mask error map only (no boundary head), two classes (e32), one head-fusion layer, three levels
+    "m_f_co_e32_l1": {"MODEL.INS_EMBED_HEAD.EEE_MASK_ON": True, "MODEL.INS_EMBED_HEAD.EEE_BOUNDARY_ON": False, "MODEL.INS_EMBED_HEAD.ERROR_TYPE": "e32",
+                      "MODEL.INS_EMBED_HEAD.NUM_FUSION_LAYERS": 1,
+                      "MODEL.INS_EMBED_HEAD.HIERARCHY": [["eee_mask"], ["foreground"], ["center", "offset"]]},
 }
 
 
@@ -447,7 +453,10 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     h, w, n = 96, 128, 3           # (at 64 x 96 the instances sit near the 512-pixel area filter: no stable scene)
+    only = set(sys.argv[1:])               # optional: the variants to (re)generate; the seeds of a variant depend on its position only
     for vi, (name, over) in enumerate(VARIANTS.items()):
+        if only and name not in only:
+            continue
         cfg = reference_cfg(**over)
         kw = qconfig.arch_kwargs(cfg)
         net = model.MaskRefiner(cfg).eval()
