@@ -73,6 +73,27 @@ def test_boundary_hand_derived():
     assert errmaps_np.boundary_width(720, 1280, 0.01) == 15
 
 
+def test_boundary_band_against_scipy_morphology():
+    """The boundary half of a2 (util.py:72-90) has no runnable reference here (cv2 absent).  An INDEPENDENT implementation of the same
+    published operation - binary erosion by a 3x3 square, d iterations, everything outside the image background: what cv2.erode
+    computes on the mask inside its one-pixel ring of zeros, the ring staying zero through every iteration - is scipy.ndimage's
+    binary_erosion(border_value=0).  Irregular synthetic instance masks (truncated by the frame border, holes, thin parts), several
+    sizes and ratios; a cross-check of the restatement, not a pin."""
+    from scipy import ndimage
+    from quber_amd import synth
+    for seed, (h, w), ratio in ((1, (96, 128), 0.01), (2, (96, 128), 0.02), (3, (120, 160), 0.01), (4, (480, 640), 0.01)):
+        sc = synth.make_scene(seed, h, w, 6)
+        d = errmaps_np.boundary_width(h, w, ratio)
+        for m in sc["masks"]:
+            m = (m > 0).astype(np.uint8)
+            m[h // 3:h // 3 + 3, w // 4:w // 4 + 3] = 0                      # a hole
+            er = ndimage.binary_erosion(m, structure=np.ones((3, 3), bool), iterations=d, border_value=0).astype(np.uint8)
+            np.testing.assert_array_equal(errmaps_np.mask_to_boundary(m, ratio), m - er)
+    full = np.ones((40, 50), np.uint8)                                       # a mask that fills the frame: the band hugs the border
+    np.testing.assert_array_equal(errmaps_np.mask_to_boundary(full, 0.05),
+                                  full - ndimage.binary_erosion(full, structure=np.ones((3, 3), bool), iterations=3, border_value=0))
+
+
 def test_quadruple_is_one_hot():
     rng = np.random.default_rng(0)
     from quber_amd import synth
