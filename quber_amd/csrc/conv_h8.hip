@@ -267,9 +267,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int BN = G::BN, SLOT = G::SLOT;
     static_assert(QT == 8, "geometry");
     // ONE shared object: a second one beside a DMA target makes hipcc wait vmcnt(0) before the fragment reads
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * SLOT + 1024 + 2 * H8_SS];
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * SLOT + 1024 + 3 * H8_SS];
     // smem + 2 * SLOT: the block's GroupNorm sums, f64 [image b0 / b0 + 1][group][sum, sum of squares]
-    constexpr int SSBASE = 2 * SLOT + 1024;       // two images of [scale (256 floats) | shift (256 floats)]: this tile's and the next one's
+    // THREE images of [scale (256 floats) | shift (256 floats)], used in turn: this tile's, the next one's (requested at the top of this tile) and
+    // the previous one's, which the waves that are still in the previous tile's epilogue may be reading - nothing orders wave 0's request against
+    // them (no barrier follows the epilogue).  With two images that request overwrote the image a late wave was still reading: harmless while
+    // the block's tiles share one (group, channel tile) - the same bytes again - and wrong, two tiles ahead of the change, when the block's run
+    // of tiles crosses a group boundary (two-stream backbones at batches where tiles % 8 != 0: 640x480 x 9, 11, 12, 14, 15;
+    // profiles/r20_h8_affine_race.md).  conv_h8n_kernel and conv_h8p_kernel likewise; conv_h8w_kernel requests inside its last channel block
+    // and conv_h8s_kernel ends every tile with a barrier: two images suffice there.
+    constexpr int SSBASE = 2 * SLOT + 1024;
 
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
@@ -414,7 +421,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         has_next = tile + tile_step < tile_end;
         if (has_next) {
             h8_tile_state<BN, K3, DUAL>(p, tile + tile_step, wave, lane, aoffN, amaskN, boffN, aoff2N, m0N, n0N, gN, dilN);
-            issue_ss(ssb ^ 1, gN, n0N);
+            issue_ss(ssb == 2 ? 0 : ssb + 1, gN, n0N);
         }
 #pragma unroll
         for (int c = 0; c < QT; ++c)
@@ -474,7 +481,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int i = 0; i < 4; ++i) { aoff[i] = aoffN[i]; amask[i] = amaskN[i]; boff[i] = boffN[i]; aoff2[i] = aoff2N[i]; }
         m0 = m0N; n0 = n0N; g = gN; dilC = dilN;
         pnext = false;
-        ssb ^= 1;
+        ssb = ssb == 2 ? 0 : ssb + 1;
     }
 #undef H8_READ_Q
 #undef H8_MMA
@@ -494,7 +501,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int BN = G::BN, SLOT = G::SLOT;
     constexpr int NQ = BN / 64;                // channel DMA pieces per wave and K-tile
     static_assert((BN == 128 && SLOT == 49152) || (BN == 64 && SLOT == 40960), "geometry");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * SLOT + 1024 + 2 * H8_SS];
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * SLOT + 1024 + 3 * H8_SS];
     constexpr int SSBASE = 3 * SLOT + 1024;
 
     const int t = threadIdx.x;
@@ -610,7 +617,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         has_next = tile + tile_step < tile_end;
         if (has_next) {
             h8_tile_state<BN, K3, false>(p, tile + tile_step, wave, lane, aoffN, amaskN, boffN, aoff2, m0N, n0N, gN, dilN);
-            issue_ss(ssb ^ 1, gN, n0N);
+            issue_ss(ssb == 2 ? 0 : ssb + 1, gN, n0N);
         }
 #pragma unroll
         for (int c = 0; c < QT; ++c)
@@ -656,7 +663,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int i = 0; i < NQ; ++i) boff[i] = boffN[i];
         m0 = m0N; n0 = n0N; g = gN; dilC = dilN;
         pnext = false;
-        ssb ^= 1;
+        ssb = ssb == 2 ? 0 : ssb + 1;
     }
 #undef H8N_READ
 #undef H8N_MMA
@@ -799,8 +806,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int COEF = WBASE + 3 * WIMG;         // one image's [channel / 8][8 scales | 8 biases] floats, at most 512 channels
     constexpr int GACC = COEF + 4096;
     constexpr int SSBASE = GACC + 1024;
-    static_assert(SSBASE + 2 * H8_SS <= 160 * 1024, "LDS");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[SSBASE + 2 * H8_SS];
+    static_assert(SSBASE + 3 * H8_SS <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SSBASE + 3 * H8_SS];
 
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
@@ -971,7 +978,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const bool has_next = tile + tile_step < tile_end;
         if (has_next) {
             tile_state(tile + tile_step, poffN, boffN, bN, y0N, x0N, gN);
-            issue_ss(ssb ^ 1, gN);
+            issue_ss(ssb == 2 ? 0 : ssb + 1, gN);
         } else {
 #pragma unroll
             for (int j = 0; j < 6; ++j) poffN[j] = H8_OOB;
@@ -1043,7 +1050,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int i = 0; i < NQ; ++i) boff[i] = boffN[i];
         b = bN; y0 = y0N; x0 = x0N; g = gN;
-        ssb ^= 1;
+        ssb = ssb == 2 ? 0 : ssb + 1;
     }
 #undef H8P_MMA
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -166,7 +166,11 @@ struct Op {
     int ctl = 0;        // 1 = fork `lane` here (it may start once the main stream has reached this point), 2 = join it
 };
 constexpr int LANES = 3;            // side lanes 1, 2: the fusion convolutions of res2 and of res3
-constexpr int LANE_BATCH = 2;       // side lanes are used up to this batch (their workspaces are sized for it)
+constexpr int LANE_BATCH = 16;      // side lanes are used up to this batch (their workspaces are sized for it) ...
+constexpr int LANE_BATCH_F32 = 12;  // ... in the exact fp32 mode up to this one.  Same-box A/B of the step with the lanes against one stream
+                                    // (profiles/r20_lanes.md): exact fp32 -5 % at 1 frame, -4.3 % at 4, -3 % at 6, -0.7 ... -1.5 % at 8, -0.8 % at 12,
+                                    // +0.2 ... +0.5 % at 16 (the headline stays on one stream); bf16x3 -4 % at 8, -2.4 % at 16; fp16 data path
+                                    // -11 % at 8, -6.7 % at 16 (640x480), -1.8 % at 1024x1024 x 8.  (Batches <= 2 until round 6's last pass.)
 
 struct quber_ctx {
     quber_config cfg;
@@ -1421,7 +1425,7 @@ int quber_finalize_weights(quber_ctx* c) {
     }
     if (c->wino_floats) c->wino_ws = (float*)b.dalloc_bytes(sizeof(float) * c->wino_floats);
     if (c->lanes_built) {          // side lanes: streams, fork / join events, workspaces sized for LANE_BATCH frames
-        c->lane_splitk_floats = (size_t)20 << 20;       // 80 MiB: the persistent kernel's 2 x 512 partial tiles of 128 x 128 are 64 MiB
+        c->lane_splitk_floats = c->splitk_floats;       // as large as the caller's stream's (160 MiB): a launch picks the same split on a lane as off it
         for (int l = 1; l < LANES; ++l) {
             QB_CHECK(hipStreamCreateWithFlags(&c->lane_stream[l], hipStreamNonBlocking));
             QB_CHECK(hipEventCreateWithFlags(&c->lane_fork[l], hipEventDisableTiming));
@@ -1607,7 +1611,8 @@ int quber_forward(quber_ctx* c, const uint8_t* bgr, const uint8_t* depth, const 
                                                    c->cfg.pixel_mean, c->cfg.pixel_std, c->cfg.streams, st);
     if (rc) return rc;
     // side lanes: at small batches the independent branches of the plan (Builder::fork / join) run on streams of the context
-    c->lanes_on = c->lanes_built && tune().lanes && batch <= LANE_BATCH && c->lane_stream[1] != nullptr && quber::g_prof == nullptr;
+    c->lanes_on = c->lanes_built && tune().lanes && batch <= (c->cfg.compute_dtype == 0 ? LANE_BATCH_F32 : LANE_BATCH) && c->lane_stream[1] != nullptr &&
+                  quber::g_prof == nullptr;
     auto lane_used = [&](int l) { return c->lanes_on && l > 0; };
     for (auto& op : c->ops) {
         if (op.ctl == 1) {
