@@ -112,8 +112,10 @@ __device__ unsigned long long g_x8_stamps[256 * 2 * 16];
 template <bool AFFINE, bool RES, bool GN, bool DUAL = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_x8_kernel(const ConvP p) {
     static_assert(!DUAL || (!RES && !GN), "the dual-input form is the 1x1 conv3 + shortcut GEMM");
-    // ONE shared object (conv_h8.hip): [2 K-slice images][GroupNorm sums f64 [2][32][2]][2 scale | shift images]
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * X8_SLOT + 1024 + 2 * X8_SS];
+    // ONE shared object (conv_h8.hip): [2 K-slice images][GroupNorm sums f64 [2][32][2]][3 scale | shift images]
+    // (three, used in turn: the image a late wave may still be reading in the previous tile's epilogue is not the one wave 0 requests the next
+    //  tile's vectors into - conv_h8.hip's note at its SSBASE, profiles/r20_h8_affine_race.md)
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * X8_SLOT + 1024 + 3 * X8_SS];
     constexpr int SSBASE = 2 * X8_SLOT + 1024;
 
     const int t = threadIdx.x;
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const bool has_next = tile + tile_step < tile_end;
         if (has_next) {
             x8_tile_state<DUAL>(p, tile + tile_step, wave, lane, aoffN, boffN, m0N, n0N, gN, aoff2N);
-            issue_ss(ssb ^ 1, gN, n0N);
+            issue_ss(ssb == 2 ? 0 : ssb + 1, gN, n0N);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { aoffN[j] = X8_OOB; aoff2N[j] = X8_OOB; }
@@ -388,7 +390,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int j = 0; j < 4; ++j) { aoff[j] = aoffN[j]; aoff2[j] = aoff2N[j]; }
         boff = boffN;
         m0 = m0N; n0 = n0N; g = gN;
-        ssb ^= 1;
+        ssb = ssb == 2 ? 0 : ssb + 1;
     }
 #undef X8_READ
 #undef X8_MMA

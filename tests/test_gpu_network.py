@@ -349,42 +349,43 @@ def test_side_lanes_equal_one_stream(dtype):
         eng.close()
 
 
-@pytest.mark.parametrize("b", [12, 15])
-def test_fp16_run_of_tiles_across_the_stream_boundary(b):
-    """Regression (round 6, profiles/r20_h8_affine_race.md).  The persistent kernels of the fp16 data path (csrc/conv_h8.hip) hand every block a
-    run of tiles; a launch of the two-stream backbone holds the RGB stream's tiles, then the depth stream's, and when tiles % 8 != 0 the run of
-    some blocks crosses from one stream to the other (640x480: batches 9, 11, 12, 14, 15 - never 8 or 16, which every other test and the bench
-    use).  Wave 0 then requested the next-but-one tile's scale / shift vectors into the LDS image that late waves were still reading in the
-    epilogue of the tile before: the bottleneck projections of res3 (conv3 + shortcut as one GEMM: 900 tiles at batch 12; conv1, 128 channels:
-    564 at batch 15) came out differently from run to run, 0.03-0.8 off at the res3 tap.  Now: three images in turn.
-    Bars: repeated forwards are bit-equal, and the taps sit within two fp16 steps of the same network with the DMA-gather kernels switched off
-    (key 32: no launch has that many tiles; the layers then run on conv_igemm.hip)."""
+@pytest.mark.parametrize("dtype,b,off_key,rel", [(2, 12, 32, 2.5 * 2.0 ** -10), (2, 15, 32, 2.5 * 2.0 ** -10), (3, 15, 35, 2e-6)],
+                         ids=["f16-12", "f16-15", "bf16x3-15"])
+def test_run_of_tiles_across_the_stream_boundary(dtype, b, off_key, rel):
+    """Regression (round 6, profiles/r20_h8_affine_race.md).  The persistent LDS-DMA kernels (csrc/conv_h8.hip: fp16 data path; csrc/conv_x8.hip:
+    bf16x3 mode) hand every block a run of tiles; a launch of the two-stream backbone holds the RGB stream's tiles, then the depth stream's, and
+    when tiles % 8 != 0 the run of some blocks crosses from one stream to the other (640x480: batches 9, 11, 12, 14, 15 - never 8 or 16, which
+    every other test and the bench use).  Wave 0 then requested the next-but-one tile's scale / shift vectors into the LDS image that late
+    waves were still reading in the epilogue of the tile before: the bottleneck projections of res3 (conv3 + shortcut as one GEMM: 900 tiles at
+    batch 12; conv1, 128 channels: 564 at batch 15) came out differently from run to run, 0.03-0.8 off at the res3 tap.  Now: three images in turn.
+    Bars: repeated forwards are bit-equal, and the taps agree with the same network with those kernels switched off (fp16: key 32, no launch has
+    that many tiles - within two fp16 steps; bf16x3: key 35 = 0 - the same partial products in the same order on conv_igemm.hip)."""
     h, w, n = 480, 640, 12
     sd = arch.init_state_dict(seed=3, loud_heads=True, center_bias=-1.6)
     batch = synth.make_batch(70 + b, b, h, w, n)
-    outs = {}
-    for key32 in (224, 1 << 20):
+    outs = []
+    for off in (False, True):
         qc = engine.make_config(h, w, max_batch=b, max_instances=n)
-        qc.compute_dtype = 2
+        qc.compute_dtype = dtype
         eng = engine.Engine(qc, "cuda:0")
-        eng.set_option(32, key32)
+        if off:
+            eng.set_option(off_key, (1 << 20) if off_key == 32 else 0)
         eng.set_option(24, 0)                      # one stream: the launches in plan order
         eng.load_state_dict(sd)
         try:
             bgr, dep = torch.from_numpy(batch["rgb"]).cuda(), torch.from_numpy(batch["depth"]).cuda()
-            off = eng.encode(torch.from_numpy(batch["masks"]).cuda())
-            first = eng.forward(bgr, dep, off).clone()
+            off_t = eng.encode(torch.from_numpy(batch["masks"]).cuda())
+            first = eng.forward(bgr, dep, off_t).clone()
             taps = {k: eng.debug_tensor(k, b).clone().float() for k in ("res2", "res3", "res5", "y")}
             for _ in range(5):
-                assert torch.equal(eng.forward(bgr, dep, off), first)
+                assert torch.equal(eng.forward(bgr, dep, off_t), first)
                 for k, v in taps.items():
                     assert torch.equal(eng.debug_tensor(k, b).float(), v), k
-            outs[key32] = taps
+            outs.append(taps)
         finally:
             eng.close()
-    for k, v in outs[224].items():
-        step = 2.0 ** -10 * float(v.abs().max())          # one fp16 step at the tap's largest magnitude (at most)
-        assert float((v - outs[1 << 20][k]).abs().max()) <= 2.5 * step, k
+    for k, v in outs[0].items():
+        assert float((v - outs[1][k]).abs().max()) <= rel * float(v.abs().max()), k
 
 
 def test_config2_1280x720_hipgraph_steady_state():
