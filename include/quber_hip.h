@@ -281,7 +281,7 @@ double quber_forward_flops_padding(quber_ctx* ctx);
  *         once; measured slower at every size: profiles/r03c_wino_subbatch_rejected.md);
  * key 21 (2; launch, ARITHMETIC) K-slices per chunk of the two-level fp32 accumulation of the GEMM kernels (the bf16x3 mode folds
  *         every `value` slices, the exact fp32 mode every slice; 0 = one sequential chain over K);
- * key 24 (1; launch) side lanes at batches <= 16 (exact fp32: <= 12), or everything on the caller's stream (0);
+ * key 24 (1; launch) side lanes at batches <= 16 (exact fp32 and bf16x3: <= 12), or everything on the caller's stream (0);
  * key 25 (1; plan) Winograd F(4x4,3x3) layers as ONE kernel - input transform, the 36 position GEMMs and the output transform, no
  *         V | M intermediates in HBM (csrc/wino_fused.hip): the eligible layers, or never (0);
  * key 27 (160; plan, ARITHMETIC) widest input, in channels, that takes the single-kernel form.  Its two accumulation chains are

@@ -175,7 +175,7 @@ struct Tuning {
     int stem_fused = 1;          // key 29 (plan): input normalisation + concat (a3) inside the first stem convolution's kernel (csrc/stem.hip); 0 = preprocess kernel + implicit GEMM; 2 = as 1, but the fp16 data path keeps the vector-FMA form (1: its matrix-pipe form)
     int lean_loader = 1;         // key 30 (launch): implicit GEMM with block-uniform filter taps and buffer loads where the layer allows it (conv_igemm.hip LEAN); 0 = per-thread tap arithmetic
     int fuse_shortcut = 1;       // key 18 (plan): conv3 + projection shortcut of a bottleneck as one dual-input GEMM
-    int lanes = 1;               // key 24 (launch): side lanes for batches <= 16, exact fp32 <= 12 (0 = everything on the caller's stream)
+    int lanes = 1;               // key 24 (launch): side lanes for batches <= 16, exact fp32 / bf16x3 <= 12 (0 = everything on the caller's stream)
     int h8 = 1;                  // key 31 (plan + launch: the plan's ASPP grouping and norm absorption read it too, include/quber_hip.h): fp16 data path: 256 x 256 tiles with the LDS-DMA pipeline for the wide layers (conv_h8.hip); 0 = conv_igemm.hip everywhere
     int x8 = 1;                  // key 35 (launch): bf16x3 mode: the wide 1x1 launches and the Winograd position GEMMs on 256 x 128 tiles with the LDS-DMA pipeline, weights pre-split at plan time
                                  //   (conv_x8.hip); 0 = conv_igemm.hip / conv_persist.hip everywhere, 2 = every covered launch (tests)

@@ -167,10 +167,10 @@ struct Op {
 };
 constexpr int LANES = 3;            // side lanes 1, 2: the fusion convolutions of res2 and of res3
 constexpr int LANE_BATCH = 16;      // side lanes are used up to this batch (their workspaces are sized for it) ...
-constexpr int LANE_BATCH_F32 = 12;  // ... in the exact fp32 mode up to this one.  Same-box A/B of the step with the lanes against one stream
-                                    // (profiles/r20_lanes.md): exact fp32 -5 % at 1 frame, -4.3 % at 4, -3 % at 6, -0.7 ... -1.5 % at 8, -0.8 % at 12,
-                                    // +0.2 ... +0.5 % at 16 (the headline stays on one stream); bf16x3 -4 % at 8, -2.4 % at 16; fp16 data path
-                                    // -11 % at 8, -6.7 % at 16 (640x480), -1.8 % at 1024x1024 x 8.  (Batches <= 2 until round 6's last pass.)
+constexpr int LANE_BATCH_F32 = 12;  // ... in the fp32-class modes (exact fp32, bf16x3) up to this one.  Same-box A/B of the step with the lanes against one
+                                    // stream (profiles/r20_lanes.md): exact fp32 -5 % at 1 frame, -4.3 % at 4, -3 % at 6, -1.5 ... -2.3 % at 8, -0.8 ... -1.3 % at 12,
+                                    // 0 ... +0.5 % at 16 (the headline stays on one stream); bf16x3 -3.4 ... -4 % at 8, -2.4 % / +1 % at 16 on two boxes (one stream);
+                                    // fp16 data path -11 % at 8, -5.8 ... -6.7 % at 16 (640x480), -1 ... -1.8 % at 1024x1024 x 8.  (Batches <= 2 until round 6's last pass.)
 
 struct quber_ctx {
     quber_config cfg;
@@ -1611,7 +1611,7 @@ int quber_forward(quber_ctx* c, const uint8_t* bgr, const uint8_t* depth, const 
                                                    c->cfg.pixel_mean, c->cfg.pixel_std, c->cfg.streams, st);
     if (rc) return rc;
     // side lanes: at small batches the independent branches of the plan (Builder::fork / join) run on streams of the context
-    c->lanes_on = c->lanes_built && tune().lanes && batch <= (c->cfg.compute_dtype == 0 ? LANE_BATCH_F32 : LANE_BATCH) && c->lane_stream[1] != nullptr &&
+    c->lanes_on = c->lanes_built && tune().lanes && batch <= (c->cfg.compute_dtype == 0 || c->cfg.compute_dtype == 3 ? LANE_BATCH_F32 : LANE_BATCH) && c->lane_stream[1] != nullptr &&
                   quber::g_prof == nullptr;
     auto lane_used = [&](int l) { return c->lanes_on && l > 0; };
     for (auto& op : c->ops) {

@@ -321,7 +321,7 @@ def test_adapter_armbench_branch(tmp_path):
 
 @pytest.mark.parametrize("dtype", [0, 3, 2], ids=["f32", "bf16x3", "f16"])
 def test_side_lanes_equal_one_stream(dtype):
-    """Batches <= 16 (exact fp32: <= 12) run the fusion convolutions of res2 / res3 on side streams of the context beside the later ResNet stages
+    """Batches <= 16 (exact fp32 and bf16x3: <= 12) run the fusion convolutions of res2 / res3 on side streams of the context beside the later ResNet stages
     (csrc/plan.hip: Builder::fork / join).  The results must equal the one-stream forward bit for bit - same launches, same
     split-K choices, own workspaces per lane - and stay equal over repeated runs (no race on a shared buffer), also on an
     engine built for a larger batch."""
