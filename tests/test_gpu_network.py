@@ -388,6 +388,36 @@ def test_run_of_tiles_across_the_stream_boundary(dtype, b, off_key, rel):
         assert float((v - outs[1][k]).abs().max()) <= rel * float(v.abs().max()), k
 
 
+@pytest.mark.parametrize("dtype", [0, 3], ids=["f32", "bf16x3"])
+def test_frames_of_an_odd_batch_equal_the_frames_one_by_one(dtype):
+    """No operation of the path crosses frames (GroupNorm is per image), so a frame's logits in a batch of 11 - a batch size
+    whose launches have tile counts that are no multiple of the 8 XCDs, ragged last tiles and runs of tiles that cross from the RGB to the depth
+    stream (profiles/r20_h8_affine_race.md: a launch structure only such batches produce) - may differ from the same frame refined alone by the
+    re-association of fp32 sums only (tile and split-K choices follow the batch).  Bar: 1e-5 of the logit scale on every frame
+    (measured 3-4e-6 at every batch 3-16: profiles/r20_batch_invariance.txt); a tile scaled, skipped or computed twice is orders above."""
+    h, w, n, b = 480, 640, 12, 11
+    sd = arch.init_state_dict(seed=3, loud_heads=True, center_bias=-1.6)
+    batch = synth.make_batch(90, b, h, w, n)
+    bgr, dep, masks = (torch.from_numpy(batch[k]).cuda() for k in ("rgb", "depth", "masks"))
+    outs = []
+    for maxb in (1, b):
+        qc = engine.make_config(h, w, max_batch=maxb, max_instances=n)
+        qc.compute_dtype = dtype
+        eng = engine.Engine(qc, "cuda:0")
+        eng.load_state_dict(sd)
+        try:
+            if maxb == 1:
+                outs.append(torch.cat([eng.forward(bgr[i:i + 1], dep[i:i + 1], eng.encode(masks[i:i + 1])).clone() for i in range(b)]))
+            else:
+                outs.append(eng.forward(bgr, dep, eng.encode(masks)).clone())
+        finally:
+            eng.close()
+    scale = float(outs[0].abs().max())
+    assert scale > 5.0                                # loud heads: the bar means something
+    per_frame = (outs[1] - outs[0]).abs().amax((1, 2, 3))
+    assert float(per_frame.max()) <= 1e-5 * scale, per_frame.tolist()
+
+
 def test_config2_1280x720_hipgraph_steady_state():
     """BASELINE.json configs[2]: 1280x720, 30 instances, the whole step captured in one hipGraph.  The replayed graph must
     give the eager results bit for bit on new inputs (it reads the device buffers, not captured values), the logits match
