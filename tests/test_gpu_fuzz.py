@@ -119,3 +119,16 @@ def test_network_random_frames(h, w, b, seed, dtype):
     # head units: the offset planes carry the common stride 4 of model.py:700
     assert float(d[:, :2].max()) < head_tol and float(d[:, 2:4].max()) < 4 * head_tol and float(d[:, 4:].max()) < head_tol
     eng.close()
+
+
+def test_network_launch_structures_random_sizes():
+    """The network on random (frame size, batch, arithmetic mode): repeated forwards bit-equal, side lanes == one stream bit for bit, the frames
+    of a batch == the frames one by one up to re-association (tools/network_fuzz.py; 196 more cases on record: profiles/r20_network_fuzz*.txt).
+    The structural net under the fixed-size parity tests: it is what would have caught profiles/r20_h8_affine_race.md two rounds earlier."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("network_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "network_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lines = []
+    assert mod.run(12, 2, lines.append) == 0, "\n".join(lines)

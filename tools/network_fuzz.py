@@ -1,0 +1,63 @@
+"""Randomised structural check of the network launches - no oracle needed, three properties that any (frame size, batch, arithmetic mode)
+must have: (a) repeated forwards of the same inputs are bit-equal, (b) the side lanes give the one-stream forward bit for bit, (c) the frames
+of a batch equal the frames refined one by one up to the re-association of fp32 sums (fp16 data path: up to its rounding).  A launch structure
+that only some sizes produce (ragged tiles, runs of tiles across streams or images, split-K of odd depth) and that scales, skips or repeats a
+tile fails (c); a race fails (a) or (b).  usage: python3 tools/network_fuzz.py [cases] [seed]"""
+import sys
+import time
+import numpy as np
+import torch
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from quber_amd import arch, engine, synth  # noqa: E402
+
+
+def run(cases, seed, log=print):
+    """-> number of failed cases"""
+    rng = np.random.default_rng(seed)
+    n = 8
+    sd = arch.init_state_dict(seed=3, loud_heads=True, center_bias=-1.6)
+    BAR = {0: 1e-5, 3: 1e-5, 2: 1.2e-2}          # (c), relative to the logit scale
+    bad = 0
+    t0 = time.time()
+    for case in range(cases):
+        dtype = int(rng.choice([0, 0, 3, 2, 2]))
+        h, w = int(rng.integers(48, 520)), int(rng.integers(64, 700))
+        b = int(rng.integers(2, 14))
+        while b * h * w > 12 * 480 * 640:
+            b -= 1
+        batch = synth.make_batch(1000 + case, b, h, w, n)
+        bgr, dep, masks = (torch.from_numpy(batch[k]).cuda() for k in ("rgb", "depth", "masks"))
+
+        def make(maxb):
+            qc = engine.make_config(h, w, max_batch=maxb, max_instances=n)
+            qc.compute_dtype = dtype
+            e = engine.Engine(qc, "cuda:0")
+            e.load_state_dict(sd)
+            return e
+
+        e1 = make(1)
+        single = torch.cat([e1.forward(bgr[i:i + 1], dep[i:i + 1], e1.encode(masks[i:i + 1])).clone() for i in range(b)])
+        e1.close()
+        eb = make(b)
+        off = eb.encode(masks)
+        eb.set_option(24, 0)
+        one = eb.forward(bgr, dep, off).clone()
+        rep = all(torch.equal(eb.forward(bgr, dep, off), one) for _ in range(3))
+        eb.set_option(24, 1)
+        lanes = all(torch.equal(eb.forward(bgr, dep, off), one) for _ in range(3))
+        eb.close()
+        scale = float(single.abs().max())
+        d = (one - single).abs().amax((1, 2, 3)) / scale
+        ok = rep and lanes and float(d.max()) <= BAR[dtype] and bool(torch.isfinite(one).all())
+        bad += not ok
+        log(f"case {case}: dtype {dtype} {h}x{w} batch {b}: repeat {rep}, lanes {lanes}, batch vs one by one (rel. to scale {scale:.1f}) max {float(d.max()):.2e} min {float(d.min()):.2e}"
+              + ("" if ok else "   <-- FAIL"))
+
+    log(f"{cases} cases, {bad} failed, {time.time() - t0:.0f} s")
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 24, int(sys.argv[2]) if len(sys.argv) > 2 else 0,
+                      lambda m: print(m, flush=True)) else 0)
