@@ -16,8 +16,17 @@ def run(cases, seed, log=print):
     """-> number of failed cases"""
     rng = np.random.default_rng(seed)
     n = 8
-    sd = arch.init_state_dict(seed=3, loud_heads=True, center_bias=-1.6)
-    BAR = {0: 1e-5, 3: 1e-5, 2: 1.2e-2}          # (c), relative to the logit scale
+    # architecture variants of SURVEY 8f-4 (tests/test_gpu_loud_parity.py VARIANTS): other channel counts, group counts and op lists
+    archs = [dict(), dict(), dict(),
+             dict(eee_mask_on=True, error_classes=2, fusion_target=("pred", "feat"),
+                  hierarchy=(("eee_mask",), ("eee_boundary",), ("foreground",), ("center",), ("offset",))),
+             dict(streams=1), dict(fusion_add=True, backbone_fusion_layers=3), dict(depth=101), dict(hierarchical=False, eee_boundary_on=False, error_classes=2),
+             dict(convs_dim=256, head_channels=64, eee_mask_on=True, head_fusion_layers=2,
+                  hierarchy=(("eee_mask",), ("eee_boundary",), ("foreground",), ("center",), ("offset",)))]
+    sds = {}
+    # (c), relative to the logit scale: the fp32-class modes differ by re-association; the fp16 data path by its rounding, which the five-level
+    # hierarchies carry through more layers (0.8-1.6e-2 there, 0.4-0.8e-2 on the canonical network) - plus: no frame far above the others
+    BAR = {0: 1e-5, 3: 1e-5, 2: 2.5e-2}
     bad = 0
     t0 = time.time()
     for case in range(cases):
@@ -26,18 +35,25 @@ def run(cases, seed, log=print):
         b = int(rng.integers(2, 14))
         while b * h * w > 12 * 480 * 640:
             b -= 1
+        ai = int(rng.integers(0, len(archs)))
+        kw = archs[ai]
+        if ai not in sds:
+            sds[ai] = arch.init_state_dict(seed=3, loud_heads=True, center_bias=-1.6, **kw)
+        sd = sds[ai]
         batch = synth.make_batch(1000 + case, b, h, w, n)
         bgr, dep, masks = (torch.from_numpy(batch[k]).cuda() for k in ("rgb", "depth", "masks"))
+        if kw.get("streams", 2) == 1:
+            dep = None
 
         def make(maxb):
-            qc = engine.make_config(h, w, max_batch=maxb, max_instances=n)
+            qc = engine.set_arch(engine.make_config(h, w, max_batch=maxb, max_instances=n), **kw)
             qc.compute_dtype = dtype
             e = engine.Engine(qc, "cuda:0")
             e.load_state_dict(sd)
             return e
 
         e1 = make(1)
-        single = torch.cat([e1.forward(bgr[i:i + 1], dep[i:i + 1], e1.encode(masks[i:i + 1])).clone() for i in range(b)])
+        single = torch.cat([e1.forward(bgr[i:i + 1], None if dep is None else dep[i:i + 1], e1.encode(masks[i:i + 1])).clone() for i in range(b)])
         e1.close()
         eb = make(b)
         off = eb.encode(masks)
@@ -49,9 +65,9 @@ def run(cases, seed, log=print):
         eb.close()
         scale = float(single.abs().max())
         d = (one - single).abs().amax((1, 2, 3)) / scale
-        ok = rep and lanes and float(d.max()) <= BAR[dtype] and bool(torch.isfinite(one).all())
+        ok = rep and lanes and float(d.max()) <= BAR[dtype] and float(d.max()) <= 3.0 * float(d.median()) + 0.1 * BAR[dtype] and bool(torch.isfinite(one).all())
         bad += not ok
-        log(f"case {case}: dtype {dtype} {h}x{w} batch {b}: repeat {rep}, lanes {lanes}, batch vs one by one (rel. to scale {scale:.1f}) max {float(d.max()):.2e} min {float(d.min()):.2e}"
+        log(f"case {case}: arch {ai} dtype {dtype} {h}x{w} batch {b}: repeat {rep}, lanes {lanes}, batch vs one by one (rel. to scale {scale:.1f}) max {float(d.max()):.2e} min {float(d.min()):.2e}"
               + ("" if ok else "   <-- FAIL"))
 
     log(f"{cases} cases, {bad} failed, {time.time() - t0:.0f} s")
