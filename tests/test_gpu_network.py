@@ -489,6 +489,63 @@ def test_config2_1280x720_hipgraph_steady_state():
     np.testing.assert_array_equal(out_masks[0, :k].cpu().numpy().astype(bool), o["masks"].numpy())     # ... and their masks
 
 
+@pytest.mark.parametrize("dtype,b", [(0, 6), (3, 6), (2, 16)], ids=["f32-6", "bf16x3-6", "f16-16"])
+def test_hipgraph_replay_with_side_lanes_at_larger_batches(dtype, b):
+    """Since round 6's last pass the side lanes run up to 16 frames (fp32-class modes: 12): a step captured at such a batch holds the lanes'
+    fork / join events inside the hipGraph (bench.py captures the step at N > 1; predict_stream users may).  The replay on NEW inputs must
+    equal the eager step bit for bit, twice over (csrc/plan.hip: event record / wait on the context's own streams are capturable)."""
+    h, w, n = 240, 320, 6
+    sd = arch.init_state_dict(seed=3, loud_heads=True, center_bias=-1.6)
+    qc = engine.make_config(h, w, max_batch=b, max_instances=n)
+    qc.compute_dtype = dtype
+    eng = engine.Engine(qc, "cuda:0")
+    eng.load_state_dict(sd)
+    dev = "cuda:0"
+    masks = torch.empty((b, n, h, w), dtype=torch.uint8, device=dev)
+    bgr = torch.empty((b, h, w, 3), dtype=torch.uint8, device=dev)
+    depth = torch.empty((b, h, w, 3), dtype=torch.uint8, device=dev)
+    offsets = torch.empty((b, 3, h, w), dtype=torch.float32, device=dev)
+    logits = torch.empty((b, eng.planes, h, w), dtype=torch.float32, device=dev)
+    post = eng.alloc_post(b)
+
+    def load(seed):
+        batch = synth.make_batch(seed, b, h, w, n)
+        masks.copy_(torch.from_numpy(batch["masks"]))
+        bgr.copy_(torch.from_numpy(batch["rgb"]))
+        depth.copy_(torch.from_numpy(batch["depth"]))
+
+    def step():
+        eng.encode(masks, offsets)
+        eng.forward(bgr, depth, offsets, logits)
+        eng.postprocess(logits, post)
+
+    try:
+        load(31)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        load(32)
+        eng.set_option(24, 0)
+        step()                             # one stream, eager: the reference
+        torch.cuda.synchronize()
+        eager = (logits.clone(), post["panoptic"].clone(), post["count"].clone())
+        eng.set_option(24, 1)
+        assert float(eager[0].abs().max()) > 1.0
+        for _ in range(2):
+            logits.zero_()
+            post["panoptic"].zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(logits, eager[0]) and torch.equal(post["panoptic"], eager[1]) and torch.equal(post["count"], eager[2])
+    finally:
+        eng.close()
+
+
 def test_winograd_modes_agree():
     """The convolution algorithms (direct only, Winograd F(2x2,3x3), F(4x4,3x3), F(6x6,3x3) forced on every layer it fits:
     quber_set_tuning keys 6 / 9, the C-level form of QUBER_WINOGRAD) give the same logits within the 1e-4 bar, and the library reports how many of the
