@@ -2,7 +2,7 @@
 must have: (a) repeated forwards of the same inputs are bit-equal, (b) the side lanes give the one-stream forward bit for bit, (c) the frames
 of a batch equal the frames refined one by one up to the re-association of fp32 sums (fp16 data path: up to its rounding).  A launch structure
 that only some sizes produce (ragged tiles, runs of tiles across streams or images, split-K of odd depth) and that scales, skips or repeats a
-tile fails (c); a race fails (a) or (b).  usage: python3 tools/network_fuzz.py [cases] [seed] [dtype]"""
+tile fails (c); a race fails (a) or (b).  usage: python3 tools/network_fuzz.py [cases] [seed] [dtype | -] [large]"""
 import sys
 import time
 import numpy as np
@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from quber_amd import arch, engine, synth  # noqa: E402
 
 
-def run(cases, seed, log=print, only_dtype=None):
+def run(cases, seed, log=print, only_dtype=None, large=False):
     """-> number of failed cases"""
     rng = np.random.default_rng(seed)
     n = 8
@@ -35,6 +35,8 @@ def run(cases, seed, log=print, only_dtype=None):
             dtype = only_dtype
         h, w = int(rng.integers(48, 520)), int(rng.integers(64, 700))
         b = int(rng.integers(2, 14))
+        if large:                          # frames up to 1100 x 1300 (BASELINE configs[2] / [4] sizes and beyond), batches 2-5
+            h, w, b = int(rng.integers(600, 1100)), int(rng.integers(700, 1300)), int(rng.integers(2, 6))
         while b * h * w > 12 * 480 * 640:
             b -= 1
         ai = int(rng.integers(0, len(archs)))
@@ -78,4 +80,5 @@ def run(cases, seed, log=print, only_dtype=None):
 
 if __name__ == "__main__":
     sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 24, int(sys.argv[2]) if len(sys.argv) > 2 else 0,
-                      lambda m: print(m, flush=True), int(sys.argv[3]) if len(sys.argv) > 3 else None) else 0)
+                      lambda m: print(m, flush=True), int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3] != "-" else None,
+                      len(sys.argv) > 4 and sys.argv[4] == "large") else 0)
