@@ -2,7 +2,7 @@
 must have: (a) repeated forwards of the same inputs are bit-equal, (b) the side lanes give the one-stream forward bit for bit, (c) the frames
 of a batch equal the frames refined one by one up to the re-association of fp32 sums (fp16 data path: up to its rounding).  A launch structure
 that only some sizes produce (ragged tiles, runs of tiles across streams or images, split-K of odd depth) and that scales, skips or repeats a
-tile fails (c); a race fails (a) or (b).  usage: python3 tools/network_fuzz.py [cases] [seed] [dtype | -] [large]"""
+tile fails (c); a race fails (a) or (b).  usage: python3 tools/network_fuzz.py [cases] [seed] [dtype | -] [large | many]"""
 import sys
 import time
 import numpy as np
@@ -35,8 +35,10 @@ def run(cases, seed, log=print, only_dtype=None, large=False):
             dtype = only_dtype
         h, w = int(rng.integers(48, 520)), int(rng.integers(64, 700))
         b = int(rng.integers(2, 14))
-        if large:                          # frames up to 1100 x 1300 (BASELINE configs[2] / [4] sizes and beyond), batches 2-5
+        if large is True:                  # frames up to 1100 x 1300 (BASELINE configs[2] / [4] sizes and beyond), batches 2-5
             h, w, b = int(rng.integers(600, 1100)), int(rng.integers(700, 1300)), int(rng.integers(2, 6))
+        if large == "many":                # many small frames: batches 14-48 (tile counts of several rounds from small maps)
+            h, w, b = int(rng.integers(48, 260)), int(rng.integers(64, 350)), int(rng.integers(14, 49))
         while b * h * w > 12 * 480 * 640:
             b -= 1
         ai = int(rng.integers(0, len(archs)))
@@ -81,4 +83,4 @@ def run(cases, seed, log=print, only_dtype=None, large=False):
 if __name__ == "__main__":
     sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 24, int(sys.argv[2]) if len(sys.argv) > 2 else 0,
                       lambda m: print(m, flush=True), int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3] != "-" else None,
-                      len(sys.argv) > 4 and sys.argv[4] == "large") else 0)
+                      (sys.argv[4] == "large" or sys.argv[4]) if len(sys.argv) > 4 else False) else 0)
