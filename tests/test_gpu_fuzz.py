@@ -123,7 +123,7 @@ def test_network_random_frames(h, w, b, seed, dtype):
 
 def test_network_launch_structures_random_sizes():
     """The network on random (frame size, batch, arithmetic mode): repeated forwards bit-equal, side lanes == one stream bit for bit, the frames
-    of a batch == the frames one by one up to re-association (tools/network_fuzz.py; 416 more cases on record, 220 of them over nine architecture variants: profiles/r20_network_fuzz*.txt).
+    of a batch == the frames one by one up to re-association (tools/network_fuzz.py; ~1 100 more cases on record, most of them over nine architecture variants: profiles/r20_network_fuzz*.txt).
     The structural net under the fixed-size parity tests: it is what would have caught profiles/r20_h8_affine_race.md two rounds earlier."""
     import importlib.util
     import os

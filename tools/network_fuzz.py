@@ -24,9 +24,10 @@ def run(cases, seed, log=print, only_dtype=None, large=False):
              dict(convs_dim=256, head_channels=64, eee_mask_on=True, head_fusion_layers=2,
                   hierarchy=(("eee_mask",), ("eee_boundary",), ("foreground",), ("center",), ("offset",)))]
     sds = {}
-    # (c), relative to the logit scale: the fp32-class modes differ by re-association; the fp16 data path by its rounding, which the five-level
+    # (c), relative to the logit scale: the fp32-class modes differ by re-association (3-6e-6; up to 1.1e-5 on the five-level hierarchies, uniformly over
+    # the frames); the fp16 data path by its rounding, which the five-level
     # hierarchies carry through more layers (0.8-1.6e-2 there, 0.4-0.8e-2 on the canonical network) - plus: no frame far above the others
-    BAR = {0: 1e-5, 3: 1e-5, 2: 2.5e-2, 1: 2e-1}          # (1 = bf16 operands, 8 significand bits: only with the dtype argument)
+    BAR = {0: 2e-5, 3: 2e-5, 2: 2.5e-2, 1: 2e-1}          # (1 = bf16 operands, 8 significand bits: only with the dtype argument)
     bad = 0
     t0 = time.time()
     for case in range(cases):
